@@ -1,0 +1,327 @@
+/*
+ * seggroup_hip.h -- C ABI of libseggroup_hip.so: the MI355X (gfx950) implementation of the SegGroup
+ * pseudo-label generation hot path (reference: antao97/SegGroup, seggroup/model.py + seggroup/infer.py).
+ *
+ * The reference has no FFI; its operator seam is the set of module-level functions that
+ * SegModel.forward resolves by global name.  Each entry point below replaces one (or a
+ * fused run) of those functions; the citation names the reference lines it stands in for.  A
+ * maintainer binds them from Python with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C types only; `d_` pointers are DEVICE pointers (tensor.data_ptr()), `h_` pointers are HOST.
+ *   - every function returns 0 on success or a negative SG_E* code; sg_last_error() gives the
+ *     message of the calling thread's last failure.  Nothing throws, nothing calls exit().
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Device entry
+ *     points only ENQUEUE work unless documented otherwise.
+ *   - indices are int32 inside the library (N < 2^31); the Python layer converts from the
+ *     reference's int64.  Features are float32.
+ *   - functions never allocate or free caller-visible memory.  Scratch comes from the caller
+ *     (`d_ws`, sizes from sg_*_ws_bytes) except for the sg_pipeline_* object, which owns its
+ *     buffers between create and destroy.
+ */
+#ifndef SEGGROUP_HIP_H
+#define SEGGROUP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_OK          0
+#define SG_EINVAL     -1   /* bad argument / inconsistent sizes                                   */
+#define SG_EHIP       -2   /* a HIP runtime call failed                                            */
+#define SG_ENOMEM     -3   /* workspace too small / allocation failed                              */
+#define SG_ESTALL     -4   /* reference would loop forever (model.py:228-239)       */
+#define SG_EUNSUP     -5   /* size outside the supported envelope (documented per function)        */
+
+#define SG_MODE_INS_INFER 0   /* infer.py --ins_infer : all five layers (model.py:684-897)         */
+#define SG_MODE_SEM_INFER 1   /* infer.py --sem_infer : returns after layer 2 (model.py:781-783)   */
+
+#define SG_NUM_LABEL_VECTORS 14 /* layer_{1..4}.{seg,ins,sem} + final.{ins,sem} (model.py:525-605) */
+
+const char* sg_last_error(void);
+int  sg_version(void);
+/* number of visible HIP devices (0 when no GPU): lets callers fail loudly before first use */
+int  sg_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3  update_adj, first call (model.py:291-302 with model.py:724-733): contract the point-level
+ * mesh adjacency through the over-segmentation.  d_adj is the [E,2] int64 tensor of <scene>.adj.pth;
+ * d_seg_of_point maps point -> segment number (rank of the segment's first point).  Output rows are
+ * (lo,hi) int32 pairs, lexicographically sorted and unique -- the order torch.unique(dim=0) gives.
+ * Implementation: one bit per (lo,hi) pair in an S*S bitmap, then an ordered compaction.
+ * Supported: S*S <= 2^31 bits.  d_ws needs sg_contract_ws_bytes(S).
+ * ------------------------------------------------------------------------------------------- */
+size_t sg_contract_ws_bytes(int S);
+int sg_contract_point_edges(const int64_t* d_adj, int E, const int32_t* d_seg_of_point, int N, int S,
+                            int32_t* d_out_adj, int out_capacity, int32_t* d_out_count,
+                            void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a2/a10  member lists of one layer's clusters (DisjointSet.indexs / get_cluster_list, model.py:
+ * 169-214; re-index blocks model.py:759-768).  A cluster is an ORDERED list of original segments
+ * (model.py:191 concatenates member lists), so its member list is the concatenation of those
+ * segments' ascending point lists.  h-side arrays come from sg_partition_layer().
+ *   d_seg_points/d_seg_off : CSR of the original over-segmentation (points ascending per segment)
+ *   d_order[S]  original segment ids in cluster-concatenated order
+ *   d_dst[S]    destination offset (in points) of each of those segments
+ *   d_cl[S]     cluster number of each of those segments
+ * writes d_members[N] (point ids in member order), d_pos_of_point[N] (inverse permutation) and
+ * d_cluster_of_pos[N].
+ * ------------------------------------------------------------------------------------------- */
+int sg_gather_members(const int32_t* d_seg_points, const int32_t* d_seg_off, int S,
+                      const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl,
+                      int32_t* d_members, int32_t* d_pos_of_point, int32_t* d_cluster_of_pos, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a4+a5  get_cluster_pointcloud + farthest_point_sampling (model.py:319-426).  For every cluster
+ * (member CSR d_members/d_cl_off, C clusters): rows = members tiled P/n times, then P%n FPS picks
+ * (start at member 0, first pick = farthest from it with the min-distance array RESET to that pick,
+ * first-index argmax, fp32 distances (dx2+dy2)+dz2 with individually rounded squares, trailing-zero
+ * fix-up of model.py:407-412).  d_data is [N,ch_in] float32 (XYZ first); ch_out (3 or 6) channels are
+ * copied.  transform != 0 applies model.py:421-423 (subtract mean XYZ of the P rows, divide by the
+ * scalar max |XYZ|).  d_sel (may be NULL) receives the chosen point ids [C,P].
+ * d_ws needs sg_fps_ws_bytes(N) (min-distance scratch for clusters that do not fit in LDS).
+ * ------------------------------------------------------------------------------------------- */
+size_t sg_fps_ws_bytes(int N);
+int sg_fps_sample(const float* d_data, int N, int ch_in, const int32_t* d_members, const int32_t* d_cl_off, int C,
+                  int P, int ch_out, int transform, float* d_samples, int32_t* d_sel,
+                  void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a6+a7  MLP1 = knn(k=10) + get_graph_feature1 + conv1x1 6->64 + BatchNorm2d(batch statistics over
+ * all C*64*10 rows, eps 1e-5, biased variance) + LeakyReLU(0.2) + max_k + [max | mean] over the 64
+ * points (model.py:30-80).  d_samples [C,64,6] -> d_feat rows of 128 floats with row stride
+ * feat_stride (floats).  d_w [64,6], d_gamma/d_beta [64].  d_ws needs sg_mlp1_ws_bytes(C).
+ * ------------------------------------------------------------------------------------------- */
+size_t sg_mlp1_ws_bytes(int C);
+int sg_mlp1_forward(const float* d_samples, int C, const float* d_w, const float* d_gamma, const float* d_beta,
+                    float* d_feat, int feat_stride, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a8  calculate_distance (model.py:269-274): d[e] = || F[a] - F[b] + 1e-6 ||_2 for every edge.
+ * ------------------------------------------------------------------------------------------- */
+int sg_edge_distance(const float* d_feat, int feat_stride, int D, const int32_t* d_adj, int E,
+                     float* d_dist, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a10  aggregate_cluster_feature (model.py:278-288): out[g] = element-wise max of rows[idx] over
+ * group g (CSR d_goff[G+1], d_gidx).  Columns [0,D) of each output row (stride out_stride).
+ * ------------------------------------------------------------------------------------------- */
+int sg_group_max_rows(const float* d_rows, int row_stride, int D, const int32_t* d_goff, const int32_t* d_gidx,
+                      int G, float* d_out, int out_stride, void* stream);
+
+/* a10 point->cluster max (model.py:793,834): rows are in member order, clusters are contiguous ranges */
+int sg_segment_max(const float* d_rows, int N, int D, const int32_t* d_cluster_of_pos,
+                   float* d_out, int out_stride, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a12  combine_centralized_pointcloud (model.py:429-436), written in MEMBER order:
+ *   d_x9m [N,12]  = [XYZ, RGB, XYZ - mean XYZ of the point's cluster, 0,0,0]   (row pos)
+ *   d_xyzw [N,4]  = [X, Y, Z, fl(fl(X2+Y2)+Z2)]                              (kNN operand)
+ * d_tile_cl / d_tile_lo / d_tile_hi describe T tiles (<=256 consecutive positions of one cluster),
+ * d_cl_tile_off[C+1] the tiles of each cluster (from sg_partition_layer); the two-level sum keeps
+ * the mean bit-reproducible.  d_ws needs sg_center_ws_bytes(T, C).
+ * ------------------------------------------------------------------------------------------- */
+size_t sg_center_ws_bytes(int T, int C);
+int sg_center_clusters(const float* d_data, int N, const int32_t* d_members, const int32_t* d_cl_off, int C,
+                       const int32_t* d_tile_cl, const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T,
+                       const int32_t* d_cl_tile_off, float* d_x9m, float* d_xyzw,
+                       void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a6+a11  get_knn (model.py:512-522) with knn (model.py:30-36), k = 20, in member-order positions.
+ * Scores are evaluated in the reference's exact fp32 order:
+ *   s_ij = ((-xx_j) - (-2 * fma(z_i,z_j, fma(y_i,y_j, fl(x_i*x_j))))) - xx_i
+ * Clusters with n <= k list all members in member order and leave the remaining columns pointing at
+ * GLOBAL POINT 0 (position pos0) -- the zero-initialised table quirk of model.py:513.
+ * d_knn [N,k] int32 positions, row = query position, descending score.
+ * ------------------------------------------------------------------------------------------- */
+int sg_cluster_knn(const float* d_xyzw, int N, const int32_t* d_cl_off,
+                   const int32_t* d_tile_cl, const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T,
+                   int k, int pos0, int32_t* d_knn, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a13  get_graph_feature2 + MLP2 / MLP3 (model.py:83-138): edge features [x_j - x_i, x_i] over the
+ * k=20 table, conv1x1 18->64 (+ conv1x1 64->64 for layers == 2), BatchNorm2d with batch statistics
+ * over all N*k rows, LeakyReLU(0.2), max over k.  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * d_out [N,64] in member order.  d_w2/d_g2/d_b2 are ignored when layers == 1.
+ * d_ws needs sg_edgeconv_ws_bytes(N).
+ * ------------------------------------------------------------------------------------------- */
+size_t sg_edgeconv_ws_bytes(int N);
+int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers,
+                        const float* d_w1, const float* d_g1, const float* d_b1,
+                        const float* d_w2, const float* d_g2, const float* d_b2,
+                        float* d_out, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a14  calculate_similarity + build_similarity_matrix + GCN (model.py:262-265,305-309,141-151):
+ * out = relu( ((I + sym(exp(-alpha*d))) row-normalised) @ X @ W^T ), evaluated sparsely over the
+ * symmetric CSR (d_rowptr[S+1], d_col, d_eid -> index into the edge list) built by the host.
+ * d_ws needs sg_gcn_ws_bytes(S, D, E).
+ * ------------------------------------------------------------------------------------------- */
+size_t sg_gcn_ws_bytes(int S, int D, int E);
+int sg_gcn_forward(const float* d_x, int S, int D, const int32_t* d_adj, int E,
+                   const int32_t* d_rowptr, const int32_t* d_col, const int32_t* d_eid,
+                   const float* d_w, float alpha, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a16  export_{segment,instance,semantic}_label (model.py:525-605), gather only:
+ *   out[t][v] = tables[t][ seg_of_point[ unmap[v] ] ]      t < T label vectors, v < V raw vertices
+ * d_tables [T,S] int32 holds each original segment's exported value for that vector.
+ * ------------------------------------------------------------------------------------------- */
+int sg_export_labels(const int32_t* d_unmap, int V, const int32_t* d_seg_of_point, int N,
+                     const int32_t* d_tables, int T, int S, int32_t* d_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a17  evaluate (model.py:608-655): integer counts on the device, ratios on the host.
+ * d_gt [V,2] int32 (sem, ins), predictions int32 [V].  Writes the three reference return values
+ * to HOST buffers h_iou_sem[2*40], h_iou_ins[2*40], h_acc[4]; SYNCHRONISES the stream.
+ * max_ins = upper bound (exclusive) of predicted instance ids.  d_ws needs sg_eval_ws_bytes(max_ins).
+ * ------------------------------------------------------------------------------------------- */
+size_t sg_eval_ws_bytes(int max_ins);
+int sg_evaluate(const int32_t* d_gt, const int32_t* d_sem_pred, const int32_t* d_ins_pred, int V, int max_ins,
+                float* h_iou_sem, float* h_iou_ins, float* h_acc, void* d_ws, size_t ws_bytes, void* stream);
+
+/* =============================================================================================
+ * Host-side grouping engine (a2, a3 later calls, a9, a10 re-index, a15): the serial, order-dependent
+ * core of the reference, restated over SEGMENT-level arrays (S <= a few thousand), plain C++.
+ * ============================================================================================= */
+typedef struct sg_partition sg_partition;
+
+/* DisjointSet + graph initialisation (model.py:169-214,712-721).  seg_first[s] = index of the first
+ * point of segment s (strictly ascending), seg_size[s] its point count, seg_ins/seg_sem the weak
+ * labels of that first point (-1 = unlabeled). */
+sg_partition* sg_partition_create(int S, const int32_t* h_seg_first, const int32_t* h_seg_size,
+                                  const int32_t* h_seg_ins, const int32_t* h_seg_sem);
+void sg_partition_destroy(sg_partition* p);
+int  sg_partition_num_clusters(const sg_partition* p);
+
+/* DisjointSet.union(id1,id2) on cluster roots given as SEGMENT numbers (model.py:181-192);
+ * returns 1 if points moved, 0 if no-op / vetoed. */
+int sg_partition_union(sg_partition* p, int seg_root1, int seg_root2);
+/* find(): root segment of the cluster that currently owns segment s (model.py:178-179) */
+int sg_partition_find(const sg_partition* p, int s);
+/* current weak labels / point count of the cluster rooted at segment r (stale for dead roots) */
+int sg_partition_label(const sg_partition* p, int r, int32_t* ins, int32_t* sem, double* npts);
+
+/* Freeze the current numbering (get_cluster_list order, model.py:209-214; re-index blocks 759-768):
+ *   h_root[C]        root segment of cluster c (ascending)
+ *   h_cl_of_seg[S]   cluster number of every original segment
+ *   h_order[S]       original segments in cluster-concatenated (member) order
+ *   h_cl_seg_off[C+1] range of h_order belonging to cluster c
+ *   h_cl_pt_off[C+1]  range of member positions (points) belonging to cluster c
+ *   h_dst[S]         point offset of h_order[i] in the member array
+ * returns C, or a negative error. */
+int sg_partition_layer(const sg_partition* p, int32_t* h_root, int32_t* h_cl_of_seg, int32_t* h_order,
+                       int32_t* h_cl_seg_off, int32_t* h_cl_pt_off, int32_t* h_dst);
+
+/* group_nearby_clusters (model.py:218-258).  adj rows index the layer frozen in h_root (C clusters).
+ * h_connected[E] receives 1 for edges whose endpoints ended in one cluster.  Returns 0, or SG_ESTALL
+ * when the reference's pass 2 would never terminate (the sweep that made no progress is the last). */
+int sg_partition_group_nearby(sg_partition* p, const int32_t* h_root, int C, const float* h_dist,
+                              const int32_t* h_adj, int E, float th, uint8_t* h_connected);
+
+/* update_adj for layers >= 2 (model.py:291-302): contract the edges with h_keep[e] != 0 (NULL = all)
+ * from the numbering h_root_old to the CURRENT partition's numbering; sorted unique rows.
+ * Returns the number of rows written (<= E) or a negative error. */
+int sg_partition_contract(const sg_partition* p, const int32_t* h_root_old, const int32_t* h_adj, int E,
+                          const uint8_t* h_keep, int32_t* h_adj_out);
+
+/* group_unlabeled_clusters, first loop (model.py:447-477): iterated nearest-feature-neighbour merges
+ * of unlabeled clusters.  h_feat [C,D] / h_adj [E,2] are updated IN PLACE to the new numbering
+ * (feature = max of absorbed rows); *C_io / *E_io likewise.  Returns 1 if an unlabeled cluster
+ * remains (the caller must then sample with P=1024 and call ..._fallback), 0 if none. */
+int sg_partition_group_unlabeled(sg_partition* p, int32_t* h_root_io, int* C_io, float* h_feat, int D,
+                                 int32_t* h_adj, int* E_io);
+/* second half (model.py:479-507): h_samples [C,1024,3] fp32 XYZ of every cluster in the numbering
+ * left by the call above. */
+int sg_partition_unlabeled_fallback(sg_partition* p, const int32_t* h_root, int C, const float* h_samples, int P);
+
+/* Export tables for one layer (model.py:525-605): per ORIGINAL segment the values that
+ * export_segment_label / export_instance_label / export_semantic_label write for its points. */
+int sg_partition_export_tables(const sg_partition* p, int32_t* h_seg_tab, int32_t* h_ins_tab, int32_t* h_sem_tab);
+
+/* =============================================================================================
+ * Whole-scene pipeline: SegModel.forward (model.py:684-897) for one scene on one stream.
+ * ============================================================================================= */
+typedef struct sg_pipeline sg_pipeline;
+
+typedef struct sg_weights {       /* HOST pointers, float32, row-major (checkpoint contract) */
+    const float* mlp1_w;  const float* mlp1_g;  const float* mlp1_b;      /* [64,6]  [64] [64]        */
+    const float* mlp2_w;  const float* mlp2_g;  const float* mlp2_b;      /* [64,18] [64] [64]        */
+    const float* gcn2_w;                                                  /* [192,192]                */
+    const float* mlp3_w1; const float* mlp3_g1; const float* mlp3_b1;     /* [64,18] [64] [64]        */
+    const float* mlp3_w2; const float* mlp3_g2; const float* mlp3_b2;     /* [64,64] [64] [64]        */
+    const float* gcn3_w;                                                  /* [256,256]                */
+} sg_weights;
+
+typedef struct sg_scene {         /* one scene, DEVICE-resident inputs (staged by the loader)          */
+    int N, S, E0, V;
+    const float*   d_data;          /* [N,6]   <scene>.pcl.pth                 (data.py:34)            */
+    const int64_t* d_adj;           /* [E0,2]  <scene>.adj.pth                 (model.py:724)          */
+    const int32_t* d_seg_of_point;  /* [N]     segment number per point        (.seg.json, model.py:714)*/
+    const int32_t* d_seg_points;    /* [N]     CSR of the .seg.json lists: points ascending per segment */
+    const int32_t* d_seg_off;       /* [S+1]                                                            */
+    const int32_t* d_unmap;         /* [V]     <scene>.unmap.pth               (model.py:533)          */
+    const int32_t* d_gt;            /* [V,2]   label/real/raw .label.pth (sem, ins) (model.py:612)     */
+    /* HOST, segment level (derived by the loader from weak_label and the segment lists) */
+    const int32_t* h_seg_first;     /* [S] first point of each segment                                 */
+    const int32_t* h_seg_size;      /* [S]                                                             */
+    const int32_t* h_seg_ins;       /* [S] weak instance label of the first point (weak_label[:,1])   */
+    const int32_t* h_seg_sem;       /* [S] weak semantic label of the first point (weak_label[:,0])   */
+} sg_scene;
+
+typedef struct sg_result {        /* HOST outputs                                                       */
+    int32_t* h_labels;              /* [14,V] int32, pinned or pageable; order: layer_1.seg, layer_1.ins,
+                                       layer_1.sem, layer_2.*, layer_3.*, layer_4.*, final.ins, final.sem.
+                                       sem_infer fills the first 6 and leaves the rest untouched.        */
+    float iou_sem[80];              /* [2,40] I then U  (model.py:628)                                   */
+    float iou_ins[80];              /* [2,40]           (model.py:640)                                   */
+    float acc[4];                   /* model.py:654                                                      */
+    int32_t trace[5];               /* cluster counts of layers 1..5                                     */
+    int32_t stalled;                /* 1 if a pass-2 sweep was cut short (SG_ESTALL condition)           */
+    int32_t used_fallback;          /* 1 if the FPS-1024 fallback of model.py:479-494 ran                */
+} sg_result;
+
+typedef struct sg_debug {         /* optional taps for stage-level parity tests (every pointer may be NULL) */
+    float*   d_samples1;            /* DEVICE [S,64,6]                                                   */
+    float*   d_feat1;               /* DEVICE [S,128]                                                    */
+    float*   d_pointfeat[2];        /* DEVICE [N,64] MLP2 / MLP3 output, MEMBER order of that layer      */
+    int32_t* d_knn[2];              /* DEVICE [N,20] member-order positions                              */
+    int32_t* d_members[2];          /* DEVICE [N]    point id at each member-order position              */
+    float*   h_gcn[2];              /* HOST [S2,192] / [S3,256]                                          */
+    float*   h_dist[3];             /* HOST distance vectors of the three group_nearby calls            */
+    int32_t* h_adj[4];              /* HOST adjacency lists adj_1..adj_4 ([E,2])                         */
+    int32_t  n_adj[4];              /* rows written to h_adj[i]                                          */
+} sg_debug;
+
+sg_pipeline* sg_pipeline_create(int max_points, int max_segments, int max_edges, int max_vertices,
+                                const sg_weights* w, void* stream);
+void sg_pipeline_destroy(sg_pipeline* pl);
+/* device + pinned bytes owned by the pipeline (for capacity planning against 288 GB HBM) */
+size_t sg_pipeline_device_bytes(const sg_pipeline* pl);
+
+/* SegModel.forward for one scene.  Blocks the calling thread until the results are in `out`
+ * (it synchronises `stream` at each of the 3-5 points where the serial grouping needs distances).
+ * Thread-safe across DIFFERENT pipeline objects (one pipeline per in-flight scene). */
+int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* scene, int mode, sg_result* out, sg_debug* dbg);
+
+/* per-stage device time of the last forward, in milliseconds (HIP events on the pipeline's stream);
+ * names via sg_pipeline_stage_name(i), count returned. */
+int sg_pipeline_stage_times(const sg_pipeline* pl, float* h_ms, int capacity);
+const char* sg_pipeline_stage_name(int i);
+
+/* =============================================================================================
+ * Output writers (a16 file side, model.py:536-547): one decimal integer per line, '\n' terminated;
+ * and the .npy twin (v1.0 header, '<i4', shape (V,)).  Host only.
+ * ============================================================================================= */
+int sg_write_label_txt(const char* path, const int32_t* h_vec, int V);
+int sg_write_label_npy(const char* path, const int32_t* h_vec, int V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGGROUP_HIP_H */

@@ -1,0 +1,278 @@
+// a13: get_graph_feature2 + MLP2 / MLP3 (reference seggroup/model.py:83-138): the EdgeConv stage.
+//
+//   edge row (point i, neighbour slot j):  e = [x_j - x_i , x_i]              (18 = 2 x 9 channels)
+//   MLP2:  max_j LReLU(BN1(W1 e))                                              (64 channels)
+//   MLP3:  max_j LReLU(BN2(W2 LReLU(BN1(W1 e))))
+//   BN = BatchNorm2d in TRAIN mode: per-channel batch mean / biased variance over all N*k rows
+//   (infer.py never calls eval()).
+//
+// This is the only dense contraction on the hot path and it is MFMA-bound (39 GFLOP/scene, ~280
+// flop/B): it runs on v_mfma_f32_32x32x2_f32 (exact fp32, bit-equal to an fmaf chain).
+//
+// Mapping (one wave = one tile of 32 points, loop over the k=20 neighbour slots):
+//   D^T[ch][row] = sum_k W[ch][k] * E[row][k]:  A operand = weights (M = 32 channels per tile, two
+//   tiles), B operand = edge features (N = 32 rows).  Lane l holds row (l & 31) and k-parity (l >> 5);
+//   the accumulator gives every lane 16 channels of ITS OWN row per tile, so
+//     * LeakyReLU / max-over-k / statistics are element-wise on registers (rows never cross lanes),
+//     * the conv1 accumulator can be fed straight back as the B operand of conv2: MFMA step r pairs
+//       channel c(r)   (lanes 0-31) with channel c(r)+4 (lanes 32-63), which is exactly how the
+//       accumulator is laid out (row = (r&3) + 8(r>>2) + 4(lane>>5)); only the A operand (W2) has to
+//       be fetched in that permuted k order, and it comes pre-arranged from LDS.
+//   BatchNorm is folded: w' = a*w (a = gamma/sqrt(var+eps)) and the shift b' = beta - a*mean enters
+//   as the accumulator's initial value (layer 1 of MLP3) or after the max (last layer: max commutes
+//   with adding a per-channel constant and LeakyReLU is monotone).
+//
+// Statistics need a global barrier, so MLP2 is 2 launches and MLP3 is 3 (recompute instead of
+// materialising the 768 MB [N,20,64] tensor): STATS1 -> FINAL1, or STATS1 -> STATS2 -> FINAL2.
+// Per-block fp64 partial sums are combined in fixed order by a one-block finalize kernel, so the
+// result is bit-reproducible run to run.
+#include "sg_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum { STATS1 = 0, FINAL1 = 1, STATS2 = 2, FINAL2 = 3 };
+
+constexpr int kWaves = 4;
+
+__device__ inline int acc_channel(int tile, int reg, int half) { return 32 * tile + (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+struct Lds {
+    float a1[2][9][64];      // conv1 A fragments: a1[t][s][lane] = W1[32t + (lane&31)][2s + (lane>>5)]
+    float a2[2][32][64];     // conv2 A fragments: a2[ot][st][lane] = W2[32ot + (lane&31)][acc_channel(st>>4, st&15, lane>>5)]
+    float sh1[64];           // folded BN1 shift
+    float sh2[64];           // folded BN2 shift (or BN1 shift for MLP2's last layer)
+    double acc[kWaves][128]; // per-wave statistics: [0,64) sum, [64,128) sum of squares
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64 * kWaves) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
+                                                          const float* __restrict__ w1, const float* __restrict__ shift1,
+                                                          const float* __restrict__ w2, const float* __restrict__ shift2,
+                                                          float* __restrict__ out, double* __restrict__ partial) {
+    __shared__ Lds lds;
+    constexpr bool kTwo = MODE == STATS2 || MODE == FINAL2;
+    constexpr bool kStats = MODE == STATS1 || MODE == STATS2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, half = lane >> 5;
+
+    for (int i = tid; i < 2 * 9 * 64; i += 64 * kWaves) {
+        const int l = i & 63, s = (i >> 6) % 9, t = i / (9 * 64);
+        lds.a1[t][s][l] = w1[(32 * t + (l & 31)) * 18 + 2 * s + (l >> 5)];
+    }
+    if (kTwo) {
+        for (int i = tid; i < 2 * 32 * 64; i += 64 * kWaves) {
+            const int l = i & 63, st = (i >> 6) & 31, ot = i >> 11;
+            lds.a2[ot][st][l] = w2[(32 * ot + (l & 31)) * 64 + acc_channel(st >> 4, st & 15, l >> 5)];
+        }
+    }
+    if (tid < 64) {
+        lds.sh1[tid] = shift1 ? shift1[tid] : 0.f;
+        lds.sh2[tid] = shift2 ? shift2[tid] : 0.f;
+    }
+    if (kStats)
+        for (int i = tid; i < kWaves * 128; i += 64 * kWaves) (&lds.acc[0][0])[i] = 0.0;
+    __syncthreads();
+
+    const int tile = blockIdx.x * kWaves + wave;
+    const int pt = tile * 32 + r;
+    const bool valid = pt < N;
+    const float vmask = valid ? 1.f : 0.f;
+    const int ptc = valid ? pt : 0;
+
+    if (tile * 32 < N) {
+        // x_i (9 of the 12 floats of the padded row)
+        const float4* xr = reinterpret_cast<const float4*>(x9m + (size_t)ptc * 12);
+        const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
+        const float xi[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+        // B operand of conv1, k = 2s + half.  e[0..8] = x_j - x_i, e[9..17] = x_i
+        float b[9];
+        b[5] = half ? xi[2] : xi[1];
+        b[6] = half ? xi[4] : xi[3];
+        b[7] = half ? xi[6] : xi[5];
+        b[8] = half ? xi[8] : xi[7];
+
+        float stat_s[32], stat_q[32];
+        f32x16 best[2];
+        if (kStats) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) { stat_s[q] = 0.f; stat_q[q] = 0.f; }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) best[t][q] = -INFINITY;
+        }
+        f32x16 init1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) init1[t][q] = kTwo ? lds.sh1[acc_channel(t, q, half)] : 0.f;
+
+        const int32_t* krow = knn + (size_t)ptc * K;
+        for (int j = 0; j < K; ++j) {
+            const int nb = krow[j];
+            const float4* xn = reinterpret_cast<const float4*>(x9m + (size_t)nb * 12);
+            const float4 n0 = xn[0], n1 = xn[1], n2 = xn[2];
+            const float d[9] = {n0.x - xi[0], n0.y - xi[1], n0.z - xi[2], n0.w - xi[3], n1.x - xi[4],
+                                n1.y - xi[5], n1.z - xi[6], n1.w - xi[7], n2.x - xi[8]};
+            b[0] = half ? d[1] : d[0];
+            b[1] = half ? d[3] : d[2];
+            b[2] = half ? d[5] : d[4];
+            b[3] = half ? d[7] : d[6];
+            b[4] = half ? xi[0] : d[8];
+
+            f32x16 acc1[2] = {init1[0], init1[1]};
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds.a1[0][s][lane], b[s], acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds.a1[1][s][lane], b[s], acc1[1], 0, 0, 0);
+            }
+            if (MODE == STATS1) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float y = acc1[t][q] * vmask;
+                        stat_s[16 * t + q] += y;
+                        stat_q[16 * t + q] = __builtin_fmaf(y, y, stat_q[16 * t + q]);
+                    }
+            } else if (MODE == FINAL1) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) best[t][q] = fmaxf(best[t][q], acc1[t][q]);
+            } else {
+                // LeakyReLU(BN1(.)) in place -> B operand of conv2
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc1[t][q] = fmaxf(acc1[t][q], 0.2f * acc1[t][q]);
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    f32x16 acc2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds.a2[ot][16 * t + q][lane], acc1[t][q], acc2, 0, 0, 0);
+                    if (MODE == STATS2) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float z = acc2[q] * vmask;
+                            stat_s[16 * ot + q] += z;
+                            stat_q[16 * ot + q] = __builtin_fmaf(z, z, stat_q[16 * ot + q]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) best[ot][q] = fmaxf(best[ot][q], acc2[q]);
+                    }
+                }
+            }
+        }
+
+        if (kStats) {
+            // sum over the 32 rows of this half (xor offsets < 32 keep the half), then one lane per half
+            // adds into the wave's fp64 LDS accumulators
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                float s = stat_s[q], v = stat_q[q];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o); v += __shfl_xor(v, o); }
+                if (r == 0) {
+                    const int ch = acc_channel(q >> 4, q & 15, half);
+                    lds.acc[wave][ch] += (double)s;
+                    lds.acc[wave][64 + ch] += (double)v;
+                }
+            }
+        } else if (valid) {
+            // last layer: + folded shift, LeakyReLU, then 4 consecutive channels per float4 store
+            float* orow = out + (size_t)pt * 64;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v;
+                    float* pv = &v.x;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float y = best[t][4 * g + u] + lds.sh2[acc_channel(t, 4 * g + u, half)];
+                        pv[u] = fmaxf(y, 0.2f * y);
+                    }
+                    *reinterpret_cast<float4*>(orow + 32 * t + 8 * g + 4 * half) = v;
+                }
+        }
+    }
+
+    if (kStats) {
+        __syncthreads();
+        if (tid < 128) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) s += lds.acc[w][tid];
+            partial[(size_t)blockIdx.x * 128 + tid] = s;
+        }
+    }
+}
+
+// fixed-order reduction of the per-block partials -> folded weights w' = a*w and shift = beta - a*mean
+__global__ void k_bn_fold(const double* __restrict__ partial, int nblocks, double rows, const float* __restrict__ gamma,
+                          const float* __restrict__ beta, const float* __restrict__ w, int kin, float* __restrict__ w_folded,
+                          float* __restrict__ shift) {
+    __shared__ double tot[128];
+    if (threadIdx.x < 128) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 128 + threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    const int ch = threadIdx.x;
+    if (ch >= 64) return;
+    const double mean = tot[ch] / rows;
+    const double var = tot[64 + ch] / rows - mean * mean;
+    const double a = (double)gamma[ch] / sqrt(var + 1e-5);
+    for (int k = 0; k < kin; ++k) w_folded[ch * kin + k] = (float)(a * (double)w[ch * kin + k]);
+    shift[ch] = (float)((double)beta[ch] - a * mean);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sg_edgeconv_ws_bytes(int N) {
+    const size_t nblocks = (size_t)sg::cdiv(sg::cdiv(std::max(N, 1), 32), kWaves);
+    return sg::align_up(nblocks * 128 * 8) + sg::align_up((64 * 18 + 64 + 64 * 64 + 64) * 4);
+}
+
+int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
+                        const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
+                        size_t ws_bytes, void* stream) {
+    SG_REQUIRE(N >= 0 && k > 0 && (layers == 1 || layers == 2) && d_ws, "sg_edgeconv_forward: bad arguments");
+    if (N == 0) return SG_OK;
+    const int nblocks = sg::cdiv(sg::cdiv(N, 32), kWaves);
+    sg::Carver cv(d_ws, ws_bytes);
+    double* partial = cv.take<double>((size_t)nblocks * 128);
+    float* fold = cv.take<float>(64 * 18 + 64 + 64 * 64 + 64);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_edgeconv_forward: workspace too small (%zu < %zu)", ws_bytes, sg_edgeconv_ws_bytes(N));
+    float* w1f = fold;
+    float* sh1 = w1f + 64 * 18;
+    float* w2f = sh1 + 64;
+    float* sh2 = w2f + 64 * 64;
+    hipStream_t st = sg::as_stream(stream);
+    const double rows = (double)N * (double)k;
+    const dim3 grid(nblocks), block(64 * kWaves);
+    k_edgeconv<STATS1><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, nullptr, partial);
+    k_bn_fold<<<1, 128, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, d_w1, 18, w1f, sh1);
+    if (layers == 1) {
+        k_edgeconv<FINAL1><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, nullptr, nullptr, sh1, d_out, nullptr);
+    } else {
+        k_edgeconv<STATS2><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, d_w2, nullptr, nullptr, partial);
+        k_bn_fold<<<1, 128, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, d_w2, 64, w2f, sh2);
+        k_edgeconv<FINAL2><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2f, sh2, d_out, nullptr);
+    }
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// a4+a5: get_cluster_pointcloud + farthest_point_sampling (reference seggroup/model.py:319-426).
+//
+// One workgroup per cluster.  The cluster's XYZ and the running min-distance array live in LDS (up
+// to kLdsCap points; larger clusters spill to an L2-resident global scratch).  Each of the P%n
+// sampling steps is one strided pass (distance to the newest pick, min with the running array,
+// first-index argmax) followed by a wave-shuffle + LDS reduction.  Small clusters run on ONE wave
+// (no workgroup barriers at all); large ones on 16 waves.
+//
+// Bit-exactness: squared distances are evaluated exactly like NumPy does for
+// ((a - b) ** 2).sum(axis=2) on float32 (model.py:326): three individually rounded squares added as
+// (dx2 + dy2) + dz2 -- this translation unit is compiled with -ffp-contract=off so no FMA is formed.
+#include <climits>
+
+#include "sg_common.h"
+
+namespace {
+
+constexpr int kLdsCap = 8192;        // points whose xyz+min-distance fit the LDS carve (16 B each)
+constexpr int kSmallMax = 2048;      // clusters up to this size run on a single wave
+
+struct Best {
+    float v;
+    int i;
+};
+
+__device__ inline Best better(Best a, Best b) {   // larger value wins, ties -> lower index (np.argmax)
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+template <int BLOCK>
+__device__ inline Best block_argmax(Best b, Best* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Best t;
+        t.v = __shfl_xor(b.v, o);
+        t.i = __shfl_xor(b.i, o);
+        b = better(b, t);
+    }
+    if constexpr (BLOCK > 64) {
+        const int wid = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) red[wid] = b;
+        __syncthreads();
+        Best r = red[0];
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; ++w) r = better(r, red[w]);
+        __syncthreads();
+        return r;
+    }
+    return b;
+}
+
+template <int BLOCK, bool RESET>
+__device__ inline Best fps_pass(const float* X, const float* Y, const float* Z, float* M, int n, float qx, float qy, float qz,
+                                Best* red) {
+    Best b{-INFINITY, INT_MAX};
+    for (int i = threadIdx.x; i < n; i += BLOCK) {
+        const float dx = X[i] - qx, dy = Y[i] - qy, dz = Z[i] - qz;
+        float d = (dx * dx + dy * dy) + dz * dz;
+        if (!RESET) d = fminf(M[i], d);
+        M[i] = d;
+        if (d > b.v) { b.v = d; b.i = i; }
+    }
+    return block_argmax<BLOCK>(b, red);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fps_sample(const float* __restrict__ data, int N, int ch_in,
+                                                      const int32_t* __restrict__ members, const int32_t* __restrict__ cl_off,
+                                                      int P, int ch_out, int transform, int n_lo, int n_hi, int lds_pts,
+                                                      float* __restrict__ samples, int32_t* __restrict__ sel,
+                                                      float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int c = blockIdx.x;
+    const int lo = cl_off[c], n = cl_off[c + 1] - lo;
+    if (n < n_lo || n > n_hi || n <= 0) return;
+    int* picks = reinterpret_cast<int*>(smem);                       // [P]
+    Best* red = reinterpret_cast<Best*>(picks + P);                  // [16]
+    float* lds_f = reinterpret_cast<float*>(red + 16);               // [4 * lds_pts]
+    const int rep = P / n, rem = P % n;
+    const int tid = threadIdx.x;
+
+    if (rem > 0) {
+        float *X, *Y, *Z, *M;
+        if (n <= lds_pts) { X = lds_f; Y = X + lds_pts; Z = Y + lds_pts; M = Z + lds_pts; }
+        else { X = ws + lo; Y = ws + (size_t)N + lo; Z = ws + 2 * (size_t)N + lo; M = ws + 3 * (size_t)N + lo; }
+        for (int i = tid; i < n; i += BLOCK) {
+            const float* row = data + (size_t)members[lo + i] * ch_in;
+            X[i] = row[0]; Y[i] = row[1]; Z[i] = row[2];
+        }
+        __syncthreads();
+        // start at member 0; first pick = farthest from it, min-distance array RESET to that pick (model.py:382-386)
+        Best b = fps_pass<BLOCK, true>(X, Y, Z, M, n, X[0], Y[0], Z[0], red);
+        int cur = b.i;
+        if (tid == 0) picks[0] = cur;
+        __syncthreads();
+        b = fps_pass<BLOCK, true>(X, Y, Z, M, n, X[cur], Y[cur], Z[cur], red);
+        for (int it = 1; it < rem; ++it) {                           // model.py:389-394
+            cur = b.i;
+            if (tid == 0) picks[it] = cur;
+            if (it + 1 < rem) {
+                __syncthreads();
+                b = fps_pass<BLOCK, false>(X, Y, Z, M, n, X[cur], Y[cur], Z[cur], red);
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && picks[rem - 1] == 0) {                       // trailing-zero fix-up (model.py:407-412)
+            int j = 1;
+            while (j <= rem && picks[rem - j] == 0) ++j;
+            if (j > rem) j = rem;
+            const int invalid = j - 1;
+            for (int t = 0; t < invalid; ++t) picks[rem - invalid + t] = picks[t];
+        }
+        __syncthreads();
+    }
+
+    // rows: members tiled rep times, then the picks (model.py:413-420)
+    float* out = samples + (size_t)c * P * ch_out;
+    double sx = 0, sy = 0, sz = 0;
+    for (int r = tid; r < P; r += BLOCK) {
+        const int local = r < rep * n ? r % n : picks[r - rep * n];
+        const int p = members[lo + local];
+        if (sel) sel[(size_t)c * P + r] = p;
+        const float* row = data + (size_t)p * ch_in;
+        for (int k = 0; k < ch_out; ++k) out[(size_t)r * ch_out + k] = row[k];
+        sx += row[0]; sy += row[1]; sz += row[2];
+    }
+    if (!transform) return;
+
+    // model.py:421-423: subtract the mean XYZ of the P rows, divide by the scalar max |XYZ|
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+    __shared__ double wsum[3][16];
+    __shared__ float wmax[16];
+    if constexpr (BLOCK > 64) {
+        if ((tid & 63) == 0) { wsum[0][tid >> 6] = sx; wsum[1][tid >> 6] = sy; wsum[2][tid >> 6] = sz; }
+        __syncthreads();
+        sx = sy = sz = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) { sx += wsum[0][w]; sy += wsum[1][w]; sz += wsum[2][w]; }
+    }
+    const float mx = (float)(sx / P), my = (float)(sy / P), mz = (float)(sz / P);
+    __syncthreads();   // rows written above are re-read below by the same threads only; barrier orders LDS scratch reuse
+    float amax = 0.f;
+    for (int r = tid; r < P; r += BLOCK) {
+        float* q = out + (size_t)r * ch_out;
+        const float x = q[0] - mx, y = q[1] - my, z = q[2] - mz;
+        q[0] = x; q[1] = y; q[2] = z;
+        amax = fmaxf(amax, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if constexpr (BLOCK > 64) {
+        if ((tid & 63) == 0) wmax[tid >> 6] = amax;
+        __syncthreads();
+        amax = 0.f;
+        for (int w = 0; w < BLOCK / 64; ++w) amax = fmaxf(amax, wmax[w]);
+    }
+    for (int r = tid; r < P; r += BLOCK) {
+        float* q = out + (size_t)r * ch_out;
+        q[0] = q[0] / amax; q[1] = q[1] / amax; q[2] = q[2] / amax;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sg_fps_ws_bytes(int N) { return sg::align_up((size_t)std::max(N, 1) * 16); }
+
+int sg_fps_sample(const float* d_data, int N, int ch_in, const int32_t* d_members, const int32_t* d_cl_off, int C, int P,
+                  int ch_out, int transform, float* d_samples, int32_t* d_sel, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(N >= 0 && C >= 0 && P > 0 && P <= 4096 && ch_in >= 3 && ch_out >= 3 && ch_out <= ch_in,
+               "sg_fps_sample: bad arguments (P=%d ch_in=%d ch_out=%d)", P, ch_in, ch_out);
+    if (C == 0) return SG_OK;
+    if (ws_bytes < (size_t)N * 16) return sg::fail(SG_ENOMEM, "sg_fps_sample: workspace too small");
+    hipStream_t st = sg::as_stream(stream);
+    const size_t head = (size_t)P * 4 + 16 * sizeof(Best);
+    // single-wave class: clusters with n <= kSmallMax
+    k_fps_sample<64><<<C, 64, head + (size_t)kSmallMax * 16, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform, 1,
+                                                                 kSmallMax, kSmallMax, d_samples, d_sel, (float*)d_ws);
+    // 16-wave class: everything larger (blocks whose cluster is small exit immediately)
+    k_fps_sample<1024><<<C, 1024, head + (size_t)kLdsCap * 16, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform,
+                                                                    kSmallMax + 1, INT_MAX, kLdsCap, d_samples, d_sel, (float*)d_ws);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // extern "C"

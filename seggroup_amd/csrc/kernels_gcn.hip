@@ -1,0 +1,85 @@
+// a14: calculate_similarity + build_similarity_matrix + GCN (reference seggroup/model.py:262-265,
+// 305-309, 141-151):   X' = relu( ((I + sym(exp(-alpha * d))) row-normalised) @ X @ W^T )
+//
+// The reference materialises the dense [S,S] matrix; the cluster graph has ~6 edges per row, so the
+// row-normalised product is evaluated over the symmetric CSR built by the host grouping engine.
+// S <= a few thousand and D <= 256: this stage is latency-, not bandwidth-bound; sums are carried in
+// fp64 so the decision distances that follow are as close to exact arithmetic as fp32 features allow.
+#include "sg_common.h"
+
+namespace {
+
+__global__ void k_transpose(const float* __restrict__ w, int D, float* __restrict__ wt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D * D) wt[(i % D) * D + (i / D)] = w[i];      // wt[k][o] = w[o][k]
+}
+
+// one block per row: agg[i] = (x_i + sum_j s_ij x_j) / (1 + sum_j s_ij)
+__global__ void k_gcn_aggregate(const float* __restrict__ x, int D, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                const int32_t* __restrict__ eid, const float* __restrict__ dist, float alpha,
+                                float* __restrict__ agg) {
+    const int i = blockIdx.x;
+    const int lo = rowptr[i], hi = rowptr[i + 1];
+    double rowsum = 1.0;
+    for (int e = lo; e < hi; ++e) rowsum += exp(-(double)dist[eid[e]] * (double)alpha);
+    for (int k = threadIdx.x; k < D; k += blockDim.x) {
+        double acc = (double)x[(size_t)i * D + k];
+        for (int e = lo; e < hi; ++e)
+            acc = fma(exp(-(double)dist[eid[e]] * (double)alpha), (double)x[(size_t)col[e] * D + k], acc);
+        agg[(size_t)i * D + k] = (float)(acc / rowsum);
+    }
+}
+
+constexpr int kRows = 8;
+// out[i][o] = relu(sum_k agg[i][k] * W[o][k]); block = kRows rows, thread o = output column
+__global__ void k_gcn_fc(const float* __restrict__ agg, int S, int D, const float* __restrict__ wt, float* __restrict__ out) {
+    __shared__ float rows[kRows][256];
+    const int r0 = blockIdx.x * kRows;
+    for (int i = threadIdx.x; i < kRows * D; i += blockDim.x) {
+        const int rr = i / D, k = i % D;
+        rows[rr][k] = (r0 + rr < S) ? agg[(size_t)(r0 + rr) * D + k] : 0.f;
+    }
+    __syncthreads();
+    const int o = threadIdx.x;
+    if (o >= D) return;
+    double acc[kRows];
+#pragma unroll
+    for (int rr = 0; rr < kRows; ++rr) acc[rr] = 0.0;
+    for (int k = 0; k < D; ++k) {
+        const double w = (double)wt[(size_t)k * D + o];
+#pragma unroll
+        for (int rr = 0; rr < kRows; ++rr) acc[rr] = fma((double)rows[rr][k], w, acc[rr]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < kRows; ++rr)
+        if (r0 + rr < S) out[(size_t)(r0 + rr) * D + o] = fmaxf((float)acc[rr], 0.f);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sg_gcn_ws_bytes(int S, int D, int E) {
+    return sg::align_up((size_t)std::max(E, 1) * 4) + sg::align_up((size_t)std::max(S, 1) * D * 4) + sg::align_up((size_t)D * D * 4);
+}
+
+int sg_gcn_forward(const float* d_x, int S, int D, const int32_t* d_adj, int E, const int32_t* d_rowptr, const int32_t* d_col,
+                   const int32_t* d_eid, const float* d_w, float alpha, float* d_out, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(S >= 0 && D > 0 && D <= 256 && E >= 0 && d_ws, "sg_gcn_forward: bad arguments (D=%d must be <= 256)", D);
+    if (S == 0) return SG_OK;
+    sg::Carver cv(d_ws, ws_bytes);
+    float* dist = cv.take<float>(std::max(E, 1));
+    float* agg = cv.take<float>((size_t)S * D);
+    float* wt = cv.take<float>((size_t)D * D);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_gcn_forward: workspace too small (%zu < %zu)", ws_bytes, sg_gcn_ws_bytes(S, D, E));
+    hipStream_t st = sg::as_stream(stream);
+    int rc = sg_edge_distance(d_x, D, D, d_adj, E, dist, stream);
+    if (rc) return rc;
+    k_transpose<<<sg::cdiv(D * D, 256), 256, 0, st>>>(d_w, D, wt);
+    k_gcn_aggregate<<<S, 64 * sg::cdiv(D, 64), 0, st>>>(d_x, D, d_rowptr, d_col, d_eid, dist, alpha, agg);
+    k_gcn_fc<<<sg::cdiv(S, kRows), 256, 0, st>>>(agg, S, D, wt, d_out);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,402 @@
+// Graph / label bookkeeping kernels (HBM-bound integer work): point-edge contraction (a3), member
+// gathering (a2/a10), edge distance (a8), row/segment max (a10), label export (a16), metric counts (a17).
+#include "sg_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------
+// a3: update_adj first call (model.py:291-302, 724-733).  One bit per (lo,hi) segment pair.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mark_pairs(const int64_t* __restrict__ adj, int E, const int32_t* __restrict__ seg, int N, int S,
+                             uint32_t* __restrict__ bitmap) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        // 16-byte coalesced read of one edge row
+        const longlong2 row = reinterpret_cast<const longlong2*>(adj)[e];
+        const long long a = row.x, b = row.y;
+        if (a < 0 || b < 0 || a >= N || b >= N) continue;
+        int sa = seg[a], sb = seg[b];
+        if (sa == sb || sa < 0 || sb < 0) continue;
+        if (sa > sb) { int t = sa; sa = sb; sb = t; }
+        const unsigned long long bit = (unsigned long long)sa * (unsigned)S + (unsigned)sb;
+        const uint32_t mask = 1u << (bit & 31);
+        uint32_t* w = bitmap + (bit >> 5);
+        if ((__builtin_nontemporal_load(w) & mask) == 0) atomicOr(w, mask);   // ~60 edges hit each bit
+    }
+}
+
+constexpr int kWordsPerThread = 4;
+constexpr int kWordsPerBlock = kBlock * kWordsPerThread;
+
+__device__ inline int block_exclusive_scan(int v, int* total) {
+    __shared__ int wsum[kBlock / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        if (w < wid) base += wsum[w];
+        tot += wsum[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ void k_count_bits(const uint32_t* __restrict__ bitmap, size_t words, int* __restrict__ block_count) {
+    const size_t w0 = (size_t)blockIdx.x * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < kWordsPerThread; ++i)
+        if (w0 + i < words) c += __popc(bitmap[w0 + i]);
+    int total;
+    block_exclusive_scan(c, &total);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the per-block counts, total -> *out_count
+__global__ void k_scan_blocks(int* __restrict__ block_count, int nblocks, int* __restrict__ out_count) {
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += kBlock) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblocks ? block_count[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total);
+        const int c = carry;
+        if (i < nblocks) block_count[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_count = carry;
+}
+
+__global__ void k_emit_pairs(const uint32_t* __restrict__ bitmap, size_t words, const int* __restrict__ block_off, int S,
+                             int32_t* __restrict__ out, int capacity) {
+    const size_t w0 = (size_t)blockIdx.x * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
+    uint32_t w[kWordsPerThread];
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < kWordsPerThread; ++i) {
+        w[i] = (w0 + i < words) ? bitmap[w0 + i] : 0u;
+        c += __popc(w[i]);
+    }
+    int total;
+    int off = block_off[blockIdx.x] + block_exclusive_scan(c, &total);
+#pragma unroll
+    for (int i = 0; i < kWordsPerThread; ++i) {
+        uint32_t bits = w[i];
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const unsigned long long bit = ((unsigned long long)(w0 + i) << 5) + b;
+            if (off < capacity) {
+                out[2 * off] = (int32_t)(bit / (unsigned)S);
+                out[2 * off + 1] = (int32_t)(bit % (unsigned)S);
+            }
+            ++off;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a2/a10: expand an ordered list of segments per cluster into point-level member arrays
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gather_members(const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
+                                 const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
+                                 const int32_t* __restrict__ cl, int32_t* __restrict__ members,
+                                 int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos) {
+    const int i = blockIdx.x;                 // i-th segment in member order
+    const int s = order[i];
+    const int lo = seg_off[s], n = seg_off[s + 1] - lo, d = dst[i], c = cl[i];
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int p = seg_points[lo + t];
+        members[d + t] = p;
+        if (pos_of_point) pos_of_point[p] = d + t;
+        if (cluster_of_pos) cluster_of_pos[d + t] = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8: calculate_distance (model.py:269-274).  One wave per edge, fp64 accumulation.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_edge_distance(const float* __restrict__ feat, int stride, int D, const int32_t* __restrict__ adj, int E,
+                                float* __restrict__ dist) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const float* a = feat + (size_t)adj[2 * e] * stride;
+    const float* b = feat + (size_t)adj[2 * e + 1] * stride;
+    double acc = 0.0;
+    for (int k = lane; k < D; k += 64) {
+        const double d = (double)a[k] - (double)b[k] + 1e-6;
+        acc = fma(d, d, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) dist[e] = (float)sqrt(acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a10: aggregate_cluster_feature (model.py:278-288)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_group_max_rows(const float* __restrict__ rows, int row_stride, int D, const int32_t* __restrict__ goff,
+                                 const int32_t* __restrict__ gidx, float* __restrict__ out, int out_stride) {
+    const int g = blockIdx.x;
+    const int lo = goff[g], hi = goff[g + 1];
+    for (int k = threadIdx.x; k < D; k += blockDim.x) {
+        float m = -INFINITY;
+        for (int i = lo; i < hi; ++i) m = fmaxf(m, rows[(size_t)gidx[i] * row_stride + k]);
+        out[(size_t)g * out_stride + k] = m;
+    }
+}
+
+__device__ inline void atomic_max_float(float* addr, float v) {
+    // order-preserving integer view: non-negative floats compare as ints, negative floats reversed as uints
+    if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ void k_fill(float* __restrict__ p, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void k_fill_rows(float* __restrict__ p, int rows, int cols, int stride, float v) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[(i / cols) * stride + (i % cols)] = v;
+}
+
+// rows are in member order (clusters contiguous).  Block = 64 channels x 4 row lanes over kRowsPerBlock rows;
+// each thread keeps a running max and flushes it when the cluster id changes.
+constexpr int kRowsPerBlock = 512;
+__global__ void k_segment_max64(const float* __restrict__ rows, int N, const int32_t* __restrict__ cluster_of_pos,
+                                float* __restrict__ out, int out_stride) {
+    const int ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * kRowsPerBlock, r1 = min(N, r0 + kRowsPerBlock);
+    int cur = -1;
+    float m = -INFINITY;
+    for (int r = r0 + rl; r < r1; r += 4) {
+        const int c = cluster_of_pos[r];
+        if (c != cur) {
+            if (cur >= 0) atomic_max_float(out + (size_t)cur * out_stride + ch, m);
+            cur = c;
+            m = -INFINITY;
+        }
+        m = fmaxf(m, rows[(size_t)r * 64 + ch]);
+    }
+    if (cur >= 0) atomic_max_float(out + (size_t)cur * out_stride + ch, m);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a16: label export gather (model.py:525-605)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_export(const int32_t* __restrict__ unmap, int V, const int32_t* __restrict__ seg_of_point, int N,
+                         const int32_t* __restrict__ tables, int T, int S, int32_t* __restrict__ out) {
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x) {
+        const int p = unmap[v];
+        const int s = (p >= 0 && p < N) ? seg_of_point[p] : -1;
+        for (int t = 0; t < T; ++t) out[(size_t)t * V + v] = (s >= 0 && s < S) ? tables[(size_t)t * S + s] : -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a17: evaluate (model.py:608-655): integer counts
+// counters layout (uint32): [0..39] sem pred hist, [40..79] sem true hist, [80..119] sem both,
+// [120..127] scalars {n_valid, sem_eq, ins_eq, n_semvalid, semvalid_eq, n_insvalid, insvalid_eq, -},
+// then 4 arrays of max_ins: ins pred count, ins true count, ins both, first valid vertex (atomicMin)
+// ------------------------------------------------------------------------------------------------
+__device__ inline bool in_sem_valid(int c) {   // SEM_VALID_CLASS_IDS (model.py:27)
+    const unsigned long long m = (1ull << 1) | (1ull << 2) | (1ull << 3) | (1ull << 4) | (1ull << 5) | (1ull << 6) | (1ull << 7) |
+                                 (1ull << 8) | (1ull << 9) | (1ull << 10) | (1ull << 11) | (1ull << 12) | (1ull << 14) |
+                                 (1ull << 16) | (1ull << 24) | (1ull << 28) | (1ull << 33) | (1ull << 34) | (1ull << 36) | (1ull << 39);
+    return c >= 0 && c < 64 && ((m >> c) & 1ull);
+}
+__device__ inline bool in_ins_valid(int c) {   // INS_VALID_CLASS_IDS (model.py:28)
+    return in_sem_valid(c) && c != 1 && c != 2;
+}
+
+__global__ void k_eval_counts(const int32_t* __restrict__ gt, const int32_t* __restrict__ sem_pred,
+                              const int32_t* __restrict__ ins_pred, int V, int max_ins, uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t h[128];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    uint32_t* ins_p = cnt + 128;
+    uint32_t* ins_t = ins_p + max_ins;
+    uint32_t* ins_b = ins_t + max_ins;
+    uint32_t* first = ins_b + max_ins;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x) {
+        const int st = gt[2 * v], it = gt[2 * v + 1];
+        if (st == 0) continue;                                   // valid_idxs (model.py:615)
+        const int sp = sem_pred[v], ip = ins_pred[v];
+        atomicAdd(&h[120], 1u);
+        if (sp >= 1 && sp <= 40) atomicAdd(&h[sp - 1], 1u);
+        if (st >= 1 && st <= 40) atomicAdd(&h[40 + st - 1], 1u);
+        if (sp == st) {
+            atomicAdd(&h[121], 1u);
+            if (sp >= 1 && sp <= 40) atomicAdd(&h[80 + sp - 1], 1u);
+        }
+        if (ip == it) atomicAdd(&h[122], 1u);
+        if (in_sem_valid(st)) { atomicAdd(&h[123], 1u); if (sp == st) atomicAdd(&h[124], 1u); }
+        if (in_ins_valid(it)) { atomicAdd(&h[125], 1u); if (ip == it) atomicAdd(&h[126], 1u); }
+        if (ip >= 0 && ip < max_ins) {
+            atomicAdd(&ins_p[ip], 1u);
+            atomicMin(&first[ip], (uint32_t)v);
+            if (it == ip) atomicAdd(&ins_b[ip], 1u);
+        }
+        if (it >= 0 && it < max_ins) atomicAdd(&ins_t[it], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 128; i += blockDim.x)
+        if (h[i]) atomicAdd(&cnt[i], h[i]);
+}
+
+// semantic prediction at the first valid vertex of every predicted instance (model.py:636)
+__global__ void k_eval_first_sem(const int32_t* __restrict__ sem_pred, int max_ins, uint32_t* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= max_ins) return;
+    const uint32_t* ins_p = cnt + 128;
+    const uint32_t* first = ins_p + 3 * (size_t)max_ins;
+    uint32_t* fsem = cnt + 128 + 4 * (size_t)max_ins;
+    fsem[i] = ins_p[i] ? (uint32_t)sem_pred[first[i]] : 0xffffffffu;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+size_t sg_contract_ws_bytes(int S) {
+    const size_t bits = (size_t)S * (size_t)S;
+    const size_t words = (bits + 31) / 32;
+    const size_t nblocks = (words + kWordsPerBlock - 1) / kWordsPerBlock;
+    return sg::align_up(words * 4) + sg::align_up((nblocks + 1) * 4) + 256;
+}
+
+int sg_contract_point_edges(const int64_t* d_adj, int E, const int32_t* d_seg_of_point, int N, int S,
+                            int32_t* d_out_adj, int out_capacity, int32_t* d_out_count,
+                            void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(E >= 0 && N >= 0 && S > 0 && d_out_count && d_ws, "sg_contract_point_edges: bad arguments");
+    const size_t bits = (size_t)S * (size_t)S;
+    if (bits > (1ull << 31)) return sg::fail(SG_EUNSUP, "sg_contract_point_edges: S=%d exceeds the bitmap envelope (S*S <= 2^31)", S);
+    const size_t words = (bits + 31) / 32;
+    const int nblocks = (int)((words + kWordsPerBlock - 1) / kWordsPerBlock);
+    sg::Carver cv(d_ws, ws_bytes);
+    uint32_t* bitmap = cv.take<uint32_t>(words);
+    int* block_count = cv.take<int>(nblocks + 1);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_contract_point_edges: workspace too small (%zu < %zu)", ws_bytes, sg_contract_ws_bytes(S));
+    hipStream_t st = sg::as_stream(stream);
+    SG_HIP(hipMemsetAsync(bitmap, 0, words * 4, st));
+    if (E > 0) {
+        const int grid = std::min(sg::cdiv(E, kBlock), 2048);
+        k_mark_pairs<<<grid, kBlock, 0, st>>>(d_adj, E, d_seg_of_point, N, S, bitmap);
+    }
+    k_count_bits<<<nblocks, kBlock, 0, st>>>(bitmap, words, block_count);
+    k_scan_blocks<<<1, kBlock, 0, st>>>(block_count, nblocks, d_out_count);
+    k_emit_pairs<<<nblocks, kBlock, 0, st>>>(bitmap, words, block_count, S, d_out_adj, out_capacity);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_gather_members(const int32_t* d_seg_points, const int32_t* d_seg_off, int S, const int32_t* d_order,
+                      const int32_t* d_dst, const int32_t* d_cl, int32_t* d_members, int32_t* d_pos_of_point,
+                      int32_t* d_cluster_of_pos, void* stream) {
+    SG_REQUIRE(S >= 0 && d_members, "sg_gather_members: bad arguments");
+    if (S == 0) return SG_OK;
+    k_gather_members<<<S, 128, 0, sg::as_stream(stream)>>>(d_seg_points, d_seg_off, d_order, d_dst, d_cl, d_members,
+                                                          d_pos_of_point, d_cluster_of_pos);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_edge_distance(const float* d_feat, int feat_stride, int D, const int32_t* d_adj, int E, float* d_dist, void* stream) {
+    SG_REQUIRE(E >= 0 && D > 0 && feat_stride >= D, "sg_edge_distance: bad arguments");
+    if (E == 0) return SG_OK;
+    k_edge_distance<<<sg::cdiv(E, 4), 256, 0, sg::as_stream(stream)>>>(d_feat, feat_stride, D, d_adj, E, d_dist);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_group_max_rows(const float* d_rows, int row_stride, int D, const int32_t* d_goff, const int32_t* d_gidx, int G,
+                      float* d_out, int out_stride, void* stream) {
+    SG_REQUIRE(G >= 0 && D > 0, "sg_group_max_rows: bad arguments");
+    if (G == 0) return SG_OK;
+    k_group_max_rows<<<G, 64 * ((std::min(D, 256) + 63) / 64), 0, sg::as_stream(stream)>>>(d_rows, row_stride, D, d_goff, d_gidx,
+                                                                                           d_out, out_stride);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_segment_max(const float* d_rows, int N, int D, const int32_t* d_cluster_of_pos, float* d_out, int out_stride, int C,
+                   void* stream) {
+    SG_REQUIRE(D == 64, "sg_segment_max: only D == 64 rows are supported (got %d)", D);
+    if (N == 0 || C == 0) return SG_OK;
+    hipStream_t st = sg::as_stream(stream);
+    k_fill_rows<<<std::min(sg::cdiv((long long)C * 64, 256), 1024), 256, 0, st>>>(d_out, C, 64, out_stride, -INFINITY);
+    k_segment_max64<<<sg::cdiv(N, kRowsPerBlock), 256, 0, st>>>(d_rows, N, d_cluster_of_pos, d_out, out_stride);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_export_labels(const int32_t* d_unmap, int V, const int32_t* d_seg_of_point, int N, const int32_t* d_tables, int T,
+                     int S, int32_t* d_out, void* stream) {
+    SG_REQUIRE(V >= 0 && T > 0 && S > 0, "sg_export_labels: bad arguments");
+    if (V == 0) return SG_OK;
+    k_export<<<std::min(sg::cdiv(V, 256), 2048), 256, 0, sg::as_stream(stream)>>>(d_unmap, V, d_seg_of_point, N, d_tables, T, S, d_out);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+size_t sg_eval_ws_bytes(int max_ins) { return sg::align_up((size_t)(128 + 5 * (size_t)std::max(max_ins, 1)) * 4); }
+
+int sg_evaluate(const int32_t* d_gt, const int32_t* d_sem_pred, const int32_t* d_ins_pred, int V, int max_ins,
+                float* h_iou_sem, float* h_iou_ins, float* h_acc, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(V >= 0 && max_ins >= 1 && h_iou_sem && h_iou_ins && h_acc, "sg_evaluate: bad arguments");
+    const size_t n = 128 + 5 * (size_t)max_ins;
+    if (ws_bytes < n * 4) return sg::fail(SG_ENOMEM, "sg_evaluate: workspace too small");
+    uint32_t* cnt = (uint32_t*)d_ws;
+    hipStream_t st = sg::as_stream(stream);
+    SG_HIP(hipMemsetAsync(cnt, 0, (128 + 3 * (size_t)max_ins) * 4, st));
+    SG_HIP(hipMemsetAsync(cnt + 128 + 3 * (size_t)max_ins, 0xff, (size_t)max_ins * 4, st));
+    if (V > 0) k_eval_counts<<<std::min(sg::cdiv(V, 256), 512), 256, 0, st>>>(d_gt, d_sem_pred, d_ins_pred, V, max_ins, cnt);
+    k_eval_first_sem<<<sg::cdiv(max_ins, 256), 256, 0, st>>>(d_sem_pred, max_ins, cnt);
+    SG_LAUNCH_CHECK();
+    std::vector<uint32_t> h(n);
+    SG_HIP(hipMemcpyAsync(h.data(), cnt, n * 4, hipMemcpyDeviceToHost, st));
+    SG_HIP(hipStreamSynchronize(st));
+    const uint32_t* ins_p = h.data() + 128;
+    const uint32_t* ins_t = ins_p + max_ins;
+    const uint32_t* ins_b = ins_t + max_ins;
+    const int32_t* first_sem = reinterpret_cast<const int32_t*>(ins_b + 2 * (size_t)max_ins);
+    for (int c = 0; c < 40; ++c) {
+        h_iou_sem[c] = (float)h[80 + c];                                  // I (model.py:626)
+        h_iou_sem[40 + c] = (float)(h[c] + h[40 + c] - h[80 + c]);        // U (model.py:627)
+    }
+    for (int c = 0; c < 80; ++c) h_iou_ins[c] = 0.f;
+    for (int i = 0; i < max_ins; ++i) {                                   // model.py:633-639
+        if (!ins_p[i]) continue;
+        int slot = first_sem[i] - 1;
+        if (slot < 0) slot += 40;                                         // Python negative index wrap
+        if (slot < 0 || slot >= 40) continue;
+        h_iou_ins[slot] += (float)ins_b[i];
+        h_iou_ins[40 + slot] += (float)(ins_p[i] + ins_t[i] - ins_b[i]);
+    }
+    auto ratio = [](uint32_t a, uint32_t b) { return b ? (float)((double)a / (double)b) : NAN; };
+    h_acc[0] = ratio(h[121], h[120]);
+    h_acc[1] = ratio(h[122], h[120]);
+    h_acc[2] = ratio(h[124], h[123]);
+    h_acc[3] = ratio(h[126], h[125]);
+    return SG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// a6+a7: MLP1 = knn(k=10) + get_graph_feature1 + conv1x1 6->64 + BatchNorm2d (batch statistics) +
+// LeakyReLU(0.2) + max over k + [max | mean] over the 64 samples (reference seggroup/model.py:30-80).
+//
+// One wave per cluster: lane i owns sample i of the cluster's 64 samples; neighbours are exchanged
+// with wave shuffles, nothing touches LDS.  BatchNorm needs statistics over ALL C*64*10 rows before
+// any output exists, so the op is three launches:
+//   1. k_mlp1_knn_moments : exact-order kNN-10 scores, top-10 per lane, first/second moments of the
+//                           6-dim edge rows (fp64), per-cluster partials;
+//   2. k_mlp1_finalize    : fixed-order sum of the partials -> per-channel mean/var of the conv output
+//                           (the conv is linear, so they follow from the 6x6 input moments), folded into
+//                           w' = a*w, b' = beta - a*mean;
+//   3. k_mlp1_apply       : conv + affine + LeakyReLU + max_k, then wave-reduced max/mean over the lanes.
+#include "sg_common.h"
+
+namespace {
+
+constexpr int K1 = 10;
+
+// knn() score in the reference's fp32 operation order (model.py:31-33)
+__device__ inline float knn_score(float xq, float yq, float zq, float xxq, float xc, float yc, float zc, float xxc) {
+    const float t = __builtin_fmaf(zq, zc, __builtin_fmaf(yq, yc, xq * xc));
+    const float inner = -2.0f * t;
+    return ((-xxc) - inner) - xxq;
+}
+
+__device__ inline float sqnorm3(float x, float y, float z) { return (x * x + y * y) + z * z; }
+
+__global__ __launch_bounds__(64) void k_mlp1_knn_moments(const float* __restrict__ samples, uint8_t* __restrict__ knn,
+                                                         double* __restrict__ partial) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float* row = samples + ((size_t)c * 64 + lane) * 6;
+    float f[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f[k] = row[k];
+    const float xx = sqnorm3(f[0], f[1], f[2]);
+
+    float bv[K1];
+    int bi[K1];
+#pragma unroll
+    for (int t = 0; t < K1; ++t) { bv[t] = -INFINITY; bi[t] = 0; }
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+        const float s = knn_score(f[0], f[1], f[2], xx, __shfl(f[0], j), __shfl(f[1], j), __shfl(f[2], j), __shfl(xx, j));
+        if (s > bv[K1 - 1]) {                       // sorted insertion, earlier candidate first on ties
+            float v = s;
+            int id = j;
+#pragma unroll
+            for (int t = 0; t < K1; ++t) {
+                if (v > bv[t]) {
+                    const float tv = bv[t]; const int ti = bi[t];
+                    bv[t] = v; bi[t] = id; v = tv; id = ti;
+                }
+            }
+        }
+    }
+    uint8_t* ko = knn + ((size_t)c * 64 + lane) * K1;
+#pragma unroll
+    for (int t = 0; t < K1; ++t) ko[t] = (uint8_t)bi[t];
+
+    // edge rows: xyz := 10 * (nbr - mean_k nbr), rgb := nbr rgb  (model.py:57-60)
+    double e[K1][6];
+    double m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+    for (int t = 0; t < K1; ++t) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) e[t][k] = (double)__shfl(f[k], bi[t]);
+        m0 += e[t][0]; m1 += e[t][1]; m2 += e[t][2];
+    }
+    m0 /= K1; m1 /= K1; m2 /= K1;
+    double acc[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+#pragma unroll
+    for (int t = 0; t < K1; ++t) {
+        e[t][0] = (e[t][0] - m0) * 10.0; e[t][1] = (e[t][1] - m1) * 10.0; e[t][2] = (e[t][2] - m2) * 10.0;
+        int q = 6;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            acc[a] += e[t][a];
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[q++] += e[t][a] * e[t][b];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 27; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) partial[(size_t)c * 27 + q] = v;
+    }
+}
+
+// one block of 64 threads: thread c derives channel c's folded affine
+__global__ void k_mlp1_finalize(const double* __restrict__ partial, int C, const float* __restrict__ w,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ folded) {
+    __shared__ double mom[27];
+    if (threadIdx.x < 27) {
+        double s = 0.0;
+        for (int c = 0; c < C; ++c) s += partial[(size_t)c * 27 + threadIdx.x];   // fixed order: reproducible
+        mom[threadIdx.x] = s / ((double)C * 64.0 * K1);
+    }
+    __syncthreads();
+    const int ch = threadIdx.x;
+    if (ch >= 64) return;
+    double cov[6][6];
+    int q = 6;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) { cov[a][b] = cov[b][a] = mom[q] - mom[a] * mom[b]; ++q; }
+    double mean = 0.0, var = 0.0;
+    for (int a = 0; a < 6; ++a) {
+        mean += (double)w[ch * 6 + a] * mom[a];
+        for (int b = 0; b < 6; ++b) var += (double)w[ch * 6 + a] * (double)w[ch * 6 + b] * cov[a][b];
+    }
+    const double a_ = (double)gamma[ch] / sqrt(var + 1e-5);
+    for (int k = 0; k < 6; ++k) folded[ch * 6 + k] = (float)(a_ * (double)w[ch * 6 + k]);
+    folded[384 + ch] = (float)((double)beta[ch] - a_ * mean);
+}
+
+__global__ __launch_bounds__(64) void k_mlp1_apply(const float* __restrict__ samples, const uint8_t* __restrict__ knn,
+                                                   const float* __restrict__ folded, float* __restrict__ feat, int feat_stride) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float* row = samples + ((size_t)c * 64 + lane) * 6;
+    float f[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f[k] = row[k];
+    const uint8_t* ki = knn + ((size_t)c * 64 + lane) * K1;
+    float e[K1][6];
+    double m0 = 0, m1 = 0, m2 = 0;
+    double ed[K1][3];
+#pragma unroll
+    for (int t = 0; t < K1; ++t) {
+        const int j = ki[t];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) e[t][k] = __shfl(f[k], j);
+        ed[t][0] = e[t][0]; ed[t][1] = e[t][1]; ed[t][2] = e[t][2];
+        m0 += ed[t][0]; m1 += ed[t][1]; m2 += ed[t][2];
+    }
+    m0 /= K1; m1 /= K1; m2 /= K1;
+#pragma unroll
+    for (int t = 0; t < K1; ++t) {
+        e[t][0] = (float)((ed[t][0] - m0) * 10.0); e[t][1] = (float)((ed[t][1] - m1) * 10.0); e[t][2] = (float)((ed[t][2] - m2) * 10.0);
+    }
+    float* out = feat + (size_t)c * feat_stride;
+    for (int ch = 0; ch < 64; ++ch) {
+        const float w0 = folded[ch * 6 + 0], w1 = folded[ch * 6 + 1], w2 = folded[ch * 6 + 2], w3 = folded[ch * 6 + 3],
+                    w4 = folded[ch * 6 + 4], w5 = folded[ch * 6 + 5], b = folded[384 + ch];
+        float h = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < K1; ++t) {
+            float y = b;
+            y = __builtin_fmaf(w0, e[t][0], y); y = __builtin_fmaf(w1, e[t][1], y); y = __builtin_fmaf(w2, e[t][2], y);
+            y = __builtin_fmaf(w3, e[t][3], y); y = __builtin_fmaf(w4, e[t][4], y); y = __builtin_fmaf(w5, e[t][5], y);
+            y = fmaxf(y, 0.2f * y);                              // LeakyReLU(0.2), slope < 1
+            h = fmaxf(h, y);                                     // max over k (model.py:76)
+        }
+        float mx = h;
+        double sm = (double)h;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); sm += __shfl_xor(sm, o); }
+        if (lane == 0) { out[ch] = mx; out[64 + ch] = (float)(sm / 64.0); }    // model.py:77-79
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sg_mlp1_ws_bytes(int C) {
+    const size_t c = (size_t)std::max(C, 1);
+    return sg::align_up(c * 64 * K1) + sg::align_up(c * 27 * 8) + sg::align_up(448 * 4);
+}
+
+int sg_mlp1_forward(const float* d_samples, int C, const float* d_w, const float* d_gamma, const float* d_beta, float* d_feat,
+                    int feat_stride, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(C >= 0 && feat_stride >= 128 && d_ws, "sg_mlp1_forward: bad arguments");
+    if (C == 0) return SG_OK;
+    sg::Carver cv(d_ws, ws_bytes);
+    uint8_t* knn = cv.take<uint8_t>((size_t)C * 64 * K1);
+    double* partial = cv.take<double>((size_t)C * 27);
+    float* folded = cv.take<float>(448);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_mlp1_forward: workspace too small (%zu < %zu)", ws_bytes, sg_mlp1_ws_bytes(C));
+    hipStream_t st = sg::as_stream(stream);
+    k_mlp1_knn_moments<<<C, 64, 0, st>>>(d_samples, knn, partial);
+    k_mlp1_finalize<<<1, 64, 0, st>>>(partial, C, d_w, d_gamma, d_beta, folded);
+    k_mlp1_apply<<<C, 64, 0, st>>>(d_samples, knn, folded, d_feat, feat_stride);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,461 @@
+// SegModel.forward (reference seggroup/model.py:684-897) for one scene on one HIP stream.
+//
+// The reference alternates device math with serial, order-dependent Python bookkeeping; here the
+// bookkeeping is the host grouping engine (grouping.cpp, segment-level, microseconds) and every
+// per-point / per-edge computation is a kernel.  Per scene the host blocks on the stream only where
+// the serial grouping needs distances: after MLP1, after each of the two semantic layers, optionally
+// after the FPS-1024 fallback, and at the end (3-5 synchronisations).  Several pipelines on distinct
+// streams (one per in-flight scene) overlap their host phases with each other's kernels.
+#include <cmath>
+#include <memory>
+
+#include "sg_common.h"
+
+namespace {
+
+constexpr int kNumEvents = 40;
+const char* kStageNames[] = {"contract_edges", "fps64", "mlp1", "dist1+d2h",
+                             "l2.gather", "l2.center", "l2.knn", "l2.edgeconv", "l2.segmax", "l2.gcn+dist",
+                             "l3.gather", "l3.center", "l3.knn", "l3.edgeconv", "l3.segmax", "l3.gcn+dist",
+                             "fallback_fps1024", "export", "evaluate"};
+constexpr int kNumStages = sizeof(kStageNames) / sizeof(kStageNames[0]);
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        n = count ? count : 1;
+        return hipMalloc((void**)&p, n * sizeof(T)) == hipSuccess ? 0 : -1;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        n = count ? count : 1;
+        return hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault) == hipSuccess ? 0 : -1;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
+}  // namespace
+
+struct sg_pipeline {
+    int maxN = 0, maxS = 0, maxE = 0, maxV = 0, maxT = 0;
+    hipStream_t stream = nullptr;
+    size_t dev_bytes = 0, pin_bytes = 0;
+
+    // weights (device)
+    DevBuf<float> w;   // all parameters, offsets below
+    size_t o_m1w, o_m1g, o_m1b, o_m2w, o_m2g, o_m2b, o_g2, o_m3w1, o_m3g1, o_m3b1, o_m3w2, o_m3g2, o_m3b2, o_g3;
+
+    // device work buffers
+    DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_center, ws_eval;
+    DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, knn, desc, tables, labels;
+    DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf;
+
+    // pinned host staging
+    PinBuf<int32_t> h_adj, h_desc, h_tables, h_count;
+    PinBuf<float> h_dist, h_feat, h_samples;
+
+    hipEvent_t ev[kNumEvents];
+    int ev_stage[kNumEvents];
+    int n_ev = 0;
+    float stage_ms[kNumStages];
+
+    void mark(int stage) {
+        if (n_ev < kNumEvents) {
+            (void)hipEventRecord(ev[n_ev], stream);
+            ev_stage[n_ev] = stage;
+            ++n_ev;
+        }
+    }
+};
+
+namespace {
+
+struct LayerDesc {               // host view of one frozen numbering + what the device needs for it
+    int C = 0, T = 0;
+    std::vector<int32_t> root, cl_of_seg, order, cl_seg_off, cl_pt_off, dst;
+};
+
+int freeze_layer(const sg_partition* part, int S, LayerDesc& L) {
+    L.root.resize(S); L.cl_of_seg.resize(S); L.order.resize(S); L.cl_seg_off.resize(S + 1); L.cl_pt_off.resize(S + 1); L.dst.resize(S);
+    L.C = sg_partition_layer(part, L.root.data(), L.cl_of_seg.data(), L.order.data(), L.cl_seg_off.data(), L.cl_pt_off.data(), L.dst.data());
+    return L.C;
+}
+
+// Device descriptor block of one layer, carved from ONE pinned buffer and shipped in ONE H2D copy.
+struct DescOffsets {
+    size_t order, dst, cl, cl_pt_off, tile_cl, tile_lo, tile_hi, cl_tile_off, goff, gidx, adj, rowptr, col, eid, total;
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* sg_pipeline_stage_name(int i) { return (i >= 0 && i < kNumStages) ? kStageNames[i] : nullptr; }
+
+int sg_pipeline_stage_times(const sg_pipeline* pl, float* h_ms, int capacity) {
+    if (!pl || !h_ms) return sg::fail(SG_EINVAL, "sg_pipeline_stage_times: null argument");
+    for (int i = 0; i < kNumStages && i < capacity; ++i) h_ms[i] = pl->stage_ms[i];
+    return kNumStages;
+}
+
+size_t sg_pipeline_device_bytes(const sg_pipeline* pl) { return pl ? pl->dev_bytes : 0; }
+
+void sg_pipeline_destroy(sg_pipeline* pl) {
+    if (!pl) return;
+    for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(pl->ev[i]);
+    delete pl;
+}
+
+sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg_weights* wt, void* stream) {
+    if (maxN <= 0 || maxS <= 0 || maxE < 0 || maxV <= 0 || !wt) {
+        sg::fail(SG_EINVAL, "sg_pipeline_create: bad arguments");
+        return nullptr;
+    }
+    if (sg_device_count() <= 0) {
+        sg::fail(SG_EHIP, "sg_pipeline_create: no HIP device visible -- the SegGroup hot path has no CPU fallback");
+        return nullptr;
+    }
+    std::unique_ptr<sg_pipeline> pl(new sg_pipeline());
+    pl->maxN = maxN; pl->maxS = maxS; pl->maxE = maxE; pl->maxV = maxV;
+    pl->maxT = maxN / 256 + maxS + 1;
+    pl->stream = sg::as_stream(stream);
+    for (int i = 0; i < kNumEvents; ++i)
+        if (hipEventCreate(&pl->ev[i]) != hipSuccess) { sg::fail(SG_EHIP, "hipEventCreate failed"); return nullptr; }
+    for (float& m : pl->stage_ms) m = 0.f;
+
+    int bad = 0;
+    size_t dev = 0, pin = 0;
+    auto D = [&](auto& buf, size_t count) { bad |= buf.alloc(count); dev += buf.n * sizeof(*buf.p); };
+    auto P = [&](auto& buf, size_t count) { bad |= buf.alloc(count); pin += buf.n * sizeof(*buf.p); };
+
+    // weights
+    size_t off = 0;
+    auto slot = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
+    pl->o_m1w = slot(64 * 6); pl->o_m1g = slot(64); pl->o_m1b = slot(64);
+    pl->o_m2w = slot(64 * 18); pl->o_m2g = slot(64); pl->o_m2b = slot(64);
+    pl->o_g2 = slot(192 * 192);
+    pl->o_m3w1 = slot(64 * 18); pl->o_m3g1 = slot(64); pl->o_m3b1 = slot(64);
+    pl->o_m3w2 = slot(64 * 64); pl->o_m3g2 = slot(64); pl->o_m3b2 = slot(64);
+    pl->o_g3 = slot(256 * 256);
+    D(pl->w, off);
+    if (!bad) {
+        std::vector<float> hw(off, 0.f);
+        auto put = [&](size_t o, const float* src, size_t n) { if (src) std::copy(src, src + n, hw.begin() + o); else bad = 1; };
+        put(pl->o_m1w, wt->mlp1_w, 64 * 6); put(pl->o_m1g, wt->mlp1_g, 64); put(pl->o_m1b, wt->mlp1_b, 64);
+        put(pl->o_m2w, wt->mlp2_w, 64 * 18); put(pl->o_m2g, wt->mlp2_g, 64); put(pl->o_m2b, wt->mlp2_b, 64);
+        put(pl->o_g2, wt->gcn2_w, 192 * 192);
+        put(pl->o_m3w1, wt->mlp3_w1, 64 * 18); put(pl->o_m3g1, wt->mlp3_g1, 64); put(pl->o_m3b1, wt->mlp3_b1, 64);
+        put(pl->o_m3w2, wt->mlp3_w2, 64 * 64); put(pl->o_m3g2, wt->mlp3_g2, 64); put(pl->o_m3b2, wt->mlp3_b2, 64);
+        put(pl->o_g3, wt->gcn3_w, 256 * 256);
+        if (bad) { sg::fail(SG_EINVAL, "sg_pipeline_create: null weight pointer"); return nullptr; }
+        if (hipMemcpy(pl->w.p, hw.data(), off * 4, hipMemcpyHostToDevice) != hipSuccess) { sg::fail(SG_EHIP, "weight upload failed"); return nullptr; }
+    }
+
+    const size_t S = maxS, N = maxN, E = maxE, V = maxV, T = pl->maxT;
+    const size_t maxE1 = std::min<size_t>(E, S * (S - 1) / 2 + 1);
+    D(pl->ws_contract, sg_contract_ws_bytes(maxS));
+    D(pl->ws_fps, sg_fps_ws_bytes(maxN));
+    D(pl->ws_mlp1, sg_mlp1_ws_bytes(maxS));
+    D(pl->ws_edge, sg_edgeconv_ws_bytes(maxN));
+    D(pl->ws_gcn, sg_gcn_ws_bytes(maxS, 256, (int)maxE1));
+    D(pl->ws_center, sg_center_ws_bytes((int)T, maxS));
+    D(pl->ws_eval, sg_eval_ws_bytes(maxS + 2));
+    D(pl->adj1, 2 * maxE1); D(pl->count, 4);
+    D(pl->members, N); D(pl->pos_of_point, N); D(pl->cluster_of_pos, N);
+    D(pl->knn, N * 20);
+    D(pl->desc, 8 * S + 8 + 3 * T + 2 * maxE1 + 4 * maxE1 + 64);
+    D(pl->tables, SG_NUM_LABEL_VECTORS * S); D(pl->labels, SG_NUM_LABEL_VECTORS * V);
+    D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
+    D(pl->feat1, S * 128); D(pl->featA, S * 256); D(pl->featB, S * 256);
+    D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64);
+    P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4);
+    P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
+    if (bad) { sg::fail(SG_ENOMEM, "sg_pipeline_create: device/pinned allocation failed (N=%d S=%d E=%d V=%d)", maxN, maxS, maxE, maxV); return nullptr; }
+    pl->dev_bytes = dev; pl->pin_bytes = pin;
+    return pl.release();
+}
+
+#define PL_CHECK(call) do { int rc__ = (call); if (rc__ < 0) { sg_partition_destroy(part); return rc__; } } while (0)
+#define PL_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { sg_partition_destroy(part); \
+    return sg::fail(SG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); } } while (0)
+
+int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result* out, sg_debug* dbg) {
+    if (!pl || !sc || !out) return sg::fail(SG_EINVAL, "sg_pipeline_forward: null argument");
+    SG_REQUIRE(mode == SG_MODE_INS_INFER || mode == SG_MODE_SEM_INFER, "sg_pipeline_forward: bad mode %d", mode);
+    const int N = sc->N, S = sc->S, E0 = sc->E0, V = sc->V;
+    SG_REQUIRE(N > 0 && S > 0 && V > 0 && E0 >= 0, "sg_pipeline_forward: empty scene");
+    SG_REQUIRE(N <= pl->maxN && S <= pl->maxS && E0 <= pl->maxE && V <= pl->maxV,
+               "sg_pipeline_forward: scene (N=%d S=%d E0=%d V=%d) exceeds the pipeline capacity (N=%d S=%d E0=%d V=%d)", N, S, E0, V,
+               pl->maxN, pl->maxS, pl->maxE, pl->maxV);
+    SG_REQUIRE(out->h_labels, "sg_pipeline_forward: out->h_labels is null");
+    hipStream_t st = pl->stream;
+    void* stv = (void*)st;
+    const float* W = pl->w.p;
+    pl->n_ev = 0;
+    out->stalled = 0; out->used_fallback = 0;
+    for (int i = 0; i < 5; ++i) out->trace[i] = 0;
+
+    sg_partition* part = sg_partition_create(S, sc->h_seg_first, sc->h_seg_size, sc->h_seg_ins, sc->h_seg_sem);
+    if (!part) return SG_EINVAL;
+    int max_ins = 1;
+    for (int s = 0; s < S; ++s) max_ins = std::max(max_ins, sc->h_seg_ins[s] + 2);
+    if (sg_eval_ws_bytes(max_ins) > pl->ws_eval.n) {
+        sg_partition_destroy(part);
+        return sg::fail(SG_EUNSUP, "weak instance ids up to %d exceed the pipeline's metric workspace (max_segments + 2)", max_ins - 2);
+    }
+
+    int32_t* tab = pl->h_tables.p;                       // [14,S]
+    auto tables_for = [&](int first_row, bool with_seg) {
+        int32_t* a = tab + (size_t)first_row * S;
+        return sg_partition_export_tables(part, with_seg ? a : nullptr, with_seg ? a + S : a, with_seg ? a + 2 * (size_t)S : a + S);
+    };
+
+    // ---------------- graph initialisation + structural grouping layer (model.py:710-783) ---------------
+    const int cap1 = (int)(pl->adj1.n / 2);
+    pl->mark(-1);
+    PL_CHECK(sg_contract_point_edges(sc->d_adj, E0, sc->d_seg_of_point, N, S, pl->adj1.p, cap1, pl->count.p, pl->ws_contract.p,
+                                     pl->ws_contract.n, stv));
+    PL_HIP(hipMemcpyAsync(pl->h_count.p, pl->count.p, 4, hipMemcpyDeviceToHost, st));
+    pl->mark(0);
+    PL_CHECK(sg_fps_sample(sc->d_data, N, 6, sc->d_seg_points, sc->d_seg_off, S, 64, 6, 1, pl->samples.p, nullptr, pl->ws_fps.p,
+                           pl->ws_fps.n, stv));
+    pl->mark(1);
+    PL_CHECK(sg_mlp1_forward(pl->samples.p, S, W + pl->o_m1w, W + pl->o_m1g, W + pl->o_m1b, pl->feat1.p, 128, pl->ws_mlp1.p,
+                             pl->ws_mlp1.n, stv));
+    pl->mark(2);
+    PL_HIP(hipStreamSynchronize(st));
+    int E1 = pl->h_count.p[0];
+    if (E1 > cap1) { sg_partition_destroy(part); return sg::fail(SG_ENOMEM, "adjacency capacity exceeded (%d > %d)", E1, cap1); }
+    PL_CHECK(sg_edge_distance(pl->feat1.p, 128, 128, pl->adj1.p, E1, pl->dist.p, stv));
+    PL_HIP(hipMemcpyAsync(pl->h_adj.p, pl->adj1.p, (size_t)E1 * 8, hipMemcpyDeviceToHost, st));
+    PL_HIP(hipMemcpyAsync(pl->h_dist.p, pl->dist.p, (size_t)E1 * 4, hipMemcpyDeviceToHost, st));
+    if (dbg) {
+        if (dbg->d_samples1) PL_HIP(hipMemcpyAsync(dbg->d_samples1, pl->samples.p, (size_t)S * 64 * 6 * 4, hipMemcpyDeviceToDevice, st));
+        if (dbg->d_feat1) PL_HIP(hipMemcpyAsync(dbg->d_feat1, pl->feat1.p, (size_t)S * 128 * 4, hipMemcpyDeviceToDevice, st));
+    }
+    pl->mark(3);
+
+    LayerDesc Lcur, Lnew;
+    freeze_layer(part, S, Lcur);                          // layer 1: every segment its own cluster
+    out->trace[0] = Lcur.C;
+    PL_CHECK(tables_for(0, true));                        // layer_1.{seg,ins,sem}
+    PL_HIP(hipStreamSynchronize(st));
+
+    std::vector<int32_t> adj(pl->h_adj.p, pl->h_adj.p + 2 * (size_t)E1), adj_next;
+    std::vector<uint8_t> connected, keep;
+    int E = E1;
+    auto tap_adj = [&](int i, const std::vector<int32_t>& a, int rows) {
+        if (dbg && dbg->h_adj[i]) std::copy(a.begin(), a.begin() + 2 * (size_t)rows, dbg->h_adj[i]);
+        if (dbg) dbg->n_adj[i] = rows;
+    };
+    auto tap_dist = [&](int i, int rows) { if (dbg && dbg->h_dist[i]) std::copy(pl->h_dist.p, pl->h_dist.p + rows, dbg->h_dist[i]); };
+    tap_adj(0, adj, E);
+    tap_dist(0, E);
+
+    // group + re-index + contract; returns the new layer in Lnew and the contracted adjacency in adj
+    auto regroup = [&](float th) -> int {
+        connected.assign(std::max(E, 1), 0);
+        int rc = sg_partition_group_nearby(part, Lcur.root.data(), Lcur.C, pl->h_dist.p, adj.data(), E, th, connected.data());
+        if (rc == SG_ESTALL) { out->stalled = 1; rc = SG_OK; }
+        if (rc < 0) return rc;
+        keep.resize(connected.size());
+        for (size_t i = 0; i < connected.size(); ++i) keep[i] = !connected[i];
+        adj_next.resize(2 * (size_t)std::max(E, 1));
+        const int En = sg_partition_contract(part, Lcur.root.data(), adj.data(), E, keep.data(), adj_next.data());
+        if (En < 0) return En;
+        freeze_layer(part, S, Lnew);
+        adj.assign(adj_next.begin(), adj_next.begin() + 2 * (size_t)En);
+        E = En;
+        return SG_OK;
+    };
+
+    PL_CHECK(regroup(mode == SG_MODE_SEM_INFER ? 3.0f : 6.0f));
+    out->trace[1] = Lnew.C;
+    PL_CHECK(tables_for(3, true));                        // layer_2.*
+    tap_adj(1, adj, E);
+
+    int n_tables = 6;
+    int ins_row = 4, sem_row = 5;
+
+    if (mode == SG_MODE_INS_INFER) {
+        // ---------------- semantic grouping layers (model.py:786-865) ----------------------------------
+        const float* feat_prev = pl->feat1.p;             // features of the PREVIOUS numbering (rows = Lcur clusters)
+        int feat_prev_stride = 128, feat_prev_dim = 128;
+        float* cat = pl->featA.p;
+        float* gcn_out = pl->featB.p;
+        for (int layer = 0; layer < 2; ++layer) {
+            const int C = Lnew.C, Dcat = feat_prev_dim + 64;
+            const int sb = 4 + 6 * layer;                 // stage index base
+            pl->mark(-1);
+            // ---- descriptor block ----
+            std::vector<int32_t> tile_cl, tile_lo, tile_hi, cl_tile_off(C + 1);
+            for (int c = 0; c < C; ++c) {
+                cl_tile_off[c] = (int)tile_cl.size();
+                for (int lo = Lnew.cl_pt_off[c]; lo < Lnew.cl_pt_off[c + 1]; lo += 256) {
+                    tile_cl.push_back(c); tile_lo.push_back(lo); tile_hi.push_back(std::min(lo + 256, Lnew.cl_pt_off[c + 1]));
+                }
+            }
+            cl_tile_off[C] = (int)tile_cl.size();
+            const int T = (int)tile_cl.size();
+            // parents: old clusters (Lcur numbering) absorbed by each new cluster, in old order (model.py:766-768)
+            std::vector<int32_t> goff(C + 1, 0), gidx(Lcur.C), cl_of_order(S);
+            for (int j = 0; j < Lcur.C; ++j) ++goff[Lnew.cl_of_seg[Lcur.root[j]] + 1];
+            for (int c = 0; c < C; ++c) goff[c + 1] += goff[c];
+            {
+                std::vector<int32_t> fill(goff.begin(), goff.end() - 1);
+                for (int j = 0; j < Lcur.C; ++j) gidx[fill[Lnew.cl_of_seg[Lcur.root[j]]]++] = j;
+            }
+            for (int i = 0; i < S; ++i) cl_of_order[i] = Lnew.cl_of_seg[Lnew.order[i]];
+            // symmetric CSR of the cluster graph
+            std::vector<int32_t> rowptr(C + 1, 0), col(2 * (size_t)E), eid(2 * (size_t)E);
+            for (int e = 0; e < E; ++e) { ++rowptr[adj[2 * e] + 1]; ++rowptr[adj[2 * e + 1] + 1]; }
+            for (int c = 0; c < C; ++c) rowptr[c + 1] += rowptr[c];
+            {
+                std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+                for (int e = 0; e < E; ++e) {
+                    const int a = adj[2 * e], b = adj[2 * e + 1];
+                    col[fill[a]] = b; eid[fill[a]++] = e;
+                    col[fill[b]] = a; eid[fill[b]++] = e;
+                }
+            }
+            DescOffsets o;
+            size_t cur = 0;
+            auto put = [&](const std::vector<int32_t>& v, size_t count) {
+                const size_t at = cur;
+                std::copy(v.begin(), v.begin() + count, pl->h_desc.p + at);
+                cur += (count + 3) / 4 * 4;
+                return at;
+            };
+            o.order = put(Lnew.order, S); o.dst = put(Lnew.dst, S); o.cl = put(cl_of_order, S); o.cl_pt_off = put(Lnew.cl_pt_off, C + 1);
+            o.tile_cl = put(tile_cl, T); o.tile_lo = put(tile_lo, T); o.tile_hi = put(tile_hi, T); o.cl_tile_off = put(cl_tile_off, C + 1);
+            o.goff = put(goff, C + 1); o.gidx = put(gidx, Lcur.C); o.adj = put(adj, 2 * (size_t)E);
+            o.rowptr = put(rowptr, C + 1); o.col = put(col, 2 * (size_t)E); o.eid = put(eid, 2 * (size_t)E);
+            o.total = cur;
+            if (o.total > pl->desc.n) { sg_partition_destroy(part); return sg::fail(SG_ENOMEM, "descriptor buffer too small"); }
+            PL_HIP(hipMemcpyAsync(pl->desc.p, pl->h_desc.p, o.total * 4, hipMemcpyHostToDevice, st));
+            const int32_t* dd = pl->desc.p;
+
+            PL_CHECK(sg_gather_members(sc->d_seg_points, sc->d_seg_off, S, dd + o.order, dd + o.dst, dd + o.cl, pl->members.p,
+                                       pl->pos_of_point.p, pl->cluster_of_pos.p, stv));
+            PL_CHECK(sg_group_max_rows(feat_prev, feat_prev_stride, feat_prev_dim, dd + o.goff, dd + o.gidx, C, cat, Dcat, stv));
+            pl->mark(sb + 0);
+            PL_CHECK(sg_center_clusters(sc->d_data, N, pl->members.p, dd + o.cl_pt_off, C, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi,
+                                        T, dd + o.cl_tile_off, pl->x9m.p, pl->xyzw.p, pl->ws_center.p, pl->ws_center.n, stv));
+            pl->mark(sb + 1);
+            // point 0 is the first member of segment 0; its member-order position is that segment's dst
+            int pos0 = 0;
+            for (int i = 0; i < S; ++i) if (Lnew.order[i] == 0) { pos0 = Lnew.dst[i]; break; }
+            PL_CHECK(sg_cluster_knn(pl->xyzw.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T, 20, pos0,
+                                    pl->knn.p, stv));
+            pl->mark(sb + 2);
+            if (layer == 0)
+                PL_CHECK(sg_edgeconv_forward(pl->x9m.p, pl->knn.p, N, 20, 1, W + pl->o_m2w, W + pl->o_m2g, W + pl->o_m2b, nullptr, nullptr,
+                                             nullptr, pl->pf.p, pl->ws_edge.p, pl->ws_edge.n, stv));
+            else
+                PL_CHECK(sg_edgeconv_forward(pl->x9m.p, pl->knn.p, N, 20, 2, W + pl->o_m3w1, W + pl->o_m3g1, W + pl->o_m3b1, W + pl->o_m3w2,
+                                             W + pl->o_m3g2, W + pl->o_m3b2, pl->pf.p, pl->ws_edge.p, pl->ws_edge.n, stv));
+            pl->mark(sb + 3);
+            PL_CHECK(sg_segment_max(pl->pf.p, N, 64, pl->cluster_of_pos.p, cat + feat_prev_dim, Dcat, C, stv));
+            pl->mark(sb + 4);
+            PL_CHECK(sg_gcn_forward(cat, C, Dcat, dd + o.adj, E, dd + o.rowptr, dd + o.col, dd + o.eid, W + (layer == 0 ? pl->o_g2 : pl->o_g3),
+                                    0.125f, gcn_out, pl->ws_gcn.p, pl->ws_gcn.n, stv));
+            PL_CHECK(sg_edge_distance(gcn_out, Dcat, Dcat, dd + o.adj, E, pl->dist.p, stv));
+            PL_HIP(hipMemcpyAsync(pl->h_dist.p, pl->dist.p, (size_t)E * 4, hipMemcpyDeviceToHost, st));
+            if (layer == 1 || (dbg && dbg->h_gcn[layer]))
+                PL_HIP(hipMemcpyAsync(pl->h_feat.p, gcn_out, (size_t)C * Dcat * 4, hipMemcpyDeviceToHost, st));
+            if (dbg) {
+                if (dbg->d_pointfeat[layer]) PL_HIP(hipMemcpyAsync(dbg->d_pointfeat[layer], pl->pf.p, (size_t)N * 64 * 4, hipMemcpyDeviceToDevice, st));
+                if (dbg->d_knn[layer]) PL_HIP(hipMemcpyAsync(dbg->d_knn[layer], pl->knn.p, (size_t)N * 20 * 4, hipMemcpyDeviceToDevice, st));
+                if (dbg->d_members[layer]) PL_HIP(hipMemcpyAsync(dbg->d_members[layer], pl->members.p, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+            }
+            pl->mark(sb + 5);
+            PL_HIP(hipStreamSynchronize(st));
+            if (dbg && dbg->h_gcn[layer]) std::copy(pl->h_feat.p, pl->h_feat.p + (size_t)C * Dcat, dbg->h_gcn[layer]);
+            tap_dist(1 + layer, E);
+
+            // ---- grouping on the GCN features (model.py:802-815 / 843-856) ----
+            Lcur = Lnew;
+            PL_CHECK(regroup(2.0f));
+            out->trace[2 + layer] = Lnew.C;
+            PL_CHECK(tables_for(6 + 3 * layer, true));    // layer_3.* / layer_4.*
+            tap_adj(2 + layer, adj, E);
+            // next layer: previous features = this GCN output (featB); its concat goes to featA again and its
+            // GCN output back into featB -- safe, the stream runs group_max_rows(featB -> featA) before gcn writes featB
+            feat_prev = gcn_out; feat_prev_stride = Dcat; feat_prev_dim = Dcat;
+        }
+
+        // ---------------- final clustering (model.py:868-888) ------------------------------------------
+        // Feat_4 = max over absorbed rows of the gcn_3 output (host copy), adj_4 = current adj
+        const int D4 = 256;
+        std::vector<float> feat4((size_t)Lnew.C * D4, -INFINITY);
+        for (int j = 0; j < Lcur.C; ++j) {
+            float* dstp = &feat4[(size_t)Lnew.cl_of_seg[Lcur.root[j]] * D4];
+            const float* src = pl->h_feat.p + (size_t)j * D4;
+            for (int k = 0; k < D4; ++k) dstp[k] = std::max(dstp[k], src[k]);
+        }
+        std::vector<int32_t> root5(Lnew.root.begin(), Lnew.root.begin() + Lnew.C);
+        root5.resize(S);
+        int C5 = Lnew.C, E5 = E;
+        adj.resize(2 * (size_t)std::max(E, 1));
+        const int need_fallback = sg_partition_group_unlabeled(part, root5.data(), &C5, feat4.data(), D4, adj.data(), &E5);
+        if (need_fallback < 0) { sg_partition_destroy(part); return need_fallback; }
+        if (need_fallback) {
+            // FPS-1024 over the current clusters (model.py:479), XYZ only, no transform
+            LayerDesc L5;
+            freeze_layer(part, S, L5);
+            std::vector<int32_t> cl_of_order(S);
+            for (int i = 0; i < S; ++i) cl_of_order[i] = L5.cl_of_seg[L5.order[i]];
+            size_t cur = 0;
+            auto put = [&](const std::vector<int32_t>& v, size_t count) {
+                const size_t at = cur;
+                std::copy(v.begin(), v.begin() + count, pl->h_desc.p + at);
+                cur += (count + 3) / 4 * 4;
+                return at;
+            };
+            const size_t o_order = put(L5.order, S), o_dst = put(L5.dst, S), o_cl = put(cl_of_order, S), o_off = put(L5.cl_pt_off, L5.C + 1);
+            pl->mark(-1);
+            PL_HIP(hipMemcpyAsync(pl->desc.p, pl->h_desc.p, cur * 4, hipMemcpyHostToDevice, st));
+            const int32_t* dd = pl->desc.p;
+            PL_CHECK(sg_gather_members(sc->d_seg_points, sc->d_seg_off, S, dd + o_order, dd + o_dst, dd + o_cl, pl->members.p, nullptr, nullptr, stv));
+            PL_CHECK(sg_fps_sample(sc->d_data, N, 6, pl->members.p, dd + o_off, L5.C, 1024, 3, 0, pl->samples_big.p, nullptr, pl->ws_fps.p,
+                                   pl->ws_fps.n, stv));
+            PL_HIP(hipMemcpyAsync(pl->h_samples.p, pl->samples_big.p, (size_t)L5.C * 1024 * 3 * 4, hipMemcpyDeviceToHost, st));
+            pl->mark(16);
+            PL_HIP(hipStreamSynchronize(st));
+            PL_CHECK(sg_partition_unlabeled_fallback(part, L5.root.data(), L5.C, pl->h_samples.p, 1024));
+            out->used_fallback = 1;
+        }
+        out->trace[4] = sg_partition_num_clusters(part);
+        PL_CHECK(tables_for(12, false));                  // final.{ins,sem}
+        n_tables = 14; ins_row = 12; sem_row = 13;
+    }
+
+    // ---------------- export + evaluate (model.py:525-655) -------------------------------------------
+    pl->mark(-1);
+    PL_HIP(hipMemcpyAsync(pl->tables.p, tab, (size_t)n_tables * S * 4, hipMemcpyHostToDevice, st));
+    PL_CHECK(sg_export_labels(sc->d_unmap, V, sc->d_seg_of_point, N, pl->tables.p, n_tables, S, pl->labels.p, stv));
+    PL_HIP(hipMemcpyAsync(out->h_labels, pl->labels.p, (size_t)n_tables * V * 4, hipMemcpyDeviceToHost, st));
+    pl->mark(17);
+    PL_CHECK(sg_evaluate(sc->d_gt, pl->labels.p + (size_t)sem_row * V, pl->labels.p + (size_t)ins_row * V, V, max_ins, out->iou_sem,
+                         out->iou_ins, out->acc, pl->ws_eval.p, pl->ws_eval.n, stv));
+    pl->mark(18);
+    PL_HIP(hipStreamSynchronize(st));
+    sg_partition_destroy(part);
+    part = nullptr;
+
+    for (float& m : pl->stage_ms) m = 0.f;
+    for (int i = 1; i < pl->n_ev; ++i) {
+        float ms = 0.f;
+        if (pl->ev_stage[i] >= 0 && hipEventElapsedTime(&ms, pl->ev[i - 1], pl->ev[i]) == hipSuccess) pl->stage_ms[pl->ev_stage[i]] += ms;
+    }
+    return SG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// Shared helpers for libseggroup_hip.so (error plumbing, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+#include "seggroup_hip.h"
+
+namespace sg {
+
+char* err_buf();                       // thread-local message buffer (defined in capi.cpp)
+int fail(int code, const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define SG_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return ::sg::fail(SG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+#define SG_LAUNCH_CHECK()                                                                 \
+    do {                                                                                  \
+        hipError_t e__ = hipGetLastError();                                               \
+        if (e__ != hipSuccess)                                                            \
+            return ::sg::fail(SG_EHIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+#define SG_REQUIRE(cond, ...)                                                             \
+    do {                                                                                  \
+        if (!(cond)) return ::sg::fail(SG_EINVAL, __VA_ARGS__);                           \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Bump allocator over a caller-provided workspace.
+struct Carver {
+    char* base;
+    size_t cap, off = 0;
+    bool ok = true;
+    Carver(void* p, size_t n) : base((char*)p), cap(n) {}
+    template <class T>
+    T* take(size_t count) {
+        size_t bytes = align_up(count * sizeof(T));
+        if (off + bytes > cap) { ok = false; return nullptr; }
+        T* r = reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+}  // namespace sg

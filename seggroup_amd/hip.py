@@ -1,0 +1,140 @@
+"""ctypes binding of libseggroup_hip.so (C ABI declared in include/seggroup_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or no HIP device is
+visible when a device entry point is needed, this module raises -- it never routes to the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseggroup_hip.so")
+
+SG_OK, SG_EINVAL, SG_EHIP, SG_ENOMEM, SG_ESTALL, SG_EUNSUP = 0, -1, -2, -3, -4, -5
+MODE_INS_INFER, MODE_SEM_INFER = 0, 1
+NUM_LABEL_VECTORS = 14
+LABEL_NAMES = [f"layer_{l}.{k}" for l in (1, 2, 3, 4) for k in ("seg", "ins", "sem")] + ["final.ins", "final.sem"]
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+
+class SgError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libseggroup_hip error {code}: {msg}")
+        self.code = code
+
+
+class Weights(C.Structure):
+    _fields_ = [(n, vp) for n in ("mlp1_w", "mlp1_g", "mlp1_b", "mlp2_w", "mlp2_g", "mlp2_b", "gcn2_w",
+                                  "mlp3_w1", "mlp3_g1", "mlp3_b1", "mlp3_w2", "mlp3_g2", "mlp3_b2", "gcn3_w")]
+
+
+class Scene(C.Structure):
+    _fields_ = [("N", C.c_int), ("S", C.c_int), ("E0", C.c_int), ("V", C.c_int),
+                ("d_data", vp), ("d_adj", vp), ("d_seg_of_point", vp), ("d_seg_points", vp), ("d_seg_off", vp),
+                ("d_unmap", vp), ("d_gt", vp),
+                ("h_seg_first", vp), ("h_seg_size", vp), ("h_seg_ins", vp), ("h_seg_sem", vp)]
+
+
+class Result(C.Structure):
+    _fields_ = [("h_labels", vp), ("iou_sem", C.c_float * 80), ("iou_ins", C.c_float * 80), ("acc", C.c_float * 4),
+                ("trace", C.c_int32 * 5), ("stalled", C.c_int32), ("used_fallback", C.c_int32)]
+
+
+class Debug(C.Structure):
+    _fields_ = [("d_samples1", vp), ("d_feat1", vp), ("d_pointfeat", vp * 2), ("d_knn", vp * 2), ("d_members", vp * 2),
+                ("h_gcn", vp * 2), ("h_dist", vp * 3), ("h_adj", vp * 4), ("n_adj", C.c_int32 * 4)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/seggroup_hip.h
+_I, _Z = C.c_int, C.c_size_t
+SIGNATURES = {
+    "sg_last_error": (C.c_char_p, []),
+    "sg_version": (_I, []),
+    "sg_device_count": (_I, []),
+    "sg_contract_ws_bytes": (_Z, [_I]),
+    "sg_contract_point_edges": (_I, [vp, _I, vp, _I, _I, vp, _I, vp, vp, _Z, vp]),
+    "sg_gather_members": (_I, [vp, vp, _I, vp, vp, vp, vp, vp, vp, vp]),
+    "sg_fps_ws_bytes": (_Z, [_I]),
+    "sg_fps_sample": (_I, [vp, _I, _I, vp, vp, _I, _I, _I, _I, vp, vp, vp, _Z, vp]),
+    "sg_mlp1_ws_bytes": (_Z, [_I]),
+    "sg_mlp1_forward": (_I, [vp, _I, vp, vp, vp, vp, _I, vp, _Z, vp]),
+    "sg_edge_distance": (_I, [vp, _I, _I, vp, _I, vp, vp]),
+    "sg_group_max_rows": (_I, [vp, _I, _I, vp, vp, _I, vp, _I, vp]),
+    "sg_segment_max": (_I, [vp, _I, _I, vp, vp, _I, _I, vp]),
+    "sg_center_ws_bytes": (_Z, [_I, _I]),
+    "sg_center_clusters": (_I, [vp, _I, vp, vp, _I, vp, vp, vp, _I, vp, vp, vp, vp, _Z, vp]),
+    "sg_cluster_knn": (_I, [vp, _I, vp, vp, vp, vp, _I, _I, _I, vp, vp]),
+    "sg_edgeconv_ws_bytes": (_Z, [_I]),
+    "sg_edgeconv_forward": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
+    "sg_gcn_ws_bytes": (_Z, [_I, _I, _I]),
+    "sg_gcn_forward": (_I, [vp, _I, _I, vp, _I, vp, vp, vp, vp, C.c_float, vp, vp, _Z, vp]),
+    "sg_export_labels": (_I, [vp, _I, vp, _I, vp, _I, _I, vp, vp]),
+    "sg_eval_ws_bytes": (_Z, [_I]),
+    "sg_evaluate": (_I, [vp, vp, vp, _I, _I, vp, vp, vp, vp, _Z, vp]),
+    "sg_partition_create": (vp, [_I, vp, vp, vp, vp]),
+    "sg_partition_destroy": (None, [vp]),
+    "sg_partition_num_clusters": (_I, [vp]),
+    "sg_partition_union": (_I, [vp, _I, _I]),
+    "sg_partition_find": (_I, [vp, _I]),
+    "sg_partition_label": (_I, [vp, _I, vp, vp, vp]),
+    "sg_partition_layer": (_I, [vp, vp, vp, vp, vp, vp, vp]),
+    "sg_partition_group_nearby": (_I, [vp, vp, _I, vp, vp, _I, C.c_float, vp]),
+    "sg_partition_contract": (_I, [vp, vp, vp, _I, vp, vp]),
+    "sg_partition_group_unlabeled": (_I, [vp, vp, vp, vp, _I, vp, vp]),
+    "sg_partition_unlabeled_fallback": (_I, [vp, vp, _I, vp, _I]),
+    "sg_partition_export_tables": (_I, [vp, vp, vp, vp]),
+    "sg_pipeline_create": (vp, [_I, _I, _I, _I, vp, vp]),
+    "sg_pipeline_destroy": (None, [vp]),
+    "sg_pipeline_device_bytes": (_Z, [vp]),
+    "sg_pipeline_forward": (_I, [vp, vp, _I, vp, vp]),
+    "sg_pipeline_stage_times": (_I, [vp, vp, _I]),
+    "sg_pipeline_stage_name": (C.c_char_p, [_I]),
+    "sg_write_label_txt": (_I, [C.c_char_p, vp, _I]),
+    "sg_write_label_npy": (_I, [C.c_char_p, vp, _I]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C seggroup_amd/csrc`).  The SegGroup hot path has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise SgError(rc, lib().sg_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def require_device() -> None:
+    if lib().sg_device_count() <= 0:
+        raise RuntimeError("no HIP device visible: the SegGroup hot path runs on MI355X only (no CPU fallback)")
+
+
+def ptr(t) -> int:
+    """Device / host address of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data

@@ -1,0 +1,261 @@
+"""SegGroup model, MI355X-native: the drop-in for the reference's `seggroup/model.py`.
+
+Same surface: `SegModel(exp_name, cuda, visualize, sem_infer, ins_infer)`, attribute
+`.epoch`, `forward(data[1,N,6], weak_label[1,N,2], info[1,1]) -> (IoU_sem[1,2,40], IoU_ins[1,2,40],
+acc[4])`, the reference's checkpoint key layout, CWD-relative dataset paths, and the
+`results/<exp>/<scene>/<tag>/layer_*.{seg,ins,sem}.txt` + `final.{ins,sem}.txt` outputs (plus a
+`.npy` twin of every file).  Underneath, one C-ABI call (`sg_pipeline_forward`) runs the whole
+forward on the GPU; there is no CPU fallback.
+
+The network modules below only hold parameters (so `load_state_dict` / DDP work unchanged); their
+arithmetic lives in seggroup_amd/csrc/*.hip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .scene import DeviceScene
+from . import weights as _weights
+
+SEM_VALID_CLASS_IDS = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 24, 28, 33, 34, 36, 39])
+INS_VALID_CLASS_IDS = np.array([3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 24, 28, 33, 34, 36, 39])
+
+
+# ---- parameter containers with the reference's module / key structure (model.py:65-166) ----------
+class MLP1(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(64)
+        self.conv1 = nn.Sequential(nn.Conv2d(6, 64, kernel_size=1, bias=False), self.bn1, nn.LeakyReLU(negative_slope=0.2))
+
+
+class MLP2(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(64)
+        self.conv1 = nn.Sequential(nn.Conv2d(18, 64, kernel_size=1, bias=False), self.bn1, nn.LeakyReLU(negative_slope=0.2))
+
+
+class MLP3(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(64)
+        self.conv1 = nn.Sequential(nn.Conv2d(18, 64, kernel_size=1, bias=False), self.bn1, nn.LeakyReLU(negative_slope=0.2))
+        self.bn2 = nn.BatchNorm2d(64)
+        self.conv2 = nn.Sequential(nn.Conv2d(64, 64, kernel_size=1, bias=False), self.bn2, nn.LeakyReLU(negative_slope=0.2))
+
+
+class GCN(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.fc = nn.Linear(dim_in, dim_out, bias=False)
+
+
+class Classifier(nn.Module):
+    """Train-only head (model.py:154-166); kept so that reference checkpoints load with strict=True."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.linear1 = nn.Linear(dim_in, 128, bias=False)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.dp1 = nn.Dropout(p=0.5)
+        self.linear2 = nn.Linear(128, dim_out)
+
+
+class SceneResult:
+    """Outputs of one forward: 14 (ins mode) or 6 (sem mode) int32 label vectors + metric tensors."""
+
+    def __init__(self, labels: np.ndarray, n_vectors: int, res: hip.Result):
+        self.labels = labels                      # [14, V] int32 (pinned)
+        self.n_vectors = n_vectors
+        self.iou_sem = np.ctypeslib.as_array(res.iou_sem).reshape(1, 2, 40).copy()
+        self.iou_ins = np.ctypeslib.as_array(res.iou_ins).reshape(1, 2, 40).copy()
+        self.acc = np.ctypeslib.as_array(res.acc).copy()
+        self.trace = list(res.trace)
+        self.stalled = bool(res.stalled)
+        self.used_fallback = bool(res.used_fallback)
+
+    def label_dict(self) -> Dict[str, np.ndarray]:
+        return {hip.LABEL_NAMES[i]: self.labels[i] for i in range(self.n_vectors)}
+
+
+class Pipeline:
+    """Owns one `sg_pipeline` (one in-flight scene on one HIP stream) and its pinned output buffer."""
+
+    def __init__(self, w: Dict[str, np.ndarray], max_points: int, max_segments: int, max_edges: int, max_vertices: int,
+                 stream: Optional[torch.cuda.Stream] = None, device=None):
+        hip.require_device()
+        self.lib = hip.lib()
+        self.device = torch.device(device if device is not None else "cuda")
+        self.stream = stream
+        self.caps = (max_points, max_segments, max_edges, max_vertices)
+        self._keep = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in w.items()}
+        k = self._keep
+        cw = hip.Weights(
+            mlp1_w=k["mlp_1.conv1.0.weight"].ctypes.data, mlp1_g=k["mlp_1.bn1.weight"].ctypes.data, mlp1_b=k["mlp_1.bn1.bias"].ctypes.data,
+            mlp2_w=k["mlp_2.conv1.0.weight"].ctypes.data, mlp2_g=k["mlp_2.bn1.weight"].ctypes.data, mlp2_b=k["mlp_2.bn1.bias"].ctypes.data,
+            gcn2_w=k["gcn_2.fc.weight"].ctypes.data,
+            mlp3_w1=k["mlp_3.conv1.0.weight"].ctypes.data, mlp3_g1=k["mlp_3.bn1.weight"].ctypes.data, mlp3_b1=k["mlp_3.bn1.bias"].ctypes.data,
+            mlp3_w2=k["mlp_3.conv2.0.weight"].ctypes.data, mlp3_g2=k["mlp_3.bn2.weight"].ctypes.data, mlp3_b2=k["mlp_3.bn2.bias"].ctypes.data,
+            gcn3_w=k["gcn_3.fc.weight"].ctypes.data)
+        with torch.cuda.device(self.device):
+            sp = stream.cuda_stream if stream is not None else None
+            self.handle = self.lib.sg_pipeline_create(max_points, max_segments, max_edges, max_vertices, C.byref(cw), sp)
+        if not self.handle:
+            raise hip.SgError(hip.SG_EHIP, self.lib.sg_last_error().decode())
+        self.labels = torch.empty((hip.NUM_LABEL_VECTORS, max_vertices), dtype=torch.int32).pin_memory()
+
+    def fits(self, sc: DeviceScene) -> bool:
+        return sc.N <= self.caps[0] and sc.S <= self.caps[1] and sc.E0 <= self.caps[2] and sc.V <= self.caps[3]
+
+    def forward(self, sc: DeviceScene, mode: int = hip.MODE_INS_INFER, debug: Optional[hip.Debug] = None) -> SceneResult:
+        res = hip.Result()
+        res.h_labels = self.labels.data_ptr()
+        with torch.cuda.device(self.device):
+            rc = self.lib.sg_pipeline_forward(self.handle, C.byref(sc.c_struct), mode, C.byref(res),
+                                              C.byref(debug) if debug is not None else None)
+        hip.check(rc)
+        nvec = 14 if mode == hip.MODE_INS_INFER else 6
+        lab = self.labels.numpy()[:, :sc.V]
+        return SceneResult(lab, nvec, res)
+
+    def stage_times(self) -> Dict[str, float]:
+        buf = (C.c_float * 32)()
+        n = self.lib.sg_pipeline_stage_times(self.handle, buf, 32)
+        return {self.lib.sg_pipeline_stage_name(i).decode(): float(buf[i]) for i in range(n)}
+
+    def device_bytes(self) -> int:
+        return int(self.lib.sg_pipeline_device_bytes(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sg_pipeline_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_label_files(output_root: str, result: SceneResult, formats=("txt", "npy")) -> List[str]:
+    """The a16 file side (model.py:536-547): `<name>.txt` one '%d\\n' per raw vertex, and `<name>.npy`."""
+    lib = hip.lib()
+    os.makedirs(output_root, exist_ok=True)
+    written = []
+    for i in range(result.n_vectors):
+        vec = np.ascontiguousarray(result.labels[i])
+        base = os.path.join(output_root, hip.LABEL_NAMES[i])
+        if "txt" in formats:
+            hip.check(lib.sg_write_label_txt((base + ".txt").encode(), vec.ctypes.data, vec.shape[0]))
+            written.append(base + ".txt")
+        if "npy" in formats:
+            hip.check(lib.sg_write_label_npy((base + ".npy").encode(), vec.ctypes.data, vec.shape[0]))
+            written.append(base + ".npy")
+    return written
+
+
+class SegModel(nn.Module):
+    """Drop-in for the reference `SegModel` (model.py:658-897), inference modes only.
+
+    Training (`epoch` not in {'sem_infer','ins_infer'} with neither infer flag set) is out of scope for
+    this build and raises NotImplementedError after the pseudo labels are exported.
+    """
+
+    def __init__(self, exp_name='exp', cuda=True, visualize=False, sem_infer=False, ins_infer=False,
+                 data_root: Optional[str] = None, out_formats=("txt", "npy"), label_style: str = "manual"):
+        super().__init__()
+        self.exp_name = exp_name
+        self.cuda_flag = cuda
+        self.visualize = visualize
+        self.sem_infer = sem_infer
+        self.ins_infer = ins_infer
+        self.out_formats = tuple(out_formats)
+        self.label_style = label_style
+        self.root = data_root if data_root is not None else "."
+        self.data_root = os.path.join(self.root, 'dataset', 'scannet')
+        scene_list_path = os.path.join(self.data_root, 'scannetv2_train.txt')
+        self.scene_list: List[str] = []
+        if os.path.exists(scene_list_path):
+            with open(scene_list_path, 'r') as f:
+                self.scene_list = f.readlines()           # entries keep their '\n' like the reference (model.py:671-672)
+        self.epoch = '0'
+        self.mlp_1 = MLP1()
+        self.mlp_2 = MLP2()
+        self.gcn_2 = GCN(dim_in=192, dim_out=192)
+        self.mlp_3 = MLP3()
+        self.gcn_3 = GCN(dim_in=256, dim_out=256)
+        self.classifier = Classifier(dim_in=256, dim_out=40)
+        self._pipe: Optional[Pipeline] = None
+        self._pipe_key = None
+        self._scene_cache: Dict[str, DeviceScene] = {}
+        self._lock = threading.Lock()
+        self.last_result: Optional[SceneResult] = None
+
+    # -- parameters -> C ABI ----------------------------------------------------------------------
+    def export_weights(self) -> Dict[str, np.ndarray]:
+        return _weights.from_state_dict(self.state_dict())
+
+    def load_weights(self, w: Dict[str, np.ndarray]) -> None:
+        self.load_state_dict(_weights.to_state_dict(w, prefix=""), strict=False)
+
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def pipeline_for(self, sc: DeviceScene) -> Pipeline:
+        key = (self._weights_key(), str(sc.device))
+        if self._pipe is None or self._pipe_key != key or not self._pipe.fits(sc):
+            if self._pipe is not None:
+                self._pipe.close()
+            caps = (sc.N, sc.S, sc.E0, sc.V) if self._pipe is None or self._pipe_key != key else \
+                tuple(max(a, b) for a, b in zip(self._pipe.caps, (sc.N, sc.S, sc.E0, sc.V)))
+            self._pipe = Pipeline(self.export_weights(), *caps, stream=None, device=sc.device)
+            self._pipe_key = key
+        return self._pipe
+
+    def mode(self) -> int:
+        if self.sem_infer:
+            return hip.MODE_SEM_INFER
+        return hip.MODE_INS_INFER
+
+    def output_root(self, scene_name: str) -> str:
+        tag = self.epoch if self.epoch in ['sem_infer', 'ins_infer'] else 'epoch_' + self.epoch   # model.py:688-691
+        return os.path.join(self.root, 'results', self.exp_name, scene_name, tag)
+
+    # -- forward ------------------------------------------------------------------------------------
+    def forward_scene(self, sc: DeviceScene, write: bool = True) -> SceneResult:
+        """Hot path on a staged scene.  Returns the SceneResult; writes the label files if `write`."""
+        with self._lock:
+            res = self.pipeline_for(sc).forward(sc, self.mode())
+            if write:
+                write_label_files(self.output_root(sc.name), res, self.out_formats)
+            self.last_result = res
+        return res
+
+    def forward(self, data, weak_label, info):
+        data, weak_label, info = data[0], weak_label[0], info[0]
+        if not data.is_cuda:
+            raise RuntimeError("seggroup_amd.SegModel.forward needs CUDA/HIP tensors: there is no CPU path "
+                               "(use oracle/cpu_ref.py only for testing)")
+        scene_name = self.scene_list[int(info)][:-1]
+        sc = self._scene_cache.get(scene_name)
+        if sc is None:
+            sc = DeviceScene.from_reference_tree(scene_name, data=data, weak_label=weak_label, root=self.root,
+                                                 label_style=self.label_style, device=data.device)
+            self._scene_cache = {scene_name: sc}          # keep one scene resident, like the reference's per-step load
+        res = self.forward_scene(sc, write=True)
+        dev = data.device
+        out = (torch.from_numpy(res.iou_sem).to(dev), torch.from_numpy(res.iou_ins).to(dev), torch.from_numpy(res.acc).to(dev))
+        if self.sem_infer or self.ins_infer:
+            return out
+        raise NotImplementedError("training step (Classifier + loss, model.py:900-932) is out of scope for this build; "
+                                  "pseudo labels and metrics were produced")

@@ -1,0 +1,214 @@
+"""Deterministic synthetic ScanNet-shaped scenes (SURVEY.md section 8d recipe).
+
+A scene is everything the reference hot path reads for one ScanNet scan:
+
+  data        [N,6]  f32   XYZ (metres, 8x6x3 box) + RGB in [-1,1]    (<scene>.pcl.pth,   seggroup/data.py:34)
+  weak_label  [N,2]  i64   [sem 0..39|-1, ins 0..K-1|-1]              (<scene>.label.pth, seggroup/data.py:36)
+  seg         [N]    i32   over-segment id per point, 0..S-1 in order of first point
+                           (<scene>.seg.json lists, seggroup/dataset/scannet/util.py:205-220)
+  adj         [E0,2] i64   point adjacency, each row sorted, rows lexicographically unique
+                           (<scene>.adj.pth, seggroup/dataset/scannet/util.py:771-792)
+  unmap       [V]    i64   raw vertex -> resampled point                (<scene>.unmap.pth, util.py:687-693)
+  gt          [V,2]  i64   [sem+1, ins+1] per raw vertex, 0 = unannotated (label/real/raw, util.py:697-729)
+
+The generator is NumPy + SciPy only and uses a counter-based splitmix64 stream, so the
+GPU box regenerates byte-identical inputs without any torch RNG state.
+"""
+from __future__ import annotations
+
+import dataclasses
+import json
+import os
+from typing import Optional
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed: int, stream: int, n: int) -> np.ndarray:
+    """n 64-bit words of the splitmix64 sequence keyed by (seed, stream); counter-based."""
+    with np.errstate(over="ignore"):
+        base = (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)) ^ (np.uint64(stream) * np.uint64(0xD1B54A32D192ED03))
+        z = base + (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed: int, stream: int, n: int) -> np.ndarray:
+    """float32 uniforms in [0,1) with 24 random bits each."""
+    return ((splitmix64(seed, stream, n) >> np.uint64(40)).astype(np.float32)) * np.float32(1.0 / (1 << 24))
+
+
+def randint(seed: int, stream: int, n: int, hi: int) -> np.ndarray:
+    return (splitmix64(seed, stream, n) % np.uint64(hi)).astype(np.int64)
+
+
+@dataclasses.dataclass
+class Scene:
+    name: str
+    data: np.ndarray        # [N,6] f32
+    weak_label: np.ndarray  # [N,2] i64
+    seg: np.ndarray         # [N] i32, segment number = rank of the segment's first point
+    adj: np.ndarray         # [E0,2] i64
+    unmap: np.ndarray       # [V] i64
+    gt: np.ndarray          # [V,2] i64
+
+    @property
+    def num_points(self) -> int:
+        return int(self.data.shape[0])
+
+    @property
+    def num_segments(self) -> int:
+        return int(self.seg.max()) + 1 if self.seg.size else 0
+
+    def seg_lists(self):
+        """The .seg.json payload: list i is non-empty iff i is the first point of a segment."""
+        n = self.num_points
+        order = np.argsort(self.seg, kind="stable")
+        counts = np.bincount(self.seg, minlength=self.num_segments)
+        out = [[] for _ in range(n)]
+        pos = 0
+        for c in counts:
+            members = order[pos:pos + c]
+            out[int(members[0])] = members.tolist()
+            pos += c
+        return out
+
+
+def _renumber_by_first_point(lab: np.ndarray) -> np.ndarray:
+    """Relabel so that segment numbers ascend with the index of each segment's first point."""
+    _, first = np.unique(lab, return_index=True)
+    order = np.argsort(first)
+    uniq = np.unique(lab)
+    remap = np.empty(int(uniq.max()) + 1, dtype=np.int32)
+    remap[uniq[order]] = np.arange(order.size, dtype=np.int32)
+    return remap[lab]
+
+
+def make_scene(num_points: int = 150000, num_segments: int = 1500, seed: int = 0, *,
+               name: Optional[str] = None, knn_edges: int = 6, dup_frac: float = 0.0,
+               raw_vertices: Optional[int] = None, min_seg: int = 6) -> Scene:
+    """Build one synthetic scene.
+
+    dup_frac > 0 overwrites that fraction of points with copies of other points (exact
+    duplicates exercise the FPS / kNN tie quirks).
+    raw_vertices = V != N adds a non-identity `unmap` (every resampled point is hit at
+    least once when V >= N; extra raw vertices map to pseudo-random points).
+    """
+    from scipy.spatial import cKDTree
+
+    n, s = int(num_points), int(num_segments)
+    u = uniform01(seed, 1, 6 * n).reshape(n, 6)
+    data = np.empty((n, 6), dtype=np.float32)
+    data[:, 0] = u[:, 0] * np.float32(8.0)
+    data[:, 1] = u[:, 1] * np.float32(6.0)
+    data[:, 2] = u[:, 2] * np.float32(3.0)
+    data[:, 3:] = u[:, 3:] * np.float32(2.0) - np.float32(1.0)
+    if dup_frac > 0:
+        m = int(n * dup_frac)
+        dst = randint(seed, 7, m, n)
+        src = randint(seed, 8, m, n)
+        data[dst] = data[src]
+
+    xyz = data[:, :3].astype(np.float64)
+    tree = cKDTree(xyz)
+
+    # Voronoi over-segmentation around S seed points drawn from the cloud
+    attempt = 0
+    while True:
+        picks = np.unique(randint(seed, 100 + attempt, 4 * s, n))
+        perm = np.argsort(splitmix64(seed, 200 + attempt, picks.size), kind="stable")
+        seeds = picks[perm][:s]
+        _, lab = cKDTree(xyz[seeds]).query(xyz, k=1, workers=-1)
+        counts = np.bincount(lab, minlength=s)
+        if seeds.size == s and counts.min() >= min_seg:
+            break
+        attempt += 1
+        if attempt > 50:
+            raise RuntimeError("could not draw segment seeds with the requested minimum size")
+    seg = _renumber_by_first_point(lab.astype(np.int64))
+
+    # mesh-like adjacency: symmetrised k-NN edges, sorted pairs, unique rows
+    _, nb = tree.query(xyz, k=knn_edges + 1, workers=-1)
+    src = np.repeat(np.arange(n, dtype=np.int64), knn_edges)
+    dst = nb[:, 1:].reshape(-1).astype(np.int64)
+    lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+    keep = lo != hi
+    key = np.unique(lo[keep] * np.int64(n) + hi[keep])
+    adj = np.stack([key // n, key % n], axis=1).astype(np.int64)
+
+    # instances: nearest of K seeds over segment centroids; one labelled segment per instance
+    counts = np.bincount(seg, minlength=s)
+    cent = np.stack([np.bincount(seg, weights=xyz[:, d], minlength=s) for d in range(3)], axis=1) / counts[:, None]
+    k_ins = max(2, s // 25)
+    ins_seed = np.argsort(splitmix64(seed, 300, s), kind="stable")[:k_ins]
+    _, seg_ins = cKDTree(cent[ins_seed]).query(cent, k=1)
+    ins_sem = randint(seed, 400, k_ins, 40)
+    weak = np.full((n, 2), -1, dtype=np.int64)
+    for k in range(k_ins):
+        segs = np.nonzero(seg_ins == k)[0]
+        if segs.size == 0:
+            continue
+        big = segs[np.argmax(counts[segs])]  # first largest
+        mask = seg == big
+        weak[mask, 0] = ins_sem[k]
+        weak[mask, 1] = k
+
+    gt_pts = np.stack([ins_sem[seg_ins[seg]] + 1, seg_ins[seg] + 1], axis=1).astype(np.int64)
+    if raw_vertices is None or raw_vertices == n:
+        unmap = np.arange(n, dtype=np.int64)
+    else:
+        v = int(raw_vertices)
+        unmap = randint(seed, 500, v, n)
+        if v >= n:
+            slots = np.argsort(splitmix64(seed, 501, v), kind="stable")[:n]
+            unmap[slots] = np.arange(n, dtype=np.int64)
+    gt = gt_pts[unmap]
+    # a few unannotated vertices (sem == 0) so that evaluate()'s valid mask is exercised
+    hole = randint(seed, 600, max(1, unmap.size // 50), unmap.size)
+    gt = gt.copy()
+    gt[hole] = 0
+
+    return Scene(name=name or f"scene{seed:04d}_00", data=data, weak_label=weak, seg=seg.astype(np.int32),
+                 adj=adj, unmap=unmap, gt=gt)
+
+
+def write_reference_tree(root: str, scenes, label_style: str = "manual") -> None:
+    """Write scenes in the reference's on-disk layout under `root`.
+
+    root/dataset/scannet/scannetv2_train.txt                          (seggroup/model.py:669-672)
+    root/dataset/scannet/data/resampled/<s>/<s>.{pcl,info,unmap}.pth  (seggroup/data.py:31-33, model.py:698)
+    root/dataset/scannet/label/seg/<style>/resampled/<s>/<s>.label.pth (data.py:32)
+    root/dataset/scannet/label/real/resampled/<s>/<s>.seg.json        (model.py:699)
+    root/dataset/scannet/label/real/raw/<s>/<s>.label.pth             (model.py:610-611)
+    root/dataset/scannet/adj/mesh/resampled/<s>/<s>.adj.pth           (model.py:696)
+    """
+    import torch
+
+    base = os.path.join(root, "dataset", "scannet")
+    os.makedirs(base, exist_ok=True)
+    with open(os.path.join(base, "scannetv2_train.txt"), "w") as f:
+        for sc in scenes:
+            f.write(sc.name + "\n")
+    for i, sc in enumerate(scenes):
+        d = os.path.join(base, "data", "resampled", sc.name)
+        os.makedirs(d, exist_ok=True)
+        torch.save(torch.from_numpy(sc.data), os.path.join(d, sc.name + ".pcl.pth"))
+        torch.save(torch.tensor([i], dtype=torch.long), os.path.join(d, sc.name + ".info.pth"))
+        torch.save(torch.from_numpy(sc.unmap), os.path.join(d, sc.name + ".unmap.pth"))
+        d = os.path.join(base, "label", "seg", label_style, "resampled", sc.name)
+        os.makedirs(d, exist_ok=True)
+        torch.save(torch.from_numpy(sc.weak_label), os.path.join(d, sc.name + ".label.pth"))
+        d = os.path.join(base, "label", "real", "resampled", sc.name)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, sc.name + ".seg.json"), "w") as f:
+            json.dump(sc.seg_lists(), f)
+        d = os.path.join(base, "label", "real", "raw", sc.name)
+        os.makedirs(d, exist_ok=True)
+        torch.save(torch.from_numpy(sc.gt), os.path.join(d, sc.name + ".label.pth"))
+        d = os.path.join(base, "adj", "mesh", "resampled", sc.name)
+        os.makedirs(d, exist_ok=True)
+        torch.save(torch.from_numpy(sc.adj), os.path.join(d, sc.name + ".adj.pth"))
