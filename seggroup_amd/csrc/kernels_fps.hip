@@ -108,7 +108,8 @@ __global__ __launch_bounds__(BLOCK) void k_fps_sample(const float* __restrict__ 
             while (j <= rem && picks[rem - j] == 0) ++j;
             if (j > rem) j = rem;
             const int invalid = j - 1;
-            for (int t = 0; t < invalid; ++t) picks[rem - invalid + t] = picks[t];
+            // NumPy copies overlapping slices through a temporary: walk downwards (dst index > src index)
+            for (int t = invalid - 1; t >= 0; --t) picks[rem - invalid + t] = picks[t];
         }
         __syncthreads();
     }

@@ -105,9 +105,11 @@ __global__ __launch_bounds__(kTile) void k_cluster_knn(const float4* __restrict_
                 if (s > bv[K - 1]) {
                     float v = s;
                     int id = base + i;
+                    bool placed = false;             // once placed, everything below shifts down (stable for ties)
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        if (v > bv[j]) {
+                        if (placed || v > bv[j]) {
+                            placed = true;
                             const float tv = bv[j]; const int ti = bi[j];
                             bv[j] = v; bi[j] = id; v = tv; id = ti;
                         }

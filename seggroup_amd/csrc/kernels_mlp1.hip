@@ -44,9 +44,11 @@ __global__ __launch_bounds__(64) void k_mlp1_knn_moments(const float* __restrict
         if (s > bv[K1 - 1]) {                       // sorted insertion, earlier candidate first on ties
             float v = s;
             int id = j;
+            bool placed = false;                    // once placed, everything below shifts down (stable for ties)
 #pragma unroll
             for (int t = 0; t < K1; ++t) {
-                if (v > bv[t]) {
+                if (placed || v > bv[t]) {
+                    placed = true;
                     const float tv = bv[t]; const int ti = bi[t];
                     bv[t] = v; bi[t] = id; v = tv; id = ti;
                 }

@@ -101,6 +101,36 @@ SIGNATURES = {
 }
 
 _lib: Optional[C.CDLL] = None
+_runtime = None
+
+
+def _load_hip_runtime():
+    """Make ONE HIP runtime visible (RTLD_GLOBAL) before libseggroup_hip.so binds its hip* symbols.
+
+    PyTorch-ROCm bundles its own libamdhip64.so; the library must use that same runtime (streams and
+    events are runtime-local objects, and a second runtime initialised in the process does not find
+    the GPU).  Without torch (plain C++/ctypes host) the system ROCm runtime is used.
+    """
+    global _runtime
+    if _runtime is not None:
+        return _runtime
+    cands = []
+    try:
+        import torch  # noqa: F401  (loads torch/lib/libamdhip64.so)
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except ImportError:
+        pass
+    cands += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    err = None
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            _runtime = C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return _runtime
+        except OSError as e:  # pragma: no cover
+            err = e
+    raise RuntimeError(f"no HIP runtime (libamdhip64.so) could be loaded: {err}")
 
 
 def lib() -> C.CDLL:
@@ -111,6 +141,7 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C seggroup_amd/csrc`).  The SegGroup hot path has no CPU fallback.")
+        _load_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
