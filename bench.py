@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pseudo-label scenes/sec on synthetic ScanNet-shaped scenes (150k points /
+1.5k segments), SegModel.forward in ins_infer mode through the C ABI (sg_pipeline_forward).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+A "step" = one batch of `--batch` distinct scenes per GPU (weak scaling: per-GPU work is fixed as N
+grows; scenes are independent, no collective in the data path -- one RCCL all-reduce of the metric
+accumulators at the end).  Scenes are staged in HBM before the timed region; the timed
+region covers everything SegModel.forward does for a scene (all kernels, the serial host grouping,
+D2H of the 14 label vectors and metrics) except writing the label files (reported separately as
+`with_npy_files`).  Several scenes are in flight per GPU (`--inflight` pipelines on separate HIP
+streams) so the host's serial grouping phases overlap other scenes' kernels.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job scenes/s, plus
+  roofline     - the dominant kernel stage measured with HIP events on the pipelines' own streams
+                 inside the timed region (algorithmic bytes/flops per launch from DESIGN.md);
+  cpu_baseline - the NumPy oracle ("port", faithful per-edge loops) timed on this box's host cores on a
+                 bounded sample (one scene of the same workload), rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def stage_model(n_points: int, k: int = 20):
+    """Algorithmic work per launch of each pipeline stage."""
+    n = float(n_points)
+    return {
+        # EdgeConv stages: dense-contraction flops of ONE evaluation (the kernel recomputes for BN statistics)
+        "l2.edgeconv": ("mfma", 2.0 * k * n * (18 * 64), "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
+        "l3.edgeconv": ("mfma", 2.0 * k * n * (18 * 64 + 64 * 64), "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
+        # kNN: reads [N,4] f32, writes [N,20] i32
+        "l2.knn": ("hbm", 96.0 * n, "GB/s", HBM_PEAK_GBS, 1e9),
+        "l3.knn": ("hbm", 96.0 * n, "GB/s", HBM_PEAK_GBS, 1e9),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="distinct scenes per GPU per step")
+    ap.add_argument("--inflight", type=int, default=4, help="pipelines (HIP streams) per GPU")
+    ap.add_argument("--points", type=int, default=150000)
+    ap.add_argument("--segments", type=int, default=1500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline leg")
+    ap.add_argument("--no-files", action="store_true", help="skip the separate with-files measurement")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from seggroup_amd import hip, synthetic, weights
+    from seggroup_amd.model import Pipeline, write_label_files
+    from seggroup_amd.scene import DeviceScene
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    hip.require_device()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    W = weights.load_npz(os.path.join(ROOT, "tests", "golden", "weights_g2.npz"))
+    # distinct synthetic scenes per rank (config 3 of BASELINE.json: batches of 150k/1.5k scenes)
+    t0 = time.time()
+    host_scenes = [synthetic.make_scene(args.points, args.segments, 30000 + 1000 * rank + i) for i in range(args.batch)]
+    scenes = [DeviceScene.from_synthetic(s, device=dev) for s in host_scenes]
+    gen_s = time.time() - t0
+    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+    pipes = [Pipeline(W, *caps, stream=torch.cuda.Stream(device=dev), device=dev) for _ in range(args.inflight)]
+    free = list(pipes)
+    lock = threading.Lock()
+    stage_acc = {}
+    acc = {"iou_sem": np.zeros(80), "iou_ins": np.zeros(80), "acc": np.zeros(4), "n": 0}
+    pool = ThreadPoolExecutor(max_workers=args.inflight)
+
+    def run_one(sc, write_dir=None, record=True):
+        with lock:
+            p = free.pop()
+        try:
+            r = p.forward(sc, hip.MODE_INS_INFER)
+            if write_dir is not None:
+                write_label_files(os.path.join(write_dir, sc.name), r, ("npy",))
+            st = p.stage_times() if record else None
+            with lock:
+                if record:
+                    for k_, v in st.items():
+                        a = stage_acc.setdefault(k_, [0.0, 0])
+                        a[0] += v
+                        a[1] += 1
+                    acc["iou_sem"] += r.iou_sem.reshape(-1)
+                    acc["iou_ins"] += r.iou_ins.reshape(-1)
+                    acc["acc"] += np.nan_to_num(r.acc)
+                    acc["n"] += 1
+            return r.trace
+        finally:
+            with lock:
+                free.append(p)
+
+    def step(write_dir=None, record=True):
+        return list(pool.map(lambda s: run_one(s, write_dir, record), scenes))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(record=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        traces = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_scenes = world * args.batch * args.steps
+    value = total_scenes / elapsed
+
+    # the path's only collective: one all-reduce of the float64 metric accumulators
+    vec = torch.from_numpy(np.concatenate([acc["iou_sem"], acc["iou_ins"], acc["acc"], [acc["n"]]])).to(dev)
+    if world > 1:
+        dist.all_reduce(vec)
+    vec = vec.cpu().numpy()
+
+    out = None
+    if rank == 0:
+        mean_ms = {k_: v[0] / max(v[1], 1) for k_, v in stage_acc.items()}
+        model = stage_model(args.points)
+        dom = max((k_ for k_ in mean_ms if k_ in model), key=lambda k_: mean_ms[k_])
+        bound, units, unit, peak, scale = model[dom]
+        achieved = units / (mean_ms[dom] * 1e-3) / scale
+        roofline = {"kernel": dom, "bound": bound, "achieved": round(achieved, 4), "peak": peak, "unit": unit,
+                    "frac": round(achieved / peak, 6), "traffic": None, "ms_per_launch": round(mean_ms[dom], 4),
+                    "stage_ms": {k_: round(v, 4) for k_, v in mean_ms.items()}}
+
+        with_files = None
+        if not args.no_files:
+            with tempfile.TemporaryDirectory(prefix="sgbench_") as td:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                step(write_dir=td, record=False)
+                torch.cuda.synchronize()
+                with_files = args.batch / (time.perf_counter() - t1)
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cpu_ref
+            from threadpoolctl import threadpool_limits
+            # bounded thread count: the oracle is many small NumPy/torch ops, oversubscribing a 256-core host
+            # makes it ~10x slower than 16 threads
+            cores = min(os.cpu_count() or 1, args.cpu_threads)
+            torch.set_num_threads(cores)
+            t1 = time.perf_counter()
+            with threadpool_limits(limits=cores):
+                ref = cpu_ref.forward_scene(host_scenes[0], W, "ins_infer", faithful=True)
+            cpu_s = time.perf_counter() - t1
+            same = ref["trace"] == list(traces[0])
+            cpu = {"value": round(1.0 / cpu_s, 5), "unit": "scenes/s", "cores": cores, "kind": "port",
+                   "sample": f"1 scene of the same workload ({args.points} pts / {args.segments} segs), oracle/cpu_ref.py "
+                             f"faithful mode, {cpu_s:.1f} s; cluster trace equals the HIP path: {same}"}
+
+        I_s, U_s = vec[:40], vec[40:80]
+        I_i, U_i = vec[80:120], vec[120:160]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            miou_sem = float(np.nanmean(I_s / U_s)) if np.any(U_s > 0) else float("nan")
+            miou_ins = float(np.nanmean(I_i / U_i)) if np.any(U_i > 0) else float("nan")
+        out = {
+            "metric": "pseudo-label scenes/sec (150k pts, 1.5k segs)", "value": round(value, 3), "unit": "scenes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.batch} distinct synthetic scenes per GPU per step, {args.points} pts / {args.segments} "
+                                   f"segs each (BASELINE.json configs[2]; configs[1] = the same scene shape, single scene)",
+                       "mode": "ins_infer", "scenes_per_step_per_gpu": args.batch, "inflight_pipelines": args.inflight,
+                       "weights": "tests/golden/weights_g2.npz", "parallelism": f"scene-parallel x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "with_npy_files_scenes_per_s": None if with_files is None else round(with_files, 3),
+            "pseudo_label_mIoU": {"semantic": round(miou_sem, 4), "instance": round(miou_ins, 4), "scenes": int(vec[164])},
+            "cluster_trace_scene0": list(traces[0]), "scene_generation_s": round(gen_s, 1),
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    pool.shutdown()
+
+
+if __name__ == "__main__":
+    main()

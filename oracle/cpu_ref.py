@@ -233,20 +233,23 @@ def knn_scores(xq, xall):
     inner = -2 * fma(z_i,z_j, fma(y_i,y_j, fl(x_i*x_j))) (MKL K=3 dot product), xx = fl(fl(x2+y2)+z2)
     with separately rounded squares.  The fma is emulated as a float64
     multiply-add rounded to fp32 (product exact in fp64; double rounding differs from a true fma
-    with probability ~2^-29 per op, irrelevant for ranks).
+    with probability ~2^-29 per op, irrelevant for ranks).  Elementwise torch ops (multi-threaded);
+    none of them contracts into an FMA.
     """
-    xq = np.asarray(xq, dtype=F32)
-    xall = np.asarray(xall, dtype=F32)
-    t = (xq[:, None, 0] * xall[None, :, 0]).astype(F32)
-    t = (xq[:, None, 1].astype(np.float64) * xall[None, :, 1].astype(np.float64) + t).astype(F32)
-    t = (xq[:, None, 2].astype(np.float64) * xall[None, :, 2].astype(np.float64) + t).astype(F32)
-    inner = F32(-2.0) * t
+    import torch
+    q = torch.from_numpy(np.ascontiguousarray(xq, dtype=F32))
+    a = torch.from_numpy(np.ascontiguousarray(xall, dtype=F32))
+    qd, ad = q.double(), a.double()
+    t = q[:, 0:1] * a[:, 0][None, :]
+    t = torch.addcmul(t.double(), qd[:, 1:2], ad[:, 1][None, :]).float()
+    t = torch.addcmul(t.double(), qd[:, 2:3], ad[:, 2][None, :]).float()
+    inner = t * -2.0
 
     def sq(x):
         s = x * x
         return (s[:, 0] + s[:, 1]) + s[:, 2]
-    xx_q, xx_a = sq(xq), sq(xall)
-    return ((-xx_a)[None, :] - inner) - xx_q[:, None]
+    xx_q, xx_a = sq(q), sq(a)
+    return (((-xx_a)[None, :] - inner) - xx_q[:, None]).numpy()
 
 
 def topk_desc(scores, k):
@@ -262,16 +265,20 @@ def topk_desc(scores, k):
     """
     import torch
     s = np.ascontiguousarray(scores, dtype=F32)
-    n = s.shape[1]
-    vk = torch.from_numpy(s).topk(k, dim=-1)[0][:, -1].numpy()          # k-th largest VALUE is well defined
-    gt = s > vk[:, None]
-    eq = s == vk[:, None]
-    need = k - gt.sum(axis=1)
-    take = gt | (eq & (np.cumsum(eq, axis=1) <= need[:, None]))
-    cols = np.nonzero(take)[1].reshape(s.shape[0], k)                     # ascending index per row
-    vals = np.take_along_axis(s, cols, axis=1)
-    order = np.argsort(-vals, axis=1, kind="stable")                     # score desc, index asc among ties
-    return np.take_along_axis(cols, order, axis=1)
+    st = torch.from_numpy(s)
+    vals_t, idx_t = st.topk(k, dim=-1)                                   # the k largest VALUES are well defined
+    vals, idx = vals_t.numpy(), idx_t.numpy()
+    vk = vals[:, -1]
+    tie = (st >= vals_t[:, -1:]).sum(dim=1).numpy() > k                  # a tie straddles rank k
+    for r in np.nonzero(tie)[0]:                                         # rare: apply the index rule explicitly
+        row = s[r]
+        gt = np.nonzero(row > vk[r])[0]
+        eq = np.nonzero(row == vk[r])[0][:k - gt.size]
+        sel = np.concatenate([gt, eq])
+        idx[r] = sel
+        vals[r] = row[sel]
+    order = np.lexsort((idx, -vals), axis=1)                             # score desc, index asc among ties
+    return np.take_along_axis(idx, order, axis=1)
 
 
 def knn_local(x, k, chunk=2048):
@@ -301,8 +308,12 @@ def cluster_knn(xyz, layer: Layer, k=20):
 # A.6  MLP1  (model.py:39-80)
 # ------------------------------------------------------------------------------------------------
 def _bn_lrelu(y, gamma, beta, mean, var):
-    y = (y - mean) / np.sqrt(var + BN_EPS) * gamma + beta
-    return np.where(y >= 0, y, LRELU * y)
+    """BatchNorm (given batch statistics) + LeakyReLU, in place on the float64 block `y`."""
+    scale = gamma / np.sqrt(var + BN_EPS)
+    y *= scale
+    y += beta - mean * scale
+    np.maximum(y, LRELU * y, out=y)      # slope < 1: LeakyReLU(y) = max(y, 0.2 y)
+    return y
 
 
 def mlp1_forward(samples, W, return_knn=False):
@@ -345,7 +356,7 @@ def _edge_rows(x9, idx, lo, hi):
     return np.concatenate([xj - xi, xi], axis=2).reshape(-1, 18), k
 
 
-def edgeconv_forward(x9, idx, W, which, chunk=16384):
+def edgeconv_forward(x9, idx, W, which, chunk=2048):
     """MLP2 (`which`='mlp_2', one conv) or MLP3 ('mlp_3', two convs) -> [N,64] f32.
     BatchNorm uses batch statistics over all N*k rows (train mode, model.py:109,124,128)."""
     N = x9.shape[0]

@@ -216,24 +216,33 @@ __global__ __launch_bounds__(64 * kWaves) void k_edgeconv(const float* __restric
     }
 }
 
-// fixed-order reduction of the per-block partials -> folded weights w' = a*w and shift = beta - a*mean
-__global__ void k_bn_fold(const double* __restrict__ partial, int nblocks, double rows, const float* __restrict__ gamma,
-                          const float* __restrict__ beta, const float* __restrict__ w, int kin, float* __restrict__ w_folded,
-                          float* __restrict__ shift) {
+// fixed-order reduction of the per-block partials -> folded weights w' = a*w and shift = beta - a*mean.
+// 1024 threads: thread (value v = tid & 127, lane group g = tid >> 7) sums blocks g, g+8, g+16, ... and the
+// eight group sums are added in a fixed order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ partial, int nblocks, double rows,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const float* __restrict__ w, int kin, float* __restrict__ w_folded,
+                                                  float* __restrict__ shift) {
+    __shared__ double part[8][128];
     __shared__ double tot[128];
+    const int v = threadIdx.x & 127, g = threadIdx.x >> 7;
+    double s = 0.0;
+    for (int b = g; b < nblocks; b += 8) s += partial[(size_t)b * 128 + v];
+    part[g][v] = s;
+    __syncthreads();
     if (threadIdx.x < 128) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 128 + threadIdx.x];
-        tot[threadIdx.x] = s;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
+        tot[threadIdx.x] = t;
     }
     __syncthreads();
-    const int ch = threadIdx.x;
-    if (ch >= 64) return;
+    const int ch = threadIdx.x & 63;
     const double mean = tot[ch] / rows;
     const double var = tot[64 + ch] / rows - mean * mean;
     const double a = (double)gamma[ch] / sqrt(var + 1e-5);
-    for (int k = 0; k < kin; ++k) w_folded[ch * kin + k] = (float)(a * (double)w[ch * kin + k]);
-    shift[ch] = (float)((double)beta[ch] - a * mean);
+    for (int k = threadIdx.x >> 6; k < kin; k += 16) w_folded[ch * kin + k] = (float)(a * (double)w[ch * kin + k]);
+    if (threadIdx.x < 64) shift[ch] = (float)((double)beta[ch] - a * mean);
 }
 
 }  // namespace
@@ -263,12 +272,12 @@ int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, 
     const double rows = (double)N * (double)k;
     const dim3 grid(nblocks), block(64 * kWaves);
     k_edgeconv<STATS1><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, nullptr, partial);
-    k_bn_fold<<<1, 128, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, d_w1, 18, w1f, sh1);
+    k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, d_w1, 18, w1f, sh1);
     if (layers == 1) {
         k_edgeconv<FINAL1><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, nullptr, nullptr, sh1, d_out, nullptr);
     } else {
         k_edgeconv<STATS2><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, d_w2, nullptr, nullptr, partial);
-        k_bn_fold<<<1, 128, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, d_w2, 64, w2f, sh2);
+        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, d_w2, 64, w2f, sh2);
         k_edgeconv<FINAL2><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2f, sh2, d_out, nullptr);
     }
     SG_LAUNCH_CHECK();

@@ -163,26 +163,50 @@ __global__ __launch_bounds__(BLOCK) void k_fps_sample(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" {
+namespace sg {
 
-size_t sg_fps_ws_bytes(int N) { return sg::align_up((size_t)std::max(N, 1) * 16); }
-
-int sg_fps_sample(const float* d_data, int N, int ch_in, const int32_t* d_members, const int32_t* d_cl_off, int C, int P,
-                  int ch_out, int transform, float* d_samples, int32_t* d_sel, void* d_ws, size_t ws_bytes, void* stream) {
+// max_n < 0: cluster sizes unknown to the host -> launch both size classes with worst-case LDS.
+int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_members, const int32_t* d_cl_off, int C, int P,
+                    int ch_out, int transform, float* d_samples, int32_t* d_sel, void* d_ws, size_t ws_bytes, void* stream,
+                    int max_n) {
     SG_REQUIRE(N >= 0 && C >= 0 && P > 0 && P <= 4096 && ch_in >= 3 && ch_out >= 3 && ch_out <= ch_in,
                "sg_fps_sample: bad arguments (P=%d ch_in=%d ch_out=%d)", P, ch_in, ch_out);
     if (C == 0) return SG_OK;
     if (ws_bytes < (size_t)N * 16) return sg::fail(SG_ENOMEM, "sg_fps_sample: workspace too small");
     hipStream_t st = sg::as_stream(stream);
     const size_t head = (size_t)P * 4 + 16 * sizeof(Best);
-    // single-wave class: clusters with n <= kSmallMax
-    k_fps_sample<64><<<C, 64, head + (size_t)kSmallMax * 16, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform, 1,
-                                                                 kSmallMax, kSmallMax, d_samples, d_sel, (float*)d_ws);
-    // 16-wave class: everything larger (blocks whose cluster is small exit immediately)
-    k_fps_sample<1024><<<C, 1024, head + (size_t)kLdsCap * 16, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform,
-                                                                    kSmallMax + 1, INT_MAX, kLdsCap, d_samples, d_sel, (float*)d_ws);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fps_sample<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(head + (size_t)kLdsCap * 16 + 4096 * 4)));
+        attr_set = true;
+    }
+    // single-wave class: clusters with n <= kSmallMax, LDS carve sized to the largest of them
+    const int small_pts = max_n < 0 ? kSmallMax : std::max(64, std::min(max_n, kSmallMax));
+    k_fps_sample<64><<<C, 64, head + (size_t)small_pts * 16, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform, 1,
+                                                                 kSmallMax, small_pts, d_samples, d_sel, (float*)d_ws);
+    // 16-wave class: everything larger (blocks whose cluster is small exit immediately); skipped when the
+    // host knows there is none
+    if (max_n < 0 || max_n > kSmallMax) {
+        const int big_pts = max_n < 0 ? kLdsCap : std::min(max_n, kLdsCap);
+        k_fps_sample<1024><<<C, 1024, head + (size_t)big_pts * 16, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform,
+                                                                        kSmallMax + 1, INT_MAX, big_pts, d_samples, d_sel,
+                                                                        (float*)d_ws);
+    }
     SG_LAUNCH_CHECK();
     return SG_OK;
+}
+
+}  // namespace sg
+
+extern "C" {
+
+size_t sg_fps_ws_bytes(int N) { return sg::align_up((size_t)std::max(N, 1) * 16); }
+
+int sg_fps_sample(const float* d_data, int N, int ch_in, const int32_t* d_members, const int32_t* d_cl_off, int C, int P,
+                  int ch_out, int transform, float* d_samples, int32_t* d_sel, void* d_ws, size_t ws_bytes, void* stream) {
+    return sg::fps_sample_hint(d_data, N, ch_in, d_members, d_cl_off, C, P, ch_out, transform, d_samples, d_sel, d_ws, ws_bytes,
+                               stream, -1);
 }
 
 }  // extern "C"

@@ -226,29 +226,44 @@ __device__ inline bool in_ins_valid(int c) {   // INS_VALID_CLASS_IDS (model.py:
     return in_sem_valid(c) && c != 1 && c != 2;
 }
 
-__global__ void k_eval_counts(const int32_t* __restrict__ gt, const int32_t* __restrict__ sem_pred,
-                              const int32_t* __restrict__ ins_pred, int V, int max_ins, uint32_t* __restrict__ cnt) {
+// Per-thread register counters for the 7 scalars (one wave-reduced atomic per wave at the end), LDS
+// histograms for the 3x40 semantic bins and -- when they fit (max_ins <= kInsLds) -- for the four
+// per-instance arrays, flushed once per block: no hot global atomics.
+constexpr int kInsLds = 2048;
+__global__ __launch_bounds__(256) void k_eval_counts(const int32_t* __restrict__ gt, const int32_t* __restrict__ sem_pred,
+                                                     const int32_t* __restrict__ ins_pred, int V, int max_ins,
+                                                     uint32_t* __restrict__ cnt) {
+    extern __shared__ uint32_t dyn[];                       // [4 * max_ins] when max_ins <= kInsLds
     __shared__ uint32_t h[128];
+    const bool lds_ins = max_ins <= kInsLds;
     for (int i = threadIdx.x; i < 128; i += blockDim.x) h[i] = 0;
+    if (lds_ins)
+        for (int i = threadIdx.x; i < 4 * max_ins; i += blockDim.x) dyn[i] = i < 3 * max_ins ? 0u : 0xffffffffu;
     __syncthreads();
-    uint32_t* ins_p = cnt + 128;
-    uint32_t* ins_t = ins_p + max_ins;
-    uint32_t* ins_b = ins_t + max_ins;
-    uint32_t* first = ins_b + max_ins;
+    uint32_t* g_p = cnt + 128;
+    uint32_t* g_t = g_p + max_ins;
+    uint32_t* g_b = g_t + max_ins;
+    uint32_t* g_f = g_b + max_ins;
+    uint32_t* ins_p = lds_ins ? dyn : g_p;
+    uint32_t* ins_t = lds_ins ? dyn + max_ins : g_t;
+    uint32_t* ins_b = lds_ins ? dyn + 2 * max_ins : g_b;
+    uint32_t* first = lds_ins ? dyn + 3 * max_ins : g_f;
+    uint32_t sc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x) {
-        const int st = gt[2 * v], it = gt[2 * v + 1];
+        const int2 g = reinterpret_cast<const int2*>(gt)[v];
+        const int st = g.x, it = g.y;
         if (st == 0) continue;                                   // valid_idxs (model.py:615)
         const int sp = sem_pred[v], ip = ins_pred[v];
-        atomicAdd(&h[120], 1u);
+        sc[0] += 1;
         if (sp >= 1 && sp <= 40) atomicAdd(&h[sp - 1], 1u);
         if (st >= 1 && st <= 40) atomicAdd(&h[40 + st - 1], 1u);
         if (sp == st) {
-            atomicAdd(&h[121], 1u);
+            sc[1] += 1;
             if (sp >= 1 && sp <= 40) atomicAdd(&h[80 + sp - 1], 1u);
         }
-        if (ip == it) atomicAdd(&h[122], 1u);
-        if (in_sem_valid(st)) { atomicAdd(&h[123], 1u); if (sp == st) atomicAdd(&h[124], 1u); }
-        if (in_ins_valid(it)) { atomicAdd(&h[125], 1u); if (ip == it) atomicAdd(&h[126], 1u); }
+        sc[2] += (ip == it);
+        if (in_sem_valid(st)) { sc[3] += 1; sc[4] += (sp == st); }
+        if (in_ins_valid(it)) { sc[5] += 1; sc[6] += (ip == it); }
         if (ip >= 0 && ip < max_ins) {
             atomicAdd(&ins_p[ip], 1u);
             atomicMin(&first[ip], (uint32_t)v);
@@ -256,9 +271,23 @@ __global__ void k_eval_counts(const int32_t* __restrict__ gt, const int32_t* __r
         }
         if (it >= 0 && it < max_ins) atomicAdd(&ins_t[it], 1u);
     }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        uint32_t x = sc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&h[120 + k], x);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < 128; i += blockDim.x)
         if (h[i]) atomicAdd(&cnt[i], h[i]);
+    if (lds_ins)
+        for (int i = threadIdx.x; i < max_ins; i += blockDim.x) {
+            if (dyn[i]) atomicAdd(&g_p[i], dyn[i]);
+            if (dyn[max_ins + i]) atomicAdd(&g_t[i], dyn[max_ins + i]);
+            if (dyn[2 * max_ins + i]) atomicAdd(&g_b[i], dyn[2 * max_ins + i]);
+            if (dyn[3 * max_ins + i] != 0xffffffffu) atomicMin(&g_f[i], dyn[3 * max_ins + i]);
+        }
 }
 
 // semantic prediction at the first valid vertex of every predicted instance (model.py:636)
@@ -368,7 +397,10 @@ int sg_evaluate(const int32_t* d_gt, const int32_t* d_sem_pred, const int32_t* d
     hipStream_t st = sg::as_stream(stream);
     SG_HIP(hipMemsetAsync(cnt, 0, (128 + 3 * (size_t)max_ins) * 4, st));
     SG_HIP(hipMemsetAsync(cnt + 128 + 3 * (size_t)max_ins, 0xff, (size_t)max_ins * 4, st));
-    if (V > 0) k_eval_counts<<<std::min(sg::cdiv(V, 256), 512), 256, 0, st>>>(d_gt, d_sem_pred, d_ins_pred, V, max_ins, cnt);
+    if (V > 0) {
+        const size_t dyn = max_ins <= kInsLds ? (size_t)max_ins * 16 : 0;
+        k_eval_counts<<<std::min(sg::cdiv(V, 1024), 256), 256, dyn, st>>>(d_gt, d_sem_pred, d_ins_pred, V, max_ins, cnt);
+    }
     k_eval_first_sem<<<sg::cdiv(max_ins, 256), 256, 0, st>>>(d_sem_pred, max_ins, cnt);
     SG_LAUNCH_CHECK();
     std::vector<uint32_t> h(n);

@@ -69,14 +69,49 @@ __global__ __launch_bounds__(kTile) void k_center_write(const float* __restrict_
 }
 
 template <int K>
+__device__ inline void topk_insert(float (&bv)[K], int (&bi)[K], float s, int id) {
+    if (s > bv[K - 1]) {
+        float v = s;
+        bool placed = false;                 // once placed, everything below shifts down (stable for ties)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (placed || v > bv[j]) {
+                placed = true;
+                const float tv = bv[j]; const int ti = bi[j];
+                bv[j] = v; bi[j] = id; v = tv; id = ti;
+            }
+        }
+    }
+}
+
+__device__ inline float knn_score4(const float4& me, const float4& p) {
+    const float tt = __builtin_fmaf(me.z, p.z, __builtin_fmaf(me.y, p.y, me.x * p.x));
+    const float inner = -2.0f * tt;
+    return ((-p.w) - inner) - me.w;
+}
+
+// Brute-force scan with a BUFFERED top-k.  A lane's sorted 20-entry list lives in registers; inserting
+// costs ~100 VALU ops and, done inline, would run whenever ANY of the 64 lanes of a wave accepts a
+// candidate (i.e. almost always).  Instead a lane that sees a candidate above its (possibly stale)
+// threshold only appends (score, index) to its private LDS buffer -- two predicated ds_writes -- and
+// the whole wave drains the buffers together once one of them is nearly full.  Draining re-checks
+// each buffered candidate against the live list in index order, so the result is identical to the
+// sequential scan (same "lower index wins ties" rule).
+constexpr int kBuf = 16;            // buffer slots per lane
+constexpr int kQuad = 4;            // candidates examined between two fullness checks
+
+template <int K>
 __global__ __launch_bounds__(kTile) void k_cluster_knn(const float4* __restrict__ xyzw, const int32_t* __restrict__ cl_off,
                                                        const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo,
                                                        const int32_t* __restrict__ tile_hi, int pos0, int32_t* __restrict__ knn) {
-    __shared__ float4 cand[kChunk];
+    __shared__ float4 cand[kChunk + kQuad];
+    __shared__ float buf_s[kBuf][kTile];
+    __shared__ int buf_i[kBuf][kTile];
     const int t = blockIdx.x;
     const int c = tile_cl[t];
     const int clo = cl_off[c], n = cl_off[c + 1] - clo;
-    const int q = tile_lo[t] + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int q = tile_lo[t] + tid;
     const bool active = q < tile_hi[t];
     if (n <= K) {                                            // model.py:516-518: all members, rest stays 0 (= point 0)
         if (active) {
@@ -91,33 +126,40 @@ __global__ __launch_bounds__(kTile) void k_cluster_knn(const float4* __restrict_
     int bi[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { bv[j] = -INFINITY; bi[j] = 0; }
+    float thr = active ? -INFINITY : INFINITY;               // idle lanes never accept
+    int cnt = 0;
+
+    auto drain = [&]() {
+        int mx = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        for (int u = 0; u < mx; ++u) {
+            if (u < cnt) topk_insert<K>(bv, bi, buf_s[u][tid], buf_i[u][tid]);
+        }
+        cnt = 0;
+        if (active) thr = bv[K - 1];
+    };
+
     for (int base = 0; base < n; base += kChunk) {
         const int m = min(kChunk, n - base);
         __syncthreads();
-        for (int i = threadIdx.x; i < m; i += kTile) cand[i] = xyzw[clo + base + i];
+        for (int i = tid; i < m + kQuad; i += kTile)         // sentinels (|p|^2 = +inf -> score -inf) pad the last quad
+            cand[i] = i < m ? xyzw[clo + base + i] : make_float4(0.f, 0.f, 0.f, INFINITY);
         __syncthreads();
-        if (active) {
-            for (int i = 0; i < m; ++i) {
-                const float4 p = cand[i];
-                const float tt = __builtin_fmaf(me.z, p.z, __builtin_fmaf(me.y, p.y, me.x * p.x));
-                const float inner = -2.0f * tt;
-                const float s = ((-p.w) - inner) - me.w;
-                if (s > bv[K - 1]) {
-                    float v = s;
-                    int id = base + i;
-                    bool placed = false;             // once placed, everything below shifts down (stable for ties)
+        for (int i = 0; i < m; i += kQuad) {
 #pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        if (placed || v > bv[j]) {
-                            placed = true;
-                            const float tv = bv[j]; const int ti = bi[j];
-                            bv[j] = v; bi[j] = id; v = tv; id = ti;
-                        }
-                    }
+            for (int u = 0; u < kQuad; ++u) {
+                const float sc = knn_score4(me, cand[i + u]);
+                if (sc > thr) {
+                    buf_s[cnt][tid] = sc;
+                    buf_i[cnt][tid] = base + i + u;
+                    ++cnt;
                 }
             }
+            if (__any(cnt > kBuf - kQuad)) drain();
         }
     }
+    drain();
     if (active) {
         int32_t* o = knn + (size_t)q * K;
 #pragma unroll

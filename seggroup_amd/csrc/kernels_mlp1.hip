@@ -92,14 +92,19 @@ __global__ __launch_bounds__(64) void k_mlp1_knn_moments(const float* __restrict
     }
 }
 
-// one block of 64 threads: thread c derives channel c's folded affine
-__global__ void k_mlp1_finalize(const double* __restrict__ partial, int C, const float* __restrict__ w,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ folded) {
+// one block of 27 x 32 threads: value q is summed by 32 lanes over clusters l, l+32, ... and the lane sums are
+// combined by a fixed shuffle tree (reproducible); then thread c < 64 derives channel c's folded affine
+__global__ __launch_bounds__(27 * 32) void k_mlp1_finalize(const double* __restrict__ partial, int C, const float* __restrict__ w,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ folded) {
     __shared__ double mom[27];
-    if (threadIdx.x < 27) {
+    {
+        const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
         double s = 0.0;
-        for (int c = 0; c < C; ++c) s += partial[(size_t)c * 27 + threadIdx.x];   // fixed order: reproducible
-        mom[threadIdx.x] = s / ((double)C * 64.0 * K1);
+        for (int c = l; c < C; c += 32) s += partial[(size_t)c * 27 + q];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);             // stays inside the 32-lane half
+        if (l == 0) mom[q] = s / ((double)C * 64.0 * K1);
     }
     __syncthreads();
     const int ch = threadIdx.x;
@@ -183,7 +188,7 @@ int sg_mlp1_forward(const float* d_samples, int C, const float* d_w, const float
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_mlp1_forward: workspace too small (%zu < %zu)", ws_bytes, sg_mlp1_ws_bytes(C));
     hipStream_t st = sg::as_stream(stream);
     k_mlp1_knn_moments<<<C, 64, 0, st>>>(d_samples, knn, partial);
-    k_mlp1_finalize<<<1, 64, 0, st>>>(partial, C, d_w, d_gamma, d_beta, folded);
+    k_mlp1_finalize<<<1, 27 * 32, 0, st>>>(partial, C, d_w, d_gamma, d_beta, folded);
     k_mlp1_apply<<<C, 64, 0, st>>>(d_samples, knn, folded, d_feat, feat_stride);
     SG_LAUNCH_CHECK();
     return SG_OK;

@@ -224,8 +224,10 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                                      pl->ws_contract.n, stv));
     PL_HIP(hipMemcpyAsync(pl->h_count.p, pl->count.p, 4, hipMemcpyDeviceToHost, st));
     pl->mark(0);
-    PL_CHECK(sg_fps_sample(sc->d_data, N, 6, sc->d_seg_points, sc->d_seg_off, S, 64, 6, 1, pl->samples.p, nullptr, pl->ws_fps.p,
-                           pl->ws_fps.n, stv));
+    int max_seg = 0;
+    for (int s = 0; s < S; ++s) max_seg = std::max(max_seg, sc->h_seg_size[s]);
+    PL_CHECK(sg::fps_sample_hint(sc->d_data, N, 6, sc->d_seg_points, sc->d_seg_off, S, 64, 6, 1, pl->samples.p, nullptr, pl->ws_fps.p,
+                                 pl->ws_fps.n, stv, max_seg));
     pl->mark(1);
     PL_CHECK(sg_mlp1_forward(pl->samples.p, S, W + pl->o_m1w, W + pl->o_m1g, W + pl->o_m1b, pl->feat1.p, 128, pl->ws_mlp1.p,
                              pl->ws_mlp1.n, stv));
@@ -424,8 +426,10 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             PL_HIP(hipMemcpyAsync(pl->desc.p, pl->h_desc.p, cur * 4, hipMemcpyHostToDevice, st));
             const int32_t* dd = pl->desc.p;
             PL_CHECK(sg_gather_members(sc->d_seg_points, sc->d_seg_off, S, dd + o_order, dd + o_dst, dd + o_cl, pl->members.p, nullptr, nullptr, stv));
-            PL_CHECK(sg_fps_sample(sc->d_data, N, 6, pl->members.p, dd + o_off, L5.C, 1024, 3, 0, pl->samples_big.p, nullptr, pl->ws_fps.p,
-                                   pl->ws_fps.n, stv));
+            int max_cl = 0;
+            for (int c = 0; c < L5.C; ++c) max_cl = std::max(max_cl, L5.cl_pt_off[c + 1] - L5.cl_pt_off[c]);
+            PL_CHECK(sg::fps_sample_hint(sc->d_data, N, 6, pl->members.p, dd + o_off, L5.C, 1024, 3, 0, pl->samples_big.p, nullptr,
+                                         pl->ws_fps.p, pl->ws_fps.n, stv, max_cl));
             PL_HIP(hipMemcpyAsync(pl->h_samples.p, pl->samples_big.p, (size_t)L5.C * 1024 * 3 * 4, hipMemcpyDeviceToHost, st));
             pl->mark(16);
             PL_HIP(hipStreamSynchronize(st));

@@ -36,6 +36,11 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
         if (!(cond)) return ::sg::fail(SG_EINVAL, __VA_ARGS__);                           \
     } while (0)
 
+// internal variant of sg_fps_sample with the largest cluster size known to the host (kernels_fps.hip)
+int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_members, const int32_t* d_cl_off, int C, int P,
+                    int ch_out, int transform, float* d_samples, int32_t* d_sel, void* d_ws, size_t ws_bytes, void* stream,
+                    int max_n);
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
