@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Inference driver: the drop-in for the reference's `seggroup/infer.py` (pseudo-label generation).
+
+Same command line (infer.py:195-212): `-n/--exp_name`, `--label_style`, `--sem_infer | --ins_infer`,
+`-j/--workers`, `--no_cuda` (rejected: there is no CPU path), `--seed`, `-v/--visualize` (ignored);
+same checkpoint (`checkpoints/<exp>/models/last.t7`, keys with or without `module.`), same
+CWD-relative dataset tree, same `results/<exp>/<scene>/<mode>/*.txt` outputs (+ `.npy` twins), same
+log lines in `checkpoints/<exp>/run_infer.log`.
+
+Parallelism: one process per GPU; rank r handles scenes {i : i mod W == r} of the scene
+list -- scenes are independent, so there is NO collective in the loop (the reference all-reduces three
+tiny tensors per scene, infer.py:154-156, which lock-steps the ranks).  One all-reduce of the float64
+accumulators [2*40 + 2*40 + 4 + 1] at the end; rank 0 prints the reference's summary.
+`--sampler reference` reproduces DistributedSampler's shuffled, padded order (1201 -> 1208 at 8 GPUs)
+so that the reduced metrics match the reference's double counting of the 7 padded scenes.
+
+Launch:  python -m seggroup_amd.infer -n EXP --ins_infer            (spawns one process per visible GPU)
+    or:  torchrun --nproc-per-node N -m seggroup_amd.infer -n EXP --ins_infer
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+from typing import Callable, List, Optional
+
+import numpy as np
+
+SEM_VALID_CLASS_IDS = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 24, 28, 33, 34, 36, 39])
+INS_VALID_CLASS_IDS = np.array([3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 24, 28, 33, 34, 36, 39])
+SEM_CLASS_LABELS = ['wall', 'floor', 'cabinet', 'bed', 'chair', 'sofa', 'table', 'door', 'window', 'bookshelf', 'picture',
+                    'counter', 'desk', 'curtain', 'refrigerator', 'shower curtain', 'toilet', 'sink', 'bathtub', 'otherfurniture']
+INS_CLASS_LABELS = SEM_CLASS_LABELS[2:]
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description='Pseudo Label Inference')
+    p.add_argument('-n', '--exp_name', required=True, type=str, default=None, help='Name of the experiment to resume.')
+    p.add_argument('--label_style', type=str, default='manual', help='Style of weak labels.')
+    p.add_argument('--sem_infer', action='store_true', help='Infer pseudo labels for semantic segmentation.')
+    p.add_argument('--ins_infer', action='store_true', help='Infer pseudo labels for instance segmentation.')
+    p.add_argument('-j', '--workers', default=8, type=int, metavar='N', help='Number of data loading workers (default: 8).')
+    p.add_argument('--no_cuda', action='store_true', help="Don't use CUDA (rejected: the hot path is GPU only).")
+    p.add_argument('--seed', type=int, default=1, metavar='S', help='Random seed (default: 1)')
+    p.add_argument('-v', '--visualize', action='store_true', help='Visualize results (ignored).')
+    # additions of this build
+    p.add_argument('--root', type=str, default='.', help='directory holding dataset/, checkpoints/, results/ (default: CWD)')
+    p.add_argument('--sampler', choices=['shard', 'reference'], default='shard',
+                   help="scene->rank assignment: 'shard' = i mod W (no padding); 'reference' = DistributedSampler order")
+    p.add_argument('--out-format', type=str, default='txt,npy', help='comma list of txt,npy')
+    p.add_argument('--world-size', type=int, default=0, help='processes to spawn (default: one per visible GPU)')
+    p.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL on ROCm)')
+    p.add_argument('--port', type=int, default=2344, help='rendezvous port on 127.0.0.1 (reference: 2344)')
+    return p
+
+
+class IOStream:
+    """print + append + flush (reference seggroup/util.py:41-51)."""
+
+    def __init__(self, path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        self.f = open(path, 'a')
+
+    def cprint(self, text):
+        print(text)
+        self.f.write(text + '\n')
+        self.f.flush()
+
+    def close(self):
+        self.f.close()
+
+
+def scene_indices(num_scenes: int, rank: int, world: int, sampler: str) -> List[int]:
+    if sampler == 'shard':
+        return list(range(rank, num_scenes, world))
+    # DistributedSampler(shuffle=True, seed=0, epoch=0): randperm, pad by wrapping, stride by world (infer.py:98,136)
+    import torch
+    g = torch.Generator()
+    g.manual_seed(0)
+    idx = torch.randperm(num_scenes, generator=g).tolist()
+    total = -(-num_scenes // world) * world
+    idx += idx[:total - num_scenes]
+    return idx[rank:total:world]
+
+
+class Accumulator:
+    """float64 sums of I/U per class and of the four accuracies (infer.py:140-169)."""
+
+    def __init__(self):
+        self.v = np.zeros(165, dtype=np.float64)
+
+    def add(self, iou_sem, iou_ins, acc):
+        self.v[0:80] += np.asarray(iou_sem, dtype=np.float64).reshape(-1)
+        self.v[80:160] += np.asarray(iou_ins, dtype=np.float64).reshape(-1)
+        self.v[160:164] += np.asarray(acc, dtype=np.float64)
+        self.v[164] += 1
+
+    def summary(self):
+        I_s, U_s, I_i, U_i = self.v[0:40], self.v[40:80], self.v[80:120], self.v[120:160]
+        n = max(self.v[164], 1)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            return dict(iou_sem=I_s / U_s, iou_ins=I_i / U_i, acc_sem=self.v[160] / n, acc_ins=self.v[161] / n,
+                        acc_sem_sel=self.v[162] / n, acc_ins_sel=self.v[163] / n, n=int(self.v[164]))
+
+
+def progress_line(done, total, s) -> str:
+    with np.errstate(invalid='ignore'):
+        return ('Infer(%04d/%04d)    Instance mIoU: %.2f%%    Semantic mIoU: %.2f%%    Instance Acc: %.2f%%    Semantic Acc: %.2f%%'
+                % (done, total, np.nanmean(s['iou_ins']) * 100, np.nanmean(s['iou_sem']) * 100, s['acc_ins'] * 100, s['acc_sem'] * 100))
+
+
+def final_report(s, io: IOStream) -> None:
+    """The '==> Infer' line and the per-class tables (infer.py:63-76,178-190)."""
+    with np.errstate(invalid='ignore'):
+        io.cprint('==> Infer           Instance mIoU: %.2f%%    Semantic mIoU: %.2f%%    Instance Acc: %.2f%%    Semantic Acc: %.2f%%'
+                  % (np.nanmean(s['iou_ins']) * 100, np.nanmean(s['iou_sem']) * 100, s['acc_ins'] * 100, s['acc_sem'] * 100))
+        sem_sel = s['iou_sem'][SEM_VALID_CLASS_IDS - 1]
+        ins_sel = s['iou_ins'][INS_VALID_CLASS_IDS - 1]
+        io.cprint('')
+        io.cprint('Instance mIoU (18 classes): %.2f%%      Acc (18 classes): %.2f%%' % (np.nanmean(ins_sel) * 100, s['acc_ins_sel'] * 100))
+        for i in range(18):
+            io.cprint('{:<16}{:<16}'.format(INS_CLASS_LABELS[i], '%.2f%%' % (ins_sel[i] * 100)))
+        io.cprint('')
+        io.cprint('Semantic mIoU (20 classes): %.2f%%      Acc (20 classes): %.2f%%' % (np.nanmean(sem_sel) * 100, s['acc_sem_sel'] * 100))
+        for i in range(20):
+            io.cprint('{:<16}{:<16}'.format(SEM_CLASS_LABELS[i], '%.2f%%' % (sem_sel[i] * 100)))
+        io.cprint('')
+
+
+def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = None, init_dist: bool = True) -> Optional[dict]:
+    """One rank's loop.  `forward_fn(scene_index) -> (iou_sem, iou_ins, acc)` replaces the model in the
+    CPU (gloo) tests of the driver logic; by default it is SegModel.forward on this rank's GPU."""
+    import torch
+    import torch.distributed as dist
+
+    io = IOStream(os.path.join(args.root, 'checkpoints', args.exp_name, 'run_infer.log')) if rank == 0 else None
+    if world > 1 and init_dist and not dist.is_initialized():
+        dist.init_process_group(backend=args.backend, init_method=f'tcp://127.0.0.1:{args.port}', world_size=world, rank=rank)
+    with open(os.path.join(args.root, 'dataset', 'scannet', 'scannetv2_train.txt')) as f:
+        scene_list = f.readlines()
+
+    dev = None
+    if forward_fn is None:
+        from .data import ScanNet
+        from .model import SegModel
+        torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))
+        dev = torch.device('cuda', torch.cuda.current_device())
+        model = SegModel(exp_name=args.exp_name, cuda=True, visualize=False, sem_infer=args.sem_infer, ins_infer=args.ins_infer,
+                         data_root=args.root, out_formats=tuple(args.out_format.split(',')), label_style=args.label_style).to(dev)
+        if rank == 0:
+            io.cprint('Network parameters: {}'.format(sum(x.nelement() for x in model.parameters())))
+        ckpt_path = os.path.join(args.root, 'checkpoints', args.exp_name, 'models', 'last.t7')
+        if not os.path.exists(ckpt_path):
+            if rank == 0:
+                io.cprint('No checkpoint model, please make sure that you use right name in --exp_name')
+            raise SystemExit(1)
+        ckpt = torch.load(ckpt_path, map_location='cpu')
+        sd = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
+        sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
+        model.load_state_dict(sd, strict=False)
+        if rank == 0:
+            io.cprint('Load model from ' + ckpt_path)
+        model.epoch = 'sem_infer' if args.sem_infer else 'ins_infer'
+        dataset = ScanNet(label_style=args.label_style, root=args.root)
+
+        def forward_fn(i):   # noqa: F811
+            data, weak, info = dataset[i]
+            with torch.no_grad():
+                out = model(data[None].to(dev, non_blocking=True), weak[None].to(dev, non_blocking=True), info[None])
+            return tuple(o.cpu().numpy() for o in out)
+
+    mine = scene_indices(len(scene_list), rank, world, args.sampler)
+    acc = Accumulator()
+    t0 = time.time()
+    for step, i in enumerate(mine):
+        acc.add(*forward_fn(i))
+        if rank == 0:   # rank 0's running view (the reference prints the all-reduced view every step)
+            io.cprint(progress_line(min((step + 1) * world, len(scene_list)), len(scene_list), acc.summary()))
+    vec = torch.from_numpy(acc.v.copy())
+    if world > 1:
+        if dev is not None and args.backend == 'nccl':
+            vec = vec.to(dev)
+        dist.all_reduce(vec)           # the ONLY collective: 165 float64 over RCCL/xGMI (1.3 KB, latency-bound)
+        vec = vec.cpu()
+    result = None
+    if rank == 0:
+        total = Accumulator()
+        total.v = vec.numpy().copy()
+        result = total.summary()
+        result['elapsed_s'] = time.time() - t0
+        final_report(result, io)
+        io.close()
+    if world > 1 and init_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def _spawn_entry(rank, world, args):
+    run_worker(rank, world, args)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.sem_infer == args.ins_infer:
+        print("Please choose either '--sem_infer' or '--ins_infer'")       # infer.py:214-216
+        raise SystemExit(1)
+    import torch
+    if args.no_cuda or not torch.cuda.is_available():
+        print('seggroup_amd runs on MI355X only: no CPU fallback (use oracle/cpu_ref.py for testing)')
+        raise SystemExit(1)
+    np.seterr(divide='ignore', invalid='ignore')
+    io = IOStream(os.path.join(args.root, 'checkpoints', args.exp_name, 'run_infer.log'))
+    io.cprint(str(args))
+    io.cprint("Let's use " + str(torch.cuda.device_count()) + " GPUs!")
+    io.close()
+    torch.manual_seed(args.seed)
+    np.random.seed(1)
+    if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:              # launched by torchrun
+        import torch.distributed as dist
+        rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+        if world > 1:
+            dist.init_process_group(backend=args.backend)
+        run_worker(rank, world, args, init_dist=False)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    world = args.world_size or torch.cuda.device_count()
+    if world == 1:
+        run_worker(0, 1, args)
+    else:
+        import torch.multiprocessing as mp
+        mp.spawn(_spawn_entry, nprocs=world, args=(world, args))
+
+
+if __name__ == '__main__':
+    main()

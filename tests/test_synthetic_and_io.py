@@ -1,0 +1,62 @@
+"""Synthetic generator determinism (the GPU box must regenerate byte-identical inputs) and the
+reference on-disk formats."""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+from conftest import make_fixture_scene
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_generator_reproduces_fixture_inputs(golden_index):
+    for name in ("tiny_4k", "tiny_dup_4k", "small_20k"):
+        sc = make_fixture_scene(golden_index, name)
+        for k, want in golden_index[name]["input_sha"].items():
+            assert _sha(getattr(sc, k)) == want, f"{name}.{k}: the generator drifted from the captured fixture inputs"
+        first = [np.nonzero(sc.seg == s)[0][0] for s in range(sc.num_segments)]
+        assert np.all(np.diff(first) > 0)                       # segment numbers ascend with their first point
+        assert np.all(np.diff(sc.adj[:, 0] * sc.num_points + sc.adj[:, 1]) > 0) and np.all(sc.adj[:, 0] < sc.adj[:, 1])
+
+
+def test_reference_tree_roundtrip(tmp_path, golden_index):
+    import torch
+    from seggroup_amd import synthetic
+    from seggroup_amd.scene import seg_from_lists
+    sc = make_fixture_scene(golden_index, "tiny_dup_4k")
+    synthetic.write_reference_tree(str(tmp_path), [sc])
+    base = tmp_path / "dataset" / "scannet"
+    assert (base / "scannetv2_train.txt").read_text() == sc.name + "\n"
+    lists = json.load(open(base / "label" / "real" / "resampled" / sc.name / (sc.name + ".seg.json")))
+    assert len(lists) == sc.num_points
+    assert np.array_equal(seg_from_lists(lists, sc.num_points), sc.seg)
+    adj = torch.load(base / "adj" / "mesh" / "resampled" / sc.name / (sc.name + ".adj.pth"))
+    assert adj.dtype == torch.int64 and np.array_equal(adj.numpy(), sc.adj)
+    from seggroup_amd.data import ScanNet
+    ds = ScanNet("manual", root=str(tmp_path))
+    data, weak, info = ds[0]
+    assert len(ds) == 1 and data.shape == (sc.num_points, 6) and weak.shape == (sc.num_points, 2) and int(info) == 0
+
+
+def test_weights_state_dict_contract():
+    """Reference checkpoint layout: module. prefix, both BN aliases, 4-D conv kernels."""
+    import torch
+    from seggroup_amd import weights
+    from seggroup_amd.model import SegModel
+    w = weights.make_weights(3, 2.0, affine_jitter=0.1)
+    sd = weights.to_state_dict(w)
+    assert "module.mlp_3.conv2.1.weight" in sd and sd["module.mlp_1.conv1.0.weight"].shape == (64, 6, 1, 1)
+    back = weights.from_state_dict({"epoch": 6, "state_dict": sd, "optimizer": {}})
+    for k in w:
+        assert np.array_equal(back[k], w[k])
+    net = SegModel(exp_name="x", ins_infer=True, data_root="/nonexistent")
+    missing = net.load_state_dict({k[len("module."):]: v for k, v in sd.items()}, strict=False)
+    assert all("classifier" in k or "running" in k or "num_batches" in k for k in missing.missing_keys) and not missing.unexpected_keys
+    assert sum(p.nelement() for p in net.parameters()) == 147880      # FAQ.md:46 / SURVEY: 147,880 parameters
+    got = net.export_weights()
+    for k in w:
+        assert np.array_equal(got[k], w[k])
