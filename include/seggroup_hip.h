@@ -68,12 +68,14 @@ int sg_contract_point_edges(const int64_t* d_adj, int E, const int32_t* d_seg_of
  *   d_order[S]  original segment ids in cluster-concatenated order
  *   d_dst[S]    destination offset (in points) of each of those segments
  *   d_cl[S]     cluster number of each of those segments
- * writes d_members[N] (point ids in member order), d_pos_of_point[N] (inverse permutation) and
- * d_cluster_of_pos[N].
+ * writes d_members[N] (point ids in member order), d_pos_of_point[N] (inverse permutation),
+ * d_cluster_of_pos[N] and d_slot_of_pos[N] (index into d_order of the segment holding each position);
+ * the last three may be NULL.
  * ------------------------------------------------------------------------------------------- */
 int sg_gather_members(const int32_t* d_seg_points, const int32_t* d_seg_off, int S,
                       const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl,
-                      int32_t* d_members, int32_t* d_pos_of_point, int32_t* d_cluster_of_pos, void* stream);
+                      int32_t* d_members, int32_t* d_pos_of_point, int32_t* d_cluster_of_pos,
+                      int32_t* d_slot_of_pos, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a4+a5  get_cluster_pointcloud + farthest_point_sampling (model.py:319-426).  For every cluster
@@ -142,6 +144,21 @@ int sg_center_clusters(const float* d_data, int N, const int32_t* d_members, con
 int sg_cluster_knn(const float* d_xyzw, int N, const int32_t* d_cl_off,
                    const int32_t* d_tile_cl, const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T,
                    int k, int pos0, int32_t* d_knn, void* stream);
+
+/* Same result as sg_cluster_knn (bit-identical tables, ties included), with whole over-segments skipped
+ * when their bounding box proves that none of their points can enter any lane's top-k.  Tiles for THIS
+ * entry point hold <= 64 positions (one workgroup = 64 queries x 4 candidate slices):
+ *   d_segbox [S,8]   = {min xyz, max xyz, max |p|^2, 0} per ORIGINAL segment (sg_segment_boxes, once per scene)
+ *   d_cl_seg_off[C+1], d_order[S], d_dst[S] : the layer's ordered segment lists (sg_partition_layer)
+ *   d_seg_off[S+1]   : CSR offsets of the original segmentation (segment sizes)
+ *   d_slot_of_pos[N] : from sg_gather_members (each wave scans its own segment first)                  */
+int sg_segment_boxes(const float* d_data, const int32_t* d_seg_points, const int32_t* d_seg_off, int S,
+                     float* d_box, void* stream);
+int sg_cluster_knn_pruned(const float* d_xyzw, int N, const int32_t* d_cl_off,
+                          const int32_t* d_tile_cl, const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T,
+                          const int32_t* d_cl_seg_off, const int32_t* d_order, const int32_t* d_dst,
+                          const int32_t* d_seg_off, const float* d_segbox, const int32_t* d_slot_of_pos,
+                          int k, int pos0, int32_t* d_knn, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a13  get_graph_feature2 + MLP2 / MLP3 (model.py:83-138): edge features [x_j - x_i, x_i] over the

@@ -115,7 +115,8 @@ __global__ void k_emit_pairs(const uint32_t* __restrict__ bitmap, size_t words, 
 __global__ void k_gather_members(const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
                                  const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
                                  const int32_t* __restrict__ cl, int32_t* __restrict__ members,
-                                 int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos) {
+                                 int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos,
+                                 int32_t* __restrict__ slot_of_pos) {
     const int i = blockIdx.x;                 // i-th segment in member order
     const int s = order[i];
     const int lo = seg_off[s], n = seg_off[s + 1] - lo, d = dst[i], c = cl[i];
@@ -124,6 +125,7 @@ __global__ void k_gather_members(const int32_t* __restrict__ seg_points, const i
         members[d + t] = p;
         if (pos_of_point) pos_of_point[p] = d + t;
         if (cluster_of_pos) cluster_of_pos[d + t] = c;
+        if (slot_of_pos) slot_of_pos[d + t] = i;
     }
 }
 
@@ -339,11 +341,11 @@ int sg_contract_point_edges(const int64_t* d_adj, int E, const int32_t* d_seg_of
 
 int sg_gather_members(const int32_t* d_seg_points, const int32_t* d_seg_off, int S, const int32_t* d_order,
                       const int32_t* d_dst, const int32_t* d_cl, int32_t* d_members, int32_t* d_pos_of_point,
-                      int32_t* d_cluster_of_pos, void* stream) {
+                      int32_t* d_cluster_of_pos, int32_t* d_slot_of_pos, void* stream) {
     SG_REQUIRE(S >= 0 && d_members, "sg_gather_members: bad arguments");
     if (S == 0) return SG_OK;
     k_gather_members<<<S, 128, 0, sg::as_stream(stream)>>>(d_seg_points, d_seg_off, d_order, d_dst, d_cl, d_members,
-                                                          d_pos_of_point, d_cluster_of_pos);
+                                                          d_pos_of_point, d_cluster_of_pos, d_slot_of_pos);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

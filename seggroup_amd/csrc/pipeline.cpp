@@ -54,8 +54,8 @@ struct sg_pipeline {
 
     // device work buffers
     DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_center, ws_eval;
-    DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, knn, desc, tables, labels;
-    DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf;
+    DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, slot_of_pos, knn, desc, tables, labels;
+    DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf, segbox;
 
     // pinned host staging
     PinBuf<int32_t> h_adj, h_desc, h_tables, h_count;
@@ -90,7 +90,7 @@ int freeze_layer(const sg_partition* part, int S, LayerDesc& L) {
 
 // Device descriptor block of one layer, carved from ONE pinned buffer and shipped in ONE H2D copy.
 struct DescOffsets {
-    size_t order, dst, cl, cl_pt_off, tile_cl, tile_lo, tile_hi, cl_tile_off, goff, gidx, adj, rowptr, col, eid, total;
+    size_t order, dst, cl, cl_pt_off, cl_seg_off, tile_cl, tile_lo, tile_hi, cl_tile_off, goff, gidx, adj, rowptr, col, eid, total;
 };
 
 }  // namespace
@@ -124,7 +124,7 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     }
     std::unique_ptr<sg_pipeline> pl(new sg_pipeline());
     pl->maxN = maxN; pl->maxS = maxS; pl->maxE = maxE; pl->maxV = maxV;
-    pl->maxT = maxN / 256 + maxS + 1;
+    pl->maxT = maxN / 64 + maxS + 1;
     pl->stream = sg::as_stream(stream);
     for (int i = 0; i < kNumEvents; ++i)
         if (hipEventCreate(&pl->ev[i]) != hipSuccess) { sg::fail(SG_EHIP, "hipEventCreate failed"); return nullptr; }
@@ -168,13 +168,13 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->ws_center, sg_center_ws_bytes((int)T, maxS));
     D(pl->ws_eval, sg_eval_ws_bytes(maxS + 2));
     D(pl->adj1, 2 * maxE1); D(pl->count, 4);
-    D(pl->members, N); D(pl->pos_of_point, N); D(pl->cluster_of_pos, N);
+    D(pl->members, N); D(pl->pos_of_point, N); D(pl->cluster_of_pos, N); D(pl->slot_of_pos, N);
     D(pl->knn, N * 20);
-    D(pl->desc, 8 * S + 8 + 3 * T + 2 * maxE1 + 4 * maxE1 + 64);
+    D(pl->desc, 9 * S + 16 + 3 * T + 2 * maxE1 + 4 * maxE1 + 64);
     D(pl->tables, SG_NUM_LABEL_VECTORS * S); D(pl->labels, SG_NUM_LABEL_VECTORS * V);
     D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
     D(pl->feat1, S * 128); D(pl->featA, S * 256); D(pl->featB, S * 256);
-    D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64);
+    D(pl->segbox, S * 8); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64);
     P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4);
     P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
     if (bad) { sg::fail(SG_ENOMEM, "sg_pipeline_create: device/pinned allocation failed (N=%d S=%d E=%d V=%d)", maxN, maxS, maxE, maxV); return nullptr; }
@@ -228,6 +228,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     for (int s = 0; s < S; ++s) max_seg = std::max(max_seg, sc->h_seg_size[s]);
     PL_CHECK(sg::fps_sample_hint(sc->d_data, N, 6, sc->d_seg_points, sc->d_seg_off, S, 64, 6, 1, pl->samples.p, nullptr, pl->ws_fps.p,
                                  pl->ws_fps.n, stv, max_seg));
+    PL_CHECK(sg_segment_boxes(sc->d_data, sc->d_seg_points, sc->d_seg_off, S, pl->segbox.p, stv));
     pl->mark(1);
     PL_CHECK(sg_mlp1_forward(pl->samples.p, S, W + pl->o_m1w, W + pl->o_m1g, W + pl->o_m1b, pl->feat1.p, 128, pl->ws_mlp1.p,
                              pl->ws_mlp1.n, stv));
@@ -300,8 +301,8 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             std::vector<int32_t> tile_cl, tile_lo, tile_hi, cl_tile_off(C + 1);
             for (int c = 0; c < C; ++c) {
                 cl_tile_off[c] = (int)tile_cl.size();
-                for (int lo = Lnew.cl_pt_off[c]; lo < Lnew.cl_pt_off[c + 1]; lo += 256) {
-                    tile_cl.push_back(c); tile_lo.push_back(lo); tile_hi.push_back(std::min(lo + 256, Lnew.cl_pt_off[c + 1]));
+                for (int lo = Lnew.cl_pt_off[c]; lo < Lnew.cl_pt_off[c + 1]; lo += 64) {   // 64 queries per tile (kNN v4)
+                    tile_cl.push_back(c); tile_lo.push_back(lo); tile_hi.push_back(std::min(lo + 64, Lnew.cl_pt_off[c + 1]));
                 }
             }
             cl_tile_off[C] = (int)tile_cl.size();
@@ -336,6 +337,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                 return at;
             };
             o.order = put(Lnew.order, S); o.dst = put(Lnew.dst, S); o.cl = put(cl_of_order, S); o.cl_pt_off = put(Lnew.cl_pt_off, C + 1);
+            o.cl_seg_off = put(Lnew.cl_seg_off, C + 1);
             o.tile_cl = put(tile_cl, T); o.tile_lo = put(tile_lo, T); o.tile_hi = put(tile_hi, T); o.cl_tile_off = put(cl_tile_off, C + 1);
             o.goff = put(goff, C + 1); o.gidx = put(gidx, Lcur.C); o.adj = put(adj, 2 * (size_t)E);
             o.rowptr = put(rowptr, C + 1); o.col = put(col, 2 * (size_t)E); o.eid = put(eid, 2 * (size_t)E);
@@ -345,7 +347,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             const int32_t* dd = pl->desc.p;
 
             PL_CHECK(sg_gather_members(sc->d_seg_points, sc->d_seg_off, S, dd + o.order, dd + o.dst, dd + o.cl, pl->members.p,
-                                       pl->pos_of_point.p, pl->cluster_of_pos.p, stv));
+                                       pl->pos_of_point.p, pl->cluster_of_pos.p, pl->slot_of_pos.p, stv));
             PL_CHECK(sg_group_max_rows(feat_prev, feat_prev_stride, feat_prev_dim, dd + o.goff, dd + o.gidx, C, cat, Dcat, stv));
             pl->mark(sb + 0);
             PL_CHECK(sg_center_clusters(sc->d_data, N, pl->members.p, dd + o.cl_pt_off, C, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi,
@@ -354,8 +356,9 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             // point 0 is the first member of segment 0; its member-order position is that segment's dst
             int pos0 = 0;
             for (int i = 0; i < S; ++i) if (Lnew.order[i] == 0) { pos0 = Lnew.dst[i]; break; }
-            PL_CHECK(sg_cluster_knn(pl->xyzw.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T, 20, pos0,
-                                    pl->knn.p, stv));
+            PL_CHECK(sg_cluster_knn_pruned(pl->xyzw.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
+                                           dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->segbox.p, pl->slot_of_pos.p, 20,
+                                           pos0, pl->knn.p, stv));
             pl->mark(sb + 2);
             if (layer == 0)
                 PL_CHECK(sg_edgeconv_forward(pl->x9m.p, pl->knn.p, N, 20, 1, W + pl->o_m2w, W + pl->o_m2g, W + pl->o_m2b, nullptr, nullptr,
@@ -425,7 +428,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             pl->mark(-1);
             PL_HIP(hipMemcpyAsync(pl->desc.p, pl->h_desc.p, cur * 4, hipMemcpyHostToDevice, st));
             const int32_t* dd = pl->desc.p;
-            PL_CHECK(sg_gather_members(sc->d_seg_points, sc->d_seg_off, S, dd + o_order, dd + o_dst, dd + o_cl, pl->members.p, nullptr, nullptr, stv));
+            PL_CHECK(sg_gather_members(sc->d_seg_points, sc->d_seg_off, S, dd + o_order, dd + o_dst, dd + o_cl, pl->members.p, nullptr, nullptr, nullptr, stv));
             int max_cl = 0;
             for (int c = 0; c < L5.C; ++c) max_cl = std::max(max_cl, L5.cl_pt_off[c + 1] - L5.cl_pt_off[c]);
             PL_CHECK(sg::fps_sample_hint(sc->d_data, N, 6, pl->members.p, dd + o_off, L5.C, 1024, 3, 0, pl->samples_big.p, nullptr,

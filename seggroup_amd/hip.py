@@ -60,7 +60,7 @@ SIGNATURES = {
     "sg_device_count": (_I, []),
     "sg_contract_ws_bytes": (_Z, [_I]),
     "sg_contract_point_edges": (_I, [vp, _I, vp, _I, _I, vp, _I, vp, vp, _Z, vp]),
-    "sg_gather_members": (_I, [vp, vp, _I, vp, vp, vp, vp, vp, vp, vp]),
+    "sg_gather_members": (_I, [vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp]),
     "sg_fps_ws_bytes": (_Z, [_I]),
     "sg_fps_sample": (_I, [vp, _I, _I, vp, vp, _I, _I, _I, _I, vp, vp, vp, _Z, vp]),
     "sg_mlp1_ws_bytes": (_Z, [_I]),
@@ -71,6 +71,8 @@ SIGNATURES = {
     "sg_center_ws_bytes": (_Z, [_I, _I]),
     "sg_center_clusters": (_I, [vp, _I, vp, vp, _I, vp, vp, vp, _I, vp, vp, vp, vp, _Z, vp]),
     "sg_cluster_knn": (_I, [vp, _I, vp, vp, vp, vp, _I, _I, _I, vp, vp]),
+    "sg_segment_boxes": (_I, [vp, vp, vp, _I, vp, vp]),
+    "sg_cluster_knn_pruned": (_I, [vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
     "sg_edgeconv_ws_bytes": (_Z, [_I]),
     "sg_edgeconv_forward": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_gcn_ws_bytes": (_Z, [_I, _I, _I]),

@@ -47,11 +47,11 @@ def _layer_arrays(layer):
     return members, off
 
 
-def _tiles(off):
+def _tiles(off, width=256):
     tc, lo, hi, cto = [], [], [], [0]
     for c in range(len(off) - 1):
-        for s in range(off[c], off[c + 1], 256):
-            tc.append(c); lo.append(s); hi.append(min(s + 256, off[c + 1]))
+        for s in range(off[c], off[c + 1], width):
+            tc.append(c); lo.append(s); hi.append(min(s + width, off[c + 1]))
         cto.append(len(tc))
     return (np.array(tc, np.int32), np.array(lo, np.int32), np.array(hi, np.int32), np.array(cto, np.int32))
 
@@ -355,3 +355,59 @@ def test_export_and_evaluate(env, golden_index):
     assert np.array_equal(iou_s.reshape(1, 2, 40), ref[0])
     assert np.array_equal(iou_i.reshape(1, 2, 40), ref[1])
     assert np.allclose(acc, ref[2], rtol=0, atol=1e-7, equal_nan=True)
+
+
+def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
+    """sg_cluster_knn_pruned (segment-box pruning) must give the same table as the brute-force kernel,
+    bit for bit, and both must equal the oracle (same defined tie rule) -- including duplicated points."""
+    lib, torch, hip = env
+    from oracle import cpu_ref as O
+    for name, target in (("tiny_dup_4k", 4), ("small_20k", 12), ("small_20k", 3)):
+        sc = make_fixture_scene(golden_index, name)
+        part, L = _semantic_inputs(sc, target)
+        members, off = _layer_arrays(L)
+        N, S = sc.num_points, sc.num_segments
+        # ordered segment list of every cluster, recovered from the member arrays
+        order, dst, cso = [], [], [0]
+        for c, m in enumerate(L.members):
+            segs = sc.seg[m]
+            starts = np.concatenate([[0], np.nonzero(np.diff(segs))[0] + 1])
+            order += segs[starts].tolist()
+            dst += (off[c] + starts).tolist()
+            cso.append(len(order))
+        assert sorted(order) == list(range(S))
+        segorder = np.argsort(sc.seg, kind="stable").astype(np.int32)
+        seg_off = np.concatenate([[0], np.cumsum(np.bincount(sc.seg, minlength=S))]).astype(np.int32)
+        tc, lo, hi, cto = _tiles(off)
+        d = {k: _up(torch, np.asarray(v, np.int32)) for k, v in dict(members=members, off=off, tc=tc, lo=lo, hi=hi, cto=cto, order=order,
+                                                                      dst=dst, cso=cso, segpts=segorder, segoff=seg_off).items()}
+        d_data = _up(torch, sc.data)
+        x9m = torch.zeros(N, 12, device="cuda:0"); xyzw = torch.zeros(N, 4, device="cuda:0")
+        ws = _ws(torch, lib.sg_center_ws_bytes(len(tc), L.count))
+        hip.check(lib.sg_center_clusters(d_data.data_ptr(), N, d["members"].data_ptr(), d["off"].data_ptr(), L.count, d["tc"].data_ptr(),
+                                         d["lo"].data_ptr(), d["hi"].data_ptr(), len(tc), d["cto"].data_ptr(), x9m.data_ptr(),
+                                         xyzw.data_ptr(), ws.data_ptr(), ws.numel(), None))
+        box = torch.zeros(S, 8, device="cuda:0")
+        hip.check(lib.sg_segment_boxes(d_data.data_ptr(), d["segpts"].data_ptr(), d["segoff"].data_ptr(), S, box.data_ptr(), None))
+        b = box.cpu().numpy()
+        for s_ in (0, S // 2, S - 1):
+            pts = sc.data[sc.seg == s_, :3]
+            assert np.array_equal(b[s_, :3], pts.min(0)) and np.array_equal(b[s_, 3:6], pts.max(0))
+        pos_of_point = np.empty(N, np.int64); pos_of_point[members] = np.arange(N)
+        k_brute = torch.zeros(N, 20, dtype=torch.int32, device="cuda:0")
+        k_prune = torch.full((N, 20), -7, dtype=torch.int32, device="cuda:0")
+        hip.check(lib.sg_cluster_knn(xyzw.data_ptr(), N, d["off"].data_ptr(), d["tc"].data_ptr(), d["lo"].data_ptr(), d["hi"].data_ptr(),
+                                     len(tc), 20, int(pos_of_point[0]), k_brute.data_ptr(), None))
+        slot_of_pos = np.repeat(np.arange(S), np.diff(np.concatenate([dst, [N]])) if False else
+                                np.diff(np.concatenate([np.asarray(dst), [N]]))).astype(np.int32)
+        d_slot = _up(torch, slot_of_pos)
+        tc4, lo4, hi4, _ = _tiles(off, 64)
+        d4 = [_up(torch, x) for x in (tc4, lo4, hi4)]
+        hip.check(lib.sg_cluster_knn_pruned(xyzw.data_ptr(), N, d["off"].data_ptr(), d4[0].data_ptr(), d4[1].data_ptr(),
+                                            d4[2].data_ptr(), len(tc4), d["cso"].data_ptr(), d["order"].data_ptr(), d["dst"].data_ptr(),
+                                            d["segoff"].data_ptr(), box.data_ptr(), d_slot.data_ptr(), 20, int(pos_of_point[0]),
+                                            k_prune.data_ptr(), None))
+        a, b_ = k_brute.cpu().numpy(), k_prune.cpu().numpy()
+        assert np.array_equal(a, b_), f"{name}/{target}: {int(np.any(a != b_, axis=1).sum())} rows differ between brute force and pruned"
+        ref = O.cluster_knn(sc.data[:, :3], L, 20)[members]
+        assert np.array_equal(members[a], ref)

@@ -127,3 +127,45 @@ def test_determinism_same_scene_twice(golden_index, weight_sets):
     la = a.labels.copy()
     b, _, _ = _run(scene, weight_sets["ins_infer"], "ins_infer")
     assert np.array_equal(la, b.labels) and np.array_equal(a.iou_ins, b.iou_ins)
+
+
+def test_dropin_forward_and_driver_write_reference_files(tmp_path, golden_index, weight_sets, monkeypatch):
+    """The reference's entry points: SegModel.forward(data, weak_label, info) reading the reference's
+    on-disk tree by scene name, and `infer.py --ins_infer` with a reference-layout checkpoint; the 14
+    txt files (one '%d\\n' per raw vertex) and their .npy twins carry the reference's integers."""
+    import torch
+    from seggroup_amd import hip, infer, synthetic, weights
+    from seggroup_amd.data import ScanNet
+    from seggroup_amd.model import SegModel
+    name = "tiny_dup_4k"                                  # V != N: exercises the unmap gather
+    scene = make_fixture_scene(golden_index, name)
+    g = load_golden(name)
+    root = str(tmp_path)
+    synthetic.write_reference_tree(root, [scene])
+    os_mod = __import__("os")
+    ck = os_mod.path.join(root, "checkpoints", "exp", "models")
+    os_mod.makedirs(ck)
+    torch.save({"epoch": 6, "state_dict": weights.to_state_dict(weight_sets["ins_infer"]), "optimizer": {}},
+               os_mod.path.join(ck, "last.t7"))
+    # (1) forward() called exactly like infer.py:150-152 does
+    net = SegModel(exp_name="exp", ins_infer=True, data_root=root).to("cuda:0")
+    sd = torch.load(os_mod.path.join(ck, "last.t7"), map_location="cpu")["state_dict"]
+    net.load_state_dict({k[len("module."):]: v for k, v in sd.items()}, strict=False)
+    net.epoch = "ins_infer"
+    data, weak, info = ScanNet("manual", root=root)[0]
+    with torch.no_grad():
+        iou_sem, iou_ins, acc = net(data[None].cuda(), weak[None].cuda(), info[None])
+    assert iou_sem.shape == (1, 2, 40) and iou_sem.is_cuda and acc.shape == (4,)
+    assert np.array_equal(iou_sem.cpu().numpy(), g["ins.metric.0"]) and np.array_equal(iou_ins.cpu().numpy(), g["ins.metric.1"])
+    out_dir = os_mod.path.join(root, "results", "exp", scene.name, "ins_infer")
+    for nm in hip.LABEL_NAMES:
+        want = g[f"ins.label.{nm}"]
+        assert [int(x) for x in open(os_mod.path.join(out_dir, nm + ".txt")).read().split()] == want.tolist(), nm
+        assert np.array_equal(np.load(os_mod.path.join(out_dir, nm + ".npy")), want)
+    # (2) the driver, single GPU
+    for f in os_mod.listdir(out_dir):
+        os_mod.remove(os_mod.path.join(out_dir, f))
+    infer.main(["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1"])
+    assert [int(x) for x in open(os_mod.path.join(out_dir, "final.ins.txt")).read().split()] == g["ins.label.final.ins"].tolist()
+    log = open(os_mod.path.join(root, "checkpoints", "exp", "run_infer.log")).read()
+    assert "Network parameters: 147880" in log and "Infer(0001/0001)" in log and "==> Infer" in log

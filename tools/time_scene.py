@@ -18,3 +18,20 @@ for it in range(4):
     st = pipe.stage_times()
     print(f'iter {it}: wall {dt*1e3:.2f} ms  gpu-stage-sum {sum(st.values()):.2f} ms trace {res.trace} fallback {res.used_fallback}')
 print({k: round(v, 3) for k, v in st.items()})
+import ctypes
+lib = hip.lib()
+buf = (ctypes.c_ulonglong * 8)()
+lib.sg_debug_knn_stats(buf, 1)
+res = pipe.forward(ds, hip.MODE_INS_INFER)
+lib.sg_debug_knn_stats(buf, 1)
+print('knn stats (one scene, both layers): scanned(wave-cands) %d  appends(lane) %d  drain-iters(wave) %d  segs visited %d skipped %d' % tuple(buf[:5]))
+
+import numpy as np
+bt = (ctypes.c_ulonglong * 8192)()
+lib.sg_debug_knn_blocktimes(bt, 8192)
+res = pipe.forward(ds, hip.MODE_INS_INFER)
+lib.sg_debug_knn_blocktimes(bt, 8192)      # holds the LAST knn launch (layer 3) of that forward
+a = np.array(bt[:], dtype=np.float64); a = a[a > 0]
+if a.size:
+    print('layer-3 knn wave runtimes (shader clocks): waves %d  sum %.3e  mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f' % (
+        a.size, a.sum(), a.mean(), np.percentile(a, 50), np.percentile(a, 90), np.percentile(a, 99), a.max()))
