@@ -38,16 +38,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 
 
-def stage_model(n_points: int, k: int = 20):
-    """Algorithmic work per launch of each pipeline stage."""
+def kernel_model(n_points: int, k: int = 20):
+    """Hot kernels: the pipeline stages that time them (HIP events), launches per scene and the ALGORITHMIC
+    work of one launch."""
     n = float(n_points)
+    c1, c12 = 2.0 * k * n * (18 * 64), 2.0 * k * n * (18 * 64 + 64 * 64)
     return {
-        # EdgeConv stages: dense-contraction flops of ONE evaluation (the kernel recomputes for BN statistics)
-        "l2.edgeconv": ("mfma", 2.0 * k * n * (18 * 64), "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
-        "l3.edgeconv": ("mfma", 2.0 * k * n * (18 * 64 + 64 * 64), "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
-        # kNN: reads [N,4] f32, writes [N,20] i32
-        "l2.knn": ("hbm", 96.0 * n, "GB/s", HBM_PEAK_GBS, 1e9),
-        "l3.knn": ("hbm", 96.0 * n, "GB/s", HBM_PEAK_GBS, 1e9),
+        # name: (stages, launches per scene, bound, units per launch, unit, peak, scale)
+        "k_edgeconv<FINAL2>": (["l3.edgeconv.final"], 1, "mfma", c12, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
+        "k_edgeconv<STATS2>": (["l3.edgeconv.stats2"], 1, "mfma", c12, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
+        "k_edgeconv<STATS1>": (["l2.edgeconv.stats1", "l3.edgeconv.stats1"], 2, "mfma", c1, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
+        "k_edgeconv<FINAL1>": (["l2.edgeconv.final"], 1, "mfma", c1, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
+        # kNN: reads [N,4] f32, writes [N,20] i32 (VALU-bound brute force inside clusters; HBM is its nominal roof)
+        "k_cluster_knn_pruned": (["l2.knn", "l3.knn"], 2, "hbm", 96.0 * n, "GB/s", HBM_PEAK_GBS, 1e9),
     }
 
 
@@ -153,12 +156,20 @@ def main():
     out = None
     if rank == 0:
         mean_ms = {k_: v[0] / max(v[1], 1) for k_, v in stage_acc.items()}
-        model = stage_model(args.points)
-        dom = max((k_ for k_ in mean_ms if k_ in model), key=lambda k_: mean_ms[k_])
-        bound, units, unit, peak, scale = model[dom]
-        achieved = units / (mean_ms[dom] * 1e-3) / scale
+        model = kernel_model(args.points)
+        per_scene = {kn: sum(mean_ms.get(st, 0.0) for st in m[0]) for kn, m in model.items()}
+        dom = max(per_scene, key=per_scene.get)                 # kernel with the largest device time per scene
+        stages, launches, bound, units, unit, peak, scale = model[dom]
+        ms_launch = per_scene[dom] / launches
+        achieved = units / (ms_launch * 1e-3) / scale
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.points == 150000:
+            traffic = json.load(open(tpath)).get("bytes_per_launch", {}).get(dom)
         roofline = {"kernel": dom, "bound": bound, "achieved": round(achieved, 4), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 6), "traffic": None, "ms_per_launch": round(mean_ms[dom], 4),
+                    "frac": round(achieved / peak, 6), "traffic": traffic, "ms_per_launch": round(ms_launch, 4),
+                    "launches_per_scene": launches, "measured_with": "HIP events on the pipeline streams, inside the timed region",
+                    "kernel_ms_per_scene": {kn: round(v, 4) for kn, v in per_scene.items()},
                     "stage_ms": {k_: round(v, 4) for k_, v in mean_ms.items()}}
 
         with_files = None

@@ -247,16 +247,11 @@ __global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ par
 
 }  // namespace
 
-extern "C" {
+namespace sg {
 
-size_t sg_edgeconv_ws_bytes(int N) {
-    const size_t nblocks = (size_t)sg::cdiv(sg::cdiv(std::max(N, 1), 32), kWaves);
-    return sg::align_up(nblocks * 128 * 8) + sg::align_up((64 * 18 + 64 + 64 * 64 + 64) * 4);
-}
-
-int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
-                        const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
-                        size_t ws_bytes, void* stream) {
+int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
+                            const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
+                            size_t ws_bytes, void* stream, const std::function<void(int)>& mark) {
     SG_REQUIRE(N >= 0 && k > 0 && (layers == 1 || layers == 2) && d_ws, "sg_edgeconv_forward: bad arguments");
     if (N == 0) return SG_OK;
     const int nblocks = sg::cdiv(sg::cdiv(N, 32), kWaves);
@@ -273,15 +268,35 @@ int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, 
     const dim3 grid(nblocks), block(64 * kWaves);
     k_edgeconv<STATS1><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, nullptr, partial);
     k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, d_w1, 18, w1f, sh1);
+    if (mark) mark(0);
     if (layers == 1) {
         k_edgeconv<FINAL1><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, nullptr, nullptr, sh1, d_out, nullptr);
+        if (mark) mark(1);
     } else {
         k_edgeconv<STATS2><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, d_w2, nullptr, nullptr, partial);
         k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, d_w2, 64, w2f, sh2);
+        if (mark) mark(1);
         k_edgeconv<FINAL2><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2f, sh2, d_out, nullptr);
+        if (mark) mark(2);
     }
     SG_LAUNCH_CHECK();
     return SG_OK;
+}
+
+}  // namespace sg
+
+extern "C" {
+
+size_t sg_edgeconv_ws_bytes(int N) {
+    const size_t nblocks = (size_t)sg::cdiv(sg::cdiv(std::max(N, 1), 32), kWaves);
+    return sg::align_up(nblocks * 128 * 8) + sg::align_up((64 * 18 + 64 + 64 * 64 + 64) * 4);
+}
+
+int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
+                        const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
+                        size_t ws_bytes, void* stream) {
+    return sg::edgeconv_forward_marked(d_x9m, d_knn, N, k, layers, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, d_out, d_ws, ws_bytes, stream,
+                                       nullptr);
 }
 
 }  // extern "C"

@@ -297,6 +297,12 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_pruned(
         int mxc = cnt;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mxc = max(mxc, __shfl_xor(mxc, o));
+        if (dbg & 4) {
+            unsigned long long tot = cnt;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+            if (lane == 0) { atomicAdd(&g_knn_stats[1], tot); atomicAdd(&g_knn_stats[2], (unsigned long long)mxc); }
+        }
         for (int u = 0; u < mxc; ++u) key_insert_par<K>(kv, u < cnt ? buf[u][tid] : 0ull);
         cnt = 0;
         if (active) { thr = kv[K - 1]; thr_pub[wave][lane] = thr; }
@@ -304,11 +310,14 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_pruned(
 
     const int so0 = cl_seg_off[c], nslots = cl_seg_off[c + 1] - so0;
     const int own = slot_of_pos[tile_lo[t]] - so0;
-    for (int r = wave; r < nslots; r += kSlices) {
+
+    auto slot_of = [&](int r) {                               // r-th segment of the rotation that starts at `own`
         int sl = own + r;
         if (sl >= nslots) sl -= nslots;
-        const int slot = so0 + sl;
-        const int sg = order[slot];
+        return so0 + sl;
+    };
+    // scan points [p0, p1) of one segment slot (sg = its original segment id, prefetched by the caller)
+    auto scan_range = [&](int slot, int sg, int p0, int p1) {
         const float* bx = segbox + (size_t)sg * 8;
         const unsigned long long use = best_thr();
         // upper bound of any score in this segment: -dmin^2 (shrunk) + 16 eps (|q|^2 + max|p|^2)
@@ -316,20 +325,23 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_pruned(
         const float dy = fmaxf(fmaxf(bx[1] - me.y, me.y - bx[4]), 0.f);
         const float dz = fmaxf(fmaxf(bx[2] - me.z, me.z - bx[5]), 0.f);
         const float ub = -((dx * dx + dy * dy) + dz * dz) * 0.999999f + 9.6e-7f * (me.w + bx[6]);
-        if (!__any(knn_key(ub, 0) >= use)) continue;           // index 0 = the best possible tie-break
-        const int m = seg_off[sg + 1] - seg_off[sg];
+        if (!__any(knn_key(ub, 0) >= use)) return;             // index 0 = the best possible tie-break
         const int base = dst[slot] - clo;                     // local member index of the segment's first point
-        for (int sub = 0; sub < m; sub += 64) {
-            const int mm = min(64, m - sub);
+        float4 nxt = (p0 + lane < p1) ? xyzw[clo + base + p0 + lane] : make_float4(0.f, 0.f, 0.f, INFINITY);
+        for (int sub = p0; sub < p1; sub += 64) {
+            const int mm = min(64, p1 - sub);
             __builtin_amdgcn_wave_barrier();
-            cw[lane] = lane < mm ? xyzw[clo + base + sub + lane] : make_float4(0.f, 0.f, 0.f, INFINITY);
+            cw[lane] = nxt;
             if (lane < kQuad) cw[64 + lane] = make_float4(0.f, 0.f, 0.f, INFINITY);
             __builtin_amdgcn_wave_barrier();
+            if (sub + 64 < p1)                                // next chunk's load flies while this one is scored
+                nxt = (sub + 64 + lane < p1) ? xyzw[clo + base + sub + 64 + lane] : make_float4(0.f, 0.f, 0.f, INFINITY);
+            const unsigned long long use2 = best_thr();       // thresholds rise while the segment is scanned
             for (int i = 0; i < mm; i += kQuad) {
 #pragma unroll
                 for (int u = 0; u < kQuad; ++u) {
                     const unsigned long long key = knn_key(knn_score4(me, cw[i + u]), base + sub + i + u);
-                    if (key > use) {
+                    if (key > use2 && key > thr) {
                         buf[cnt][tid] = key;
                         ++cnt;
                     }
@@ -337,9 +349,60 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_pruned(
                 if (__any(cnt > kBuf4 - kQuad)) drain();
             }
         }
+    };
+
+    // phase A: the queries' own segment (the likeliest neighbours), a quarter of its points per wave; a 4-way
+    // merge of the four partial lists gives every lane its exact 20th best so far, published as the
+    // threshold all slices filter and prune with -- without it every slice would first have to collect (and
+    // insert) 20 candidates of its own.
+    {
+        const int slot = slot_of(0);
+        const int sg = order[slot];
+        const int m = seg_off[sg + 1] - seg_off[sg];
+        const int per = (m + kSlices - 1) / kSlices;
+        scan_range(slot, sg, min(m, wave * per), min(m, (wave + 1) * per));
+        drain();
+    }
+    const unsigned long long t_a = (dbg & 8) ? __builtin_readcyclecounter() : 0ull;
+    __syncthreads();
+    {
+        unsigned long long* lists = &buf[0][0];               // [slice][K][64]; the append buffers are empty now
+#pragma unroll
+        for (int j = 0; j < K; ++j) lists[((size_t)wave * K + j) * 64 + lane] = kv[j];
+        __syncthreads();
+        if (wave == 0) {
+            int p[kSlices];
+            unsigned long long h[kSlices], bk = 0ull;
+#pragma unroll
+            for (int w = 0; w < kSlices; ++w) { p[w] = 0; h[w] = lists[((size_t)w * K) * 64 + lane]; }
+            for (int j = 0; j < K; ++j) {
+                int bw = 0;
+                bk = h[0];
+#pragma unroll
+                for (int w = 1; w < kSlices; ++w) if (h[w] > bk) { bk = h[w]; bw = w; }
+#pragma unroll
+                for (int w = 0; w < kSlices; ++w)
+                    if (w == bw) { ++p[w]; h[w] = p[w] < K ? lists[((size_t)w * K + p[w]) * 64 + lane] : 0ull; }
+            }
+            if (active) thr_pub[0][lane] = bk;                // the 20th best of the union (0 if fewer than 20 exist)
+        }
+        __syncthreads();
+    }
+    const unsigned long long t_a2 = (dbg & 8) ? __builtin_readcyclecounter() : 0ull;
+    // phase B: the remaining segments, every 4th one per wave, all filtered by the best published threshold
+    {
+        int r = 1 + wave;
+        int sg_next = r < nslots ? order[slot_of(r)] : 0;
+        for (; r < nslots; r += kSlices) {
+            const int slot = slot_of(r), sg = sg_next;
+            if (r + kSlices < nslots) sg_next = order[slot_of(r + kSlices)];     // prefetch the next descriptor
+            scan_range(slot, sg, 0, seg_off[sg + 1] - seg_off[sg]);
+        }
     }
     drain();
+    const unsigned long long t_b = (dbg & 8) ? __builtin_readcyclecounter() : 0ull;
     __syncthreads();                                          // every wave is done with its append buffer
+    const unsigned long long t_b2 = (dbg & 8) ? __builtin_readcyclecounter() : 0ull;
     unsigned long long* lists = &buf[0][0];                   // [slice][K][64]
 #pragma unroll
     for (int j = 0; j < K; ++j) lists[((size_t)wave * K + j) * 64 + lane] = kv[j];
@@ -361,7 +424,16 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_pruned(
                 if (w == bw) { ++p[w]; h[w] = p[w] < K ? lists[((size_t)w * K + p[w]) * 64 + lane] : 0ull; }
         }
     }
-    if ((dbg & 8) && lane == 0 && t * 4 + wave < 8192) g_knn_blocktime[(t * 4 + wave) & 8191] = __builtin_readcyclecounter() - t_begin;
+    if ((dbg & 8) && lane == 0) {
+        // [0..3]: wave-0 phase A, barrier wait after A (all waves), phase B work (all waves), barrier wait after B
+        if (wave == 0) atomicAdd(&g_knn_stats[0], t_a - t_begin);
+        atomicAdd(&g_knn_stats[1], t_a2 - t_a);
+        atomicAdd(&g_knn_stats[2], t_b - t_a2);
+        atomicAdd(&g_knn_stats[3], t_b2 - t_b);
+        atomicAdd(&g_knn_stats[4], __builtin_readcyclecounter() - t_b2);
+        atomicAdd(&g_knn_stats[5], 1ull);
+        if (t * 4 + wave < 8192) g_knn_blocktime[(t * 4 + wave) & 8191] = __builtin_readcyclecounter() - t_begin;
+    }
 }
 
 }  // namespace

@@ -13,11 +13,14 @@
 
 namespace {
 
-constexpr int kNumEvents = 40;
+constexpr int kNumEvents = 48;
 const char* kStageNames[] = {"contract_edges", "fps64", "mlp1", "dist1+d2h",
                              "l2.gather", "l2.center", "l2.knn", "l2.edgeconv", "l2.segmax", "l2.gcn+dist",
                              "l3.gather", "l3.center", "l3.knn", "l3.edgeconv", "l3.segmax", "l3.gcn+dist",
-                             "fallback_fps1024", "export", "evaluate"};
+                             "fallback_fps1024", "export", "evaluate",
+                             // sub-passes of the two EdgeConv stages (their sum is l2.edgeconv / l3.edgeconv)
+                             "l2.edgeconv.stats1", "l2.edgeconv.final", "l3.edgeconv.stats1", "l3.edgeconv.stats2",
+                             "l3.edgeconv.final"};
 constexpr int kNumStages = sizeof(kStageNames) / sizeof(kStageNames[0]);
 
 template <class T>
@@ -360,13 +363,17 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                                            dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->segbox.p, pl->slot_of_pos.p, 20,
                                            pos0, pl->knn.p, stv));
             pl->mark(sb + 2);
+            // sub-pass marks: the last pass is marked with the stage id itself, so "lN.edgeconv" keeps meaning the
+            // time of the LAST pass here and the reporting side adds the sub-passes up (see sg_pipeline_stage_times)
+            const int sub0 = layer == 0 ? 19 : 21;
+            auto mark_pass = [&](int i) { pl->mark(sub0 + i); };
             if (layer == 0)
-                PL_CHECK(sg_edgeconv_forward(pl->x9m.p, pl->knn.p, N, 20, 1, W + pl->o_m2w, W + pl->o_m2g, W + pl->o_m2b, nullptr, nullptr,
-                                             nullptr, pl->pf.p, pl->ws_edge.p, pl->ws_edge.n, stv));
+                PL_CHECK(sg::edgeconv_forward_marked(pl->x9m.p, pl->knn.p, N, 20, 1, W + pl->o_m2w, W + pl->o_m2g, W + pl->o_m2b, nullptr,
+                                                     nullptr, nullptr, pl->pf.p, pl->ws_edge.p, pl->ws_edge.n, stv, mark_pass));
             else
-                PL_CHECK(sg_edgeconv_forward(pl->x9m.p, pl->knn.p, N, 20, 2, W + pl->o_m3w1, W + pl->o_m3g1, W + pl->o_m3b1, W + pl->o_m3w2,
-                                             W + pl->o_m3g2, W + pl->o_m3b2, pl->pf.p, pl->ws_edge.p, pl->ws_edge.n, stv));
-            pl->mark(sb + 3);
+                PL_CHECK(sg::edgeconv_forward_marked(pl->x9m.p, pl->knn.p, N, 20, 2, W + pl->o_m3w1, W + pl->o_m3g1, W + pl->o_m3b1,
+                                                     W + pl->o_m3w2, W + pl->o_m3g2, W + pl->o_m3b2, pl->pf.p, pl->ws_edge.p,
+                                                     pl->ws_edge.n, stv, mark_pass));
             PL_CHECK(sg_segment_max(pl->pf.p, N, 64, pl->cluster_of_pos.p, cat + feat_prev_dim, Dcat, C, stv));
             pl->mark(sb + 4);
             PL_CHECK(sg_gcn_forward(cat, C, Dcat, dd + o.adj, E, dd + o.rowptr, dd + o.col, dd + o.eid, W + (layer == 0 ? pl->o_g2 : pl->o_g3),
@@ -462,6 +469,8 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
         float ms = 0.f;
         if (pl->ev_stage[i] >= 0 && hipEventElapsedTime(&ms, pl->ev[i - 1], pl->ev[i]) == hipSuccess) pl->stage_ms[pl->ev_stage[i]] += ms;
     }
+    pl->stage_ms[7] = pl->stage_ms[19] + pl->stage_ms[20];
+    pl->stage_ms[13] = pl->stage_ms[21] + pl->stage_ms[22] + pl->stage_ms[23];
     return SG_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <functional>
 #include <vector>
 
 #include "seggroup_hip.h"
@@ -40,6 +41,12 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_members, const int32_t* d_cl_off, int C, int P,
                     int ch_out, int transform, float* d_samples, int32_t* d_sel, void* d_ws, size_t ws_bytes, void* stream,
                     int max_n);
+
+// internal variant of sg_edgeconv_forward: `mark(i)` is called after pass i (0 = STATS1+fold, 1 = STATS2+fold
+// or FINAL1, 2 = FINAL2) so the pipeline can time the passes separately (kernels_edgeconv.hip)
+int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
+                            const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
+                            size_t ws_bytes, void* stream, const std::function<void(int)>& mark);
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -24,7 +24,7 @@ buf = (ctypes.c_ulonglong * 8)()
 lib.sg_debug_knn_stats(buf, 1)
 res = pipe.forward(ds, hip.MODE_INS_INFER)
 lib.sg_debug_knn_stats(buf, 1)
-print('knn stats (one scene, both layers): scanned(wave-cands) %d  appends(lane) %d  drain-iters(wave) %d  segs visited %d skipped %d' % tuple(buf[:5]))
+print('raw', list(buf)); print('knn stats (one scene, both layers): scanned(wave-cands) %d  appends(lane) %d  drain-iters(wave) %d  segs visited %d skipped %d' % tuple(buf[:5]))
 
 import numpy as np
 bt = (ctypes.c_ulonglong * 8192)()
