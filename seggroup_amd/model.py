@@ -24,6 +24,12 @@ import torch.nn as nn
 from . import hip
 from .scene import DeviceScene
 from . import weights as _weights
+from . import functional as _F
+# module-level functions of the reference's model.py, same names: the operator seam
+from .functional import (DisjointSet, aggregate_cluster_feature, build_distance_matrix, build_similarity_matrix,  # noqa: F401
+                         calculate_distance, calculate_similarity, combine_centralized_pointcloud, evaluate,
+                         export_instance_label, export_segment_label, export_semantic_label, farthest_point_sampling,
+                         get_cluster_pointcloud, get_knn, group_nearby_clusters, knn, l2_norm, update_adj)
 
 SEM_VALID_CLASS_IDS = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 24, 28, 33, 34, 36, 39])
 INS_VALID_CLASS_IDS = np.array([3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 24, 28, 33, 34, 36, 39])
@@ -36,12 +42,18 @@ class MLP1(nn.Module):
         self.bn1 = nn.BatchNorm2d(64)
         self.conv1 = nn.Sequential(nn.Conv2d(6, 64, kernel_size=1, bias=False), self.bn1, nn.LeakyReLU(negative_slope=0.2))
 
+    def forward(self, x):                                  # [S,6,64] -> [S,128]  (model.py:73-80)
+        return _F.mlp1_forward(x, self.conv1[0].weight, self.bn1.weight, self.bn1.bias)
+
 
 class MLP2(nn.Module):
     def __init__(self):
         super().__init__()
         self.bn1 = nn.BatchNorm2d(64)
         self.conv1 = nn.Sequential(nn.Conv2d(18, 64, kernel_size=1, bias=False), self.bn1, nn.LeakyReLU(negative_slope=0.2))
+
+    def forward(self, x, idx):                             # [1,9,N], [1,N,20] -> [1,64,N]  (model.py:114-118)
+        return _F.edgeconv_forward(x, idx, self.conv1[0].weight, self.bn1.weight, self.bn1.bias)
 
 
 class MLP3(nn.Module):
@@ -52,11 +64,23 @@ class MLP3(nn.Module):
         self.bn2 = nn.BatchNorm2d(64)
         self.conv2 = nn.Sequential(nn.Conv2d(64, 64, kernel_size=1, bias=False), self.bn2, nn.LeakyReLU(negative_slope=0.2))
 
+    def forward(self, x, idx):                             # model.py:133-138
+        return _F.edgeconv_forward(x, idx, self.conv1[0].weight, self.bn1.weight, self.bn1.bias,
+                                   self.conv2[0].weight, self.bn2.weight, self.bn2.bias)
+
 
 class GCN(nn.Module):
     def __init__(self, dim_in, dim_out):
         super().__init__()
         self.fc = nn.Linear(dim_in, dim_out, bias=False)
+
+    def forward(self, X, Edge):
+        """model.py:146-151.  `Edge` is either the reference's dense similarity matrix [S,S] or -- cheaper -- the
+        adjacency list [E,2] it was built from (the similarities are then recomputed sparsely on the device)."""
+        if Edge.dim() == 2 and Edge.shape[0] == Edge.shape[1] and Edge.shape[0] == X.shape[0] and Edge.is_floating_point():
+            iu = torch.nonzero(torch.triu(Edge, diagonal=1))
+            return _F.gcn_forward(X, iu, self.fc.weight)
+        return _F.gcn_forward(X, Edge, self.fc.weight)
 
 
 class Classifier(nn.Module):

@@ -1,0 +1,102 @@
+"""The reference's module-level functions (seggroup_amd.model re-exports them under the reference's names):
+a forward written the way the reference writes it (model.py:710-815), using only those functions, must
+reproduce the oracle's intermediate results and the golden layer-1..3 label vectors."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, make_fixture_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_style_forward_through_the_wrappers(tmp_path, golden_index, weight_sets):
+    import torch
+    from oracle import cpu_ref
+    from seggroup_amd import model as M
+    from seggroup_amd import synthetic
+    name = "tiny_4k"
+    sc = make_fixture_scene(golden_index, name)
+    g = load_golden(name)
+    ref = cpu_ref.forward_scene(sc, weight_sets["ins_infer"], "ins_infer", keep=True)
+    st = ref["stages"]
+    root = str(tmp_path)
+    synthetic.write_reference_tree(root, [sc])
+    net = M.SegModel(exp_name="w", ins_infer=True, data_root=root).to("cuda:0")
+    net.load_weights(weight_sets["ins_infer"])
+    data = torch.from_numpy(sc.data).cuda()
+    weak = torch.from_numpy(sc.weak_label).cuda()
+    unmap = torch.from_numpy(sc.unmap)
+    out_root = str(tmp_path / "out")
+
+    # --- graph initialisation (model.py:710-738) ---
+    ds = M.DisjointSet.from_seg_lists(weak[:, 1].cpu(), weak[:, 0].cpu(), sc.seg_lists())
+    adj_0 = torch.from_numpy(sc.adj).cuda()
+    cluster_unmap_0 = {i: i for i in range(data.shape[0])}
+    ds_list_1 = ds.get_cluster_list()
+    cluster_1, cluster_map_1, cluster_unmap_1 = {}, {}, {}
+    for i, indexs in enumerate(ds_list_1):
+        cluster_1[i] = indexs
+        cluster_map_1[ds.find(indexs[0])] = i
+        cluster_unmap_1[i] = ds.find(indexs[0])
+    adj_1 = M.update_adj(adj_0, ds, cluster_unmap_0, cluster_map_1)
+    assert np.array_equal(adj_1.cpu().numpy(), st["adj1"])
+    seg1 = M.export_segment_label(ds, cluster_unmap_1, out_root, unmap, layer=1)
+    ins1 = M.export_instance_label(ds, cluster_unmap_1, out_root, unmap, layer=1)
+    assert np.array_equal(seg1.numpy(), g["ins.label.layer_1.seg"]) and np.array_equal(ins1.numpy(), g["ins.label.layer_1.ins"])
+    assert [int(x) for x in open(f"{out_root}/layer_1.seg.txt").read().split()] == g["ins.label.layer_1.seg"].tolist()
+
+    # --- structural grouping layer (model.py:745-775) ---
+    data_1 = M.get_cluster_pointcloud(data, ds, point_num=64)
+    assert np.abs(data_1.cpu().numpy() - st["samples"]).max() < 1e-5
+    Feat_1 = net.mlp_1(data_1.transpose(2, 1))
+    assert np.abs(Feat_1.cpu().numpy() - st["feat1"]).max() < 1e-4
+    dists_1 = M.calculate_distance(Feat_1, adj_1)
+    assert np.abs(dists_1.cpu().numpy() - st["d1"]).max() < 1e-4
+    ds, adj_connected_1, adj_unconnected_1 = M.group_nearby_clusters(ds, dists_1, adj_1, cluster_unmap_1, th=6)
+    assert np.array_equal(ds.cluster_id, st["root2"])
+    ds_list_2 = ds.get_cluster_list()
+    cluster_2, cluster_map_2, cluster_unmap_2, cluster_2_to_1 = {}, {}, {}, {}
+    for i, indexs in enumerate(ds_list_2):
+        cluster_2[i] = indexs
+        cluster_map_2[ds.find(indexs[0])] = i
+        cluster_unmap_2[i] = ds.find(indexs[0])
+        cluster_2_to_1[i] = []
+    for j in range(len(ds_list_1)):
+        cluster_2_to_1[cluster_map_2[ds.find(cluster_unmap_1[j])]].append(j)
+    adj_2 = M.update_adj(adj_unconnected_1, ds, cluster_unmap_1, cluster_map_2)
+    assert np.array_equal(adj_2.numpy(), st["adj2"])
+    Feat_2 = M.aggregate_cluster_feature(Feat_1, cluster_2_to_1)
+    ins2 = M.export_instance_label(ds, cluster_unmap_2, out_root, unmap, layer=2)
+    sem2 = M.export_semantic_label(ds, cluster_unmap_2, out_root, unmap, layer=2)
+    assert np.array_equal(ins2.numpy(), g["ins.label.layer_2.ins"]) and np.array_equal(sem2.numpy(), g["ins.label.layer_2.sem"])
+
+    # --- semantic grouping layer 1 (model.py:786-815) ---
+    knn_2 = M.get_knn(data[:, :3], cluster_2, k=20)
+    assert np.array_equal(knn_2.cpu().numpy(), st["mlp_2"]["knn"])
+    data_2 = M.combine_centralized_pointcloud(data, ds)
+    Feat_mlp_2 = net.mlp_2(data_2.transpose(1, 0).unsqueeze(0), knn_2.unsqueeze(0))
+    Feat_mlp_2 = Feat_mlp_2.squeeze(0).transpose(1, 0).contiguous()
+    assert np.abs(Feat_mlp_2.cpu().numpy() - st["mlp_2"]["point_feat"]).max() < 1e-4
+    Feat_mlp_2 = M.aggregate_cluster_feature(Feat_mlp_2, cluster_2)
+    Feat_2 = torch.cat([Feat_2, Feat_mlp_2], dim=-1)
+    assert np.abs(Feat_2.cpu().numpy() - st["mlp_2"]["cat"]).max() < 1e-4
+    sims_2 = M.calculate_similarity(Feat_2, adj_2, alpha=1 / 8)
+    sim_matrix_2 = M.build_similarity_matrix(sims_2, adj_2.cuda(), size=Feat_2.shape[0])
+    Feat_2g = net.gcn_2(Feat_2, sim_matrix_2)
+    assert np.abs(Feat_2g.cpu().numpy() - st["mlp_2"]["gcn"]).max() < 1e-4
+    assert np.abs(net.gcn_2(Feat_2, adj_2).cpu().numpy() - st["mlp_2"]["gcn"]).max() < 1e-4      # sparse form
+    dists_2 = M.calculate_distance(Feat_2g, adj_2)
+    ds, _, adj_unconnected_2 = M.group_nearby_clusters(ds, dists_2, adj_2, cluster_unmap_2, th=2)
+    assert np.array_equal(ds.cluster_id, st["mlp_2"]["root"])
+    # evaluate() on the golden final labels reproduces the golden metric tensors
+    iou_sem, iou_ins, acc = M.evaluate(sc.name, torch.from_numpy(g["ins.label.final.sem"]), torch.from_numpy(g["ins.label.final.ins"]), root=root)
+    assert np.array_equal(iou_sem.numpy(), g["ins.metric.0"]) and np.array_equal(iou_ins.numpy(), g["ins.metric.1"])
+    assert np.allclose(acc.numpy(), g["ins.metric.2"], equal_nan=True)
+    # knn() in the reference's [B,C,n] form and farthest_point_sampling on one segment
+    m0 = np.asarray(cluster_2[0])
+    idx = M.knn(data[m0, :3].t().unsqueeze(0), 20) if len(m0) > 20 else None
+    if idx is not None:
+        assert np.array_equal(m0[idx[0].cpu().numpy()], st["mlp_2"]["knn"][m0])
+    seg0 = np.asarray(cluster_1[0])
+    picks, _ = M.farthest_point_sampling(data[seg0, :3], 5)
+    assert picks.shape == (1, 5) and np.array_equal(picks[0], cpu_ref.fps_with_fixup(sc.data[seg0, :3], 5))

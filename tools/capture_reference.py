@@ -41,7 +41,7 @@ FIXTURES = {
     "tiny_dup_4k": dict(n=4000, s=40, seed=12, kw=dict(dup_frac=0.05, raw_vertices=4500), full=True),
     "small_20k": dict(n=20000, s=200, seed=10000, kw={}, full=True),
     "scene_150k": dict(n=150000, s=1500, seed=20004, kw={}, full=False),
-    "stress_500k": dict(n=500000, s=5000, seed=50000, kw={}, full=False),
+    "stress_500k": dict(n=500000, s=5000, seed=50004, kw={}, full=False),
 }
 
 
