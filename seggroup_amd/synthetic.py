@@ -90,13 +90,17 @@ def _renumber_by_first_point(lab: np.ndarray) -> np.ndarray:
 
 def make_scene(num_points: int = 150000, num_segments: int = 1500, seed: int = 0, *,
                name: Optional[str] = None, knn_edges: int = 6, dup_frac: float = 0.0,
-               raw_vertices: Optional[int] = None, min_seg: int = 6) -> Scene:
+               raw_vertices: Optional[int] = None, min_seg: int = 6, island_radius: float = 0.0) -> Scene:
     """Build one synthetic scene.
 
     dup_frac > 0 overwrites that fraction of points with copies of other points (exact
     duplicates exercise the FPS / kNN tie quirks).
     raw_vertices = V != N adds a non-identity `unmap` (every resampled point is hit at
     least once when V >= N; extra raw vertices map to pseudo-random points).
+    island_radius > 0 moves every point within that radius of point 0 by +20 m in x BEFORE the
+    segmentation / adjacency are built and strips the weak labels there: an unlabeled, disconnected
+    component that ends up as cluster 0, i.e. the one situation in which group_unlabeled_clusters has to
+    fall back to FPS-1024 nearest-labelled-cluster merging (model.py:479-494).
     """
     from scipy.spatial import cKDTree
 
@@ -112,6 +116,17 @@ def make_scene(num_points: int = 150000, num_segments: int = 1500, seed: int = 0
         dst = randint(seed, 7, m, n)
         src = randint(seed, 8, m, n)
         data[dst] = data[src]
+
+    island = None
+    if island_radius > 0:
+        d0 = np.linalg.norm(data[:, :3].astype(np.float64) - data[0, :3].astype(np.float64), axis=1)
+        island = d0 < island_radius
+        data[island, 0] += np.float32(20.0)
+        # island points first: every island segment then has a smaller root id than any other cluster, so the
+        # (merged, isolated, unlabeled) island ends up as cluster 0, whose all-1000 distance row picks itself
+        order = np.argsort(~island, kind="stable")
+        data = data[order]
+        island = island[order]
 
     xyz = data[:, :3].astype(np.float64)
     tree = cKDTree(xyz)
@@ -157,6 +172,8 @@ def make_scene(num_points: int = 150000, num_segments: int = 1500, seed: int = 0
         weak[mask, 0] = ins_sem[k]
         weak[mask, 1] = k
 
+    if island is not None:
+        weak[island] = -1
     gt_pts = np.stack([ins_sem[seg_ins[seg]] + 1, seg_ins[seg] + 1], axis=1).astype(np.int64)
     if raw_vertices is None or raw_vertices == n:
         unmap = np.arange(n, dtype=np.int64)

@@ -55,7 +55,7 @@ def _run(scene, w, mode_name, debug=False):
     return res, taps, pipe
 
 
-@pytest.mark.parametrize("name", ["tiny_4k", "tiny_dup_4k", "small_20k"])
+@pytest.mark.parametrize("name", ["tiny_4k", "tiny_dup_4k", "small_20k", "island_20k"])
 @pytest.mark.parametrize("mode", ["ins_infer", "sem_infer"])
 def test_labels_and_metrics_match_reference_capture(golden_index, weight_sets, name, mode):
     from seggroup_amd import hip
@@ -70,9 +70,13 @@ def test_labels_and_metrics_match_reference_capture(golden_index, weight_sets, n
     assert np.array_equal(res.iou_sem, g[f"{pre}.metric.0"])
     assert np.array_equal(res.iou_ins, g[f"{pre}.metric.1"])
     assert np.allclose(res.acc, g[f"{pre}.metric.2"], rtol=0, atol=1e-7, equal_nan=True)
+    if mode == "ins_infer":
+        # island_20k has an unlabeled, disconnected component holding cluster 0: the FPS-1024 fallback
+        # (model.py:479-494) must have run there and nowhere else
+        assert res.used_fallback == (name == "island_20k")
 
 
-@pytest.mark.parametrize("name", ["tiny_4k", "tiny_dup_4k", "small_20k"])
+@pytest.mark.parametrize("name", ["tiny_4k", "tiny_dup_4k", "small_20k", "island_20k"])
 def test_stage_taps_match_oracle(golden_index, weight_sets, name):
     """Every stage tap of the pipeline vs the oracle (which tests/test_oracle_golden.py pins to the
     reference capture): adjacency lists and kNN tables bit-exact (same defined tie rule), floats

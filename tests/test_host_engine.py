@@ -43,7 +43,7 @@ class Engine:
         self.lib.sg_partition_destroy(self.p)
 
 
-@pytest.mark.parametrize("name", ["tiny_4k", "tiny_dup_4k", "small_20k"])
+@pytest.mark.parametrize("name", ["tiny_4k", "tiny_dup_4k", "small_20k", "island_20k"])
 def test_engine_follows_oracle_through_a_whole_scene(sg_lib, golden_index, weight_sets, name):
     """Drive the C++ engine with the oracle's decision distances: every layer's member lists (order
     included), contracted adjacency, export tables and the final-stage merges must be identical."""

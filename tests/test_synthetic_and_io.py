@@ -14,7 +14,7 @@ def _sha(a):
 
 
 def test_generator_reproduces_fixture_inputs(golden_index):
-    for name in ("tiny_4k", "tiny_dup_4k", "small_20k"):
+    for name in ("tiny_4k", "tiny_dup_4k", "small_20k", "island_20k"):
         sc = make_fixture_scene(golden_index, name)
         for k, want in golden_index[name]["input_sha"].items():
             assert _sha(getattr(sc, k)) == want, f"{name}.{k}: the generator drifted from the captured fixture inputs"

@@ -39,6 +39,7 @@ FIXTURES = {
     # name: (num_points, num_segments, seed, extra kwargs, store_full)
     "tiny_4k": dict(n=4000, s=40, seed=11, kw={}, full=True),
     "tiny_dup_4k": dict(n=4000, s=40, seed=12, kw=dict(dup_frac=0.05, raw_vertices=4500), full=True),
+    "island_20k": dict(n=20000, s=200, seed=10013, kw=dict(island_radius=1.2), full=True),
     "small_20k": dict(n=20000, s=200, seed=10000, kw={}, full=True),
     "scene_150k": dict(n=150000, s=1500, seed=20004, kw={}, full=False),
     "stress_500k": dict(n=500000, s=5000, seed=50004, kw={}, full=False),
