@@ -42,12 +42,13 @@ struct Lds {
     float a1[2][9][64];      // conv1 A fragments: a1[t][s][lane] = W1[32t + (lane&31)][2s + (lane>>5)]
     float a2[2][32][64];     // conv2 A fragments: a2[ot][st][lane] = W2[32ot + (lane&31)][acc_channel(st>>4, st&15, lane>>5)]
     float sh1[64];           // folded BN1 shift
+    float sh1r[2][2][16];    // the same, in accumulator-register order: sh1r[tile][half][reg] (b128 reads)
     float sh2[64];           // folded BN2 shift (or BN1 shift for MLP2's last layer)
     double acc[kWaves][128]; // per-wave statistics: [0,64) sum, [64,128) sum of squares
 };
 
 template <int MODE>
-__global__ __launch_bounds__(64 * kWaves) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
+__global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                                           const float* __restrict__ w1, const float* __restrict__ shift1,
                                                           const float* __restrict__ w2, const float* __restrict__ shift2,
                                                           float* __restrict__ out, double* __restrict__ partial) {
@@ -70,6 +71,8 @@ __global__ __launch_bounds__(64 * kWaves) void k_edgeconv(const float* __restric
     if (tid < 64) {
         lds.sh1[tid] = shift1 ? shift1[tid] : 0.f;
         lds.sh2[tid] = shift2 ? shift2[tid] : 0.f;
+        const int t_ = tid >> 5, h_ = (tid >> 4) & 1, q_ = tid & 15;
+        lds.sh1r[t_][h_][q_] = shift1 ? shift1[acc_channel(t_, q_, h_)] : 0.f;
     }
     if (kStats)
         for (int i = tid; i < kWaves * 128; i += 64 * kWaves) (&lds.acc[0][0])[i] = 0.0;
@@ -104,17 +107,20 @@ __global__ __launch_bounds__(64 * kWaves) void k_edgeconv(const float* __restric
 #pragma unroll
                 for (int q = 0; q < 16; ++q) best[t][q] = -INFINITY;
         }
-        f32x16 init1[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) init1[t][q] = kTwo ? lds.sh1[acc_channel(t, q, half)] : 0.f;
 
         const int32_t* krow = knn + (size_t)ptc * K;
+        // software pipeline: the next slot's neighbour row is requested before this slot's MFMAs start
+        int nb_next = krow[0];
+        const float4* xp = reinterpret_cast<const float4*>(x9m + (size_t)nb_next * 12);
+        float4 p0 = xp[0], p1 = xp[1], p2 = xp[2];
+        nb_next = K > 1 ? krow[1] : 0;
         for (int j = 0; j < K; ++j) {
-            const int nb = krow[j];
-            const float4* xn = reinterpret_cast<const float4*>(x9m + (size_t)nb * 12);
-            const float4 n0 = xn[0], n1 = xn[1], n2 = xn[2];
+            const float4 n0 = p0, n1 = p1, n2 = p2;
+            if (j + 1 < K) {
+                const float4* xq = reinterpret_cast<const float4*>(x9m + (size_t)nb_next * 12);
+                p0 = xq[0]; p1 = xq[1]; p2 = xq[2];
+                if (j + 2 < K) nb_next = krow[j + 2];
+            }
             const float d[9] = {n0.x - xi[0], n0.y - xi[1], n0.z - xi[2], n0.w - xi[3], n1.x - xi[4],
                                 n1.y - xi[5], n1.z - xi[6], n1.w - xi[7], n2.x - xi[8]};
             b[0] = half ? d[1] : d[0];
@@ -123,7 +129,23 @@ __global__ __launch_bounds__(64 * kWaves) void k_edgeconv(const float* __restric
             b[3] = half ? d[7] : d[6];
             b[4] = half ? xi[0] : d[8];
 
-            f32x16 acc1[2] = {init1[0], init1[1]};
+            // accumulator starts at the folded BN1 shift (inner layer) or at zero; re-read from LDS each slot
+            // (8 x ds_read_b128) instead of parking 32 VGPRs on it
+            f32x16 acc1[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (kTwo) {
+                    const float4* sp = reinterpret_cast<const float4*>(&lds.sh1r[t][half][0]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 v = sp[g];
+                        acc1[t][4 * g] = v.x; acc1[t][4 * g + 1] = v.y; acc1[t][4 * g + 2] = v.z; acc1[t][4 * g + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc1[t][q] = 0.f;
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
                 acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds.a1[0][s][lane], b[s], acc1[0], 0, 0, 0);
@@ -226,9 +248,17 @@ __global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ par
     __shared__ double part[8][128];
     __shared__ double tot[128];
     const int v = threadIdx.x & 127, g = threadIdx.x >> 7;
-    double s = 0.0;
-    for (int b = g; b < nblocks; b += 8) s += partial[(size_t)b * 128 + v];
-    part[g][v] = s;
+    // four independent chains per thread keep ~4 loads in flight (a single chain is one L2 round trip per add)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = g;
+    for (; b + 24 < nblocks; b += 32) {
+        s0 += partial[(size_t)b * 128 + v];
+        s1 += partial[(size_t)(b + 8) * 128 + v];
+        s2 += partial[(size_t)(b + 16) * 128 + v];
+        s3 += partial[(size_t)(b + 24) * 128 + v];
+    }
+    for (; b < nblocks; b += 8) s0 += partial[(size_t)b * 128 + v];
+    part[g][v] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (threadIdx.x < 128) {
         double t = 0.0;

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_pruned(
     static_assert(kBuf4 >= K, "the merge area aliases the append buffers");
     __shared__ float4 slab[kSlices][64 + kQuad];
     __shared__ unsigned long long buf[kBuf4][64 * kSlices];      // append buffers; later lists[slice][K][64]
-    __shared__ unsigned long long thr_pub[kSlices][64];
+    __shared__ unsigned int thr_pub[kSlices][64];             // published score part only: 32-bit LDS stores cannot tear
     const int t = blockIdx.x;
     const int c = tile_cl[t];
     const int clo = cl_off[c], n = cl_off[c + 1] - clo;
@@ -282,16 +282,20 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_pruned(
 #pragma unroll
     for (int j = 0; j < K; ++j) kv[j] = 0ull;
     unsigned long long thr = active ? 0ull : ~0ull;          // idle lanes never accept
-    thr_pub[wave][lane] = thr;
+    thr_pub[wave][lane] = (unsigned int)(thr >> 32);
     int cnt = 0;
     float4* cw = slab[wave];
     __syncthreads();
 
-    auto best_thr = [&]() {                                   // stale reads are fine: thresholds only rise
-        unsigned long long b = thr;
+    // Best published threshold, as a key with the index part cleared (= the weakest key of that score: ties at
+    // the threshold score are still accepted and settled exactly by the sorted lists).  Stale reads are fine:
+    // thresholds only rise.
+    auto best_thr = [&]() {
+        unsigned int b = 0u;
 #pragma unroll
-        for (int w = 0; w < kSlices; ++w) { const unsigned long long o = thr_pub[w][lane]; b = o > b ? o : b; }
-        return b;
+        for (int w = 0; w < kSlices; ++w) b = max(b, thr_pub[w][lane]);
+        const unsigned long long pub = (unsigned long long)b << 32;
+        return pub > thr ? pub : thr;
     };
     auto drain = [&]() {
         int mxc = cnt;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_pruned(
         }
         for (int u = 0; u < mxc; ++u) key_insert_par<K>(kv, u < cnt ? buf[u][tid] : 0ull);
         cnt = 0;
-        if (active) { thr = kv[K - 1]; thr_pub[wave][lane] = thr; }
+        if (active) { thr = kv[K - 1]; thr_pub[wave][lane] = (unsigned int)(thr >> 32); }
     };
 
     const int so0 = cl_seg_off[c], nslots = cl_seg_off[c + 1] - so0;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_pruned(
                 for (int w = 0; w < kSlices; ++w)
                     if (w == bw) { ++p[w]; h[w] = p[w] < K ? lists[((size_t)w * K + p[w]) * 64 + lane] : 0ull; }
             }
-            if (active) thr_pub[0][lane] = bk;                // the 20th best of the union (0 if fewer than 20 exist)
+            if (active) thr_pub[0][lane] = max(thr_pub[0][lane], (unsigned int)(bk >> 32));   // 20th best of the union (0 if < 20)
         }
         __syncthreads();
     }
