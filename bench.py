@@ -10,7 +10,8 @@ accumulators at the end).  Scenes are staged in HBM before the tim
 region covers everything SegModel.forward does for a scene (all kernels, the serial host grouping,
 D2H of the 14 label vectors and metrics) except writing the label files (reported separately as
 `with_npy_files`).  Several scenes are in flight per GPU (`--inflight` pipelines on separate HIP
-streams) so the host's serial grouping phases overlap other scenes' kernels.
+streams, driven by native host threads inside sg_batch_forward) so the host's serial grouping phases overlap
+other scenes' kernels.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job scenes/s, plus
   roofline     - the dominant kernel stage measured with HIP events on the pipelines' own streams
@@ -25,14 +26,15 @@ import json
 import os
 import sys
 import tempfile
-import threading
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one hardware queue per in-flight pipeline (HIP's default of 4 makes 4 streams + the null stream share queues);
+# must be set before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
@@ -66,13 +68,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline leg")
     ap.add_argument("--no-files", action="store_true", help="skip the separate with-files measurement")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU rehearsals)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
     from seggroup_amd import hip, synthetic, weights
-    from seggroup_amd.model import Pipeline, write_label_files
+    from seggroup_amd.model import write_label_files
     from seggroup_amd.scene import DeviceScene
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,11 +84,15 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     hip.require_device()
+    local = local % torch.cuda.device_count()          # several ranks on one GPU only in gloo rehearsals
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     W = weights.load_npz(os.path.join(ROOT, "tests", "golden", "weights_g2.npz"))
     # distinct synthetic scenes per rank (config 3 of BASELINE.json: batches of 150k/1.5k scenes)
@@ -93,39 +100,23 @@ def main():
     host_scenes = [synthetic.make_scene(args.points, args.segments, 30000 + 1000 * rank + i) for i in range(args.batch)]
     scenes = [DeviceScene.from_synthetic(s, device=dev) for s in host_scenes]
     gen_s = time.time() - t0
-    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
-    pipes = [Pipeline(W, *caps, stream=torch.cuda.Stream(device=dev), device=dev) for _ in range(args.inflight)]
-    free = list(pipes)
-    lock = threading.Lock()
-    stage_acc = {}
+    from seggroup_amd.model import BatchRunner
+    runner = BatchRunner(W, scenes, inflight=args.inflight, device=dev)
     acc = {"iou_sem": np.zeros(80), "iou_ins": np.zeros(80), "acc": np.zeros(4), "n": 0}
-    pool = ThreadPoolExecutor(max_workers=args.inflight)
-
-    def run_one(sc, write_dir=None, record=True):
-        with lock:
-            p = free.pop()
-        try:
-            r = p.forward(sc, hip.MODE_INS_INFER)
-            if write_dir is not None:
-                write_label_files(os.path.join(write_dir, sc.name), r, ("npy",))
-            st = p.stage_times() if record else None
-            with lock:
-                if record:
-                    for k_, v in st.items():
-                        a = stage_acc.setdefault(k_, [0.0, 0])
-                        a[0] += v
-                        a[1] += 1
-                    acc["iou_sem"] += r.iou_sem.reshape(-1)
-                    acc["iou_ins"] += r.iou_ins.reshape(-1)
-                    acc["acc"] += np.nan_to_num(r.acc)
-                    acc["n"] += 1
-            return r.trace
-        finally:
-            with lock:
-                free.append(p)
 
     def step(write_dir=None, record=True):
-        return list(pool.map(lambda s: run_one(s, write_dir, record), scenes))
+        """One step = every scene of the batch through SegModel.forward (sg_batch_forward: native host threads)."""
+        res = runner.run(scenes, hip.MODE_INS_INFER)
+        if write_dir is not None:
+            for sc_, r in zip(scenes, res):
+                write_label_files(os.path.join(write_dir, sc_.name), r, ("npy",))
+        if record:
+            for r in res:
+                acc["iou_sem"] += r.iou_sem.reshape(-1)
+                acc["iou_ins"] += r.iou_ins.reshape(-1)
+                acc["acc"] += np.nan_to_num(r.acc)
+                acc["n"] += 1
+        return [r.trace for r in res]
 
     def barrier():
         if world > 1:
@@ -134,6 +125,7 @@ def main():
 
     for _ in range(args.warmup):
         step(record=False)
+    runner.reset_stage_stats()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -141,21 +133,23 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_scenes = world * args.batch * args.steps
     value = total_scenes / elapsed
 
     # the path's only collective: one all-reduce of the float64 metric accumulators
-    vec = torch.from_numpy(np.concatenate([acc["iou_sem"], acc["iou_ins"], acc["acc"], [acc["n"]]])).to(dev)
+    vec = torch.from_numpy(np.concatenate([acc["iou_sem"], acc["iou_ins"], acc["acc"], [acc["n"]]]))
+    if args.backend == "nccl":
+        vec = vec.to(dev)
     if world > 1:
         dist.all_reduce(vec)
     vec = vec.cpu().numpy()
 
     out = None
     if rank == 0:
-        mean_ms = {k_: v[0] / max(v[1], 1) for k_, v in stage_acc.items()}
+        mean_ms = runner.mean_stage_ms()
         model = kernel_model(args.points)
         per_scene = {kn: sum(mean_ms.get(st, 0.0) for st in m[0]) for kn, m in model.items()}
         dom = max(per_scene, key=per_scene.get)                 # kernel with the largest device time per scene
@@ -220,7 +214,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    pool.shutdown()
 
 
 if __name__ == "__main__":

@@ -326,6 +326,13 @@ size_t sg_pipeline_device_bytes(const sg_pipeline* pl);
  * Thread-safe across DIFFERENT pipeline objects (one pipeline per in-flight scene). */
 int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* scene, int mode, sg_result* out, sg_debug* dbg);
 
+/* Many scenes through `npipes` pipelines: one native host thread per pipeline pulls scenes until all `count` are
+ * done (the infer.py:149-152 loop without the interpreter in it).  results[i].h_labels must point at [14,V_i]
+ * int32 host buffers (pinned for full D2H speed).  h_stage_ms_sum (may be NULL) accumulates the per-stage device
+ * times of every forward (same order as sg_pipeline_stage_name).  Blocks until every scene is done. */
+int sg_batch_forward(sg_pipeline* const* pipes, int npipes, const sg_scene* scenes, int count, int mode,
+                     sg_result* results, float* h_stage_ms_sum);
+
 /* per-stage device time of the last forward, in milliseconds (HIP events on the pipeline's stream);
  * names via sg_pipeline_stage_name(i), count returned. */
 int sg_pipeline_stage_times(const sg_pipeline* pl, float* h_ms, int capacity);

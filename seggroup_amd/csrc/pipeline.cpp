@@ -6,8 +6,13 @@
 // the serial grouping needs distances: after MLP1, after each of the two semantic layers, optionally
 // after the FPS-1024 fallback, and at the end (3-5 synchronisations).  Several pipelines on distinct
 // streams (one per in-flight scene) overlap their host phases with each other's kernels.
+#include <atomic>
 #include <cmath>
 #include <memory>
+#include <mutex>
+#include <thread>
+
+#include <string>
 
 #include "sg_common.h"
 
@@ -48,6 +53,7 @@ struct PinBuf {
 
 struct sg_pipeline {
     int maxN = 0, maxS = 0, maxE = 0, maxV = 0, maxT = 0;
+    int device = 0;
     hipStream_t stream = nullptr;
     size_t dev_bytes = 0, pin_bytes = 0;
 
@@ -126,6 +132,7 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
         return nullptr;
     }
     std::unique_ptr<sg_pipeline> pl(new sg_pipeline());
+    if (hipGetDevice(&pl->device) != hipSuccess) { sg::fail(SG_EHIP, "hipGetDevice failed"); return nullptr; }
     pl->maxN = maxN; pl->maxS = maxS; pl->maxE = maxE; pl->maxV = maxV;
     pl->maxT = maxN / 64 + maxS + 1;
     pl->stream = sg::as_stream(stream);
@@ -198,6 +205,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                "sg_pipeline_forward: scene (N=%d S=%d E0=%d V=%d) exceeds the pipeline capacity (N=%d S=%d E0=%d V=%d)", N, S, E0, V,
                pl->maxN, pl->maxS, pl->maxE, pl->maxV);
     SG_REQUIRE(out->h_labels, "sg_pipeline_forward: out->h_labels is null");
+    SG_HIP(hipSetDevice(pl->device));                     // the calling thread may be a fresh worker thread
     hipStream_t st = pl->stream;
     void* stv = (void*)st;
     const float* W = pl->w.p;
@@ -471,6 +479,45 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     }
     pl->stage_ms[7] = pl->stage_ms[19] + pl->stage_ms[20];
     pl->stage_ms[13] = pl->stage_ms[21] + pl->stage_ms[22] + pl->stage_ms[23];
+    return SG_OK;
+}
+
+// Batch driver (infer.py:149-152 loop body for many scenes): `npipes` host threads, one per pipeline, pull scene
+// indices from an atomic counter until all `count` scenes are done.  Everything between two scenes' kernels --
+// the grouping engine, descriptor building, result hand-over -- runs in these native threads, so one scene's
+// host phase overlaps the others' kernels without the Python interpreter in the loop.
+int sg_batch_forward(sg_pipeline* const* pipes, int npipes, const sg_scene* scenes, int count, int mode, sg_result* results,
+                     float* h_stage_ms_sum) {
+    if (!pipes || npipes <= 0 || count < 0 || (count > 0 && (!scenes || !results))) return sg::fail(SG_EINVAL, "sg_batch_forward: bad arguments");
+    std::atomic<int> next(0);
+    std::atomic<int> first_err(0);
+    std::mutex mu;
+    std::string msg;
+    std::vector<float> sums(kNumStages, 0.f);
+    auto worker = [&](int w) {
+        std::vector<float> mine(kNumStages, 0.f);
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= count || first_err.load() != 0) break;
+            const int rc = sg_pipeline_forward(pipes[w], &scenes[i], mode, &results[i], nullptr);
+            if (rc < 0) {
+                int zero = 0;
+                if (first_err.compare_exchange_strong(zero, rc)) { std::lock_guard<std::mutex> g(mu); msg = sg_last_error(); }
+                break;
+            }
+            for (int k = 0; k < kNumStages; ++k) mine[k] += pipes[w]->stage_ms[k];
+        }
+        std::lock_guard<std::mutex> g(mu);
+        for (int k = 0; k < kNumStages; ++k) sums[k] += mine[k];
+    };
+    std::vector<std::thread> th;
+    const int nt = std::min(npipes, std::max(count, 1));
+    for (int w = 1; w < nt; ++w) th.emplace_back(worker, w);
+    worker(0);
+    for (auto& t : th) t.join();
+    if (h_stage_ms_sum)
+        for (int k = 0; k < kNumStages; ++k) h_stage_ms_sum[k] += sums[k];
+    if (first_err.load() != 0) return sg::fail(first_err.load(), "sg_batch_forward: %s", msg.c_str());
     return SG_OK;
 }
 

@@ -96,6 +96,7 @@ SIGNATURES = {
     "sg_pipeline_destroy": (None, [vp]),
     "sg_pipeline_device_bytes": (_Z, [vp]),
     "sg_pipeline_forward": (_I, [vp, vp, _I, vp, vp]),
+    "sg_batch_forward": (_I, [vp, _I, vp, _I, _I, vp, vp]),
     "sg_pipeline_stage_times": (_I, [vp, vp, _I]),
     "sg_pipeline_stage_name": (C.c_char_p, [_I]),
     "sg_write_label_txt": (_I, [C.c_char_p, vp, _I]),

@@ -171,6 +171,53 @@ class Pipeline:
             pass
 
 
+class BatchRunner:
+    """Several scenes in flight on one GPU: `inflight` pipelines (one HIP stream each) driven by native host
+    threads inside `sg_batch_forward` -- no Python between a scene's kernels."""
+
+    def __init__(self, w: Dict[str, np.ndarray], scenes: List[DeviceScene], inflight: int = 4, device=None):
+        dev = torch.device(device if device is not None else scenes[0].device)
+        caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+        self.lib = hip.lib()
+        self.device = dev
+        self.pipes = [Pipeline(w, *caps, stream=torch.cuda.Stream(device=dev), device=dev) for _ in range(inflight)]
+        self._handles = (C.c_void_p * inflight)(*[p.handle for p in self.pipes])
+        self.max_v = caps[3]
+        self._labels = None
+        self._nstage = len(self.pipes[0].stage_times())
+        self.stage_sum = (C.c_float * 32)()
+        self.stage_count = 0
+
+    def run(self, scenes: List[DeviceScene], mode: int = hip.MODE_INS_INFER) -> List[SceneResult]:
+        n = len(scenes)
+        if self._labels is None or self._labels.shape[0] < n:
+            self._labels = torch.empty((n, hip.NUM_LABEL_VECTORS, self.max_v), dtype=torch.int32).pin_memory()
+        c_scenes = (hip.Scene * n)(*[s.c_struct for s in scenes])
+        c_res = (hip.Result * n)()
+        for i in range(n):
+            c_res[i].h_labels = self._labels[i].data_ptr()
+        with torch.cuda.device(self.device):
+            rc = self.lib.sg_batch_forward(self._handles, len(self.pipes), c_scenes, n, mode, c_res, self.stage_sum)
+        hip.check(rc)
+        self.stage_count += n
+        nvec = 14 if mode == hip.MODE_INS_INFER else 6
+        lab = self._labels.numpy()
+        return [SceneResult(lab[i][:, :scenes[i].V], nvec, c_res[i]) for i in range(n)]
+
+    def mean_stage_ms(self) -> Dict[str, float]:
+        names = [self.lib.sg_pipeline_stage_name(i).decode() for i in range(self._nstage)]
+        return {nm: float(self.stage_sum[i]) / max(self.stage_count, 1) for i, nm in enumerate(names)}
+
+    def reset_stage_stats(self):
+        for i in range(32):
+            self.stage_sum[i] = 0.0
+        self.stage_count = 0
+
+    def close(self):
+        for p in self.pipes:
+            p.close()
+
+
 def write_label_files(output_root: str, result: SceneResult, formats=("txt", "npy")) -> List[str]:
     """The a16 file side (model.py:536-547): `<name>.txt` one '%d\\n' per raw vertex, and `<name>.npy`."""
     lib = hip.lib()

@@ -42,7 +42,7 @@ FIXTURES = {
     "island_20k": dict(n=20000, s=200, seed=10013, kw=dict(island_radius=1.2), full=True),
     "small_20k": dict(n=20000, s=200, seed=10000, kw={}, full=True),
     "scene_150k": dict(n=150000, s=1500, seed=20004, kw={}, full=False),
-    "stress_500k": dict(n=500000, s=5000, seed=50004, kw={}, full=False),
+    "stress_500k": dict(n=500000, s=5000, seed=50005, kw={}, full=False),
 }
 
 
