@@ -125,6 +125,27 @@ def test_150k_scene_matches_reference_digests_and_oracle(golden_index, weight_se
     assert np.array_equal(res.iou_sem, g["ins.metric.0"]) and np.array_equal(res.iou_ins, g["ins.metric.1"])
 
 
+def test_stress_500k_matches_reference_and_oracle_digests(golden_index, weight_sets):
+    """BASELINE.json configs[4]: 500k points / 5k segments / 20-NN.  Labels must equal the digests of the
+    reference capture AND of the oracle (both committed in tests/golden/index.json; the seed was screened to be
+    reference-stable: captures A and B agree, minimum decision margin 4e-5)."""
+    from seggroup_amd import hip
+    name = "stress_500k"
+    scene = make_fixture_scene(golden_index, name)
+    res, _, pipe = _run(scene, weight_sets["ins_infer"], "ins_infer")
+    e = golden_index[name]["ins_infer"]
+    assert e["labels_A_equal_B"] and e["oracle_equals_reference"]
+    assert res.trace[1:5] == e["nclusters"] and res.trace == e["oracle_trace"]
+    for i in range(14):
+        nm = hip.LABEL_NAMES[i]
+        sha = hashlib.sha256(np.ascontiguousarray(res.labels[i]).tobytes()).hexdigest()
+        assert sha == e["oracle_label_sha"][nm], f"{nm}: HIP != oracle"
+        assert sha == e["label_sha"][nm], f"{nm}: HIP != reference capture"
+    g = load_golden(name)
+    assert np.array_equal(res.iou_sem, g["ins.metric.0"]) and np.array_equal(res.iou_ins, g["ins.metric.1"])
+    assert pipe.device_bytes() < 1 << 30          # one in-flight 500k scene needs < 1 GiB of the 288 GB
+
+
 def test_determinism_same_scene_twice(golden_index, weight_sets):
     scene = make_fixture_scene(golden_index, "small_20k")
     a, _, _ = _run(scene, weight_sets["ins_infer"], "ins_infer")
