@@ -52,7 +52,7 @@ def kernel_model(n_points: int, k: int = 20):
         "k_edgeconv<STATS1>": (["l2.edgeconv.stats1", "l3.edgeconv.stats1"], 2, "mfma", c1, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
         "k_edgeconv<FINAL1>": (["l2.edgeconv.final"], 1, "mfma", c1, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
         # kNN: reads [N,4] f32, writes [N,20] i32 (VALU-bound brute force inside clusters; HBM is its nominal roof)
-        "k_cluster_knn_pruned": (["l2.knn", "l3.knn"], 2, "hbm", 96.0 * n, "GB/s", HBM_PEAK_GBS, 1e9),
+        "k_cluster_knn_sorted": (["l2.knn", "l3.knn"], 2, "hbm", 96.0 * n, "GB/s", HBM_PEAK_GBS, 1e9),
     }
 
 

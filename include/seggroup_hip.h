@@ -160,6 +160,25 @@ int sg_cluster_knn_pruned(const float* d_xyzw, int N, const int32_t* d_cl_off,
                           const int32_t* d_seg_off, const float* d_segbox, const int32_t* d_slot_of_pos,
                           int k, int pos0, int32_t* d_knn, void* stream);
 
+/* Fastest variant (same tables again).  Once per scene sg_segment_spatial_sort puts the points of every original
+ * segment in Morton order (d_sperm[N]: sorted position -> index into d_seg_points) and boxes every run of 32
+ * sorted points (d_chunk_box [(sum_s ceil(size_s/32)), 8]; d_seg_chunk_off[S+1] = first chunk of each segment,
+ * computed by the caller from the segment sizes).  Per layer sg_knn_operands lays the kNN operand out in that
+ * order (d_sxyzw [N,4], d_smpos [N] = member position of each sorted position) and sg_cluster_knn_sorted scans
+ * only chunks whose box can still beat a lane's 20th best.  Tiles hold <= 64 SORTED positions of one cluster
+ * (same ranges as member order: sorting only permutes inside a segment). */
+size_t sg_spatial_sort_ws_bytes(int N);
+int sg_segment_spatial_sort(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off,
+                            const int32_t* d_seg_of_point, int S, const float* d_segbox, const int32_t* d_seg_chunk_off,
+                            int32_t* d_sperm, float* d_chunk_box, void* d_ws, size_t ws_bytes, void* stream);
+int sg_knn_operands(const float* d_data, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
+                    const int32_t* d_order, const int32_t* d_dst, float* d_sxyzw, int32_t* d_smpos, void* stream);
+int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off,
+                          const int32_t* d_tile_cl, const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T,
+                          const int32_t* d_cl_seg_off, const int32_t* d_order, const int32_t* d_dst,
+                          const int32_t* d_seg_off, const int32_t* d_seg_chunk_off, const float* d_segbox,
+                          const float* d_chunk_box, const int32_t* d_slot_of_pos, int k, int pos0, int32_t* d_knn, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a13  get_graph_feature2 + MLP2 / MLP3 (model.py:83-138): edge features [x_j - x_i, x_i] over the
  * k=20 table, conv1x1 18->64 (+ conv1x1 64->64 for layers == 2), BatchNorm2d with batch statistics

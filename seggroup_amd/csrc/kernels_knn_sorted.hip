@@ -1,0 +1,397 @@
+// In-cluster kNN-20 with spatially sorted candidates (reference seggroup/model.py:512-522, 30-36).
+//
+// Same result as k_cluster_knn / k_cluster_knn_pruned (bit-identical tables), much less work:
+//   * once per scene the points of every ORIGINAL over-segment are put in Morton order (one device radix sort
+//     keyed by segment | 30-bit Morton code inside the segment's box) and every run of 32 sorted points gets a
+//     bounding box;
+//   * per layer the kNN operand [x, y, z, |p|^2] and each point's member position are laid out in that order
+//     (clusters stay contiguous: only the order INSIDE a segment changes);
+//   * a workgroup = 64 spatially adjacent queries x 4 waves; the cluster's 32-point chunks are dealt round-robin
+//     to the waves and a chunk is scanned only if its box can still beat some lane's 20th best.  Adjacent queries
+//     share their neighbourhood, so after the queries' own segment almost every chunk is rejected by its box.
+// The 64-bit keys carry the MEMBER index, so ties resolve exactly as in the member-order scan ("lower member
+// index wins"), whatever order candidates arrive in.
+#include <cstdlib>
+
+#include <hipcub/hipcub.hpp>
+
+#include "knn_device.h"
+#include "sg_common.h"
+
+namespace {
+
+using namespace sgknn;
+
+constexpr int kChunkPts = 32;
+constexpr int kSlices = 4;
+constexpr int kBufS = 20;
+constexpr int kQuadS = 4;
+constexpr int kSlotBatch = 128;
+
+__device__ inline unsigned int spread10(unsigned int v) {      // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// i indexes the ascending CSR of the over-segmentation (seg_points); key = segment << 32 | morton30 in its box
+__global__ void k_morton_keys(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                              const int32_t* __restrict__ seg_of_point, const float* __restrict__ segbox, int N,
+                              unsigned long long* __restrict__ keys, int32_t* __restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int p = seg_points[i];
+    const int s = seg_of_point[p];
+    const float* b = segbox + (size_t)s * 8;
+    const float* r = data + (size_t)p * 6;
+    unsigned int q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float ext = b[3 + k] - b[k];
+        const float t = ext > 0.f ? (r[k] - b[k]) / ext : 0.f;
+        q[k] = (unsigned int)fminf(fmaxf(t * 1023.f, 0.f), 1023.f);
+    }
+    const unsigned int m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    keys[i] = ((unsigned long long)(unsigned int)s << 32) | m;
+    vals[i] = i;
+}
+
+// one wave per segment: boxes of its 32-point chunks in sorted order
+__global__ __launch_bounds__(64) void k_chunk_boxes(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                                                    const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
+                                                    const int32_t* __restrict__ sperm, float* __restrict__ chunk_box) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int lo = seg_off[s], n = seg_off[s + 1] - lo;
+    const int c0 = seg_chunk_off[s];
+    const int half = lane >> 5, l = lane & 31;                 // two chunks per iteration
+    for (int j = half; j * kChunkPts < n; j += 2) {
+        const int t = j * kChunkPts + l;
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, xx = 0.f;
+        if (t < n) {
+            const float* r = data + (size_t)seg_points[sperm[lo + t]] * 6;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { mn[k] = r[k]; mx[k] = r[k]; }
+            xx = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+            xx = fmaxf(xx, __shfl_xor(xx, o));
+        }
+        if (l == 0) {
+            float* b = chunk_box + (size_t)(c0 + j) * 8;
+            b[0] = mn[0]; b[1] = mn[1]; b[2] = mn[2]; b[3] = mx[0]; b[4] = mx[1]; b[5] = mx[2]; b[6] = xx; b[7] = 0.f;
+        }
+    }
+}
+
+// per layer: block i = i-th segment in member order; writes the operand and the member position in SORTED order
+__global__ void k_knn_operands(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                               const int32_t* __restrict__ seg_off, const int32_t* __restrict__ sperm,
+                               const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
+                               float4* __restrict__ sxyzw, int32_t* __restrict__ smpos) {
+    const int i = blockIdx.x;
+    const int s = order[i];
+    const int lo = seg_off[s], n = seg_off[s + 1] - lo, d = dst[i];
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        const int ci = sperm[lo + r];
+        const float* row = data + (size_t)seg_points[ci] * 6;
+        const float x = row[0], y = row[1], z = row[2];
+        sxyzw[d + r] = make_float4(x, y, z, (x * x + y * y) + z * z);     // torch.sum(x**2, dim=1)
+        smpos[d + r] = d + (ci - lo);
+    }
+}
+
+// profiling aid (SG_KNN_DEBUG & 16): [0] blocks, [1] cycles phase A, [2] merge A, [3] phase B, [4] final merge+write,
+// [5] chunks scanned (wave level), [6] chunks tested, [7] segments tested, [8] lane appends, [9] drain iterations
+__device__ unsigned long long g_knn5_stats[16];
+
+template <int K>
+__global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
+    const float4* __restrict__ sxyzw, const int32_t* __restrict__ smpos, const int32_t* __restrict__ cl_off,
+    const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi,
+    const int32_t* __restrict__ cl_seg_off, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
+    const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off, const float* __restrict__ segbox,
+    const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg) {
+    static_assert(kBufS >= K, "the merge area aliases the append buffers");
+    __shared__ float4 slab[kSlices][kChunkPts + kQuadS];
+    __shared__ int slab_i[kSlices][kChunkPts + kQuadS];
+    __shared__ unsigned long long buf[kBufS][64 * kSlices];     // append buffers; later lists[slice][K][64]
+    __shared__ unsigned int thr_pub[kSlices][64];
+    __shared__ float chunkbox_lds[kSlices][64];
+    __shared__ int st_m[kSlotBatch], st_c0[kSlotBatch], st_d[kSlotBatch];
+    __shared__ __attribute__((aligned(16))) float st_box[kSlotBatch][8];
+    const int t = blockIdx.x;
+    const int c = tile_cl[t];
+    const int clo = cl_off[c], n = cl_off[c + 1] - clo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = tile_lo[t] + lane;                          // SORTED position
+    const bool active = q < tile_hi[t];
+    const int myrow = active ? smpos[q] : 0;                  // member position = output row
+    if (n <= K) {                                            // model.py:516-518 (block-uniform)
+        if (active && wave == 0) {
+            int32_t* o = knn + (size_t)myrow * K;
+#pragma unroll
+            for (int j = 0; j < K; ++j) o[j] = j < n ? clo + j : pos0;
+        }
+        return;
+    }
+    const float4 me = active ? sxyzw[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned long long kv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) kv[j] = 0ull;
+    unsigned long long thr = active ? 0ull : ~0ull;          // idle lanes never accept
+    thr_pub[wave][lane] = (unsigned int)(thr >> 32);
+    int cnt = 0;
+    float4* cw = slab[wave];
+    int* ci = slab_i[wave];
+    __syncthreads();
+
+    auto best_thr = [&]() {                                   // published score parts only rise; stale reads are safe
+        unsigned int b = 0u;
+#pragma unroll
+        for (int w = 0; w < kSlices; ++w) b = max(b, thr_pub[w][lane]);
+        const unsigned long long pub = (unsigned long long)b << 32;
+        return pub > thr ? pub : thr;
+    };
+    auto drain = [&]() {
+        int mxc = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mxc = max(mxc, __shfl_xor(mxc, o));
+        if (dbg & 32) {
+            unsigned long long tot = cnt;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+            if (lane == 0) { atomicAdd(&g_knn5_stats[8], tot); atomicAdd(&g_knn5_stats[9], (unsigned long long)mxc); }
+        }
+        for (int u = 0; u < mxc; ++u) key_insert<K>(kv, u < cnt ? buf[u][tid] : 0ull);
+        cnt = 0;
+        if (active) { thr = kv[K - 1]; thr_pub[wave][lane] = (unsigned int)(thr >> 32); }
+    };
+    // one 32-point chunk: sorted positions [p0, p0 + m)
+    auto scan_chunk = [&](const float* bx, int p0, int m) {
+        const unsigned long long use = best_thr();
+        if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[6], 1ull);
+        if (!__any(make_key(box_score_bound(me, bx), 0) >= use)) return;
+        if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[5], 1ull);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < kChunkPts + kQuadS) {
+            const bool in = lane < m;
+            cw[lane] = in ? sxyzw[p0 + lane] : make_float4(0.f, 0.f, 0.f, INFINITY);
+            ci[lane] = in ? smpos[p0 + lane] - clo : 0x7fffffff;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < m; i += kQuadS) {
+#pragma unroll
+            for (int u = 0; u < kQuadS; ++u) {
+                const unsigned long long key = make_key(score4(me, cw[i + u]), ci[i + u]);
+                if (key > use && key > thr) {
+                    buf[cnt][tid] = key;
+                    ++cnt;
+                }
+            }
+            if (__any(cnt > kBufS - kQuadS)) drain();
+        }
+    };
+    const int so0 = cl_seg_off[c], nslots = cl_seg_off[c + 1] - so0;
+    const int own = slot_of_pos[active ? myrow : smpos[tile_lo[t]]] - so0;   // lanes of a tile may span segments: lane 0 decides
+    const int own0 = __shfl(own, 0);
+    auto slot_of = [&](int r) {
+        int sl = own0 + r;
+        if (sl >= nslots) sl -= nslots;
+        return so0 + sl;
+    };
+    // all chunks of one segment (descriptor already in registers / LDS); chunk number `item` decides which wave
+    // takes it.  The segment's chunk boxes are staged 8 at a time through a wave-private LDS strip (one coalesced
+    // load instead of one dependent global load per chunk).
+    float* cbx = &chunkbox_lds[wave][0];
+    auto scan_segment = [&](int sg_m, int sg_c0, int d, const float* sbox, int& item) {
+        const int nch = (sg_m + kChunkPts - 1) / kChunkPts;
+        const unsigned long long use = best_thr();
+        if ((dbg & 32) && lane == 0 && wave == 0) atomicAdd(&g_knn5_stats[7], 1ull);
+        if (!__any(make_key(box_score_bound(me, sbox), 0) >= use)) { item += nch; return; }
+        for (int j0 = 0; j0 < nch; j0 += 8) {
+            const int nb = min(8, nch - j0);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nb * 8) cbx[lane] = chunk_box[(size_t)(sg_c0 + j0) * 8 + lane];
+            __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < nb; ++j, ++item)
+                if ((item & (kSlices - 1)) == wave)
+                    scan_chunk(cbx + j * 8, d + (j0 + j) * kChunkPts, min(kChunkPts, sg_m - (j0 + j) * kChunkPts));
+        }
+    };
+
+    int item = 0;
+    const unsigned long long t0 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+    // phase A: the queries' own segment, its chunks dealt to the four waves; then the four partial lists are merged
+    // so that every lane publishes its exact 20th best so far
+    {
+        const int slot = slot_of(0), sg = order[slot];
+        float sbox[8];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sbox[k] = segbox[(size_t)sg * 8 + k];
+        scan_segment(seg_off[sg + 1] - seg_off[sg], seg_chunk_off[sg], dst[slot], sbox, item);
+    }
+    drain();
+    const unsigned long long t1 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+    __syncthreads();
+    {
+        unsigned long long* lists = &buf[0][0];               // [slice][K][64]; the append buffers are empty now
+#pragma unroll
+        for (int j = 0; j < K; ++j) lists[((size_t)wave * K + j) * 64 + lane] = kv[j];
+        __syncthreads();
+        if (wave == 0) {
+            int p[kSlices];
+            unsigned long long h[kSlices], bk = 0ull;
+#pragma unroll
+            for (int w = 0; w < kSlices; ++w) { p[w] = 0; h[w] = lists[((size_t)w * K) * 64 + lane]; }
+            for (int j = 0; j < K; ++j) {
+                int bw = 0;
+                bk = h[0];
+#pragma unroll
+                for (int w = 1; w < kSlices; ++w) if (h[w] > bk) { bk = h[w]; bw = w; }
+#pragma unroll
+                for (int w = 0; w < kSlices; ++w)
+                    if (w == bw) { ++p[w]; h[w] = p[w] < K ? lists[((size_t)w * K + p[w]) * 64 + lane] : 0ull; }
+            }
+            if (active) thr_pub[0][lane] = max(thr_pub[0][lane], (unsigned int)(bk >> 32));
+        }
+        __syncthreads();
+    }
+    const unsigned long long t2 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+    // phase B: every other segment of the cluster.  The segment descriptors (id, member offset, size, first chunk,
+    // box) are staged kSlotBatch at a time in LDS by the whole workgroup: walking the list straight from global
+    // memory costs two dependent round trips per segment and dominated the kernel for clusters of many segments.
+    for (int r0 = 1; r0 < nslots; r0 += kSlotBatch) {
+        const int nb = min(kSlotBatch, nslots - r0);
+        __syncthreads();                                      // previous batch fully consumed
+        if (tid < nb) {
+            const int slot = slot_of(r0 + tid), sg = order[slot];
+            st_m[tid] = seg_off[sg + 1] - seg_off[sg];
+            st_c0[tid] = seg_chunk_off[sg];
+            st_d[tid] = dst[slot];
+            const float4* bp = reinterpret_cast<const float4*>(segbox + (size_t)sg * 8);
+            reinterpret_cast<float4*>(&st_box[tid][0])[0] = bp[0];
+            reinterpret_cast<float4*>(&st_box[tid][0])[1] = bp[1];
+        }
+        __syncthreads();
+        for (int i = 0; i < nb; ++i) scan_segment(st_m[i], st_c0[i], st_d[i], &st_box[i][0], item);
+    }
+    drain();
+    const unsigned long long t3 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+    __syncthreads();                                          // every wave is done with its append buffer
+    unsigned long long* lists = &buf[0][0];
+#pragma unroll
+    for (int j = 0; j < K; ++j) lists[((size_t)wave * K + j) * 64 + lane] = kv[j];
+    __syncthreads();
+    if (wave == 0 && active) {
+        int p[kSlices];
+        unsigned long long h[kSlices];
+#pragma unroll
+        for (int w = 0; w < kSlices; ++w) { p[w] = 0; h[w] = lists[((size_t)w * K) * 64 + lane]; }
+        int32_t* o = knn + (size_t)myrow * K;
+        for (int j = 0; j < K; ++j) {
+            int bw = 0;
+            unsigned long long bk = h[0];
+#pragma unroll
+            for (int w = 1; w < kSlices; ++w) if (h[w] > bk) { bk = h[w]; bw = w; }
+            o[j] = clo + key_index(bk);
+#pragma unroll
+            for (int w = 0; w < kSlices; ++w)
+                if (w == bw) { ++p[w]; h[w] = p[w] < K ? lists[((size_t)w * K + p[w]) * 64 + lane] : 0ull; }
+        }
+    }
+    if ((dbg & 16) && lane == 0) {
+        const unsigned long long t4 = __builtin_readcyclecounter();
+        if (wave == 0) atomicAdd(&g_knn5_stats[0], 1ull);
+        atomicAdd(&g_knn5_stats[1], t1 - t0);
+        atomicAdd(&g_knn5_stats[2], t2 - t1);
+        atomicAdd(&g_knn5_stats[3], t3 - t2);
+        atomicAdd(&g_knn5_stats[4], t4 - t3);
+    }
+}
+
+}  // namespace
+
+static int g_knn5_dbg = getenv("SG_KNN_DEBUG") ? atoi(getenv("SG_KNN_DEBUG")) : 0;   // profiling knob (16 = counters + cycle stamps)
+
+extern "C" {
+
+// undocumented profiling aid: copies and clears the sorted-kNN work counters
+int sg_debug_knn5_stats(unsigned long long* h_out) {
+    SG_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_knn5_stats), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    SG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_knn5_stats), z, sizeof z));
+    return SG_OK;
+}
+
+size_t sg_spatial_sort_ws_bytes(int N) {
+    size_t temp = 0;
+    hipcub::DoubleBuffer<unsigned long long> dk(nullptr, nullptr);
+    hipcub::DoubleBuffer<int32_t> dv(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, dk, dv, std::max(N, 1), 0, 64, (hipStream_t)0);
+    const size_t n = (size_t)std::max(N, 1);
+    return sg::align_up(temp) + 2 * sg::align_up(n * 8) + 2 * sg::align_up(n * 4) + 256;
+}
+
+int sg_segment_spatial_sort(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off,
+                            const int32_t* d_seg_of_point, int S, const float* d_segbox, const int32_t* d_seg_chunk_off,
+                            int32_t* d_sperm, float* d_chunk_box, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(N >= 0 && S >= 0 && d_sperm && d_chunk_box && d_ws, "sg_segment_spatial_sort: bad arguments");
+    if (N == 0 || S == 0) return SG_OK;
+    hipStream_t st = sg::as_stream(stream);
+    size_t temp = 0;
+    {
+        hipcub::DoubleBuffer<unsigned long long> dk(nullptr, nullptr);
+        hipcub::DoubleBuffer<int32_t> dv(nullptr, nullptr);
+        SG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp, dk, dv, N, 0, 64, st));
+    }
+    sg::Carver cv(d_ws, ws_bytes);
+    char* tmp = cv.take<char>(temp);
+    unsigned long long* k0 = cv.take<unsigned long long>(N);
+    unsigned long long* k1 = cv.take<unsigned long long>(N);
+    int32_t* v0 = cv.take<int32_t>(N);
+    int32_t* v1 = cv.take<int32_t>(N);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_segment_spatial_sort: workspace too small (%zu < %zu)", ws_bytes, sg_spatial_sort_ws_bytes(N));
+    k_morton_keys<<<sg::cdiv(N, 256), 256, 0, st>>>(d_data, d_seg_points, d_seg_of_point, d_segbox, N, k0, v0);
+    int seg_bits = 1;
+    while ((1 << seg_bits) < S) ++seg_bits;
+    hipcub::DoubleBuffer<unsigned long long> dk(k0, k1);
+    hipcub::DoubleBuffer<int32_t> dv(v0, v1);
+    SG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, temp, dk, dv, N, 0, 32 + seg_bits, st));
+    SG_HIP(hipMemcpyAsync(d_sperm, dv.Current(), (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+    k_chunk_boxes<<<S, 64, 0, st>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_sperm, d_chunk_box);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_knn_operands(const float* d_data, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
+                    const int32_t* d_order, const int32_t* d_dst, float* d_sxyzw, int32_t* d_smpos, void* stream) {
+    SG_REQUIRE(S >= 0 && d_sxyzw && d_smpos, "sg_knn_operands: bad arguments");
+    if (S == 0) return SG_OK;
+    k_knn_operands<<<S, 128, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_sperm, d_order, d_dst,
+                                                        reinterpret_cast<float4*>(d_sxyzw), d_smpos);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off, const int32_t* d_tile_cl,
+                          const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T, const int32_t* d_cl_seg_off,
+                          const int32_t* d_order, const int32_t* d_dst, const int32_t* d_seg_off, const int32_t* d_seg_chunk_off,
+                          const float* d_segbox, const float* d_chunk_box, const int32_t* d_slot_of_pos, int k, int pos0,
+                          int32_t* d_knn, void* stream) {
+    SG_REQUIRE(N >= 0 && T >= 0 && d_knn && d_sxyzw && d_smpos, "sg_cluster_knn_sorted: bad arguments");
+    if (k != 20) return sg::fail(SG_EUNSUP, "sg_cluster_knn_sorted: only k == 20 is built (model.py:788,829), got %d", k);
+    if (T == 0) return SG_OK;
+    k_cluster_knn_sorted<20><<<T, 64 * kSlices, 0, sg::as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(d_sxyzw), d_smpos, d_cl_off, d_tile_cl, d_tile_lo, d_tile_hi, d_cl_seg_off, d_order, d_dst,
+        d_seg_off, d_seg_chunk_off, d_segbox, d_chunk_box, d_slot_of_pos, pos0, d_knn, g_knn5_dbg);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // extern "C"

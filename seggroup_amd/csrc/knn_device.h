@@ -1,0 +1,45 @@
+// Device helpers shared by the in-cluster kNN kernels (kernels_knn.hip, kernels_knn_sorted.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sgknn {
+
+// knn() score in the reference's fp32 operation order (model.py:31-33); this code is compiled
+// with -ffp-contract=off, the two FMAs are the ones MKL's K=3 dot product performs
+__device__ inline float score4(const float4& me, const float4& p) {
+    const float tt = __builtin_fmaf(me.z, p.z, __builtin_fmaf(me.y, p.y, me.x * p.x));
+    const float inner = -2.0f * tt;
+    return ((-p.w) - inner) - me.w;
+}
+
+// 64-bit key: order-preserving uint of the fp32 score << 32 | ~member index.  One unsigned compare implements
+// the total order (score descending, index ascending), independent of arrival order.
+__device__ inline unsigned long long make_key(float score, int idx) {
+    const unsigned int u = __float_as_uint(score);
+    const unsigned int o = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+    return ((unsigned long long)o << 32) | (unsigned int)(0xffffffffu - (unsigned int)idx);
+}
+__device__ inline int key_index(unsigned long long key) { return (int)(0xffffffffu - (unsigned int)(key & 0xffffffffu)); }
+
+// Sorted insertion in PARALLEL form: every slot decides independently from two compares (no K-step chain):
+// new[j] = x > old[j] ? (x > old[j-1] ? old[j-1] : x) : old[j]
+template <int K>
+__device__ inline void key_insert(unsigned long long (&kv)[K], unsigned long long x) {
+    bool c[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) c[j] = x > kv[j];
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) kv[j] = c[j] ? (c[j - 1] ? kv[j - 1] : x) : kv[j];
+    kv[0] = c[0] ? x : kv[0];
+}
+
+// upper bound of the score of ANY point inside an axis-aligned box {min xyz, max xyz, max |p|^2}:
+// -dmin^2 (shrunk by 1e-6) + 16 eps (|q|^2 + max |p|^2) -- the margin covers the fp32 rounding of score4()
+__device__ inline float box_score_bound(const float4& me, const float* bx) {
+    const float dx = fmaxf(fmaxf(bx[0] - me.x, me.x - bx[3]), 0.f);
+    const float dy = fmaxf(fmaxf(bx[1] - me.y, me.y - bx[4]), 0.f);
+    const float dz = fmaxf(fmaxf(bx[2] - me.z, me.z - bx[5]), 0.f);
+    return -((dx * dx + dy * dy) + dz * dz) * 0.999999f + 9.6e-7f * (me.w + bx[6]);
+}
+
+}  // namespace sgknn

@@ -62,12 +62,12 @@ struct sg_pipeline {
     size_t o_m1w, o_m1g, o_m1b, o_m2w, o_m2g, o_m2b, o_g2, o_m3w1, o_m3g1, o_m3b1, o_m3w2, o_m3g2, o_m3b2, o_g3;
 
     // device work buffers
-    DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_center, ws_eval;
-    DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, slot_of_pos, knn, desc, tables, labels;
-    DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf, segbox;
+    DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_center, ws_eval, ws_sort;
+    DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, slot_of_pos, sperm, smpos, seg_chunk_off, knn, desc, tables, labels;
+    DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf, segbox, chunk_box;
 
     // pinned host staging
-    PinBuf<int32_t> h_adj, h_desc, h_tables, h_count;
+    PinBuf<int32_t> h_adj, h_desc, h_tables, h_count, h_chunk_off;
     PinBuf<float> h_dist, h_feat, h_samples;
 
     hipEvent_t ev[kNumEvents];
@@ -184,8 +184,9 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->tables, SG_NUM_LABEL_VECTORS * S); D(pl->labels, SG_NUM_LABEL_VECTORS * V);
     D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
     D(pl->feat1, S * 128); D(pl->featA, S * 256); D(pl->featB, S * 256);
-    D(pl->segbox, S * 8); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64);
-    P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4);
+    D(pl->segbox, S * 8); D(pl->chunk_box, (N / 32 + S + 1) * 8); D(pl->sperm, N); D(pl->smpos, N); D(pl->seg_chunk_off, S + 1);
+    D(pl->ws_sort, sg_spatial_sort_ws_bytes(maxN)); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64);
+    P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4); P(pl->h_chunk_off, S + 1);
     P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
     if (bad) { sg::fail(SG_ENOMEM, "sg_pipeline_create: device/pinned allocation failed (N=%d S=%d E=%d V=%d)", maxN, maxS, maxE, maxV); return nullptr; }
     pl->dev_bytes = dev; pl->pin_bytes = pin;
@@ -240,6 +241,15 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     PL_CHECK(sg::fps_sample_hint(sc->d_data, N, 6, sc->d_seg_points, sc->d_seg_off, S, 64, 6, 1, pl->samples.p, nullptr, pl->ws_fps.p,
                                  pl->ws_fps.n, stv, max_seg));
     PL_CHECK(sg_segment_boxes(sc->d_data, sc->d_seg_points, sc->d_seg_off, S, pl->segbox.p, stv));
+    if (mode == SG_MODE_INS_INFER) {
+        // once per scene: Morton order inside every over-segment + boxes of its 32-point chunks (kNN pruning)
+        int32_t* co = pl->h_chunk_off.p;
+        co[0] = 0;
+        for (int s = 0; s < S; ++s) co[s + 1] = co[s] + (sc->h_seg_size[s] + 31) / 32;
+        PL_HIP(hipMemcpyAsync(pl->seg_chunk_off.p, co, (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
+        PL_CHECK(sg_segment_spatial_sort(sc->d_data, N, sc->d_seg_points, sc->d_seg_off, sc->d_seg_of_point, S, pl->segbox.p,
+                                         pl->seg_chunk_off.p, pl->sperm.p, pl->chunk_box.p, pl->ws_sort.p, pl->ws_sort.n, stv));
+    }
     pl->mark(1);
     PL_CHECK(sg_mlp1_forward(pl->samples.p, S, W + pl->o_m1w, W + pl->o_m1g, W + pl->o_m1b, pl->feat1.p, 128, pl->ws_mlp1.p,
                              pl->ws_mlp1.n, stv));
@@ -367,9 +377,11 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             // point 0 is the first member of segment 0; its member-order position is that segment's dst
             int pos0 = 0;
             for (int i = 0; i < S; ++i) if (Lnew.order[i] == 0) { pos0 = Lnew.dst[i]; break; }
-            PL_CHECK(sg_cluster_knn_pruned(pl->xyzw.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
-                                           dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->segbox.p, pl->slot_of_pos.p, 20,
-                                           pos0, pl->knn.p, stv));
+            PL_CHECK(sg_knn_operands(sc->d_data, sc->d_seg_points, sc->d_seg_off, pl->sperm.p, S, dd + o.order, dd + o.dst, pl->xyzw.p,
+                                     pl->smpos.p, stv));
+            PL_CHECK(sg_cluster_knn_sorted(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
+                                           dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->segbox.p,
+                                           pl->chunk_box.p, pl->slot_of_pos.p, 20, pos0, pl->knn.p, stv));
             pl->mark(sb + 2);
             // sub-pass marks: the last pass is marked with the stage id itself, so "lN.edgeconv" keeps meaning the
             // time of the LAST pass here and the reporting side adds the sub-passes up (see sg_pipeline_stage_times)

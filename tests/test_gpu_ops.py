@@ -409,5 +409,30 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
                                             k_prune.data_ptr(), None))
         a, b_ = k_brute.cpu().numpy(), k_prune.cpu().numpy()
         assert np.array_equal(a, b_), f"{name}/{target}: {int(np.any(a != b_, axis=1).sum())} rows differ between brute force and pruned"
+        # spatially sorted variant: Morton order inside every segment + 32-point chunk boxes
+        chunk_off = np.concatenate([[0], np.cumsum((np.diff(seg_off) + 31) // 32)]).astype(np.int32)
+        d_co = _up(torch, chunk_off)
+        sperm = torch.zeros(N, dtype=torch.int32, device="cuda:0")
+        cbox = torch.zeros(int(chunk_off[-1]) + 1, 8, device="cuda:0")
+        wss = _ws(torch, lib.sg_spatial_sort_ws_bytes(N))
+        d_sop = _up(torch, sc.seg)
+        hip.check(lib.sg_segment_spatial_sort(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), d_sop.data_ptr(), S,
+                                              box.data_ptr(), d_co.data_ptr(), sperm.data_ptr(), cbox.data_ptr(), wss.data_ptr(),
+                                              wss.numel(), None))
+        sp = sperm.cpu().numpy()
+        for s_ in (0, S - 1):      # a permutation of the segment's CSR range
+            assert sorted(sp[seg_off[s_]:seg_off[s_ + 1]].tolist()) == list(range(seg_off[s_], seg_off[s_ + 1]))
+        sxyzw = torch.zeros(N, 4, device="cuda:0")
+        smpos = torch.zeros(N, dtype=torch.int32, device="cuda:0")
+        hip.check(lib.sg_knn_operands(d_data.data_ptr(), d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S,
+                                      d["order"].data_ptr(), d["dst"].data_ptr(), sxyzw.data_ptr(), smpos.data_ptr(), None))
+        assert sorted(smpos.cpu().numpy().tolist()) == list(range(N))
+        k_sorted = torch.full((N, 20), -7, dtype=torch.int32, device="cuda:0")
+        hip.check(lib.sg_cluster_knn_sorted(sxyzw.data_ptr(), smpos.data_ptr(), N, d["off"].data_ptr(), d4[0].data_ptr(), d4[1].data_ptr(),
+                                            d4[2].data_ptr(), len(tc4), d["cso"].data_ptr(), d["order"].data_ptr(), d["dst"].data_ptr(),
+                                            d["segoff"].data_ptr(), d_co.data_ptr(), box.data_ptr(), cbox.data_ptr(), d_slot.data_ptr(), 20,
+                                            int(pos_of_point[0]), k_sorted.data_ptr(), None))
+        c_ = k_sorted.cpu().numpy()
+        assert np.array_equal(a, c_), f"{name}/{target}: {int(np.any(a != c_, axis=1).sum())} rows differ between brute force and sorted"
         ref = O.cluster_knn(sc.data[:, :3], L, 20)[members]
         assert np.array_equal(members[a], ref)

@@ -35,3 +35,13 @@ a = np.array(bt[:], dtype=np.float64); a = a[a > 0]
 if a.size:
     print('layer-3 knn wave runtimes (shader clocks): waves %d  sum %.3e  mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f' % (
         a.size, a.sum(), a.mean(), np.percentile(a, 50), np.percentile(a, 90), np.percentile(a, 99), a.max()))
+
+b5 = (ctypes.c_ulonglong * 16)()
+lib.sg_debug_knn5_stats(b5)
+res = pipe.forward(ds, hip.MODE_INS_INFER)
+lib.sg_debug_knn5_stats(b5)
+v = list(b5)
+if v[0]:
+    nb = v[0]
+    print('knn5 (one scene): blocks %d | per-wave cycles: phaseA %.0f mergeA %.0f phaseB %.0f final %.0f | per block: chunks scanned %.1f tested %.1f segs tested %.1f appends/lane %.1f drain iters/wave %.1f' % (
+        nb, v[1] / nb / 4, v[2] / nb / 4, v[3] / nb / 4, v[4] / nb / 4, v[5] / nb, v[6] / nb, v[7] / nb, v[8] / nb / 64, v[9] / nb / 4))
