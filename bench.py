@@ -9,7 +9,7 @@ grows; scenes are independent, no collective in the data path -- one RCCL all-re
 accumulators at the end).  Scenes are staged in HBM before the timed region; the timed
 region covers everything SegModel.forward does for a scene (all kernels, the serial host grouping,
 D2H of the 14 label vectors and metrics) except writing the label files (reported separately as
-`with_npy_files`).  Several scenes are in flight per GPU (`--inflight` pipelines on separate HIP
+`with_label_files_scenes_per_s`, through the asynchronous native writer pool).  Several scenes are in flight per GPU (`--inflight` pipelines on separate HIP
 streams, driven by native host threads inside sg_batch_forward) so the host's serial grouping phases overlap
 other scenes' kernels.
 
@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline leg")
     ap.add_argument("--no-files", action="store_true", help="skip the separate with-files measurement")
+    ap.add_argument("--writer-threads", type=int, default=8, help="native writer threads for the with-files leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU rehearsals)")
     args = ap.parse_args()
 
@@ -75,7 +76,6 @@ def main():
     import torch.distributed as dist
 
     from seggroup_amd import hip, synthetic, weights
-    from seggroup_amd.model import write_label_files
     from seggroup_amd.scene import DeviceScene
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,12 +104,9 @@ def main():
     runner = BatchRunner(W, scenes, inflight=args.inflight, device=dev)
     acc = {"iou_sem": np.zeros(80), "iou_ins": np.zeros(80), "acc": np.zeros(4), "n": 0}
 
-    def step(write_dir=None, record=True):
+    def step(record=True):
         """One step = every scene of the batch through SegModel.forward (sg_batch_forward: native host threads)."""
         res = runner.run(scenes, hip.MODE_INS_INFER)
-        if write_dir is not None:
-            for sc_, r in zip(scenes, res):
-                write_label_files(os.path.join(write_dir, sc_.name), r, ("npy",))
         if record:
             for r in res:
                 acc["iou_sem"] += r.iou_sem.reshape(-1)
@@ -166,14 +163,22 @@ def main():
                     "kernel_ms_per_scene": {kn: round(v, 4) for kn, v in per_scene.items()},
                     "stage_ms": {k_: round(v, 4) for k_, v in mean_ms.items()}}
 
-        with_files = None
+        with_files = {}
         if not args.no_files:
-            with tempfile.TemporaryDirectory(prefix="sgbench_") as td:
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                step(write_dir=td, record=False)
-                torch.cuda.synchronize()
-                with_files = args.batch / (time.perf_counter() - t1)
+            # file side (model.py:536-547), reported separately: the same step + the 14 label files of every
+            # scene written by the native writer pool (sg_writer_*), flushed inside the timed region
+            from seggroup_amd.model import AsyncLabelWriter
+            writer = AsyncLabelWriter(threads=args.writer_threads)
+            for fmts in (("npy",), ("txt", "npy")):
+                with tempfile.TemporaryDirectory(prefix="sgbench_") as td:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    dirs = [os.path.join(td, sc_.name) for sc_ in scenes]
+                    for _ in range(2):
+                        runner.run(scenes, hip.MODE_INS_INFER, writer=writer, out_dirs=dirs, formats=fmts)
+                    writer.flush()
+                    with_files["+".join(fmts)] = round(2 * args.batch / (time.perf_counter() - t1), 3)
+            writer.close()
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -206,7 +211,7 @@ def main():
                        "mode": "ins_infer", "scenes_per_step_per_gpu": args.batch, "inflight_pipelines": args.inflight,
                        "weights": "tests/golden/weights_g2.npz", "parallelism": f"scene-parallel x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
-            "with_npy_files_scenes_per_s": None if with_files is None else round(with_files, 3),
+            "with_label_files_scenes_per_s": with_files or None,
             "pseudo_label_mIoU": {"semantic": round(miou_sem, 4), "instance": round(miou_ins, 4), "scenes": int(vec[164])},
             "cluster_trace_scene0": list(traces[0]), "scene_generation_s": round(gen_s, 1),
         }

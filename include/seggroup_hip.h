@@ -347,10 +347,14 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* scene, int mode, sg_res
 
 /* Many scenes through `npipes` pipelines: one native host thread per pipeline pulls scenes until all `count` are
  * done (the infer.py:149-152 loop without the interpreter in it).  results[i].h_labels must point at [14,V_i]
- * int32 host buffers (pinned for full D2H speed).  h_stage_ms_sum (may be NULL) accumulates the per-stage device
+ * int32 host buffers, vector v at h_labels + v * V_i (pinned for full D2H speed).  h_stage_ms_sum (may be NULL) accumulates the per-stage device
  * times of every forward (same order as sg_pipeline_stage_name).  Blocks until every scene is done. */
+struct sg_writer;   /* asynchronous label-file writer pool, declared below */
+/* writer / out_dirs / formats (all optional): after each scene its label vectors are submitted to `writer` as
+ * <out_dirs[i]>/<layer_k.seg|ins|sem, final.ins|sem>.{txt,npy} (formats: 1 txt | 2 npy); directories must exist. */
 int sg_batch_forward(sg_pipeline* const* pipes, int npipes, const sg_scene* scenes, int count, int mode,
-                     sg_result* results, float* h_stage_ms_sum);
+                     sg_result* results, float* h_stage_ms_sum,
+                     struct sg_writer* writer, const char* const* out_dirs, int formats);
 
 /* per-stage device time of the last forward, in milliseconds (HIP events on the pipeline's stream);
  * names via sg_pipeline_stage_name(i), count returned. */
@@ -363,6 +367,15 @@ const char* sg_pipeline_stage_name(int i);
  * ============================================================================================= */
 int sg_write_label_txt(const char* path, const int32_t* h_vec, int V);
 int sg_write_label_npy(const char* path, const int32_t* h_vec, int V);
+
+/* Asynchronous writer pool: submit() copies h_vec and returns; `formats` = 1 txt | 2 npy | 3 both, written to
+ * <path_without_ext>.txt / .npy by one of `threads` native threads.  At most `max_queue` vectors are pending
+ * (submit blocks beyond that).  flush() waits for everything submitted so far and reports the first error. */
+typedef struct sg_writer sg_writer;
+sg_writer* sg_writer_create(int threads, int max_queue);
+int  sg_writer_submit(sg_writer* w, const char* path_without_ext, const int32_t* h_vec, int V, int formats);
+int  sg_writer_flush(sg_writer* w);
+void sg_writer_destroy(sg_writer* w);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,11 @@
 // Error plumbing, version / device probe, and the label-file writers (a16 file side,
 // reference seggroup/model.py:536-547) of libseggroup_hip.so.
 #include <cerrno>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "sg_common.h"
 
@@ -81,6 +85,96 @@ int sg_write_label_npy(const char* path, const int32_t* h_vec, int V) {
     w += fwrite(h_vec, 4, (size_t)V, f);
     if (fclose(f) != 0 || w != hdr.size() + (size_t)V) return sg::fail(SG_EINVAL, "sg_write_label_npy: short write to %s", path);
     return SG_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Asynchronous label writer: formatting 14 x V integers as text is ~8 MB per 150k scene, far
+// slower than the forward itself, so the files are written by a small pool of native threads while the next
+// scenes are already on the GPU.  submit() copies the vector, so the caller's (pinned) buffer is free at once.
+// ---------------------------------------------------------------------------------------------------------
+struct sg_writer {
+    struct Job { std::string base; std::vector<int32_t> vec; int formats; };
+    std::mutex mu;
+    std::condition_variable cv_job, cv_idle;
+    std::deque<Job> q;
+    std::vector<std::thread> threads;
+    size_t max_queue = 64;
+    int busy = 0;
+    bool stop = false;
+    int first_err = 0;
+    std::string err;
+
+    void run() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                j = std::move(q.front());
+                q.pop_front();
+                ++busy;
+            }
+            cv_idle.notify_all();
+            int rc = 0;
+            if (j.formats & 1) rc = sg_write_label_txt((j.base + ".txt").c_str(), j.vec.data(), (int)j.vec.size());
+            if (rc == 0 && (j.formats & 2)) rc = sg_write_label_npy((j.base + ".npy").c_str(), j.vec.data(), (int)j.vec.size());
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc < 0 && first_err == 0) { first_err = rc; err = sg_last_error(); }
+                --busy;
+            }
+            cv_idle.notify_all();
+        }
+    }
+};
+
+extern "C" {
+
+sg_writer* sg_writer_create(int threads, int max_queue) {
+    if (threads <= 0 || max_queue <= 0) { sg::fail(SG_EINVAL, "sg_writer_create: bad arguments"); return nullptr; }
+    auto* w = new sg_writer();
+    w->max_queue = (size_t)max_queue;
+    for (int i = 0; i < threads; ++i) w->threads.emplace_back([w] { w->run(); });
+    return w;
+}
+
+int sg_writer_submit(sg_writer* w, const char* path_without_ext, const int32_t* h_vec, int V, int formats) {
+    if (!w || !path_without_ext || (V > 0 && !h_vec) || V < 0 || !(formats & 3)) return sg::fail(SG_EINVAL, "sg_writer_submit: bad arguments");
+    sg_writer::Job j{path_without_ext, std::vector<int32_t>(h_vec, h_vec + V), formats};
+    {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv_idle.wait(lk, [&] { return w->q.size() < w->max_queue; });     // back-pressure: bounded memory
+        w->q.push_back(std::move(j));
+    }
+    w->cv_job.notify_one();
+    return SG_OK;
+}
+
+int sg_writer_flush(sg_writer* w) {
+    if (!w) return sg::fail(SG_EINVAL, "sg_writer_flush: null writer");
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv_idle.wait(lk, [&] { return w->q.empty() && w->busy == 0; });
+    if (w->first_err) {
+        const int rc = w->first_err;
+        const std::string msg = w->err;
+        w->first_err = 0;
+        return sg::fail(rc, "sg_writer: %s", msg.c_str());
+    }
+    return SG_OK;
+}
+
+void sg_writer_destroy(sg_writer* w) {
+    if (!w) return;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->stop = true;
+    }
+    w->cv_job.notify_all();
+    for (auto& t : w->threads) t.join();
+    delete w;
 }
 
 }  // extern "C"

@@ -498,8 +498,12 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
 // indices from an atomic counter until all `count` scenes are done.  Everything between two scenes' kernels --
 // the grouping engine, descriptor building, result hand-over -- runs in these native threads, so one scene's
 // host phase overlaps the others' kernels without the Python interpreter in the loop.
+static const char* kLabelNames[SG_NUM_LABEL_VECTORS] = {"layer_1.seg", "layer_1.ins", "layer_1.sem", "layer_2.seg", "layer_2.ins",
+                                                        "layer_2.sem", "layer_3.seg", "layer_3.ins", "layer_3.sem", "layer_4.seg",
+                                                        "layer_4.ins", "layer_4.sem", "final.ins", "final.sem"};
+
 int sg_batch_forward(sg_pipeline* const* pipes, int npipes, const sg_scene* scenes, int count, int mode, sg_result* results,
-                     float* h_stage_ms_sum) {
+                     float* h_stage_ms_sum, sg_writer* writer, const char* const* out_dirs, int formats) {
     if (!pipes || npipes <= 0 || count < 0 || (count > 0 && (!scenes || !results))) return sg::fail(SG_EINVAL, "sg_batch_forward: bad arguments");
     std::atomic<int> next(0);
     std::atomic<int> first_err(0);
@@ -518,6 +522,18 @@ int sg_batch_forward(sg_pipeline* const* pipes, int npipes, const sg_scene* scen
                 break;
             }
             for (int k = 0; k < kNumStages; ++k) mine[k] += pipes[w]->stage_ms[k];
+            if (writer && out_dirs && out_dirs[i]) {          // hand the label vectors to the writer pool (it copies them)
+                const int nvec = mode == SG_MODE_INS_INFER ? SG_NUM_LABEL_VECTORS : 6;
+                for (int v = 0; v < nvec && rc >= 0; ++v) {
+                    const std::string base = std::string(out_dirs[i]) + "/" + kLabelNames[v];
+                    const int wrc = sg_writer_submit(writer, base.c_str(), results[i].h_labels + (size_t)v * scenes[i].V, scenes[i].V, formats);
+                    if (wrc < 0) {
+                        int zero = 0;
+                        if (first_err.compare_exchange_strong(zero, wrc)) { std::lock_guard<std::mutex> g(mu); msg = sg_last_error(); }
+                        break;
+                    }
+                }
+            }
         }
         std::lock_guard<std::mutex> g(mu);
         for (int k = 0; k < kNumStages; ++k) sums[k] += mine[k];

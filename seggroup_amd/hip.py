@@ -100,11 +100,15 @@ SIGNATURES = {
     "sg_pipeline_destroy": (None, [vp]),
     "sg_pipeline_device_bytes": (_Z, [vp]),
     "sg_pipeline_forward": (_I, [vp, vp, _I, vp, vp]),
-    "sg_batch_forward": (_I, [vp, _I, vp, _I, _I, vp, vp]),
+    "sg_batch_forward": (_I, [vp, _I, vp, _I, _I, vp, vp, vp, vp, _I]),
     "sg_pipeline_stage_times": (_I, [vp, vp, _I]),
     "sg_pipeline_stage_name": (C.c_char_p, [_I]),
     "sg_write_label_txt": (_I, [C.c_char_p, vp, _I]),
     "sg_write_label_npy": (_I, [C.c_char_p, vp, _I]),
+    "sg_writer_create": (vp, [_I, _I]),
+    "sg_writer_submit": (_I, [vp, C.c_char_p, vp, _I, _I]),
+    "sg_writer_flush": (_I, [vp]),
+    "sg_writer_destroy": (None, [vp]),
 }
 
 _lib: Optional[C.CDLL] = None

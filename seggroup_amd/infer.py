@@ -169,6 +169,7 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
             with torch.no_grad():
                 out = model(data[None].to(dev, non_blocking=True), weak[None].to(dev, non_blocking=True), info[None])
             return tuple(o.cpu().numpy() for o in out)
+        forward_fn.flush = model.flush
 
     mine = scene_indices(len(scene_list), rank, world, args.sampler)
     acc = Accumulator()
@@ -177,6 +178,8 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         acc.add(*forward_fn(i))
         if rank == 0:   # rank 0's running view (the reference prints the all-reduced view every step)
             io.cprint(progress_line(min((step + 1) * world, len(scene_list)), len(scene_list), acc.summary()))
+    if forward_fn is not None and hasattr(forward_fn, "flush"):
+        forward_fn.flush()               # label files are written asynchronously: wait for them before reporting
     vec = torch.from_numpy(acc.v.copy())
     if world > 1:
         if dev is not None and args.backend == 'nccl':

@@ -188,16 +188,28 @@ class BatchRunner:
         self.stage_sum = (C.c_float * 32)()
         self.stage_count = 0
 
-    def run(self, scenes: List[DeviceScene], mode: int = hip.MODE_INS_INFER) -> List[SceneResult]:
+    def run(self, scenes: List[DeviceScene], mode: int = hip.MODE_INS_INFER, writer: "Optional[AsyncLabelWriter]" = None,
+            out_dirs: Optional[List[str]] = None, formats=("txt", "npy")) -> List[SceneResult]:
+        """Forward every scene; with `writer` + `out_dirs` the native threads also hand each scene's label vectors to
+        the writer pool (files appear asynchronously: call writer.flush())."""
         n = len(scenes)
+        if any(s.V != self.max_v for s in scenes):
+            raise ValueError("BatchRunner.run: scenes of one batch must share the vertex count (label rows are V-strided)")
         if self._labels is None or self._labels.shape[0] < n:
             self._labels = torch.empty((n, hip.NUM_LABEL_VECTORS, self.max_v), dtype=torch.int32).pin_memory()
         c_scenes = (hip.Scene * n)(*[s.c_struct for s in scenes])
         c_res = (hip.Result * n)()
         for i in range(n):
             c_res[i].h_labels = self._labels[i].data_ptr()
+        c_dirs, wh, fm = None, None, 0
+        if writer is not None and out_dirs is not None:
+            for d_ in out_dirs:
+                os.makedirs(d_, exist_ok=True)
+            c_dirs = (C.c_char_p * n)(*[d_.encode() for d_ in out_dirs])
+            wh = writer.handle
+            fm = (1 if "txt" in formats else 0) | (2 if "npy" in formats else 0)
         with torch.cuda.device(self.device):
-            rc = self.lib.sg_batch_forward(self._handles, len(self.pipes), c_scenes, n, mode, c_res, self.stage_sum)
+            rc = self.lib.sg_batch_forward(self._handles, len(self.pipes), c_scenes, n, mode, c_res, self.stage_sum, wh, c_dirs, fm)
         hip.check(rc)
         self.stage_count += n
         nvec = 14 if mode == hip.MODE_INS_INFER else 6
@@ -216,6 +228,39 @@ class BatchRunner:
     def close(self):
         for p in self.pipes:
             p.close()
+
+
+class AsyncLabelWriter:
+    """Pool of native threads writing label files (`sg_writer_*`): submit() copies the vectors and returns."""
+
+    def __init__(self, threads: int = 4, max_queue: int = 256):
+        self.lib = hip.lib()
+        self.handle = self.lib.sg_writer_create(threads, max_queue)
+        if not self.handle:
+            raise hip.SgError(hip.SG_EINVAL, self.lib.sg_last_error().decode())
+
+    def submit(self, output_root: str, result: "SceneResult", formats=("txt", "npy")) -> None:
+        os.makedirs(output_root, exist_ok=True)
+        fm = (1 if "txt" in formats else 0) | (2 if "npy" in formats else 0)
+        for i in range(result.n_vectors):
+            vec = np.ascontiguousarray(result.labels[i])
+            hip.check(self.lib.sg_writer_submit(self.handle, os.path.join(output_root, hip.LABEL_NAMES[i]).encode(), vec.ctypes.data,
+                                                vec.shape[0], fm))
+
+    def flush(self) -> None:
+        hip.check(self.lib.sg_writer_flush(self.handle))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.sg_writer_flush(self.handle)
+            self.lib.sg_writer_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def write_label_files(output_root: str, result: SceneResult, formats=("txt", "npy")) -> List[str]:
@@ -270,6 +315,8 @@ class SegModel(nn.Module):
         self._pipe_key = None
         self._scene_cache: Dict[str, DeviceScene] = {}
         self._lock = threading.Lock()
+        self._writer: Optional[AsyncLabelWriter] = None
+        self.async_write = True          # label files are written by native threads; flush() waits for them
         self.last_result: Optional[SceneResult] = None
 
     # -- parameters -> C ABI ----------------------------------------------------------------------
@@ -308,9 +355,19 @@ class SegModel(nn.Module):
         with self._lock:
             res = self.pipeline_for(sc).forward(sc, self.mode())
             if write:
-                write_label_files(self.output_root(sc.name), res, self.out_formats)
+                if self.async_write:
+                    if self._writer is None:
+                        self._writer = AsyncLabelWriter()
+                    self._writer.submit(self.output_root(sc.name), res, self.out_formats)
+                else:
+                    write_label_files(self.output_root(sc.name), res, self.out_formats)
             self.last_result = res
         return res
+
+    def flush(self) -> None:
+        """Wait until every label file submitted so far is on disk (raises on the first I/O error)."""
+        if self._writer is not None:
+            self._writer.flush()
 
     def forward(self, data, weak_label, info):
         data, weak_label, info = data[0], weak_label[0], info[0]

@@ -180,6 +180,7 @@ def test_dropin_forward_and_driver_write_reference_files(tmp_path, golden_index,
     data, weak, info = ScanNet("manual", root=root)[0]
     with torch.no_grad():
         iou_sem, iou_ins, acc = net(data[None].cuda(), weak[None].cuda(), info[None])
+    net.flush()                                            # label files are written by the async writer pool
     assert iou_sem.shape == (1, 2, 40) and iou_sem.is_cuda and acc.shape == (4,)
     assert np.array_equal(iou_sem.cpu().numpy(), g["ins.metric.0"]) and np.array_equal(iou_ins.cpu().numpy(), g["ins.metric.1"])
     out_dir = os_mod.path.join(root, "results", "exp", scene.name, "ins_infer")
@@ -194,3 +195,20 @@ def test_dropin_forward_and_driver_write_reference_files(tmp_path, golden_index,
     assert [int(x) for x in open(os_mod.path.join(out_dir, "final.ins.txt")).read().split()] == g["ins.label.final.ins"].tolist()
     log = open(os_mod.path.join(root, "checkpoints", "exp", "run_infer.log")).read()
     assert "Network parameters: 147880" in log and "Infer(0001/0001)" in log and "==> Infer" in log
+
+
+@pytest.mark.parametrize("n,s,seed", [(20000, 8, 77), (6000, 3, 78), (30000, 900, 79)])
+def test_unusual_segmentations_match_oracle(weight_sets, n, s, seed):
+    """Shapes the fixtures do not cover: a handful of huge over-segments (2.5k points each: FPS on the 16-wave
+    path, kNN chunks inside one segment, clusters of 1-3 segments) and very many tiny ones (33 points each: most
+    clusters at or below k = 20 neighbours after few merges).  HIP must equal the oracle computed on the spot."""
+    from oracle import cpu_ref
+    from seggroup_amd import hip, synthetic
+    scene = synthetic.make_scene(n, s, seed, min_seg=4)
+    res, _, _ = _run(scene, weight_sets["ins_infer"], "ins_infer")
+    ref = cpu_ref.forward_scene(scene, weight_sets["ins_infer"], "ins_infer")
+    assert res.trace == ref["trace"]
+    for i in range(14):
+        nm = hip.LABEL_NAMES[i]
+        assert np.array_equal(res.labels[i], ref["labels"][nm].astype(np.int32)), nm
+    assert np.array_equal(res.iou_sem, ref["metrics"][0]) and np.array_equal(res.iou_ins, ref["metrics"][1])

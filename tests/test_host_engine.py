@@ -165,3 +165,26 @@ def test_label_writers(sg_lib, tmp_path):
     assert sg_lib.sg_write_label_txt(str(tmp_path / "nodir" / "x.txt").encode(), vec.ctypes.data, len(vec)) < 0
     # the downstream consumers parse one int per line (pointgroup prepare_data_inst2.py:32-54)
     assert [int(x) for x in open(pt).read().split()] == vec.tolist()
+
+
+def test_async_writer_pool(sg_lib, tmp_path):
+    """sg_writer_*: many vectors through 3 threads with a tiny queue (back-pressure), byte-identical to the
+    synchronous writers; an unwritable path surfaces at flush()."""
+    from seggroup_amd import hip
+    rng = np.random.default_rng(0)
+    w = sg_lib.sg_writer_create(3, 2)
+    assert w
+    vecs = [rng.integers(-1, 200000, 5000).astype(np.int32) for _ in range(24)]
+    for i, v in enumerate(vecs):
+        assert sg_lib.sg_writer_submit(w, str(tmp_path / f"v{i}").encode(), v.ctypes.data, len(v), 3) == 0
+        v[:] = -7                                          # submit() copied: later changes must not leak
+    assert sg_lib.sg_writer_flush(w) == 0
+    rng = np.random.default_rng(0)
+    for i in range(24):
+        want = rng.integers(-1, 200000, 5000).astype(np.int32)
+        assert np.array_equal(np.load(tmp_path / f"v{i}.npy"), want)
+        assert [int(x) for x in open(tmp_path / f"v{i}.txt").read().split()] == want.tolist()
+    assert sg_lib.sg_writer_submit(w, str(tmp_path / "missing_dir" / "x").encode(), vecs[0].ctypes.data, 10, 1) == 0
+    assert sg_lib.sg_writer_flush(w) < 0 and b"cannot open" in sg_lib.sg_last_error()
+    assert sg_lib.sg_writer_flush(w) == 0                  # error reported once
+    sg_lib.sg_writer_destroy(w)
