@@ -121,7 +121,8 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     __shared__ float4 slab[kSlices][kChunkPts + kQuadS];
     __shared__ int slab_i[kSlices][kChunkPts + kQuadS];
     __shared__ unsigned long long buf[kBufS][64 * kSlices];     // append buffers; later lists[slice][K][64]
-    __shared__ unsigned int thr_pub[kSlices][64];
+    __shared__ unsigned int thr_pub[kSlices][64];             // score part of each slice's 20th best
+    __shared__ unsigned int thr5_pub[kSlices][64];            // score part of each slice's 5th best
     __shared__ float chunkbox_lds[kSlices][64];
     __shared__ int st_m[kSlotBatch], st_c0[kSlotBatch], st_d[kSlotBatch];
     __shared__ __attribute__((aligned(16))) float st_box[kSlotBatch][8];
@@ -146,16 +147,20 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     for (int j = 0; j < K; ++j) kv[j] = 0ull;
     unsigned long long thr = active ? 0ull : ~0ull;          // idle lanes never accept
     thr_pub[wave][lane] = (unsigned int)(thr >> 32);
+    thr5_pub[wave][lane] = 0u;
     int cnt = 0;
     float4* cw = slab[wave];
     int* ci = slab_i[wave];
     __syncthreads();
 
-    auto best_thr = [&]() {                                   // published score parts only rise; stale reads are safe
-        unsigned int b = 0u;
+    // Lower bounds of the query's final 20th-best key that need no merge: (a) any slice's own 20th best, (b) the
+    // weakest of the four slices' 5th bests (4 x 5 = 20 candidates are at least that good).  Published score parts
+    // only rise, so stale reads are safe; the index part is cleared (ties at the bound are still accepted).
+    auto best_thr = [&]() {
+        unsigned int b = 0u, m5 = 0xffffffffu;
 #pragma unroll
-        for (int w = 0; w < kSlices; ++w) b = max(b, thr_pub[w][lane]);
-        const unsigned long long pub = (unsigned long long)b << 32;
+        for (int w = 0; w < kSlices; ++w) { b = max(b, thr_pub[w][lane]); m5 = min(m5, thr5_pub[w][lane]); }
+        const unsigned long long pub = (unsigned long long)max(b, m5) << 32;
         return pub > thr ? pub : thr;
     };
     auto drain = [&]() {
@@ -170,7 +175,11 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
         }
         for (int u = 0; u < mxc; ++u) key_insert<K>(kv, u < cnt ? buf[u][tid] : 0ull);
         cnt = 0;
-        if (active) { thr = kv[K - 1]; thr_pub[wave][lane] = (unsigned int)(thr >> 32); }
+        if (active) {
+            thr = kv[K - 1];
+            thr_pub[wave][lane] = (unsigned int)(thr >> 32);
+            thr5_pub[wave][lane] = (unsigned int)(kv[4] >> 32);
+        }
     };
     // one 32-point chunk: sorted positions [p0, p0 + m)
     auto scan_chunk = [&](const float* bx, int p0, int m) {
@@ -227,8 +236,8 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
 
     int item = 0;
     const unsigned long long t0 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
-    // phase A: the queries' own segment, its chunks dealt to the four waves; then the four partial lists are merged
-    // so that every lane publishes its exact 20th best so far
+    // phase A: the queries' own segment, its chunks dealt to the four waves; afterwards best_thr() already is a tight
+    // bound (weakest of the four 5th bests) without merging the four partial lists
     {
         const int slot = slot_of(0), sg = order[slot];
         float sbox[8];
@@ -238,30 +247,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     }
     drain();
     const unsigned long long t1 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
-    __syncthreads();
-    {
-        unsigned long long* lists = &buf[0][0];               // [slice][K][64]; the append buffers are empty now
-#pragma unroll
-        for (int j = 0; j < K; ++j) lists[((size_t)wave * K + j) * 64 + lane] = kv[j];
-        __syncthreads();
-        if (wave == 0) {
-            int p[kSlices];
-            unsigned long long h[kSlices], bk = 0ull;
-#pragma unroll
-            for (int w = 0; w < kSlices; ++w) { p[w] = 0; h[w] = lists[((size_t)w * K) * 64 + lane]; }
-            for (int j = 0; j < K; ++j) {
-                int bw = 0;
-                bk = h[0];
-#pragma unroll
-                for (int w = 1; w < kSlices; ++w) if (h[w] > bk) { bk = h[w]; bw = w; }
-#pragma unroll
-                for (int w = 0; w < kSlices; ++w)
-                    if (w == bw) { ++p[w]; h[w] = p[w] < K ? lists[((size_t)w * K + p[w]) * 64 + lane] : 0ull; }
-            }
-            if (active) thr_pub[0][lane] = max(thr_pub[0][lane], (unsigned int)(bk >> 32));
-        }
-        __syncthreads();
-    }
+    __syncthreads();                                          // every slice has published its 5th / 20th best of the own segment
     const unsigned long long t2 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
     // phase B: every other segment of the cluster.  The segment descriptors (id, member offset, size, first chunk,
     // box) are staged kSlotBatch at a time in LDS by the whole workgroup: walking the list straight from global
