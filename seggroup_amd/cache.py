@@ -1,0 +1,126 @@
+"""Packed binary scene cache.
+
+The reference reads, per scene and per forward, three `.pth` files in the DataLoader (seggroup/data.py:34-37)
+plus `<s>.adj.pth`, `<s>.seg.json` (a 150k-entry list of lists, ~1.5 MB of JSON), the GT `.label.pth`
+and -- 14 times -- `<s>.unmap.pth` inside `SegModel.forward` (model.py:696-699,714,724,533,612).  That is ~60-80 ms
+of parsing per scene, 20x the GPU time of the whole forward here.  A pack is ONE file per (scene, label style):
+
+    magic "SGPACK01" | u32 header length | JSON header {name, N, S, E0, V, arrays: {name: [dtype, shape, offset]}} | raw arrays
+    (64-byte aligned, little endian)
+
+holding exactly the staged form `DeviceScene` needs: data f32[N,6], adj i64[E0,2], seg_of_point i32[N], the CSR of
+the `.seg.json` lists (seg_points i32[N], seg_off i32[S+1]), unmap i32[V], gt i32[V,2] and the per-segment host arrays
+(seg_first, seg_size, seg_ins, seg_sem i32[S]).  `load_pack` memory-maps the file and uploads each array once.
+Packs are derived data: they are rebuilt when any source file is newer.
+"""
+from __future__ import annotations
+
+import json
+import os
+import struct
+from typing import Dict, List, Optional
+
+import numpy as np
+
+MAGIC = b"SGPACK01"
+ARRAYS = ("data", "adj", "seg_of_point", "seg_points", "seg_off", "unmap", "gt", "seg_first", "seg_size", "seg_ins", "seg_sem")
+
+
+def pack_path(root: str, scene_name: str, label_style: str = "manual") -> str:
+    return os.path.join(root, "dataset", "scannet", "cache", label_style, scene_name + ".sgpack")
+
+
+def source_files(root: str, scene_name: str, label_style: str = "manual") -> List[str]:
+    base = os.path.join(root, "dataset", "scannet")
+    return [os.path.join(base, "data", "resampled", scene_name, scene_name + ".pcl.pth"),
+            os.path.join(base, "data", "resampled", scene_name, scene_name + ".unmap.pth"),
+            os.path.join(base, "label", "seg", label_style, "resampled", scene_name, scene_name + ".label.pth"),
+            os.path.join(base, "label", "real", "resampled", scene_name, scene_name + ".seg.json"),
+            os.path.join(base, "label", "real", "raw", scene_name, scene_name + ".label.pth"),
+            os.path.join(base, "adj", "mesh", "resampled", scene_name, scene_name + ".adj.pth")]
+
+
+def stage_arrays(data, weak_label, seg, adj, unmap, gt) -> Dict[str, np.ndarray]:
+    """The staged arrays of one scene from the reference's tensors (same derivation as DeviceScene.__init__)."""
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    weak_label = np.asarray(weak_label, dtype=np.int64)
+    seg = np.ascontiguousarray(seg, dtype=np.int32)
+    n = data.shape[0]
+    if data.shape[1] != 6 or weak_label.shape != (n, 2) or seg.shape != (n,):
+        raise ValueError("stage_arrays: inconsistent input shapes")
+    s = int(seg.max()) + 1
+    order = np.argsort(seg, kind="stable").astype(np.int32)
+    counts = np.bincount(seg, minlength=s).astype(np.int32)
+    off = np.zeros(s + 1, dtype=np.int32)
+    np.cumsum(counts, out=off[1:])
+    first = order[off[:-1]].astype(np.int32)
+    if s > 1 and not (np.diff(first) > 0).all():
+        raise ValueError("segment numbers must ascend with each segment's first point")
+    return dict(data=data, adj=np.ascontiguousarray(np.asarray(adj, dtype=np.int64).reshape(-1, 2)), seg_of_point=seg,
+                seg_points=order, seg_off=off, unmap=np.ascontiguousarray(unmap, dtype=np.int32),
+                gt=np.ascontiguousarray(gt, dtype=np.int32), seg_first=first, seg_size=counts,
+                seg_ins=np.ascontiguousarray(weak_label[first, 1], dtype=np.int32),
+                seg_sem=np.ascontiguousarray(weak_label[first, 0], dtype=np.int32))
+
+
+def write_pack(path: str, name: str, arrays: Dict[str, np.ndarray]) -> None:
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    meta, blobs, off = {}, [], 0
+    for k in ARRAYS:
+        a = np.ascontiguousarray(arrays[k])
+        meta[k] = [a.dtype.str, list(a.shape), off]
+        blobs.append(a)
+        off += (a.nbytes + 63) // 64 * 64
+    hdr = json.dumps({"name": name, "N": int(arrays["data"].shape[0]), "S": int(arrays["seg_first"].shape[0]),
+                      "E0": int(arrays["adj"].shape[0]), "V": int(arrays["unmap"].shape[0]), "arrays": meta}).encode()
+    pad = (64 - (len(MAGIC) + 4 + len(hdr)) % 64) % 64
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(MAGIC)
+        f.write(struct.pack("<I", len(hdr) + pad))
+        f.write(hdr + b" " * pad)
+        for a in blobs:
+            f.write(a.tobytes())
+            f.write(b"\0" * ((64 - a.nbytes % 64) % 64))
+    os.replace(tmp, path)                       # atomic: concurrent ranks may race to build the same pack
+
+
+def read_pack(path: str) -> Dict[str, object]:
+    """-> {'name', 'N', 'S', 'E0', 'V', arrays...} with the arrays as read-only memory maps."""
+    with open(path, "rb") as f:
+        if f.read(8) != MAGIC:
+            raise ValueError(f"{path}: not a SegGroup scene pack")
+        (hlen,) = struct.unpack("<I", f.read(4))
+        hdr = json.loads(f.read(hlen).decode())
+    base = 12 + hlen
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    out = {k: hdr[k] for k in ("name", "N", "S", "E0", "V")}
+    for k, (dt, shape, off) in hdr["arrays"].items():
+        n = int(np.prod(shape)) * np.dtype(dt).itemsize
+        out[k] = mm[base + off: base + off + n].view(np.dtype(dt)).reshape(shape)
+    return out
+
+
+def pack_scene(root: str, scene_name: str, label_style: str = "manual", force: bool = False) -> str:
+    """Build (or reuse) the pack of one scene of the reference's on-disk tree; returns its path."""
+    import torch
+    from .scene import seg_from_lists
+
+    path = pack_path(root, scene_name, label_style)
+    src = source_files(root, scene_name, label_style)
+    if not force and os.path.exists(path) and os.path.getmtime(path) >= max(os.path.getmtime(p) for p in src):
+        return path
+    ld = lambda p: torch.load(p, map_location="cpu")
+    data, unmap, weak = ld(src[0]).numpy(), ld(src[1]).numpy(), ld(src[2]).numpy()
+    with open(src[3]) as f:
+        seg = seg_from_lists(json.load(f), data.shape[0])
+    gt, adj = ld(src[4]).numpy(), ld(src[5]).numpy()
+    write_pack(path, scene_name, stage_arrays(data, weak, seg, adj, unmap, gt))
+    return path
+
+
+def load_pack(path: str, device="cuda"):
+    """Pack -> DeviceScene (each array uploaded once from the memory map)."""
+    from .scene import DeviceScene
+    p = read_pack(path)
+    return DeviceScene.from_staged({k: p[k] for k in ARRAYS}, name=p["name"], device=device)

@@ -52,6 +52,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--world-size', type=int, default=0, help='processes to spawn (default: one per visible GPU)')
     p.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL on ROCm)')
     p.add_argument('--port', type=int, default=2344, help='rendezvous port on 127.0.0.1 (reference: 2344)')
+    p.add_argument('--batch', type=int, default=8, help='scenes per batch in the packed fast path (0 = the per-scene SegModel.forward loop)')
+    p.add_argument('--inflight', type=int, default=4, help='pipelines (HIP streams) per GPU in the packed fast path')
+    p.add_argument('--no-cache', action='store_true', help='do not build / use packed scene files (dataset/scannet/cache/...)')
     return p
 
 
@@ -174,10 +177,16 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
     mine = scene_indices(len(scene_list), rank, world, args.sampler)
     acc = Accumulator()
     t0 = time.time()
-    for step, i in enumerate(mine):
-        acc.add(*forward_fn(i))
-        if rank == 0:   # rank 0's running view (the reference prints the all-reduced view every step)
-            io.cprint(progress_line(min((step + 1) * world, len(scene_list)), len(scene_list), acc.summary()))
+    fast = dev is not None and args.batch > 0 and not args.no_cache
+    if fast:
+        # packed fast path: scene packs are built once, loader threads stage the next batch while the
+        # GPU runs the current one through sg_batch_forward, label files are written by the native writer pool
+        _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev)
+    else:
+        for step, i in enumerate(mine):
+            acc.add(*forward_fn(i))
+            if rank == 0:   # rank 0's running view (the reference prints the all-reduced view every step)
+                io.cprint(progress_line(min((step + 1) * world, len(scene_list)), len(scene_list), acc.summary()))
     if forward_fn is not None and hasattr(forward_fn, "flush"):
         forward_fn.flush()               # label files are written asynchronously: wait for them before reporting
     vec = torch.from_numpy(acc.v.copy())
@@ -198,6 +207,46 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
+    from concurrent.futures import ThreadPoolExecutor
+    from . import cache, hip
+    from .model import AsyncLabelWriter, BatchRunner
+
+    names = [scene_list[i][:-1] for i in mine]
+    formats = tuple(args.out_format.split(','))
+    mode = hip.MODE_SEM_INFER if args.sem_infer else hip.MODE_INS_INFER
+    workers = max(1, int(args.workers))
+
+    def stage(name):
+        return cache.load_pack(cache.pack_scene(args.root, name, args.label_style), device=dev)
+
+    pool = ThreadPoolExecutor(max_workers=workers)
+    batches = [names[k:k + args.batch] for k in range(0, len(names), args.batch)]
+    pending = [pool.submit(stage, n) for n in batches[0]] if batches else []
+    writer = AsyncLabelWriter(threads=max(2, workers))
+    runner, done = None, 0
+    w = model.export_weights()
+    for bi, batch in enumerate(batches):
+        scenes = [f.result() for f in pending]
+        pending = [pool.submit(stage, n) for n in batches[bi + 1]] if bi + 1 < len(batches) else []
+        if runner is None or any(not runner.pipes[0].fits(s_) for s_ in scenes):
+            caps = [runner.pipes[0].caps] if runner is not None else []
+            if runner is not None:
+                runner.close()
+            runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps[0] if caps else None)
+        res = runner.run(scenes, mode, writer=writer, out_dirs=[model.output_root(s_.name) for s_ in scenes], formats=formats)
+        for r in res:
+            acc.add(r.iou_sem, r.iou_ins, r.acc)
+            done += 1
+            if rank == 0:
+                io.cprint(progress_line(min(done * world, len(scene_list)), len(scene_list), acc.summary()))
+    writer.flush()
+    writer.close()
+    if runner is not None:
+        runner.close()
+    pool.shutdown()
 
 
 def _spawn_entry(rank, world, args):

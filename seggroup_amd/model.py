@@ -148,7 +148,8 @@ class Pipeline:
                                               C.byref(debug) if debug is not None else None)
         hip.check(rc)
         nvec = 14 if mode == hip.MODE_INS_INFER else 6
-        lab = self.labels.numpy()[:, :sc.V]
+        # the C side packs the vectors at stride V of THIS scene (include/seggroup_hip.h, sg_result.h_labels)
+        lab = self.labels.numpy().reshape(-1)[:hip.NUM_LABEL_VECTORS * sc.V].reshape(hip.NUM_LABEL_VECTORS, sc.V)
         return SceneResult(lab, nvec, res)
 
     def stage_times(self) -> Dict[str, float]:
@@ -175,9 +176,11 @@ class BatchRunner:
     """Several scenes in flight on one GPU: `inflight` pipelines (one HIP stream each) driven by native host
     threads inside `sg_batch_forward` -- no Python between a scene's kernels."""
 
-    def __init__(self, w: Dict[str, np.ndarray], scenes: List[DeviceScene], inflight: int = 4, device=None):
+    def __init__(self, w: Dict[str, np.ndarray], scenes: List[DeviceScene], inflight: int = 4, device=None, min_caps=None):
         dev = torch.device(device if device is not None else scenes[0].device)
         caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+        if min_caps is not None:                    # regrowing: never shrink below the previous capacities
+            caps = tuple(max(a, b) for a, b in zip(caps, min_caps))
         self.lib = hip.lib()
         self.device = dev
         self.pipes = [Pipeline(w, *caps, stream=torch.cuda.Stream(device=dev), device=dev) for _ in range(inflight)]
@@ -193,8 +196,8 @@ class BatchRunner:
         """Forward every scene; with `writer` + `out_dirs` the native threads also hand each scene's label vectors to
         the writer pool (files appear asynchronously: call writer.flush())."""
         n = len(scenes)
-        if any(s.V != self.max_v for s in scenes):
-            raise ValueError("BatchRunner.run: scenes of one batch must share the vertex count (label rows are V-strided)")
+        if any(not self.pipes[0].fits(s) for s in scenes):
+            raise ValueError("BatchRunner.run: a scene exceeds the capacities this runner was created with")
         if self._labels is None or self._labels.shape[0] < n:
             self._labels = torch.empty((n, hip.NUM_LABEL_VECTORS, self.max_v), dtype=torch.int32).pin_memory()
         c_scenes = (hip.Scene * n)(*[s.c_struct for s in scenes])
@@ -214,7 +217,8 @@ class BatchRunner:
         self.stage_count += n
         nvec = 14 if mode == hip.MODE_INS_INFER else 6
         lab = self._labels.numpy()
-        return [SceneResult(lab[i][:, :scenes[i].V], nvec, c_res[i]) for i in range(n)]
+        nv = hip.NUM_LABEL_VECTORS                  # scene i's vectors are packed at stride V_i inside its slot
+        return [SceneResult(lab[i].reshape(-1)[:nv * scenes[i].V].reshape(nv, scenes[i].V), nvec, c_res[i]) for i in range(n)]
 
     def mean_stage_ms(self) -> Dict[str, float]:
         names = [self.lib.sg_pipeline_stage_name(i).decode() for i in range(self._nstage)]

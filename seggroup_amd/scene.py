@@ -38,43 +38,37 @@ class DeviceScene:
     """One scene resident on a HIP device (torch tensors) + the segment-level host arrays."""
 
     def __init__(self, data, weak_label, seg, adj, unmap, gt, device="cuda", name: str = "scene"):
+        from .cache import stage_arrays
+        self._from_staged(stage_arrays(data, weak_label, seg, adj, unmap, gt), name, device)
+
+    @classmethod
+    def from_staged(cls, arrays, name: str = "scene", device="cuda") -> "DeviceScene":
+        """From the staged arrays of `cache.stage_arrays` / a scene pack (no recomputation, one upload per array)."""
+        self = cls.__new__(cls)
+        self._from_staged(arrays, name, device)
+        return self
+
+    def _from_staged(self, a, name, device):
         import torch
 
-        data = np.ascontiguousarray(data, dtype=np.float32)
-        weak_label = np.asarray(weak_label, dtype=np.int64)
-        seg = np.ascontiguousarray(seg, dtype=np.int32)
-        adj = np.ascontiguousarray(np.asarray(adj, dtype=np.int64).reshape(-1, 2))
-        unmap = np.ascontiguousarray(unmap, dtype=np.int32)
-        gt = np.ascontiguousarray(gt, dtype=np.int32)
-        n = data.shape[0]
-        if data.shape[1] != 6 or weak_label.shape != (n, 2) or seg.shape != (n,):
-            raise ValueError("DeviceScene: inconsistent input shapes")
-        s = int(seg.max()) + 1
-        order = np.argsort(seg, kind="stable").astype(np.int32)     # points ascending inside each segment
-        counts = np.bincount(seg, minlength=s).astype(np.int32)
-        off = np.zeros(s + 1, dtype=np.int32)
-        np.cumsum(counts, out=off[1:])
-        first = order[off[:-1]].astype(np.int32)
-        if s > 1 and not (np.diff(first) > 0).all():
-            raise ValueError("segment numbers must ascend with each segment's first point (see synthetic._renumber_by_first_point)")
         self.name = name
-        self.N, self.S, self.E0, self.V = n, s, int(adj.shape[0]), int(unmap.shape[0])
-        # host, segment level
-        self.h_seg_first = first
-        self.h_seg_size = counts
-        self.h_seg_ins = np.ascontiguousarray(weak_label[first, 1], dtype=np.int32)
-        self.h_seg_sem = np.ascontiguousarray(weak_label[first, 0], dtype=np.int32)
-        # device
+        self.N, self.S = int(a["data"].shape[0]), int(a["seg_first"].shape[0])
+        self.E0, self.V = int(a["adj"].shape[0]), int(a["unmap"].shape[0])
+        # host, segment level (contiguous copies: the C ABI keeps raw pointers to them)
+        self.h_seg_first = np.ascontiguousarray(a["seg_first"], dtype=np.int32)
+        self.h_seg_size = np.ascontiguousarray(a["seg_size"], dtype=np.int32)
+        self.h_seg_ins = np.ascontiguousarray(a["seg_ins"], dtype=np.int32)
+        self.h_seg_sem = np.ascontiguousarray(a["seg_sem"], dtype=np.int32)
         dev = torch.device(device)
         self.device = dev
-        up = lambda a: torch.from_numpy(a).to(dev)
-        self.d_data = up(data)
-        self.d_adj = up(adj)
-        self.d_seg_of_point = up(seg)
-        self.d_seg_points = up(order)
-        self.d_seg_off = up(off)
-        self.d_unmap = up(unmap)
-        self.d_gt = up(gt)
+        up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev, non_blocking=False)
+        self.d_data = up(a["data"])
+        self.d_adj = up(a["adj"])
+        self.d_seg_of_point = up(a["seg_of_point"])
+        self.d_seg_points = up(a["seg_points"])
+        self.d_seg_off = up(a["seg_off"])
+        self.d_unmap = up(a["unmap"])
+        self.d_gt = up(a["gt"])
         self._c = hip.Scene(N=self.N, S=self.S, E0=self.E0, V=self.V,
                             d_data=self.d_data.data_ptr(), d_adj=self.d_adj.data_ptr(),
                             d_seg_of_point=self.d_seg_of_point.data_ptr(), d_seg_points=self.d_seg_points.data_ptr(),

@@ -1,0 +1,75 @@
+"""Packed scene cache: the pack holds exactly the staged arrays `DeviceScene` uploads, is rebuilt
+when a source file of the reference's tree changes, and rejects foreign files.  CPU only (no upload here)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import make_fixture_scene
+
+
+def _tree(tmp_path, golden_index, name="tiny_dup_4k"):
+    from seggroup_amd import synthetic
+    scene = make_fixture_scene(golden_index, name)
+    synthetic.write_reference_tree(str(tmp_path), [scene])
+    return scene
+
+
+def test_pack_roundtrip_equals_staged_arrays(tmp_path, golden_index):
+    from seggroup_amd import cache
+    scene = _tree(tmp_path, golden_index)
+    want = cache.stage_arrays(scene.data, scene.weak_label, scene.seg, scene.adj, scene.unmap, scene.gt)
+    path = cache.pack_scene(str(tmp_path), scene.name)
+    assert path == cache.pack_path(str(tmp_path), scene.name) and os.path.exists(path)
+    got = cache.read_pack(path)
+    assert got["name"] == scene.name and got["N"] == scene.data.shape[0] and got["V"] == scene.unmap.shape[0]
+    assert got["S"] == int(scene.seg.max()) + 1 and got["E0"] == scene.adj.shape[0]
+    for k in cache.ARRAYS:
+        assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape, k
+        assert np.array_equal(got[k], want[k]), k
+        assert got[k].ctypes.data % 64 == 0 or got[k].size == 0, k        # 64-byte aligned inside the page-aligned map
+    # CSR invariants the kernels rely on: ascending point index inside each segment, first point ascending
+    off, pts = got["seg_off"], got["seg_points"]
+    assert off[0] == 0 and off[-1] == got["N"] and (np.diff(off) == got["seg_size"]).all()
+    assert (pts[off[:-1]] == got["seg_first"]).all()
+    inner = np.ones(got["N"], bool)
+    inner[off[:-1]] = False
+    assert (np.diff(pts)[inner[1:]] > 0).all()
+
+
+def test_pack_is_reused_then_rebuilt_when_a_source_is_newer(tmp_path, golden_index):
+    from seggroup_amd import cache
+    scene = _tree(tmp_path, golden_index, "tiny_4k")
+    path = cache.pack_scene(str(tmp_path), scene.name)
+    m0 = os.stat(path).st_mtime_ns
+    assert cache.pack_scene(str(tmp_path), scene.name) == path and os.stat(path).st_mtime_ns == m0     # reused
+    src = cache.source_files(str(tmp_path), scene.name)[3]                                             # the seg.json
+    future = time.time() + 5
+    os.utime(src, (future, future))
+    cache.pack_scene(str(tmp_path), scene.name)
+    assert os.stat(path).st_mtime_ns != m0                                                             # rebuilt
+    m1 = os.stat(path).st_mtime_ns
+    cache.pack_scene(str(tmp_path), scene.name, force=True)
+    assert os.stat(path).st_mtime_ns != m1
+
+
+def test_label_styles_get_separate_packs_and_foreign_files_are_rejected(tmp_path, golden_index):
+    from seggroup_amd import cache
+    assert cache.pack_path("r", "s", "manual") != cache.pack_path("r", "s", "rand_inside")
+    bad = tmp_path / "x.sgpack"
+    bad.write_bytes(b"NOTAPACK" + b"\0" * 64)
+    with pytest.raises(ValueError):
+        cache.read_pack(str(bad))
+
+
+def test_stage_arrays_rejects_inconsistent_input(golden_index):
+    from seggroup_amd import cache
+    scene = make_fixture_scene(golden_index, "tiny_4k")
+    with pytest.raises(ValueError):
+        cache.stage_arrays(scene.data[:, :5], scene.weak_label, scene.seg, scene.adj, scene.unmap, scene.gt)
+    seg = scene.seg.copy()
+    a, b = seg == 0, seg == 1
+    seg[a], seg[b] = 1, 0                     # segment numbers no longer ascend with first points
+    with pytest.raises(ValueError):
+        cache.stage_arrays(scene.data, scene.weak_label, seg, scene.adj, scene.unmap, scene.gt)

@@ -195,6 +195,79 @@ def test_dropin_forward_and_driver_write_reference_files(tmp_path, golden_index,
     assert [int(x) for x in open(os_mod.path.join(out_dir, "final.ins.txt")).read().split()] == g["ins.label.final.ins"].tolist()
     log = open(os_mod.path.join(root, "checkpoints", "exp", "run_infer.log")).read()
     assert "Network parameters: 147880" in log and "Infer(0001/0001)" in log and "==> Infer" in log
+    # (3) the same driver through the per-scene SegModel.forward loop (no packs, no batching)
+    for f in os_mod.listdir(out_dir):
+        os_mod.remove(os_mod.path.join(out_dir, f))
+    infer.main(["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--batch", "0"])
+    assert [int(x) for x in open(os_mod.path.join(out_dir, "final.ins.txt")).read().split()] == g["ins.label.final.ins"].tolist()
+
+
+def test_pipeline_larger_than_scene_and_ragged_batches(golden_index, weight_sets):
+    """A pipeline (or a batch slot) sized for a bigger scene: the label vectors of a smaller scene are packed at
+    ITS vertex stride (sg_result.h_labels) -- regression for reading them at the capacity stride."""
+    from seggroup_amd import hip
+    from seggroup_amd.model import BatchRunner, Pipeline
+    from seggroup_amd.scene import DeviceScene
+    w = weight_sets["ins_infer"]
+    names = ["small_20k", "tiny_dup_4k", "tiny_4k", "island_20k", "tiny_dup_4k"]
+    scenes = [DeviceScene.from_synthetic(make_fixture_scene(golden_index, n), device="cuda:0") for n in names]
+    assert len({s.V for s in scenes}) > 2
+    big = Pipeline(w, max(s.N for s in scenes) + 1000, max(s.S for s in scenes) + 10, max(s.E0 for s in scenes) + 10,
+                   max(s.V for s in scenes) + 999, device="cuda:0")
+    for n, sc in zip(names, scenes):
+        g = load_golden(n)
+        res = big.forward(sc, hip.MODE_INS_INFER)
+        for i in range(14):
+            assert np.array_equal(res.labels[i], g[f"ins.label.{hip.LABEL_NAMES[i]}"].astype(np.int32)), (n, i)
+    big.close()
+    runner = BatchRunner(w, scenes, inflight=3, device="cuda:0")
+    for _ in range(2):
+        out = runner.run(scenes, hip.MODE_INS_INFER)
+        for n, sc, res in zip(names, scenes, out):
+            g = load_golden(n)
+            assert res.labels.shape == (14, sc.V)
+            for i in range(14):
+                assert np.array_equal(res.labels[i], g[f"ins.label.{hip.LABEL_NAMES[i]}"].astype(np.int32)), (n, i)
+            assert np.array_equal(res.iou_ins, g["ins.metric.1"])
+    runner.close()
+
+
+def test_packed_scene_and_fast_driver_match_reference_capture(tmp_path, golden_index, weight_sets):
+    """scene packs -> prefetching loader -> sg_batch_forward -> async writer, over a ragged
+    5-scene list with batch 2 (the runner regrows once); every file carries the reference's integers and the
+    summary equals the per-scene loop's."""
+    import os
+    import torch
+    from seggroup_amd import cache, hip, infer, synthetic, weights
+    names = ["tiny_4k", "small_20k", "tiny_dup_4k", "island_20k"]
+    scenes = [make_fixture_scene(golden_index, n) for n in names]
+    root = str(tmp_path)
+    synthetic.write_reference_tree(root, scenes)
+    # a pack-loaded scene is the same device scene as one staged from the arrays
+    from seggroup_amd.scene import DeviceScene
+    a = cache.load_pack(cache.pack_scene(root, scenes[2].name), device="cuda:0")
+    b = DeviceScene.from_synthetic(scenes[2], device="cuda:0")
+    for k in ("d_data", "d_adj", "d_seg_of_point", "d_seg_points", "d_seg_off", "d_unmap", "d_gt"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    for k in ("h_seg_first", "h_seg_size", "h_seg_ins", "h_seg_sem"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    ck = os.path.join(root, "checkpoints", "exp", "models")
+    os.makedirs(ck)
+    torch.save({"state_dict": weights.to_state_dict(weight_sets["ins_infer"])}, os.path.join(ck, "last.t7"))
+    fast = infer.run_worker(0, 1, infer.build_parser().parse_args(
+        ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--batch", "2", "--inflight", "2", "-j", "2"]))
+    for sc, n in zip(scenes, names):
+        g = load_golden(n)
+        out_dir = os.path.join(root, "results", "exp", sc.name, "ins_infer")
+        for nm in hip.LABEL_NAMES:
+            want = g[f"ins.label.{nm}"]
+            assert np.array_equal(np.load(os.path.join(out_dir, nm + ".npy")), want), (n, nm)
+            assert [int(x) for x in open(os.path.join(out_dir, nm + ".txt")).read().split()] == want.tolist(), (n, nm)
+    slow = infer.run_worker(0, 1, infer.build_parser().parse_args(
+        ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--batch", "0"]))
+    for k in fast:
+        if k != "elapsed_s":
+            assert np.array_equal(np.asarray(fast[k]), np.asarray(slow[k])), k
 
 
 @pytest.mark.parametrize("n,s,seed", [(20000, 8, 77), (6000, 3, 78), (30000, 900, 79)])

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""End-to-end driver timing on one GPU: `seggroup_amd.infer` over a synthetic reference-layout
+tree, (a) per-scene loop reading the reference's files each step (--batch 0), (b) packed fast path, cold (packs are
+built) and warm.  Prints one JSON object; files really are written (txt+npy unless --out-format says otherwise).
+
+    python tools/time_driver.py --scenes 16 --points 150000 --out gpurun_out/driver.json
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", type=int, default=16)
+    ap.add_argument("--points", type=int, default=150000)
+    ap.add_argument("--segments", type=int, default=1000)
+    ap.add_argument("--out-format", default="txt,npy")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--inflight", type=int, default=4)
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+
+    import torch
+    from seggroup_amd import infer, synthetic, weights
+
+    root = tempfile.mkdtemp(prefix="sg_driver_", dir="/tmp")
+    try:
+        t0 = time.time()
+        base = [synthetic.make_scene(a.points, a.segments, 20004 + i, name=f"scene{i:04d}_00") for i in range(min(a.scenes, 4))]
+        scenes = []
+        for i in range(a.scenes):          # distinct names, 4 distinct geometries (generation is the slow part here)
+            b = base[i % len(base)]
+            scenes.append(synthetic.Scene(f"scene{i:04d}_00", b.data, b.weak_label, b.seg, b.adj, b.unmap, b.gt))
+        synthetic.write_reference_tree(root, scenes)
+        ck = os.path.join(root, "checkpoints", "exp", "models")
+        os.makedirs(ck)
+        torch.save({"state_dict": weights.to_state_dict(weights.make_weights(1, bn1_gamma=2.0))}, os.path.join(ck, "last.t7"))
+        gen_s = time.time() - t0
+        common = ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--out-format", a.out_format, "-j", str(a.workers)]
+
+        def run(extra):
+            shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
+            args = infer.build_parser().parse_args(common + extra)
+            t = time.time()
+            r = infer.run_worker(0, 1, args)
+            return time.time() - t, r
+
+        out = {"scenes": a.scenes, "points": a.points, "out_format": a.out_format, "tree_build_s": round(gen_s, 1)}
+        run(["--batch", "0"])                                  # warm-up: HIP context, page cache
+        t, r0 = run(["--batch", "0"])
+        out["per_scene_loop"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
+        fast = ["--batch", str(a.batch), "--inflight", str(a.inflight)]
+        t, r1 = run(fast)
+        out["packed_cold"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
+        t, r2 = run(fast)
+        out["packed_warm"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
+        t, r3 = run(fast)
+        out["packed_warm_2"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
+        out["summaries_equal"] = all(repr(r0[k]) == repr(r2[k]) for k in r0 if k != "elapsed_s")
+        nfiles = sum(len(f) for _, _, f in os.walk(os.path.join(root, "results")))
+        out["files_written"] = nfiles
+        print(json.dumps(out))
+        if a.out:
+            os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+            with open(a.out, "w") as f:
+                json.dump(out, f, indent=1)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
