@@ -86,14 +86,14 @@ def write_pack(path: str, name: str, arrays: Dict[str, np.ndarray]) -> None:
 
 
 def read_pack(path: str) -> Dict[str, object]:
-    """-> {'name', 'N', 'S', 'E0', 'V', arrays...} with the arrays as read-only memory maps."""
+    """-> {'name', 'N', 'S', 'E0', 'V', arrays...} with the arrays as (private, copy-on-write) memory maps."""
     with open(path, "rb") as f:
         if f.read(8) != MAGIC:
             raise ValueError(f"{path}: not a SegGroup scene pack")
         (hlen,) = struct.unpack("<I", f.read(4))
         hdr = json.loads(f.read(hlen).decode())
     base = 12 + hlen
-    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    mm = np.memmap(path, dtype=np.uint8, mode="c")      # copy-on-write: torch wants writable buffers; nothing writes
     out = {k: hdr[k] for k in ("name", "N", "S", "E0", "V")}
     for k, (dt, shape, off) in hdr["arrays"].items():
         n = int(np.prod(shape)) * np.dtype(dt).itemsize

@@ -73,3 +73,48 @@ def test_stage_arrays_rejects_inconsistent_input(golden_index):
     seg[a], seg[b] = 1, 0                     # segment numbers no longer ascend with first points
     with pytest.raises(ValueError):
         cache.stage_arrays(scene.data, scene.weak_label, seg, scene.adj, scene.unmap, scene.gt)
+
+
+# ---- the label files as the three downstream trainers read them ---------------------------------
+
+def _read_like_consumers(path, as_type):
+    """pointgroup/dataset/scannetv2/prepare_data_inst2.py:41-53, minkowski/lib/datasets/preprocessing/scannet2.py:29-34,
+    kpconv/datasets/Scannet2.py:148-153 all do: readlines(), drop the last character of every line, np.array().astype()."""
+    with open(path, "r") as f:
+        lines = f.readlines()
+    return np.array([ln[:-1] for ln in lines]).astype(as_type)
+
+
+@pytest.mark.parametrize("use_pool", [False, True])
+def test_label_files_are_what_the_reference_writes_and_its_consumers_parse(tmp_path, use_pool):
+    import ctypes as C
+    from seggroup_amd import hip
+    lib = hip.lib()
+    rng = np.random.default_rng(5)
+    vecs = [np.concatenate([[-1, 0, 1, 9, 10, 40, -100, 2**31 - 1, -(2**31) + 1], rng.integers(-1, 150000, 20000)]).astype(np.int32),
+            np.zeros(0, np.int32), np.array([7], np.int32)]
+    paths = []
+    if use_pool:
+        w = lib.sg_writer_create(3, 4)
+        assert w
+        for i, v in enumerate(vecs):
+            base = str(tmp_path / f"final.{i}")
+            hip.check(lib.sg_writer_submit(w, base.encode(), v.ctypes.data if v.size else None, v.size, 3))
+            paths.append(base)
+        hip.check(lib.sg_writer_flush(w))
+        lib.sg_writer_destroy(w)
+    else:
+        for i, v in enumerate(vecs):
+            base = str(tmp_path / f"final.{i}")
+            hip.check(lib.sg_write_label_txt((base + ".txt").encode(), v.ctypes.data if v.size else None, v.size))
+            hip.check(lib.sg_write_label_npy((base + ".npy").encode(), v.ctypes.data if v.size else None, v.size))
+            paths.append(base)
+    for base, v in zip(paths, vecs):
+        # byte-for-byte what model.py:541-545 writes: '%d\n' per raw vertex
+        assert open(base + ".txt", "rb").read() == "".join("%d\n" % x for x in v.tolist()).encode()
+        got = np.load(base + ".npy")
+        assert got.dtype == np.int32 and np.array_equal(got, v)
+        if v.size:
+            assert np.array_equal(_read_like_consumers(base + ".txt", int), v.astype(np.int64))
+            assert np.array_equal(_read_like_consumers(base + ".txt", float), v.astype(np.float64))
+            assert np.array_equal(_read_like_consumers(base + ".txt", "float32"), v.astype(np.float32))

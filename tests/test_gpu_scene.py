@@ -267,7 +267,7 @@ def test_packed_scene_and_fast_driver_match_reference_capture(tmp_path, golden_i
         ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--batch", "0"]))
     for k in fast:
         if k != "elapsed_s":
-            assert np.array_equal(np.asarray(fast[k]), np.asarray(slow[k])), k
+            assert np.array_equal(np.asarray(fast[k]), np.asarray(slow[k]), equal_nan=True), k   # classes absent from a scene set are NaN
 
 
 @pytest.mark.parametrize("n,s,seed", [(20000, 8, 77), (6000, 3, 78), (30000, 900, 79)])
