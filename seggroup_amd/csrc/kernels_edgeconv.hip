@@ -18,12 +18,18 @@
 //       channel c(r)   (lanes 0-31) with channel c(r)+4 (lanes 32-63), which is exactly how the
 //       accumulator is laid out (row = (r&3) + 8(r>>2) + 4(lane>>5)); only the A operand (W2) has to
 //       be fetched in that permuted k order, and it comes pre-arranged from LDS.
-//   BatchNorm is folded: w' = a*w (a = gamma/sqrt(var+eps)) and the shift b' = beta - a*mean enters
-//   as the accumulator's initial value (layer 1 of MLP3) or after the max (last layer: max commutes
-//   with adding a per-channel constant and LeakyReLU is monotone).
+//   Inner BatchNorm (layer 1 of MLP3) is folded: w' = a*w (a = gamma/sqrt(var+eps)) and the shift
+//   b' = beta - a*mean enters as the accumulator's initial value.
 //
-// Statistics need a global barrier, so MLP2 is 2 launches and MLP3 is 3 (recompute instead of
-// materialising the 768 MB [N,20,64] tensor): STATS1 -> FINAL1, or STATS1 -> STATS2 -> FINAL2.
+// Statistics need a global barrier, but the LAST layer does not need a second evaluation: per channel,
+// y -> LReLU(a*y + b') is monotone (non-decreasing for a >= 0, non-increasing for a < 0, also in fp32:
+// rounding is monotone), so  max_j LReLU(a*y_j + b') == LReLU(a*ext_j y_j + b')  with ext = max or min by
+// the sign of gamma -- known before the statistics are.  The sign is folded into the weight ROWS while
+// they are staged in LDS (negation commutes exactly with an fma chain), so the pass that accumulates the
+// statistics of y' = sgn(gamma)*y also keeps  E = max_j y'_j  per (point, channel); a one-pass element-wise
+// epilogue then applies  LReLU(|a|*E + b').  MLP2 is therefore ONE MFMA pass (S1X) and MLP3 two (S1 -> S2X),
+// 44 GFLOP executed per scene for 39.4 GFLOP of single-evaluation work, instead of 2 and 3 passes (82 GFLOP)
+// or materialising the 768 MB [N,20,64] tensor.
 // Per-block fp64 partial sums are combined in fixed order by a one-block finalize kernel, so the
 // result is bit-reproducible run to run.
 #include "sg_common.h"
@@ -32,50 +38,51 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-enum { STATS1 = 0, FINAL1 = 1, STATS2 = 2, FINAL2 = 3 };
+enum { S1 = 0, S1X = 1, S2X = 2 };     // conv1 statistics | conv1 statistics + extremum | conv1' -> conv2 statistics + extremum
 
 constexpr int kWaves = 4;
+
 
 __device__ inline int acc_channel(int tile, int reg, int half) { return 32 * tile + (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
 struct Lds {
     float a1[2][9][64];      // conv1 A fragments: a1[t][s][lane] = W1[32t + (lane&31)][2s + (lane>>5)]
     float a2[2][32][64];     // conv2 A fragments: a2[ot][st][lane] = W2[32ot + (lane&31)][acc_channel(st>>4, st&15, lane>>5)]
-    float sh1[64];           // folded BN1 shift
-    float sh1r[2][2][16];    // the same, in accumulator-register order: sh1r[tile][half][reg] (b128 reads)
-    float sh2[64];           // folded BN2 shift (or BN1 shift for MLP2's last layer)
+    float sh1r[2][2][16];    // folded BN1 shift in accumulator-register order: sh1r[tile][half][reg] (b128 reads)
     double acc[kWaves][128]; // per-wave statistics: [0,64) sum, [64,128) sum of squares
 };
 
-template <int MODE>
+template <int MODE, bool REREAD_A = false>
 __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                                           const float* __restrict__ w1, const float* __restrict__ shift1,
-                                                          const float* __restrict__ w2, const float* __restrict__ shift2,
-                                                          float* __restrict__ out, double* __restrict__ partial) {
+                                                          const float* __restrict__ w2, const float* __restrict__ gamma_last,
+                                                          float* __restrict__ ext, double* __restrict__ partial) {
     __shared__ Lds lds;
-    constexpr bool kTwo = MODE == STATS2 || MODE == FINAL2;
-    constexpr bool kStats = MODE == STATS1 || MODE == STATS2;
+    constexpr bool kTwo = MODE == S2X;
+    constexpr bool kExt = MODE == S1X || MODE == S2X;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
 
+    // the last layer's rows carry the sign of its BN gamma (see the header): y' = sgn(gamma) * y exactly
     for (int i = tid; i < 2 * 9 * 64; i += 64 * kWaves) {
         const int l = i & 63, s = (i >> 6) % 9, t = i / (9 * 64);
-        lds.a1[t][s][l] = w1[(32 * t + (l & 31)) * 18 + 2 * s + (l >> 5)];
+        const int ch = 32 * t + (l & 31);
+        const float v = w1[ch * 18 + 2 * s + (l >> 5)];
+        lds.a1[t][s][l] = (MODE == S1X && gamma_last[ch] < 0.f) ? -v : v;
     }
     if (kTwo) {
         for (int i = tid; i < 2 * 32 * 64; i += 64 * kWaves) {
             const int l = i & 63, st = (i >> 6) & 31, ot = i >> 11;
-            lds.a2[ot][st][l] = w2[(32 * ot + (l & 31)) * 64 + acc_channel(st >> 4, st & 15, l >> 5)];
+            const int ch = 32 * ot + (l & 31);
+            const float v = w2[ch * 64 + acc_channel(st >> 4, st & 15, l >> 5)];
+            lds.a2[ot][st][l] = gamma_last[ch] < 0.f ? -v : v;
         }
     }
     if (tid < 64) {
-        lds.sh1[tid] = shift1 ? shift1[tid] : 0.f;
-        lds.sh2[tid] = shift2 ? shift2[tid] : 0.f;
         const int t_ = tid >> 5, h_ = (tid >> 4) & 1, q_ = tid & 15;
         lds.sh1r[t_][h_][q_] = shift1 ? shift1[acc_channel(t_, q_, h_)] : 0.f;
     }
-    if (kStats)
-        for (int i = tid; i < kWaves * 128; i += 64 * kWaves) (&lds.acc[0][0])[i] = 0.0;
+    for (int i = tid; i < kWaves * 128; i += 64 * kWaves) (&lds.acc[0][0])[i] = 0.0;
     __syncthreads();
 
     const int tile = blockIdx.x * kWaves + wave;
@@ -98,10 +105,9 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
 
         float stat_s[32], stat_q[32];
         f32x16 best[2];
-        if (kStats) {
 #pragma unroll
-            for (int q = 0; q < 32; ++q) { stat_s[q] = 0.f; stat_q[q] = 0.f; }
-        } else {
+        for (int q = 0; q < 32; ++q) { stat_s[q] = 0.f; stat_q[q] = 0.f; }
+        if (kExt) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -115,6 +121,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
         float4 p0 = xp[0], p1 = xp[1], p2 = xp[2];
         nb_next = K > 1 ? krow[1] : 0;
         for (int j = 0; j < K; ++j) {
+            // S2X holds 64 statistics + 32 maxima + 48 accumulator registers: do not let the compiler also park the 82
+            // loop-invariant A fragments in VGPRs (it then spills ~60 of them to scratch: 0.56 vs 0.48 ms per MLP3 at
+            // 150k points); re-read them from LDS per slot
+            if (REREAD_A) asm volatile("" ::: "memory");
             const float4 n0 = p0, n1 = p1, n2 = p2;
             if (j + 1 < K) {
                 const float4* xq = reinterpret_cast<const float4*>(x9m + (size_t)nb_next * 12);
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
                 acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds.a1[0][s][lane], b[s], acc1[0], 0, 0, 0);
                 acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds.a1[1][s][lane], b[s], acc1[1], 0, 0, 0);
             }
-            if (MODE == STATS1) {
+            if (!kTwo) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -159,12 +169,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
                         const float y = acc1[t][q] * vmask;
                         stat_s[16 * t + q] += y;
                         stat_q[16 * t + q] = __builtin_fmaf(y, y, stat_q[16 * t + q]);
+                        if (kExt) best[t][q] = fmaxf(best[t][q], acc1[t][q]);
                     }
-            } else if (MODE == FINAL1) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) best[t][q] = fmaxf(best[t][q], acc1[t][q]);
             } else {
                 // LeakyReLU(BN1(.)) in place -> B operand of conv2
 #pragma unroll
@@ -179,62 +185,49 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
 #pragma unroll
                         for (int q = 0; q < 16; ++q)
                             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds.a2[ot][16 * t + q][lane], acc1[t][q], acc2, 0, 0, 0);
-                    if (MODE == STATS2) {
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const float z = acc2[q] * vmask;
-                            stat_s[16 * ot + q] += z;
-                            stat_q[16 * ot + q] = __builtin_fmaf(z, z, stat_q[16 * ot + q]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) best[ot][q] = fmaxf(best[ot][q], acc2[q]);
+                    for (int q = 0; q < 16; ++q) {
+                        const float z = acc2[q] * vmask;
+                        stat_s[16 * ot + q] += z;
+                        stat_q[16 * ot + q] = __builtin_fmaf(z, z, stat_q[16 * ot + q]);
+                        best[ot][q] = fmaxf(best[ot][q], acc2[q]);
                     }
                 }
             }
         }
 
-        if (kStats) {
-            // sum over the 32 rows of this half (xor offsets < 32 keep the half), then one lane per half
-            // adds into the wave's fp64 LDS accumulators
+        // sum over the 32 rows of this half (xor offsets < 32 keep the half), then one lane per half
+        // adds into the wave's fp64 LDS accumulators
 #pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                float s = stat_s[q], v = stat_q[q];
+        for (int q = 0; q < 32; ++q) {
+            float s = stat_s[q], v = stat_q[q];
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o); v += __shfl_xor(v, o); }
-                if (r == 0) {
-                    const int ch = acc_channel(q >> 4, q & 15, half);
-                    lds.acc[wave][ch] += (double)s;
-                    lds.acc[wave][64 + ch] += (double)v;
-                }
+            for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o); v += __shfl_xor(v, o); }
+            if (r == 0) {
+                const int ch = acc_channel(q >> 4, q & 15, half);
+                lds.acc[wave][ch] += (double)s;
+                lds.acc[wave][64 + ch] += (double)v;
             }
-        } else if (valid) {
-            // last layer: + folded shift, LeakyReLU, then 4 consecutive channels per float4 store
-            float* orow = out + (size_t)pt * 64;
+        }
+        if (kExt && valid) {
+            // E = max_j y'_j : 4 consecutive channels per float4 store
+            float* orow = ext + (size_t)pt * 64;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float4 v;
-                    float* pv = &v.x;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float y = best[t][4 * g + u] + lds.sh2[acc_channel(t, 4 * g + u, half)];
-                        pv[u] = fmaxf(y, 0.2f * y);
-                    }
+                    const float4 v = make_float4(best[t][4 * g], best[t][4 * g + 1], best[t][4 * g + 2], best[t][4 * g + 3]);
                     *reinterpret_cast<float4*>(orow + 32 * t + 8 * g + 4 * half) = v;
                 }
         }
     }
 
-    if (kStats) {
-        __syncthreads();
-        if (tid < 128) {
-            double s = 0.0;
+    __syncthreads();
+    if (tid < 128) {
+        double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) s += lds.acc[w][tid];
-            partial[(size_t)blockIdx.x * 128 + tid] = s;
-        }
+        for (int w = 0; w < kWaves; ++w) s += lds.acc[w][tid];
+        partial[(size_t)blockIdx.x * 128 + tid] = s;
     }
 }
 
@@ -268,11 +261,41 @@ __global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ par
     }
     __syncthreads();
     const int ch = threadIdx.x & 63;
-    const double mean = tot[ch] / rows;
-    const double var = tot[64 + ch] / rows - mean * mean;
-    const double a = (double)gamma[ch] / sqrt(var + 1e-5);
-    for (int k = threadIdx.x >> 6; k < kin; k += 16) w_folded[ch * kin + k] = (float)(a * (double)w[ch * kin + k]);
-    if (threadIdx.x < 64) shift[ch] = (float)((double)beta[ch] - a * mean);
+    if (w) {
+        // inner layer: folded weights + shift
+        const double mean = tot[ch] / rows;
+        const double var = tot[64 + ch] / rows - mean * mean;
+        const double a = (double)gamma[ch] / sqrt(var + 1e-5);
+        for (int k = threadIdx.x >> 6; k < kin; k += 16) w_folded[ch * kin + k] = (float)(a * (double)w[ch * kin + k]);
+        if (threadIdx.x < 64) shift[ch] = (float)((double)beta[ch] - a * mean);
+    } else if (threadIdx.x < 64) {
+        // last layer: the statistics are those of y' = sgn(gamma)*y (mean' = sgn*mean, same variance), so
+        // a*y + (beta - a*mean) == |a|*y' + (beta - |a|*mean'):  w_folded[0..64) = |a|, shift = beta - |a|*mean'
+        const double mean = tot[ch] / rows;
+        const double var = tot[64 + ch] / rows - mean * mean;
+        const double a = fabs((double)gamma[ch]) / sqrt(var + 1e-5);
+        w_folded[ch] = (float)a;
+        shift[ch] = (float)((double)beta[ch] - a * mean);
+    }
+}
+
+// epilogue of the last layer, in place: out = LReLU(|a| * E + b')
+__global__ __launch_bounds__(256) void k_bn_lrelu_apply(float* __restrict__ e, size_t n4, const float* __restrict__ a,
+                                                        const float* __restrict__ shift) {
+    __shared__ float sa[64], sb[64];
+    if (threadIdx.x < 64) { sa[threadIdx.x] = a[threadIdx.x]; sb[threadIdx.x] = shift[threadIdx.x]; }
+    __syncthreads();
+    float4* p = reinterpret_cast<float4*>(e);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 15) * 4;
+        float4 v = p[i];
+        float y;
+        y = __builtin_fmaf(sa[c], v.x, sb[c]);         v.x = fmaxf(y, 0.2f * y);
+        y = __builtin_fmaf(sa[c + 1], v.y, sb[c + 1]); v.y = fmaxf(y, 0.2f * y);
+        y = __builtin_fmaf(sa[c + 2], v.z, sb[c + 2]); v.z = fmaxf(y, 0.2f * y);
+        y = __builtin_fmaf(sa[c + 3], v.w, sb[c + 3]); v.w = fmaxf(y, 0.2f * y);
+        p[i] = v;
+    }
 }
 
 }  // namespace
@@ -296,17 +319,22 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     hipStream_t st = sg::as_stream(stream);
     const double rows = (double)N * (double)k;
     const dim3 grid(nblocks), block(64 * kWaves);
-    k_edgeconv<STATS1><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, nullptr, partial);
-    k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, d_w1, 18, w1f, sh1);
-    if (mark) mark(0);
+    const size_t n4 = (size_t)N * 16;
+    const int egrid = (int)std::min<size_t>((n4 + 255) / 256, 2048);
     if (layers == 1) {
-        k_edgeconv<FINAL1><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, nullptr, nullptr, sh1, d_out, nullptr);
+        k_edgeconv<S1X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, d_g1, d_out, partial);
+        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, nullptr, 0, w1f, sh1);
+        if (mark) mark(0);
+        k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w1f, sh1);
         if (mark) mark(1);
     } else {
-        k_edgeconv<STATS2><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, d_w2, nullptr, nullptr, partial);
-        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, d_w2, 64, w2f, sh2);
+        k_edgeconv<S1><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, nullptr, partial);
+        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, d_w1, 18, w1f, sh1);
+        if (mark) mark(0);
+        k_edgeconv<S2X, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, d_w2, d_g2, d_out, partial);
+        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, nullptr, 0, w2f, sh2);
         if (mark) mark(1);
-        k_edgeconv<FINAL2><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2f, sh2, d_out, nullptr);
+        k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w2f, sh2);
         if (mark) mark(2);
     }
     SG_LAUNCH_CHECK();

@@ -281,8 +281,11 @@ def test_edgeconv_forward(env, N):
     x9[:, :3] *= 4
     knn = rng.integers(0, N, (N, K)).astype(np.int32)
     W = weights.make_weights(1, 2.0, affine_jitter=0.3)
-    W["mlp_3.bn2.weight"][::7] *= -1.0                      # negative gamma: the folded max must still be right
+    W["mlp_3.bn2.weight"][::7] *= -1.0                      # negative gamma: the kernel keeps max_k of sgn(gamma)*y
     W["mlp_2.bn1.weight"][::5] *= -1.0
+    W["mlp_3.bn1.weight"][::3] *= -1.0                      # inner BN (folded into conv1's weights)
+    W["mlp_3.bn2.weight"][9] = 0.0                          # gamma == 0: the channel is LReLU(beta) everywhere
+    W["mlp_2.bn1.weight"][11] = 0.0
     x12 = np.zeros((N, 12), np.float32)
     x12[:, :9] = x9
     d_x, d_k = _up(torch, x12), _up(torch, knn)

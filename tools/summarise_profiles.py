@@ -36,8 +36,8 @@ for name, src in (("FETCH_SIZE", f"{tag}_pmc_fetch"), ("WRITE_SIZE", f"{tag}_pmc
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         traffic[k][name] = sum(v) / len(v)
-alias = {"k_edgeconv<3>": "k_edgeconv<FINAL2>", "k_edgeconv<2>": "k_edgeconv<STATS2>", "k_edgeconv<0>": "k_edgeconv<STATS1>",
-         "k_edgeconv<1>": "k_edgeconv<FINAL1>", "k_cluster_knn_pruned<20>": "k_cluster_knn_pruned", "k_cluster_knn_sorted<20>": "k_cluster_knn_sorted"}
+alias = {"k_edgeconv<2, true>": "k_edgeconv<S2X>", "k_edgeconv<2>": "k_edgeconv<S2X>", "k_edgeconv<0, false>": "k_edgeconv<S1>",
+         "k_edgeconv<0>": "k_edgeconv<S1>", "k_edgeconv<1, false>": "k_edgeconv<S1X>", "k_edgeconv<1>": "k_edgeconv<S1X>", "k_cluster_knn_pruned<20>": "k_cluster_knn_pruned", "k_cluster_knn_sorted<20>": "k_cluster_knn_sorted"}
 out = {"note": "HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB * 1024 from two separate rocprofv3 --pmc passes over "
                "tools/time_scene.py 150000 1500; on gfx950 FETCH_SIZE can under-count wide coalesced reads by up to 2x "
                "(MI355X_MICROARCH.md, HBM section), so read the fetch side as a lower bound",
@@ -63,10 +63,9 @@ if sf:
     N, S, k = 500000.0, 5000.0, 20.0
     E0 = 3.57 * N
     model = {   # kernel: (bound, algorithmic units per launch, note)   -- DESIGN.md section 4
-        "k_edgeconv<3>": ("mfma", 2 * k * N * (18 * 64 + 64 * 64), "MLP3 final pass"),
-        "k_edgeconv<2>": ("mfma", 2 * k * N * (18 * 64 + 64 * 64), "MLP3 BN2 statistics pass"),
-        "k_edgeconv<0>": ("mfma", 2 * k * N * 18 * 64, "conv1 BN statistics pass (MLP2 and MLP3)"),
-        "k_edgeconv<1>": ("mfma", 2 * k * N * 18 * 64, "MLP2 final pass"),
+        "k_edgeconv<2, true>": ("mfma", 2 * k * N * (18 * 64 + 64 * 64), "MLP3 conv1'->conv2 + BN2 statistics + max (S2X)"),
+        "k_edgeconv<0, false>": ("mfma", 2 * k * N * 18 * 64, "MLP3 conv1 BN statistics pass (S1)"),
+        "k_edgeconv<1, false>": ("mfma", 2 * k * N * 18 * 64, "MLP2 conv + BN statistics + max (S1X)"),
         "k_cluster_knn_sorted<20>": ("hbm", 96 * N, "in-cluster kNN-20 (VALU/latency-bound; HBM is the nominal roof)"),
         "k_segment_max64": ("hbm", 260 * N, "per-cluster max of [N,64]"),
         "k_export": ("hbm", 60 * N, "14 label vectors gather"),
