@@ -46,8 +46,9 @@ constexpr int kWaves = 4;
 __device__ inline int acc_channel(int tile, int reg, int half) { return 32 * tile + (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
 struct Lds {
-    float a1[2][9][64];      // conv1 A fragments: a1[t][s][lane] = W1[32t + (lane&31)][2s + (lane>>5)]
-    float a2[2][32][64];     // conv2 A fragments: a2[ot][st][lane] = W2[32ot + (lane&31)][acc_channel(st>>4, st&15, lane>>5)]
+    // A fragments, four MFMA steps per ds_read_b128 (conflict-free: consecutive lanes, 16 B each)
+    float4 a1[2][3][64];     // conv1: a1[t][s>>2][lane][s&3] = W1[32t + (lane&31)][2s + (lane>>5)], s < 9 (steps 9..11 unused)
+    float4 a2[2][8][64];     // conv2: a2[ot][st>>2][lane][st&3] = W2[32ot + (lane&31)][acc_channel(st>>4, st&15, lane>>5)]
     float sh1r[2][2][16];    // folded BN1 shift in accumulator-register order: sh1r[tile][half][reg] (b128 reads)
     double acc[kWaves][128]; // per-wave statistics: [0,64) sum, [64,128) sum of squares
 };
@@ -64,18 +65,20 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
     const int r = lane & 31, half = lane >> 5;
 
     // the last layer's rows carry the sign of its BN gamma (see the header): y' = sgn(gamma) * y exactly
+    for (int i = tid; i < 2 * 3 * 64; i += 64 * kWaves) (&lds.a1[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
     for (int i = tid; i < 2 * 9 * 64; i += 64 * kWaves) {
         const int l = i & 63, s = (i >> 6) % 9, t = i / (9 * 64);
         const int ch = 32 * t + (l & 31);
         const float v = w1[ch * 18 + 2 * s + (l >> 5)];
-        lds.a1[t][s][l] = (MODE == S1X && gamma_last[ch] < 0.f) ? -v : v;
+        (&lds.a1[t][s >> 2][l].x)[s & 3] = (MODE == S1X && gamma_last[ch] < 0.f) ? -v : v;
     }
     if (kTwo) {
         for (int i = tid; i < 2 * 32 * 64; i += 64 * kWaves) {
             const int l = i & 63, st = (i >> 6) & 31, ot = i >> 11;
             const int ch = 32 * ot + (l & 31);
             const float v = w2[ch * 64 + acc_channel(st >> 4, st & 15, l >> 5)];
-            lds.a2[ot][st][l] = gamma_last[ch] < 0.f ? -v : v;
+            (&lds.a2[ot][st >> 2][l].x)[st & 3] = gamma_last[ch] < 0.f ? -v : v;
         }
     }
     if (tid < 64) {
@@ -157,9 +160,18 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
                 }
             }
 #pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds.a1[0][s][lane], b[s], acc1[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds.a1[1][s][lane], b[s], acc1[1], 0, 0, 0);
+            for (int s4 = 0; s4 < 3; ++s4) {
+                const float4 wa = lds.a1[0][s4][lane], wb = lds.a1[1][s4][lane];
+                const float* pa = &wa.x;
+                const float* pb = &wb.x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = 4 * s4 + u;
+                    if (s < 9) {
+                        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[u], b[s], acc1[0], 0, 0, 0);
+                        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u], b[s], acc1[1], 0, 0, 0);
+                    }
+                }
             }
             if (!kTwo) {
 #pragma unroll
@@ -177,22 +189,35 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc1[t][q] = fmaxf(acc1[t][q], 0.2f * acc1[t][q]);
+                // both output tiles at once: two independent accumulator chains interleaved, each A-operand read
+                // (ds_read_b32) feeds one MFMA of either chain
+                f32x16 acc2[2];
 #pragma unroll
-                for (int ot = 0; ot < 2; ++ot) {
-                    f32x16 acc2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                    for (int q = 0; q < 16; ++q) acc2[ot][q] = 0.f;
 #pragma unroll
-                        for (int q = 0; q < 16; ++q)
-                            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(lds.a2[ot][16 * t + q][lane], acc1[t][q], acc2, 0, 0, 0);
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 wa = lds.a2[0][4 * t + g][lane], wb = lds.a2[1][4 * t + g][lane];
+                        const float* pa = &wa.x;
+                        const float* pb = &wb.x;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[u], acc1[t][4 * g + u], acc2[0], 0, 0, 0);
+                            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u], acc1[t][4 * g + u], acc2[1], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const float z = acc2[q] * vmask;
+                        const float z = acc2[ot][q] * vmask;
                         stat_s[16 * ot + q] += z;
                         stat_q[16 * ot + q] = __builtin_fmaf(z, z, stat_q[16 * ot + q]);
-                        best[ot][q] = fmaxf(best[ot][q], acc2[q]);
+                        best[ot][q] = fmaxf(best[ot][q], acc2[ot][q]);
                     }
-                }
             }
         }
 
