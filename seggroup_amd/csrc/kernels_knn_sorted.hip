@@ -23,7 +23,6 @@ namespace {
 using namespace sgknn;
 
 constexpr int kChunkPts = 32;
-constexpr int kSlices = 4;
 constexpr int kBufS = 20;
 constexpr int kQuadS = 4;
 constexpr int kSlotBatch = 128;
@@ -110,7 +109,11 @@ __global__ void k_knn_operands(const float* __restrict__ data, const int32_t* __
 // [5] chunks scanned (wave level), [6] chunks tested, [7] segments tested, [8] lane appends, [9] drain iterations
 __device__ unsigned long long g_knn5_stats[16];
 
-template <int K>
+// kSlices = waves per 64-query tile (1, 2 or 4): the cluster's candidate chunks are dealt round-robin to them.  More
+// slices shorten a tile's critical path but every slice warms up its own top-K list: at 150k points one tile costs
+// 124 list insertions per query with 4 slices and about half of that with 1, and a launch with >= 2048 tiles fills
+// the GPU without slicing (bench: 584 -> 670 scenes/s at 4 -> 1 slices; the host picks by tile count).
+template <int K, int kSlices>
 __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     const float4* __restrict__ sxyzw, const int32_t* __restrict__ smpos, const int32_t* __restrict__ cl_off,
     const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi,
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     __shared__ int slab_i[kSlices][kChunkPts + kQuadS];
     __shared__ unsigned long long buf[kBufS][64 * kSlices];     // append buffers; later lists[slice][K][64]
     __shared__ unsigned int thr_pub[kSlices][64];             // score part of each slice's 20th best
-    __shared__ unsigned int thr5_pub[kSlices][64];            // score part of each slice's 5th best
+    __shared__ unsigned int thr5_pub[kSlices][64];            // score part of each slice's (K / kSlices)-th best
     __shared__ float chunkbox_lds[kSlices][64];
     __shared__ int st_m[kSlotBatch], st_c0[kSlotBatch], st_d[kSlotBatch];
     __shared__ __attribute__((aligned(16))) float st_box[kSlotBatch][8];
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     __syncthreads();
 
     // Lower bounds of the query's final 20th-best key that need no merge: (a) any slice's own 20th best, (b) the
-    // weakest of the four slices' 5th bests (4 x 5 = 20 candidates are at least that good).  Published score parts
+    // weakest of the slices' (K / kSlices)-th bests (kSlices x K / kSlices = K candidates are at least that good).  Published score parts
     // only rise, so stale reads are safe; the index part is cleared (ties at the bound are still accepted).
     auto best_thr = [&]() {
         unsigned int b = 0u, m5 = 0xffffffffu;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
         if (active) {
             thr = kv[K - 1];
             thr_pub[wave][lane] = (unsigned int)(thr >> 32);
-            thr5_pub[wave][lane] = (unsigned int)(kv[4] >> 32);
+            thr5_pub[wave][lane] = (unsigned int)(kv[K / kSlices - 1] >> 32);
         }
     };
     // one 32-point chunk: sorted positions [p0, p0 + m)
@@ -255,14 +258,14 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     for (int r0 = 1; r0 < nslots; r0 += kSlotBatch) {
         const int nb = min(kSlotBatch, nslots - r0);
         __syncthreads();                                      // previous batch fully consumed
-        if (tid < nb) {
-            const int slot = slot_of(r0 + tid), sg = order[slot];
-            st_m[tid] = seg_off[sg + 1] - seg_off[sg];
-            st_c0[tid] = seg_chunk_off[sg];
-            st_d[tid] = dst[slot];
+        for (int e = tid; e < nb; e += 64 * kSlices) {
+            const int slot = slot_of(r0 + e), sg = order[slot];
+            st_m[e] = seg_off[sg + 1] - seg_off[sg];
+            st_c0[e] = seg_chunk_off[sg];
+            st_d[e] = dst[slot];
             const float4* bp = reinterpret_cast<const float4*>(segbox + (size_t)sg * 8);
-            reinterpret_cast<float4*>(&st_box[tid][0])[0] = bp[0];
-            reinterpret_cast<float4*>(&st_box[tid][0])[1] = bp[1];
+            reinterpret_cast<float4*>(&st_box[e][0])[0] = bp[0];
+            reinterpret_cast<float4*>(&st_box[e][0])[1] = bp[1];
         }
         __syncthreads();
         for (int i = 0; i < nb; ++i) scan_segment(st_m[i], st_c0[i], st_d[i], &st_box[i][0], item);
@@ -373,9 +376,16 @@ int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, c
     SG_REQUIRE(N >= 0 && T >= 0 && d_knn && d_sxyzw && d_smpos, "sg_cluster_knn_sorted: bad arguments");
     if (k != 20) return sg::fail(SG_EUNSUP, "sg_cluster_knn_sorted: only k == 20 is built (model.py:788,829), got %d", k);
     if (T == 0) return SG_OK;
-    k_cluster_knn_sorted<20><<<T, 64 * kSlices, 0, sg::as_stream(stream)>>>(
-        reinterpret_cast<const float4*>(d_sxyzw), d_smpos, d_cl_off, d_tile_cl, d_tile_lo, d_tile_hi, d_cl_seg_off, d_order, d_dst,
-        d_seg_off, d_seg_chunk_off, d_segbox, d_chunk_box, d_slot_of_pos, pos0, d_knn, g_knn5_dbg);
+    static const int forced = getenv("SG_KNN_SLICES") ? atoi(getenv("SG_KNN_SLICES")) : 0;     // experiments only
+    const int slices = forced ? forced : (T >= 2048 ? 1 : T >= 1024 ? 2 : 4);
+#define SG_KNN_LAUNCH(S)                                                                                                  \
+    k_cluster_knn_sorted<20, S><<<T, 64 * S, 0, sg::as_stream(stream)>>>(                                                 \
+        reinterpret_cast<const float4*>(d_sxyzw), d_smpos, d_cl_off, d_tile_cl, d_tile_lo, d_tile_hi, d_cl_seg_off, d_order, d_dst, \
+        d_seg_off, d_seg_chunk_off, d_segbox, d_chunk_box, d_slot_of_pos, pos0, d_knn, g_knn5_dbg)
+    if (slices == 1) SG_KNN_LAUNCH(1);
+    else if (slices == 2) SG_KNN_LAUNCH(2);
+    else SG_KNN_LAUNCH(4);
+#undef SG_KNN_LAUNCH
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

@@ -37,7 +37,9 @@ for name, src in (("FETCH_SIZE", f"{tag}_pmc_fetch"), ("WRITE_SIZE", f"{tag}_pmc
     for k, v in agg.items():
         traffic[k][name] = sum(v) / len(v)
 alias = {"k_edgeconv<2, true>": "k_edgeconv<S2X>", "k_edgeconv<2>": "k_edgeconv<S2X>", "k_edgeconv<0, false>": "k_edgeconv<S1>",
-         "k_edgeconv<0>": "k_edgeconv<S1>", "k_edgeconv<1, false>": "k_edgeconv<S1X>", "k_edgeconv<1>": "k_edgeconv<S1X>", "k_cluster_knn_pruned<20>": "k_cluster_knn_pruned", "k_cluster_knn_sorted<20>": "k_cluster_knn_sorted"}
+         "k_edgeconv<0>": "k_edgeconv<S1>", "k_edgeconv<1, false>": "k_edgeconv<S1X>", "k_edgeconv<1>": "k_edgeconv<S1X>", "k_cluster_knn_pruned<20>": "k_cluster_knn_pruned", "k_cluster_knn_sorted<20>": "k_cluster_knn_sorted",
+         "k_cluster_knn_sorted<20, 1>": "k_cluster_knn_sorted", "k_cluster_knn_sorted<20, 2>": "k_cluster_knn_sorted<2 slices>",
+         "k_cluster_knn_sorted<20, 4>": "k_cluster_knn_sorted<4 slices>"}
 out = {"note": "HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB * 1024 from two separate rocprofv3 --pmc passes over "
                "tools/time_scene.py 150000 1500; on gfx950 FETCH_SIZE can under-count wide coalesced reads by up to 2x "
                "(MI355X_MICROARCH.md, HBM section), so read the fetch side as a lower bound",
@@ -66,7 +68,7 @@ if sf:
         "k_edgeconv<2, true>": ("mfma", 2 * k * N * (18 * 64 + 64 * 64), "MLP3 conv1'->conv2 + BN2 statistics + max (S2X)"),
         "k_edgeconv<0, false>": ("mfma", 2 * k * N * 18 * 64, "MLP3 conv1 BN statistics pass (S1)"),
         "k_edgeconv<1, false>": ("mfma", 2 * k * N * 18 * 64, "MLP2 conv + BN statistics + max (S1X)"),
-        "k_cluster_knn_sorted<20>": ("hbm", 96 * N, "in-cluster kNN-20 (VALU/latency-bound; HBM is the nominal roof)"),
+        "k_cluster_knn_sorted<20, 1>": ("hbm", 96 * N, "in-cluster kNN-20 (VALU/latency-bound; HBM is the nominal roof)"),
         "k_segment_max64": ("hbm", 260 * N, "per-cluster max of [N,64]"),
         "k_export": ("hbm", 60 * N, "14 label vectors gather"),
         "k_mark_pairs": ("hbm", 16 * E0, "mesh-edge contraction (bitmap)"),
