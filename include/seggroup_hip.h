@@ -178,6 +178,29 @@ int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, c
                           const int32_t* d_cl_seg_off, const int32_t* d_order, const int32_t* d_dst,
                           const int32_t* d_seg_off, const int32_t* d_seg_chunk_off, const float* d_segbox,
                           const float* d_chunk_box, const int32_t* d_slot_of_pos, int k, int pos0, int32_t* d_knn, void* stream);
+/* Two-pass kernel over a cluster-ordered chunk table (same tables once more; variant 0 of sg_knn_set_variant:
+ * faster on 500k-point scenes and on large segments, on par with the one-pass kernel at 150k / 1.5k).  Per layer the host provides d_slot_chunk0[S+1] (exclusive prefix, in cluster slot order, of the
+ * 32-point chunk counts of the segments d_order[slot]), d_cl_chunk_off[C+1] (= slot_chunk0 at each cluster's first
+ * slot) and d_tile_chunk0[T] (cluster-relative number of the chunk holding the tile's first sorted position).
+ * sg_knn_chunk_table writes d_cc [(slot_chunk0[S]), 8]: {box min xyz, box max xyz, max |p|^2, bits: first sorted
+ * position << 6 | points - 1} of every chunk in that order (needs N < 2^25).  sg_cluster_knn_2pass: pass 1 keeps the
+ * k best SCORES per query (one v_med3_f32 per list slot), pass 2 rescans with that floor and inserts only the ~k
+ * survivors as exact (score, index) keys; 64 chunk boxes are tested per coalesced load and the next surviving
+ * chunk's operands are prefetched while the current one is scanned. */
+int sg_knn_chunk_table(const int32_t* d_order, const int32_t* d_dst, const int32_t* d_seg_off, const int32_t* d_seg_chunk_off,
+                       const float* d_chunk_box, int S, const int32_t* d_slot_chunk0, float* d_cc, void* stream);
+int sg_cluster_knn_2pass(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off,
+                         const int32_t* d_tile_cl, const int32_t* d_tile_lo, const int32_t* d_tile_hi,
+                         const int32_t* d_tile_chunk0, int T, const int32_t* d_cl_chunk_off, const float* d_cc,
+                         int k, int pos0, int32_t* d_knn, void* stream);
+/* Which in-cluster kNN kernel sg_pipeline_forward uses for a layer of T tiles, and how many waves per tile
+ * sg_cluster_knn_sorted launches (all variants give the same table; the GPU tests compare them):
+ *   -1  by tile count (default): one-pass with 1 wave per tile when T >= 2048 tiles fill the GPU, else 2 or 4 waves
+ *    0  two-pass (sg_cluster_knn_2pass)
+ *    1 | 2 | 4  one-pass (sg_cluster_knn_sorted) with that many waves per 64-query tile: a shorter critical path per
+ *       tile, but every wave warms up its own top-k list
+ * Process-wide; returns the previous setting.  Meant for tests and measurements. */
+int sg_knn_set_variant(int variant);
 
 /* ---------------------------------------------------------------------------------------------
  * a13  get_graph_feature2 + MLP2 / MLP3 (model.py:83-138): edge features [x_j - x_i, x_i] over the

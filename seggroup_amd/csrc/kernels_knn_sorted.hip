@@ -304,7 +304,237 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two-pass kernel over a cluster-ordered chunk table, one wave per 64-query tile (sg_knn_set_variant(0); faster than
+// the kernel above on large scenes and large segments, on par at 150k / 1.5k -- numbers at sg::knn_variant_for).
+// Two measurements of the kernel above shaped it (150k points, one wave per tile):
+//   * ~3/4 of its instructions are sorted insertions of 64-bit (score, index) keys -- one compare and four selects
+//     per list slot, ~105 instructions per insertion, executed wave-wide for the largest count of any lane (158 per
+//     tile for 71 appended keys per lane);
+//   * yet a pass that inserts almost nothing costs the same ~180k cycles per tile: every segment that survives its box
+//     test costs a dependent global load of its chunk boxes, every surviving chunk another one of its operands -- about
+//     25 exposed round trips per tile with 2-3 waves per SIMD to hide them.
+// Hence
+//   * k_knn_chunk_table lays the chunks of every cluster out contiguously per layer: {box min, box max, max |p|^2,
+//     first sorted position << 6 | points - 1}.  A lane tests one chunk per 32-byte coalesced load against the
+//     tile's query box and weakest threshold, one ballot names the survivors of 64 chunks, each survivor's descriptor is
+//     broadcast with v_readlane for the exact per-query test, and the operands of the NEXT survivor are already on
+//     their way to registers while the current chunk is scanned out of LDS;
+//   * pass 1 keeps only the K best SCORES per query: inserting into a descending list of floats is one v_med3_f32 per
+//     slot, new[j] = med3(old[j-1], old[j], x).  Its result s_K is the exact K-th best score;
+//   * pass 2 rescans with the fixed floor s_K: only candidates with score >= s_K are appended (K of them plus ties at
+//     the floor) and only those go through the exact 64-bit insertion; most chunks fail the box test at once.
+// The key order refines the float order (ties: lower member index wins; -0.0 < +0.0), so the K best keys all have
+// score >= s_K under float comparison and pass 2 sees every one of them: the table is bit-identical to the kernels above.
+// ---------------------------------------------------------------------------------------------------------------
+template <int K>
+__device__ inline void score_insert(float (&sv)[K], float x) {
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) sv[j] = __builtin_amdgcn_fmed3f(sv[j - 1], sv[j], x);
+    sv[0] = fmaxf(sv[0], x);
+}
+
+// one block per cluster slot (a segment inside its cluster): copy its chunk boxes into cluster order
+__global__ void k_knn_chunk_table(const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
+                                  const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
+                                  const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_chunk0,
+                                  float* __restrict__ cc) {
+    const int slot = blockIdx.x, sg = order[slot];
+    const int m = seg_off[sg + 1] - seg_off[sg], d = dst[slot];
+    const int nch = (m + kChunkPts - 1) / kChunkPts;
+    const float* src = chunk_box + (size_t)seg_chunk_off[sg] * 8;
+    float* out = cc + (size_t)slot_chunk0[slot] * 8;
+    for (int i = threadIdx.x; i < nch * 8; i += blockDim.x) {
+        const int j = i >> 3;
+        out[i] = (i & 7) == 7 ? __int_as_float(((d + j * kChunkPts) << 6) | (min(kChunkPts, m - j * kChunkPts) - 1)) : src[i];
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_cluster_knn_2pass(
+    const float4* __restrict__ sxyzw, const int32_t* __restrict__ smpos, const int32_t* __restrict__ cl_off,
+    const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi,
+    const int32_t* __restrict__ tile_chunk0, const int32_t* __restrict__ cl_chunk_off, const float4* __restrict__ cc,
+    int pos0, int32_t* __restrict__ knn, int dbg) {
+    __shared__ float4 cw[kChunkPts + kQuadS];
+    __shared__ int ci[kChunkPts + kQuadS];
+    constexpr int kBuf2 = 12;                                 // pass 2 appends ~K keys per lane in total; pass 1 gets 2x the slots
+    __shared__ unsigned long long buf[kBuf2][64];             // pass 2 append buffer; pass 1 uses it as float[2 * kBuf2][64]
+    const int t = blockIdx.x;
+    const int c = tile_cl[t];
+    const int clo = cl_off[c], n = cl_off[c + 1] - clo;
+    const int lane = threadIdx.x;
+    const int q = tile_lo[t] + lane;                          // SORTED position
+    const bool active = q < tile_hi[t];
+    const int myrow = active ? smpos[q] : 0;                  // member position = output row
+    if (n <= K) {                                            // model.py:516-518 (block-uniform)
+        if (active) {
+            int32_t* o = knn + (size_t)myrow * K;
+#pragma unroll
+            for (int j = 0; j < K; ++j) o[j] = j < n ? clo + j : pos0;
+        }
+        return;
+    }
+    const float4 me = active ? sxyzw[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ch0 = cl_chunk_off[c], nch = cl_chunk_off[c + 1] - ch0;
+    const int start = tile_chunk0[t];                         // cluster-relative chunk holding the tile's first query
+    // the tile's query box (idle lanes repeat lane 0) and largest |q|^2, for the coarse chunk test
+    float qlo[3], qhi[3], qw;
+    {
+        const float4 m0 = active ? me : make_float4(__shfl(me.x, 0), __shfl(me.y, 0), __shfl(me.z, 0), __shfl(me.w, 0));
+        qlo[0] = qhi[0] = m0.x; qlo[1] = qhi[1] = m0.y; qlo[2] = qhi[2] = m0.z; qw = m0.w;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { qlo[k] = fminf(qlo[k], __shfl_xor(qlo[k], o)); qhi[k] = fmaxf(qhi[k], __shfl_xor(qhi[k], o)); }
+            qw = fmaxf(qw, __shfl_xor(qw, o));
+        }
+    }
+    float* fbuf = reinterpret_cast<float*>(&buf[0][0]);       // [2 * kBuf2][64]
+    constexpr int kBufF = 2 * kBuf2;
+
+    // The walk over the cluster's chunks (ring order from the tile's own chunk) is the same in both passes.
+    //   weakest()            smallest score any lane still accepts (coarse test, one value per wave)
+    //   reject(box)          exact test: no lane can use a point of this box
+    //   consider(score, i)   the pass's sink; full() / drain() its buffer management
+    auto walk = [&](auto weakest, auto reject, auto consider, auto full, auto drain) {
+        for (int b0 = 0; b0 < nch; b0 += 64) {
+            const int nb = min(64, nch - b0);
+            int rel = start + b0 + lane;
+            if (rel >= nch) rel -= nch;
+            const float4 d0 = lane < nb ? cc[(size_t)(ch0 + rel) * 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 d1 = lane < nb ? cc[(size_t)(ch0 + rel) * 2 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            // coarse: box-to-box distance, the margin of box_score_bound for the largest |q|^2 of the tile
+            const float gx = fmaxf(fmaxf(d0.x - qhi[0], qlo[0] - d0.w), 0.f);
+            const float gy = fmaxf(fmaxf(d0.y - qhi[1], qlo[1] - d1.x), 0.f);
+            const float gz = fmaxf(fmaxf(d0.z - qhi[2], qlo[2] - d1.y), 0.f);
+            const float coarse = -((gx * gx + gy * gy) + gz * gz) * 0.999999f + 9.6e-7f * (qw + d1.z);
+            unsigned long long live = __ballot(lane < nb && coarse >= weakest());
+            // software pipeline: the operands of the next live chunk are requested before the current one is scanned
+            float4 pre_v = make_float4(0.f, 0.f, 0.f, INFINITY);
+            int pre_i = 0x7fffffff;
+            auto request = [&](int j) {
+                const int w = __float_as_int(__shfl(d1.w, j)), p0 = w >> 6, m = (w & 63) + 1;
+                const bool in = lane < m;
+                pre_v = in ? sxyzw[p0 + lane] : make_float4(0.f, 0.f, 0.f, INFINITY);
+                pre_i = in ? smpos[p0 + lane] - clo : 0x7fffffff;
+            };
+            if (live) request(__ffsll((unsigned long long)live) - 1);
+            while (live) {
+                const int j = __ffsll((unsigned long long)live) - 1;
+                live &= live - 1;
+                const float4 nv = pre_v;
+                const int ni = pre_i;
+                if (live) request(__ffsll((unsigned long long)live) - 1);
+                float bx[7] = {__shfl(d0.x, j), __shfl(d0.y, j), __shfl(d0.z, j), __shfl(d0.w, j), __shfl(d1.x, j), __shfl(d1.y, j), __shfl(d1.z, j)};
+                if (reject(bx)) continue;
+                const int m = (__float_as_int(__shfl(d1.w, j)) & 63) + 1;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < kChunkPts + kQuadS) { cw[lane] = nv; ci[lane] = ni; }
+                __builtin_amdgcn_wave_barrier();
+                for (int e = 0; e < m; e += kQuadS) {
+#pragma unroll
+                    for (int u = 0; u < kQuadS; ++u) consider(score4(me, cw[e + u]), ci[e + u]);
+                    if (full()) drain();
+                }
+            }
+        }
+        drain();
+    };
+
+    const unsigned long long t0 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+    // ---- pass 1: the K best scores
+    float floor_score;
+    {
+        float sv[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) sv[j] = -INFINITY;
+        float thr = active ? -INFINITY : INFINITY;            // idle lanes never accept
+        int cnt = 0;
+        auto drain = [&]() {
+            int mxc = cnt;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mxc = max(mxc, __shfl_xor(mxc, o));
+            for (int u = 0; u < mxc; ++u) score_insert<K>(sv, u < cnt ? fbuf[u * 64 + lane] : -INFINITY);
+            cnt = 0;
+            if (active) thr = sv[K - 1];
+        };
+        walk([&]() {
+                 float w = thr;
+#pragma unroll
+                 for (int o = 32; o > 0; o >>= 1) w = fminf(w, __shfl_xor(w, o));
+                 return w;
+             },
+             [&](const float* bx) { return !__any(box_score_bound(me, bx) >= thr); },
+             [&](float sc, int) {
+                 if (sc > thr) {
+                     fbuf[cnt * 64 + lane] = sc;
+                     ++cnt;
+                 }
+             },
+             [&]() { return __any(cnt > kBufF - kQuadS - 1); }, drain);
+        floor_score = sv[K - 1];
+    }
+    const unsigned long long t1 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+    // ---- pass 2: exact keys of everything at or above the floor
+    unsigned long long kv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) kv[j] = 0ull;
+    {
+        // lowest key of any score that compares equal to the floor (+-0 compare equal, -0.0 has the lower key)
+        const unsigned long long floor_key = make_key(floor_score == 0.f ? -0.f : floor_score, 0x7fffffff) & 0xffffffff00000000ull;
+        unsigned long long thr = active ? floor_key - 1ull : ~0ull;
+        float wk = active ? floor_score : INFINITY;           // the floor never moves: one reduction for the whole pass
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wk = fminf(wk, __shfl_xor(wk, o));
+        int cnt = 0;
+        auto drain = [&]() {
+            int mxc = cnt;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mxc = max(mxc, __shfl_xor(mxc, o));
+            for (int u = 0; u < mxc; ++u) key_insert<K>(kv, u < cnt ? buf[u][lane] : 0ull);
+            cnt = 0;
+            if (active && kv[K - 1] > thr) thr = kv[K - 1];
+        };
+        walk([&]() { return wk; },
+             [&](const float* bx) { return !__any(make_key(box_score_bound(me, bx), 0) > thr); },
+             [&](float sc, int idx) {
+                 const unsigned long long key = make_key(sc, idx);
+                 if (key > thr) {
+                     buf[cnt][lane] = key;
+                     ++cnt;
+                 }
+             },
+             [&]() { return __any(cnt > kBuf2 - kQuadS - 1); }, drain);
+    }
+    if (active) {
+        int32_t* o = knn + (size_t)myrow * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j) o[j] = clo + key_index(kv[j]);
+    }
+    if ((dbg & 16) && lane == 0) {
+        const unsigned long long t2 = __builtin_readcyclecounter();
+        atomicAdd(&g_knn5_stats[0], 1ull);
+        atomicAdd(&g_knn5_stats[1], t1 - t0);
+        atomicAdd(&g_knn5_stats[3], t2 - t1);
+    }
+}
+
 }  // namespace
+
+static int g_knn_variant = getenv("SG_KNN_SLICES") ? atoi(getenv("SG_KNN_SLICES")) : -1;   // see sg_knn_set_variant
+// Which in-cluster kNN kernel the pipeline launches for a layer of T tiles: 0 = two-pass over the chunk table,
+// 1 / 2 / 4 = one-pass with that many waves per tile.  Measured on MI355X (ms per launch, layers 2 + 3, solo):
+//   150k pts / 1.5k segs   one-pass x1 0.36 + 0.46   two-pass 0.38 + 0.50   (x4: 0.32 + 0.50, but 584 vs 670 scenes/s in the bench)
+//   500k pts / 5k segs     one-pass x1 0.70 + 1.10   two-pass 0.59 + 1.06
+//   150k pts / 100 segs    one-pass x1 1.27 + 1.42   two-pass 1.13 + 1.23
+// and the same bench throughput for x1 and two-pass (650-690 scenes/s).  Default: one wave per tile once the launch
+// fills the GPU; sg_knn_set_variant(0) selects the two-pass kernel.
+int sg::knn_variant_for(int T) {
+    if (g_knn_variant >= 0) return g_knn_variant;
+    return T >= 2048 ? 1 : T >= 1024 ? 2 : 4;
+}
 
 static int g_knn5_dbg = getenv("SG_KNN_DEBUG") ? atoi(getenv("SG_KNN_DEBUG")) : 0;   // profiling knob (16 = counters + cycle stamps)
 
@@ -368,6 +598,35 @@ int sg_knn_operands(const float* d_data, const int32_t* d_seg_points, const int3
     return SG_OK;
 }
 
+int sg_knn_set_variant(int variant) {
+    const int prev = g_knn_variant;
+    g_knn_variant = (variant == 0 || variant == 1 || variant == 2 || variant == 4) ? variant : -1;
+    return prev;
+}
+
+int sg_knn_chunk_table(const int32_t* d_order, const int32_t* d_dst, const int32_t* d_seg_off, const int32_t* d_seg_chunk_off,
+                       const float* d_chunk_box, int S, const int32_t* d_slot_chunk0, float* d_cc, void* stream) {
+    SG_REQUIRE(S >= 0 && d_cc && d_slot_chunk0, "sg_knn_chunk_table: bad arguments");
+    if (S == 0) return SG_OK;
+    k_knn_chunk_table<<<S, 64, 0, sg::as_stream(stream)>>>(d_order, d_dst, d_seg_off, d_seg_chunk_off, d_chunk_box, d_slot_chunk0, d_cc);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_cluster_knn_2pass(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off, const int32_t* d_tile_cl,
+                         const int32_t* d_tile_lo, const int32_t* d_tile_hi, const int32_t* d_tile_chunk0, int T,
+                         const int32_t* d_cl_chunk_off, const float* d_cc, int k, int pos0, int32_t* d_knn, void* stream) {
+    SG_REQUIRE(N >= 0 && T >= 0 && d_knn && d_sxyzw && d_smpos && d_cc, "sg_cluster_knn_2pass: bad arguments");
+    SG_REQUIRE(N < (1 << 25), "sg_cluster_knn_2pass: sorted positions are packed in 25 bits (N < 2^25)");
+    if (k != 20) return sg::fail(SG_EUNSUP, "sg_cluster_knn_2pass: only k == 20 is built (model.py:788,829), got %d", k);
+    if (T == 0) return SG_OK;
+    k_cluster_knn_2pass<20><<<T, 64, 0, sg::as_stream(stream)>>>(reinterpret_cast<const float4*>(d_sxyzw), d_smpos, d_cl_off, d_tile_cl,
+                                                                 d_tile_lo, d_tile_hi, d_tile_chunk0, d_cl_chunk_off,
+                                                                 reinterpret_cast<const float4*>(d_cc), pos0, d_knn, g_knn5_dbg);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
 int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off, const int32_t* d_tile_cl,
                           const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T, const int32_t* d_cl_seg_off,
                           const int32_t* d_order, const int32_t* d_dst, const int32_t* d_seg_off, const int32_t* d_seg_chunk_off,
@@ -376,8 +635,7 @@ int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, c
     SG_REQUIRE(N >= 0 && T >= 0 && d_knn && d_sxyzw && d_smpos, "sg_cluster_knn_sorted: bad arguments");
     if (k != 20) return sg::fail(SG_EUNSUP, "sg_cluster_knn_sorted: only k == 20 is built (model.py:788,829), got %d", k);
     if (T == 0) return SG_OK;
-    static const int forced = getenv("SG_KNN_SLICES") ? atoi(getenv("SG_KNN_SLICES")) : 0;     // experiments only
-    const int slices = forced ? forced : (T >= 2048 ? 1 : T >= 1024 ? 2 : 4);
+    const int slices = (g_knn_variant == 1 || g_knn_variant == 2 || g_knn_variant == 4) ? g_knn_variant : (T >= 2048 ? 1 : T >= 1024 ? 2 : 4);
 #define SG_KNN_LAUNCH(S)                                                                                                  \
     k_cluster_knn_sorted<20, S><<<T, 64 * S, 0, sg::as_stream(stream)>>>(                                                 \
         reinterpret_cast<const float4*>(d_sxyzw), d_smpos, d_cl_off, d_tile_cl, d_tile_lo, d_tile_hi, d_cl_seg_off, d_order, d_dst, \

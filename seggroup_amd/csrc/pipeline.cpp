@@ -64,7 +64,7 @@ struct sg_pipeline {
     // device work buffers
     DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_center, ws_eval, ws_sort;
     DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, slot_of_pos, sperm, smpos, seg_chunk_off, knn, desc, tables, labels;
-    DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf, segbox, chunk_box;
+    DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf, segbox, chunk_box, chunk_table;
 
     // pinned host staging
     PinBuf<int32_t> h_adj, h_desc, h_tables, h_count, h_chunk_off;
@@ -99,7 +99,8 @@ int freeze_layer(const sg_partition* part, int S, LayerDesc& L) {
 
 // Device descriptor block of one layer, carved from ONE pinned buffer and shipped in ONE H2D copy.
 struct DescOffsets {
-    size_t order, dst, cl, cl_pt_off, cl_seg_off, tile_cl, tile_lo, tile_hi, cl_tile_off, goff, gidx, adj, rowptr, col, eid, total;
+    size_t order, dst, cl, cl_pt_off, cl_seg_off, tile_cl, tile_lo, tile_hi, cl_tile_off, goff, gidx, adj, rowptr, col, eid,
+        slot_chunk0, cl_chunk_off, tile_chunk0, total;
 };
 
 }  // namespace
@@ -180,11 +181,11 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->adj1, 2 * maxE1); D(pl->count, 4);
     D(pl->members, N); D(pl->pos_of_point, N); D(pl->cluster_of_pos, N); D(pl->slot_of_pos, N);
     D(pl->knn, N * 20);
-    D(pl->desc, 9 * S + 16 + 3 * T + 2 * maxE1 + 4 * maxE1 + 64);
+    D(pl->desc, 11 * S + 16 + 4 * T + 2 * maxE1 + 4 * maxE1 + 96);
     D(pl->tables, SG_NUM_LABEL_VECTORS * S); D(pl->labels, SG_NUM_LABEL_VECTORS * V);
     D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
     D(pl->feat1, S * 128); D(pl->featA, S * 256); D(pl->featB, S * 256);
-    D(pl->segbox, S * 8); D(pl->chunk_box, (N / 32 + S + 1) * 8); D(pl->sperm, N); D(pl->smpos, N); D(pl->seg_chunk_off, S + 1);
+    D(pl->segbox, S * 8); D(pl->chunk_box, (N / 32 + S + 1) * 8); D(pl->chunk_table, (N / 32 + S + 1) * 8); D(pl->sperm, N); D(pl->smpos, N); D(pl->seg_chunk_off, S + 1);
     D(pl->ws_sort, sg_spatial_sort_ws_bytes(maxN)); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64);
     P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4); P(pl->h_chunk_off, S + 1);
     P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
@@ -328,6 +329,22 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             }
             cl_tile_off[C] = (int)tile_cl.size();
             const int T = (int)tile_cl.size();
+            // cluster-ordered chunk table of the two-pass kNN: chunk numbers per slot / cluster, and per tile the
+            // (cluster-relative) chunk that holds its first sorted position
+            const int knn_variant = sg::knn_variant_for(T);
+            std::vector<int32_t> slot_chunk0(S + 1, 0), cl_chunk_off(C + 1, 0), tile_chunk0(T, 0);
+            if (knn_variant == 0) {
+                for (int i = 0; i < S; ++i) slot_chunk0[i + 1] = slot_chunk0[i] + (sc->h_seg_size[Lnew.order[i]] + 31) / 32;
+                for (int c = 0; c <= C; ++c) cl_chunk_off[c] = slot_chunk0[Lnew.cl_seg_off[c]];
+                for (int c = 0; c < C; ++c) {
+                    int slot = Lnew.cl_seg_off[c];
+                    for (int tt = cl_tile_off[c]; tt < cl_tile_off[c + 1]; ++tt) {
+                        const int pos = tile_lo[tt];
+                        while (slot + 1 < Lnew.cl_seg_off[c + 1] && Lnew.dst[slot + 1] <= pos) ++slot;
+                        tile_chunk0[tt] = slot_chunk0[slot] + (pos - Lnew.dst[slot]) / 32 - cl_chunk_off[c];
+                    }
+                }
+            }
             // parents: old clusters (Lcur numbering) absorbed by each new cluster, in old order (model.py:766-768)
             std::vector<int32_t> goff(C + 1, 0), gidx(Lcur.C), cl_of_order(S);
             for (int j = 0; j < Lcur.C; ++j) ++goff[Lnew.cl_of_seg[Lcur.root[j]] + 1];
@@ -360,6 +377,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             o.order = put(Lnew.order, S); o.dst = put(Lnew.dst, S); o.cl = put(cl_of_order, S); o.cl_pt_off = put(Lnew.cl_pt_off, C + 1);
             o.cl_seg_off = put(Lnew.cl_seg_off, C + 1);
             o.tile_cl = put(tile_cl, T); o.tile_lo = put(tile_lo, T); o.tile_hi = put(tile_hi, T); o.cl_tile_off = put(cl_tile_off, C + 1);
+            o.slot_chunk0 = put(slot_chunk0, S + 1); o.cl_chunk_off = put(cl_chunk_off, C + 1); o.tile_chunk0 = put(tile_chunk0, T);
             o.goff = put(goff, C + 1); o.gidx = put(gidx, Lcur.C); o.adj = put(adj, 2 * (size_t)E);
             o.rowptr = put(rowptr, C + 1); o.col = put(col, 2 * (size_t)E); o.eid = put(eid, 2 * (size_t)E);
             o.total = cur;
@@ -379,9 +397,16 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             for (int i = 0; i < S; ++i) if (Lnew.order[i] == 0) { pos0 = Lnew.dst[i]; break; }
             PL_CHECK(sg_knn_operands(sc->d_data, sc->d_seg_points, sc->d_seg_off, pl->sperm.p, S, dd + o.order, dd + o.dst, pl->xyzw.p,
                                      pl->smpos.p, stv));
-            PL_CHECK(sg_cluster_knn_sorted(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
-                                           dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->segbox.p,
-                                           pl->chunk_box.p, pl->slot_of_pos.p, 20, pos0, pl->knn.p, stv));
+            if (knn_variant == 0) {
+                PL_CHECK(sg_knn_chunk_table(dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->chunk_box.p, S,
+                                            dd + o.slot_chunk0, pl->chunk_table.p, stv));
+                PL_CHECK(sg_cluster_knn_2pass(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi,
+                                              dd + o.tile_chunk0, T, dd + o.cl_chunk_off, pl->chunk_table.p, 20, pos0, pl->knn.p, stv));
+            } else {
+                PL_CHECK(sg_cluster_knn_sorted(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
+                                               dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->segbox.p,
+                                               pl->chunk_box.p, pl->slot_of_pos.p, 20, pos0, pl->knn.p, stv));
+            }
             pl->mark(sb + 2);
             // sub-pass marks: the last pass is marked with the stage id itself, so "lN.edgeconv" keeps meaning the
             // time of the LAST pass here and the reporting side adds the sub-passes up (see sg_pipeline_stage_times)

@@ -77,6 +77,9 @@ SIGNATURES = {
     "sg_segment_spatial_sort": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_knn_operands": (_I, [vp, vp, vp, vp, _I, vp, vp, vp, vp, vp]),
     "sg_cluster_knn_sorted": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
+    "sg_knn_set_variant": (_I, [_I]),
+    "sg_knn_chunk_table": (_I, [vp, vp, vp, vp, vp, _I, vp, vp, vp]),
+    "sg_cluster_knn_2pass": (_I, [vp, vp, _I, vp, vp, vp, vp, vp, _I, vp, vp, _I, _I, vp, vp]),
     "sg_edgeconv_ws_bytes": (_Z, [_I]),
     "sg_edgeconv_forward": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_gcn_ws_bytes": (_Z, [_I, _I, _I]),

@@ -430,12 +430,38 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         hip.check(lib.sg_knn_operands(d_data.data_ptr(), d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S,
                                       d["order"].data_ptr(), d["dst"].data_ptr(), sxyzw.data_ptr(), smpos.data_ptr(), None))
         assert sorted(smpos.cpu().numpy().tolist()) == list(range(N))
-        k_sorted = torch.full((N, 20), -7, dtype=torch.int32, device="cuda:0")
-        hip.check(lib.sg_cluster_knn_sorted(sxyzw.data_ptr(), smpos.data_ptr(), N, d["off"].data_ptr(), d4[0].data_ptr(), d4[1].data_ptr(),
-                                            d4[2].data_ptr(), len(tc4), d["cso"].data_ptr(), d["order"].data_ptr(), d["dst"].data_ptr(),
-                                            d["segoff"].data_ptr(), d_co.data_ptr(), box.data_ptr(), cbox.data_ptr(), d_slot.data_ptr(), 20,
-                                            int(pos_of_point[0]), k_sorted.data_ptr(), None))
-        c_ = k_sorted.cpu().numpy()
-        assert np.array_equal(a, c_), f"{name}/{target}: {int(np.any(a != c_, axis=1).sum())} rows differ between brute force and sorted"
+        for variant in (1, 2, 4, -1):        # one-pass with 1 / 2 / 4 waves per tile | the default choice
+            prev = lib.sg_knn_set_variant(variant)
+            k_sorted = torch.full((N, 20), -7, dtype=torch.int32, device="cuda:0")
+            hip.check(lib.sg_cluster_knn_sorted(sxyzw.data_ptr(), smpos.data_ptr(), N, d["off"].data_ptr(), d4[0].data_ptr(), d4[1].data_ptr(),
+                                                d4[2].data_ptr(), len(tc4), d["cso"].data_ptr(), d["order"].data_ptr(), d["dst"].data_ptr(),
+                                                d["segoff"].data_ptr(), d_co.data_ptr(), box.data_ptr(), cbox.data_ptr(), d_slot.data_ptr(), 20,
+                                                int(pos_of_point[0]), k_sorted.data_ptr(), None))
+            lib.sg_knn_set_variant(prev)
+            c_ = k_sorted.cpu().numpy()
+            assert np.array_equal(a, c_), f"{name}/{target}/variant {variant}: {int(np.any(a != c_, axis=1).sum())} rows differ between brute force and sorted"
+        # two-pass kernel over the cluster-ordered chunk table (host side of the table as in pipeline.cpp)
+        nch_slot = (np.diff(seg_off)[np.asarray(order)] + 31) // 32
+        slot_chunk0 = np.concatenate([[0], np.cumsum(nch_slot)]).astype(np.int32)
+        cl_chunk_off = slot_chunk0[np.asarray(cso)].astype(np.int32)
+        dst_a = np.asarray(dst)
+        tile_chunk0 = np.zeros(len(tc4), np.int32)
+        for t_, (c__, lo_) in enumerate(zip(tc4, lo4)):
+            slot = cso[c__] + int(np.searchsorted(dst_a[cso[c__]:cso[c__ + 1]], lo_, side="right")) - 1
+            tile_chunk0[t_] = slot_chunk0[slot] + (lo_ - dst_a[slot]) // 32 - cl_chunk_off[c__]
+        d_sc0, d_cco, d_tc0 = _up(torch, slot_chunk0), _up(torch, cl_chunk_off), _up(torch, tile_chunk0)
+        cc = torch.zeros(int(slot_chunk0[-1]) + 1, 8, device="cuda:0")
+        hip.check(lib.sg_knn_chunk_table(d["order"].data_ptr(), d["dst"].data_ptr(), d["segoff"].data_ptr(), d_co.data_ptr(), cbox.data_ptr(),
+                                         S, d_sc0.data_ptr(), cc.data_ptr(), None))
+        cch = cc.cpu().numpy()[:-1]
+        packed = cch[:, 7].copy().view(np.int32)
+        assert np.array_equal(np.sort(packed >> 6), np.sort(np.concatenate([dst_a[i] + 32 * np.arange(nch_slot[i]) for i in range(S)])))
+        assert int(((packed & 63) + 1).sum()) == N
+        k_two = torch.full((N, 20), -7, dtype=torch.int32, device="cuda:0")
+        hip.check(lib.sg_cluster_knn_2pass(sxyzw.data_ptr(), smpos.data_ptr(), N, d["off"].data_ptr(), d4[0].data_ptr(), d4[1].data_ptr(),
+                                           d4[2].data_ptr(), d_tc0.data_ptr(), len(tc4), d_cco.data_ptr(), cc.data_ptr(), 20,
+                                           int(pos_of_point[0]), k_two.data_ptr(), None))
+        e_ = k_two.cpu().numpy()
+        assert np.array_equal(a, e_), f"{name}/{target}: {int(np.any(a != e_, axis=1).sum())} rows differ between brute force and two-pass"
         ref = O.cluster_knn(sc.data[:, :3], L, 20)[members]
         assert np.array_equal(members[a], ref)

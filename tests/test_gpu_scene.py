@@ -125,6 +125,25 @@ def test_150k_scene_matches_reference_digests_and_oracle(golden_index, weight_se
     assert np.array_equal(res.iou_sem, g["ins.metric.0"]) and np.array_equal(res.iou_ins, g["ins.metric.1"])
 
 
+@pytest.mark.parametrize("variant", [0, 2, 4])
+def test_150k_scene_labels_do_not_depend_on_the_knn_kernel(golden_index, weight_sets, variant):
+    """The pipeline's alternative in-cluster kNN kernels (two-pass over the chunk table; 2 / 4 waves per tile) give
+    the reference's labels as well (the default at this size is one wave per tile, covered above)."""
+    from seggroup_amd import hip
+    name = "scene_150k"
+    scene = make_fixture_scene(golden_index, name)
+    prev = hip.lib().sg_knn_set_variant(variant)
+    try:
+        res, _, _ = _run(scene, weight_sets["ins_infer"], "ins_infer")
+    finally:
+        hip.lib().sg_knn_set_variant(prev)
+    e = golden_index[name]["ins_infer"]
+    assert res.trace[1:5] == e["nclusters"]
+    for i in range(14):
+        nm = hip.LABEL_NAMES[i]
+        assert hashlib.sha256(np.ascontiguousarray(res.labels[i]).tobytes()).hexdigest() == e["label_sha"][nm], nm
+
+
 def test_stress_500k_matches_reference_and_oracle_digests(golden_index, weight_sets):
     """BASELINE.json configs[4]: 500k points / 5k segments / 20-NN.  Labels must equal the digests of the
     reference capture AND of the oracle (both committed in tests/golden/index.json; the seed was screened to be
