@@ -162,6 +162,11 @@ def main():
                     "frac": round(achieved / peak, 6), "traffic": traffic, "ms_per_launch": round(ms_launch, 4),
                     "launches_per_scene": launches, "measured_with": "HIP events on the pipeline streams, inside the timed region",
                     "kernel_ms_per_scene": {kn: round(v, 4) for kn, v in per_scene.items()},
+                    # the same figures for every modelled kernel (the in-cluster kNN is VALU/latency-bound: its HBM
+                    # fraction is nominal; the EdgeConv passes are the MFMA-bound ones)
+                    "all_kernels": {kn: {"bound": m[2], "achieved": round(m[3] / (per_scene[kn] / m[1] * 1e-3) / m[6], 3), "peak": m[5],
+                                         "unit": m[4], "frac": round(m[3] / (per_scene[kn] / m[1] * 1e-3) / m[6] / m[5], 5)}
+                                    for kn, m in model.items() if per_scene[kn] > 0},
                     "stage_ms": {k_: round(v, 4) for k_, v in mean_ms.items()}}
 
         with_files = {}
