@@ -400,6 +400,49 @@ int  sg_writer_submit(sg_writer* w, const char* path_without_ext, const int32_t*
 int  sg_writer_flush(sg_writer* w);
 void sg_writer_destroy(sg_writer* w);
 
+/* =============================================================================================
+ * Raw scan -> hot-path inputs (reference seggroup/dataset/scannet/util.py).  The compute parts
+ * of the reference's offline pre-processing; file formats stay on the Python side (seggroup_amd/prepare.py).
+ * Index types follow the reference's tensors: mapper / unmapper / adjacency are int64 (LongTensor), the raw
+ * inputs (PLY faces, segIndices) int32.  Every function synchronises the stream before it returns host counts.
+ * ============================================================================================= */
+
+/* get_unmapper (util.py:538-550, cal_pairwise_distance 530-535): d_idx[u] = argmax_j ((-|x_u|^2) - (-2 x_u.y_j)) - |y_j|^2
+ * in the reference's fp32 operation order, lowest j among equal maxima.  d_x [U,3]; d_y rows of `y_stride` floats
+ * (>= 3: xyz first).  Brute force: U*N pair evaluations. */
+size_t sg_nearest_point_ws_bytes(int N);
+int sg_nearest_point(const float* d_x, int U, const float* d_y, int y_stride, int N, int64_t* d_idx,
+                     void* d_ws, size_t ws_bytes, void* stream);
+
+/* generate_pointcloud_pth (util.py:633-693) without the file I/O and the random draw: given the mapper (which
+ * raw vertex every sampled point copies), d_pcl [Np,6] = [xyz, rgb / 127.5 - 1 (evaluated in double, stored fp32)]
+ * and d_unmap [V] = the LAST sampled point that copies the vertex (687-689) or, for a vertex that was not sampled,
+ * its nearest sampled point (sg_nearest_point against d_pcl).  *h_unsampled = number of such vertices. */
+size_t sg_prep_sample_ws_bytes(int V, int Np);
+int sg_prep_sample_points(const float* d_xyz, const uint8_t* d_rgb, int V, const int64_t* d_mapper, int Np,
+                          float* d_pcl, int64_t* d_unmap, int* h_unsampled, void* d_ws, size_t ws_bytes, void* stream);
+
+/* get_adj_from_mesh (util.py:771-792).  d_faces [F,3]: edges (0,1), (0,2), (1,2) of every face, zero-length ones
+ * dropped (783); d_adj_raw = ascending ids per row, unique rows in lexicographic order; d_adj_res (may be NULL)
+ * = the same rows mapped through d_unmap first (rows that collapse to (a, a) only then are kept, as in the
+ * reference).  Both need room for [3F,2] int64; the row counts come back in *h_n_raw / *h_n_res. */
+size_t sg_mesh_adjacency_ws_bytes(int F);
+int sg_mesh_adjacency(const int32_t* d_faces, int F, const int64_t* d_unmap, int V, int64_t* d_adj_raw, int* h_n_raw,
+                      int64_t* d_adj_res, int* h_n_res, void* d_ws, size_t ws_bytes, void* stream);
+
+/* generate_seg_labels_and_ds_set (util.py:174-220) without the file I/O.  d_seg_indices [V] (non-negative raw
+ * segment ids) -> d_raw_label [V] = rank of the id among the sorted unique ids (the `.seg.txt` column), and the
+ * member lists of the SAMPLED cloud as a CSR: d_seg_points [Np] grouped by ascending compacted id, ascending point
+ * index inside a group, d_seg_off [G+1] (room for min(V, Np) + 1).  h_counts[0] = number of raw segments,
+ * h_counts[1] = G (a segment none of whose vertices was sampled has no group). */
+size_t sg_segment_lists_ws_bytes(int V, int Np);
+int sg_segment_lists(const int32_t* d_seg_indices, int V, const int64_t* d_mapper, int Np, int32_t* d_raw_label,
+                     int32_t* d_seg_points, int32_t* d_seg_off, int* h_counts, void* d_ws, size_t ws_bytes, void* stream);
+
+/* `.seg.json` exactly as json.dump writes it (util.py:205-220): one list per sampled point, a segment's members at
+ * the index of its smallest member, [] elsewhere.  Host arrays of sg_segment_lists (any group order). */
+int sg_write_seg_json(const char* path, const int32_t* h_seg_points, const int32_t* h_seg_off, int G, int Np);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,45 @@ int sg_write_label_npy(const char* path, const int32_t* h_vec, int V) {
     return SG_OK;
 }
 
+// `.seg.json` (util.py:205-220): json.dump of a list with one entry per sampled point -- the ascending member list of a
+// segment at the index of its smallest member, [] everywhere else -- byte for byte as Python writes it ("[[], [3, 7], []]").
+// Groups come as a CSR (any group order); members ascending inside a group.
+int sg_write_seg_json(const char* path, const int32_t* h_seg_points, const int32_t* h_seg_off, int G, int Np) {
+    if (!path || G < 0 || Np < 0 || (G > 0 && (!h_seg_points || !h_seg_off))) return sg::fail(SG_EINVAL, "sg_write_seg_json: bad arguments");
+    std::vector<int32_t> group_at(Np, -1);
+    for (int g = 0; g < G; ++g) {
+        const int first = h_seg_points[h_seg_off[g]];
+        if (h_seg_off[g + 1] <= h_seg_off[g] || first < 0 || first >= Np) return sg::fail(SG_EINVAL, "sg_write_seg_json: bad group %d", g);
+        group_at[first] = g;
+    }
+    std::string buf;
+    buf.reserve((size_t)Np * 10 + 16);
+    auto put_int = [&](int64_t v) {
+        char tmp[12];
+        int n = 0;
+        do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (n) buf.push_back(tmp[--n]);
+    };
+    buf.push_back('[');
+    for (int i = 0; i < Np; ++i) {
+        if (i) buf.append(", ");
+        buf.push_back('[');
+        const int g = group_at[i];
+        if (g >= 0)
+            for (int k = h_seg_off[g]; k < h_seg_off[g + 1]; ++k) {
+                if (k > h_seg_off[g]) buf.append(", ");
+                put_int(h_seg_points[k]);
+            }
+        buf.push_back(']');
+    }
+    buf.push_back(']');
+    FILE* f = fopen(path, "wb");
+    if (!f) return sg::fail(SG_EINVAL, "sg_write_seg_json: cannot open %s: %s", path, strerror(errno));
+    const size_t w = fwrite(buf.data(), 1, buf.size(), f);
+    if (fclose(f) != 0 || w != buf.size()) return sg::fail(SG_EINVAL, "sg_write_seg_json: short write to %s", path);
+    return SG_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------

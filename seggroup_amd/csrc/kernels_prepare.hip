@@ -1,0 +1,352 @@
+// raw scan -> hot-path inputs (reference seggroup/dataset/scannet/util.py).
+//
+//   sg_prep_sample_points   generate_pointcloud_pth 633-693 without the file I/O: gather + colour centring, the
+//                           unmapper (last occurrence of a vertex in the mapper wins, 687-689), and for vertices that
+//                           were not sampled the nearest sampled point (get_unmapper 538-550)
+//   sg_nearest_point        get_unmapper / cal_pairwise_distance 530-550
+//   sg_mesh_adjacency       get_adj_from_mesh 771-792: per-row sorted, lexicographically unique edge lists, raw and resampled
+//   sg_segment_lists        generate_seg_labels_and_ds_set 174-220: compacted segment ids + member lists
+//
+// All of it is index / byte work (HBM- and sort-bound) except the nearest-point search, a brute-force scan in the
+// reference's exact fp32 formula  s_ij = ((-xx_i) - (-2 x_i.y_j)) - yy_j  (argmax, lowest j on ties): at ScanNet's worst
+// case (380k unsampled vertices x 150k samples = 5.7e10 pairs) that is ~4.6e11 VALU lane-ops, ~15 ms on MI355X, so a
+// spatial index is not worth its exactness proof.
+#include <hipcub/hipcub.hpp>
+
+#include "sg_common.h"
+
+namespace {
+
+constexpr int kTile = 256;      // candidates staged per LDS tile = queries per block
+
+// score of candidate c = (x, y, z, yy) for the query (qx, qy, qz) with squared norm qq, in the reference's order
+__device__ inline float pair_score(float qx, float qy, float qz, float qq, const float4& c) {
+    const float tt = __builtin_fmaf(qz, c.z, __builtin_fmaf(qy, c.y, qx * c.x));      // MKL's K=3 dot product
+    const float inner = -2.0f * tt;
+    return ((-qq) - inner) - c.w;
+}
+
+// [n,3] (row stride `stride` floats) -> float4 (x, y, z, (x*x + y*y) + z*z): torch.sum(y**2, dim=1)
+__global__ void k_pack_xyzw(const float* __restrict__ p, int stride, int n, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = p[(size_t)i * stride], y = p[(size_t)i * stride + 1], z = p[(size_t)i * stride + 2];
+    out[i] = make_float4(x, y, z, (x * x + y * y) + z * z);
+}
+
+// queries qid[0..U) (indices into qxyz rows, or the identity when qid == nullptr) against all N candidates.
+// One query per thread; candidates stream through LDS in ascending order, so `>` keeps the lowest index of a tie.
+__global__ __launch_bounds__(kTile) void k_nearest(const float* __restrict__ qxyz, int qstride, const int32_t* __restrict__ qid, int U,
+                                                   const float4* __restrict__ cand, int N, int64_t* __restrict__ out, int scatter) {
+    __shared__ float4 tile[kTile];
+    const int u = blockIdx.x * kTile + threadIdx.x;
+    const bool live = u < U;
+    const int row = live ? (qid ? qid[u] : u) : 0;
+    const float qx = qxyz[(size_t)row * qstride], qy = qxyz[(size_t)row * qstride + 1], qz = qxyz[(size_t)row * qstride + 2];
+    const float qq = (qx * qx + qy * qy) + qz * qz;
+    float best = -INFINITY;
+    int arg = 0;
+    for (int c0 = 0; c0 < N; c0 += kTile) {
+        __syncthreads();
+        tile[threadIdx.x] = c0 + threadIdx.x < N ? cand[c0 + threadIdx.x] : make_float4(0.f, 0.f, 0.f, INFINITY);
+        __syncthreads();
+        const int m = min(kTile, N - c0);
+        int j = 0;
+        for (; j + 4 <= m; j += 4) {
+            const float s0 = pair_score(qx, qy, qz, qq, tile[j]), s1 = pair_score(qx, qy, qz, qq, tile[j + 1]);
+            const float s2 = pair_score(qx, qy, qz, qq, tile[j + 2]), s3 = pair_score(qx, qy, qz, qq, tile[j + 3]);
+            if (s0 > best) { best = s0; arg = c0 + j; }
+            if (s1 > best) { best = s1; arg = c0 + j + 1; }
+            if (s2 > best) { best = s2; arg = c0 + j + 2; }
+            if (s3 > best) { best = s3; arg = c0 + j + 3; }
+        }
+        for (; j < m; ++j) {
+            const float s = pair_score(qx, qy, qz, qq, tile[j]);
+            if (s > best) { best = s; arg = c0 + j; }
+        }
+    }
+    if (live) out[scatter ? row : u] = arg;
+}
+
+// pcl[i] = [xyz[m], rgb[m] / 127.5 - 1 evaluated in double, rounded to fp32]; unmap[m] = max i (last occurrence)
+__global__ void k_sample_gather(const float* __restrict__ xyz, const uint8_t* __restrict__ rgb, const int64_t* __restrict__ mapper,
+                                int Np, float* __restrict__ pcl, int32_t* __restrict__ last) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Np) return;
+    const int m = (int)mapper[i];
+    float* o = pcl + (size_t)i * 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = xyz[(size_t)m * 3 + k];
+        o[3 + k] = (float)((double)rgb[(size_t)m * 3 + k] / 127.5 - 1.0);
+    }
+    atomicMax(&last[m], i);
+}
+
+__global__ void k_fill_i32(int32_t* p, int n, int32_t v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void k_unmap_finish(const int32_t* __restrict__ last, int V, int64_t* __restrict__ unmap, int32_t* __restrict__ missing,
+                               int32_t* __restrict__ n_missing) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    unmap[v] = last[v];
+    if (last[v] < 0) missing[atomicAdd(n_missing, 1)] = v;           // order is irrelevant: every entry owns its output slot
+}
+
+// edges (0,1), (0,2), (1,2) of every face; zero-length edges (util.py:783) and, for the resampled list, the same rows
+// mapped through `unmap` -- packed as lo << 32 | hi; dropped rows become ~0 and sort to the end
+__global__ void k_face_edges(const int32_t* __restrict__ faces, int F, const int64_t* __restrict__ unmap,
+                             unsigned long long* __restrict__ raw, unsigned long long* __restrict__ res) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int v[3] = {faces[(size_t)f * 3], faces[(size_t)f * 3 + 1], faces[(size_t)f * 3 + 2]};
+    const int pa[3] = {0, 0, 1}, pb[3] = {1, 2, 2};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int a = v[pa[e]], b = v[pb[e]];
+        const bool keep = a != b;
+        raw[(size_t)f * 3 + e] = keep ? ((unsigned long long)(unsigned)min(a, b) << 32) | (unsigned)max(a, b) : ~0ull;
+        if (res) {
+            const long long ua = keep ? unmap[a] : 0, ub = keep ? unmap[b] : 0;
+            res[(size_t)f * 3 + e] = keep ? ((unsigned long long)(unsigned)min(ua, ub) << 32) | (unsigned)max(ua, ub) : ~0ull;
+        }
+    }
+}
+
+__global__ void k_unpack_edges(const unsigned long long* __restrict__ keys, int n, int64_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[(size_t)i * 2] = (int64_t)(keys[i] >> 32);
+    out[(size_t)i * 2 + 1] = (int64_t)(keys[i] & 0xffffffffull);
+}
+
+// raw_label[v] = rank of seg_indices[v] among the sorted unique ids (np.unique + seg_remapper, util.py:181-186)
+__global__ void k_rank_labels(const int32_t* __restrict__ seg, int V, const int32_t* __restrict__ uniq, const int32_t* __restrict__ n_uniq,
+                              int32_t* __restrict__ raw_label) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int x = seg[v];
+    int lo = 0, hi = *n_uniq;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (uniq[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    raw_label[v] = lo;
+}
+
+__global__ void k_sampled_labels(const int32_t* __restrict__ raw_label, const int64_t* __restrict__ mapper, int Np,
+                                 int32_t* __restrict__ key, int32_t* __restrict__ val) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Np) return;
+    key[i] = raw_label[mapper[i]];
+    val[i] = i;
+}
+
+// heads[i] = 1 where a new group starts in the label-sorted order
+__global__ void k_group_heads(const int32_t* __restrict__ key, int Np, int32_t* __restrict__ head_pos, int32_t* __restrict__ n_groups) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Np) return;
+    if (i == 0 || key[i] != key[i - 1]) head_pos[atomicAdd(n_groups, 1)] = i;          // sorted afterwards (G is small)
+}
+
+int bits_for(long long n) {
+    int b = 1;
+    while ((1ll << b) < n) ++b;
+    return b;
+}
+
+size_t sort_keys_temp(int n) {
+    size_t t = 0;
+    hipcub::DoubleBuffer<unsigned long long> d(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t, d, std::max(n, 1), 0, 64, (hipStream_t)0);
+    return t;
+}
+
+size_t unique_temp(int n) {
+    size_t t = 0;
+    (void)hipcub::DeviceSelect::Unique(nullptr, t, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, std::max(n, 1),
+                                       (hipStream_t)0);
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sg_nearest_point_ws_bytes(int N) { return sg::align_up((size_t)std::max(N, 1) * 16); }
+
+int sg_nearest_point(const float* d_x, int U, const float* d_y, int y_stride, int N, int64_t* d_idx, void* d_ws, size_t ws_bytes,
+                     void* stream) {
+    SG_REQUIRE(U >= 0 && N > 0 && y_stride >= 3 && d_idx && d_ws, "sg_nearest_point: bad arguments");
+    if (ws_bytes < sg_nearest_point_ws_bytes(N)) return sg::fail(SG_ENOMEM, "sg_nearest_point: workspace too small");
+    if (U == 0) return SG_OK;
+    hipStream_t st = sg::as_stream(stream);
+    float4* cand = reinterpret_cast<float4*>(d_ws);
+    k_pack_xyzw<<<sg::cdiv(N, 256), 256, 0, st>>>(d_y, y_stride, N, cand);
+    k_nearest<<<sg::cdiv(U, kTile), kTile, 0, st>>>(d_x, 3, nullptr, U, cand, N, d_idx, 0);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+size_t sg_prep_sample_ws_bytes(int V, int Np) {
+    return sg::align_up((size_t)std::max(Np, 1) * 16) + 2 * sg::align_up((size_t)std::max(V, 1) * 4) + 256;
+}
+
+int sg_prep_sample_points(const float* d_xyz, const uint8_t* d_rgb, int V, const int64_t* d_mapper, int Np, float* d_pcl,
+                          int64_t* d_unmap, int* h_unsampled, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(V > 0 && Np > 0 && d_xyz && d_rgb && d_mapper && d_pcl && d_unmap && d_ws, "sg_prep_sample_points: bad arguments");
+    sg::Carver cv(d_ws, ws_bytes);
+    float4* cand = cv.take<float4>(Np);
+    int32_t* last = cv.take<int32_t>(V);
+    int32_t* missing = cv.take<int32_t>(V);
+    int32_t* n_missing = cv.take<int32_t>(1);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_prep_sample_points: workspace too small (%zu < %zu)", ws_bytes, sg_prep_sample_ws_bytes(V, Np));
+    hipStream_t st = sg::as_stream(stream);
+    k_fill_i32<<<sg::cdiv(V, 256), 256, 0, st>>>(last, V, -1);
+    SG_HIP(hipMemsetAsync(n_missing, 0, 4, st));
+    k_sample_gather<<<sg::cdiv(Np, 256), 256, 0, st>>>(d_xyz, d_rgb, d_mapper, Np, d_pcl, last);
+    k_unmap_finish<<<sg::cdiv(V, 256), 256, 0, st>>>(last, V, d_unmap, missing, n_missing);
+    int nm = 0;
+    SG_HIP(hipMemcpyAsync(&nm, n_missing, 4, hipMemcpyDeviceToHost, st));
+    SG_HIP(hipStreamSynchronize(st));
+    if (h_unsampled) *h_unsampled = nm;
+    if (nm > 0) {
+        k_pack_xyzw<<<sg::cdiv(Np, 256), 256, 0, st>>>(d_pcl, 6, Np, cand);
+        k_nearest<<<sg::cdiv(nm, kTile), kTile, 0, st>>>(d_xyz, 3, missing, nm, cand, Np, d_unmap, 1);
+    }
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+size_t sg_mesh_adjacency_ws_bytes(int F) {
+    const size_t n = (size_t)std::max(F, 1) * 3;
+    return sg::align_up(std::max(sort_keys_temp((int)n), unique_temp((int)n))) + 4 * sg::align_up(n * 8) + 256;
+}
+
+// d_adj_raw / d_adj_res: room for [3F,2] int64 each; the row counts come back through h_n_raw / h_n_res
+int sg_mesh_adjacency(const int32_t* d_faces, int F, const int64_t* d_unmap, int V, int64_t* d_adj_raw, int* h_n_raw, int64_t* d_adj_res,
+                      int* h_n_res, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(F >= 0 && V > 0 && d_adj_raw && h_n_raw && d_ws && (!d_adj_res || (d_unmap && h_n_res)), "sg_mesh_adjacency: bad arguments");
+    *h_n_raw = 0;
+    if (h_n_res) *h_n_res = 0;
+    if (F == 0) return SG_OK;
+    const int n = 3 * F;
+    const size_t temp = std::max(sort_keys_temp(n), unique_temp(n));
+    sg::Carver cv(d_ws, ws_bytes);
+    char* tmp = cv.take<char>(temp);
+    unsigned long long* k0 = cv.take<unsigned long long>(n);
+    unsigned long long* k1 = cv.take<unsigned long long>(n);
+    unsigned long long* r0 = cv.take<unsigned long long>(n);
+    unsigned long long* r1 = cv.take<unsigned long long>(n);
+    int* d_count = cv.take<int>(2);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_mesh_adjacency: workspace too small (%zu < %zu)", ws_bytes, sg_mesh_adjacency_ws_bytes(F));
+    hipStream_t st = sg::as_stream(stream);
+    const bool res = d_adj_res != nullptr;
+    k_face_edges<<<sg::cdiv(F, 256), 256, 0, st>>>(d_faces, F, d_unmap, k0, res ? r0 : nullptr);
+    auto sort_unique = [&](unsigned long long* a, unsigned long long* b, int* cnt) -> int {
+        size_t t = temp;
+        hipcub::DoubleBuffer<unsigned long long> d(a, b);
+        SG_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, t, d, n, 0, 64, st));
+        unsigned long long* sorted = d.Current();
+        unsigned long long* other = sorted == a ? b : a;
+        t = temp;
+        SG_HIP(hipcub::DeviceSelect::Unique(tmp, t, sorted, other, cnt, n, st));
+        if (other != b) SG_HIP(hipMemcpyAsync(b, other, (size_t)n * 8, hipMemcpyDeviceToDevice, st));     // result always in b
+        return SG_OK;
+    };
+    int rc = sort_unique(k0, k1, d_count);
+    if (rc < 0) return rc;
+    if (res && (rc = sort_unique(r0, r1, d_count + 1)) < 0) return rc;
+    int cnt[2] = {0, 0};
+    unsigned long long tail[2] = {0, 0};
+    SG_HIP(hipMemcpyAsync(cnt, d_count, res ? 8 : 4, hipMemcpyDeviceToHost, st));
+    SG_HIP(hipStreamSynchronize(st));
+    // the dropped rows, if any, collapsed into one trailing ~0 key
+    SG_HIP(hipMemcpyAsync(&tail[0], k1 + cnt[0] - 1, 8, hipMemcpyDeviceToHost, st));
+    if (res) SG_HIP(hipMemcpyAsync(&tail[1], r1 + cnt[1] - 1, 8, hipMemcpyDeviceToHost, st));
+    SG_HIP(hipStreamSynchronize(st));
+    if (tail[0] == ~0ull) --cnt[0];
+    if (res && tail[1] == ~0ull) --cnt[1];
+    if (cnt[0] > 0) k_unpack_edges<<<sg::cdiv(cnt[0], 256), 256, 0, st>>>(k1, cnt[0], d_adj_raw);
+    if (res && cnt[1] > 0) k_unpack_edges<<<sg::cdiv(cnt[1], 256), 256, 0, st>>>(r1, cnt[1], d_adj_res);
+    *h_n_raw = cnt[0];
+    if (res) *h_n_res = cnt[1];
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+size_t sg_segment_lists_ws_bytes(int V, int Np) {
+    const size_t n = (size_t)std::max(std::max(V, Np), 1);
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    hipcub::DoubleBuffer<int32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t1, dk, (int)n, 0, 32, (hipStream_t)0);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, dk, dv, (int)n, 0, 32, (hipStream_t)0);
+    (void)hipcub::DeviceSelect::Unique(nullptr, t3, (int32_t*)nullptr, (int32_t*)nullptr, (int*)nullptr, (int)n, (hipStream_t)0);
+    return sg::align_up(std::max(t1, std::max(t2, t3))) + 5 * sg::align_up(n * 4) + 256;
+}
+
+// d_raw_label [V]: compacted ids (the `.seg.txt` column).  d_seg_points [Np] / d_seg_off [G+1]: sampled points grouped
+// by ascending compacted id, ascending point index inside a group (G <= number of raw segments: a segment none of whose
+// vertices was sampled has no group).  h_counts = {number of raw segments, G}.
+int sg_segment_lists(const int32_t* d_seg_indices, int V, const int64_t* d_mapper, int Np, int32_t* d_raw_label, int32_t* d_seg_points,
+                     int32_t* d_seg_off, int* h_counts, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(V > 0 && Np > 0 && d_seg_indices && d_mapper && d_raw_label && d_seg_points && d_seg_off && h_counts && d_ws,
+               "sg_segment_lists: bad arguments");
+    const size_t n = (size_t)std::max(V, Np);
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    {
+        hipcub::DoubleBuffer<int32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
+        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t1, dk, (int)n, 0, 32, (hipStream_t)0);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, dk, dv, (int)n, 0, 32, (hipStream_t)0);
+        (void)hipcub::DeviceSelect::Unique(nullptr, t3, (int32_t*)nullptr, (int32_t*)nullptr, (int*)nullptr, (int)n, (hipStream_t)0);
+    }
+    const size_t temp = std::max(t1, std::max(t2, t3));
+    sg::Carver cv(d_ws, ws_bytes);
+    char* tmp = cv.take<char>(temp);
+    int32_t* a = cv.take<int32_t>(n);
+    int32_t* b = cv.take<int32_t>(n);
+    int32_t* c = cv.take<int32_t>(n);
+    int32_t* d = cv.take<int32_t>(n);
+    int32_t* e = cv.take<int32_t>(n);
+    int* d_cnt = cv.take<int>(2);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_segment_lists: workspace too small (%zu < %zu)", ws_bytes, sg_segment_lists_ws_bytes(V, Np));
+    hipStream_t st = sg::as_stream(stream);
+    // 1. sorted unique raw ids (ids are non-negative in ScanNet; the sort is on the signed value's bits)
+    SG_HIP(hipMemcpyAsync(a, d_seg_indices, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
+    size_t t = temp;
+    hipcub::DoubleBuffer<int32_t> ids(a, b);
+    SG_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, t, ids, V, 0, 32, st));
+    int32_t* uniq = ids.Current() == a ? b : a;
+    t = temp;
+    SG_HIP(hipcub::DeviceSelect::Unique(tmp, t, ids.Current(), uniq, d_cnt, V, st));
+    k_rank_labels<<<sg::cdiv(V, 256), 256, 0, st>>>(d_seg_indices, V, uniq, d_cnt, d_raw_label);
+    // 2. stable sort of (sampled label, point index): groups in ascending label order, ascending index inside
+    k_sampled_labels<<<sg::cdiv(Np, 256), 256, 0, st>>>(d_raw_label, d_mapper, Np, c, d);
+    hipcub::DoubleBuffer<int32_t> keys(c, ids.Current()), vals(d, e);      // ids.Current() is free again
+    t = temp;
+    SG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, t, keys, vals, Np, 0, 32, st));
+    SG_HIP(hipMemcpyAsync(d_seg_points, vals.Current(), (size_t)Np * 4, hipMemcpyDeviceToDevice, st));
+    // 3. group starts
+    SG_HIP(hipMemsetAsync(d_cnt + 1, 0, 4, st));
+    int32_t* heads = vals.Alternate();
+    k_group_heads<<<sg::cdiv(Np, 256), 256, 0, st>>>(keys.Current(), Np, heads, d_cnt + 1);
+    int cnt[2] = {0, 0};
+    SG_HIP(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    SG_HIP(hipStreamSynchronize(st));
+    const int G = cnt[1];
+    hipcub::DoubleBuffer<int32_t> hs(heads, keys.Alternate());
+    t = temp;
+    SG_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, t, hs, G, 0, 32, st));
+    SG_HIP(hipMemcpyAsync(d_seg_off, hs.Current(), (size_t)G * 4, hipMemcpyDeviceToDevice, st));
+    SG_HIP(hipMemcpyAsync(d_seg_off + G, &Np, 4, hipMemcpyHostToDevice, st));
+    SG_HIP(hipStreamSynchronize(st));
+    h_counts[0] = cnt[0];
+    h_counts[1] = G;
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // extern "C"

@@ -80,6 +80,15 @@ SIGNATURES = {
     "sg_knn_set_variant": (_I, [_I]),
     "sg_knn_chunk_table": (_I, [vp, vp, vp, vp, vp, _I, vp, vp, vp]),
     "sg_cluster_knn_2pass": (_I, [vp, vp, _I, vp, vp, vp, vp, vp, _I, vp, vp, _I, _I, vp, vp]),
+    "sg_nearest_point_ws_bytes": (_Z, [_I]),
+    "sg_nearest_point": (_I, [vp, _I, vp, _I, _I, vp, vp, _Z, vp]),
+    "sg_prep_sample_ws_bytes": (_Z, [_I, _I]),
+    "sg_prep_sample_points": (_I, [vp, vp, _I, vp, _I, vp, vp, C.POINTER(C.c_int), vp, _Z, vp]),
+    "sg_mesh_adjacency_ws_bytes": (_Z, [_I]),
+    "sg_mesh_adjacency": (_I, [vp, _I, vp, _I, vp, C.POINTER(C.c_int), vp, C.POINTER(C.c_int), vp, _Z, vp]),
+    "sg_segment_lists_ws_bytes": (_Z, [_I, _I]),
+    "sg_segment_lists": (_I, [vp, _I, vp, _I, vp, vp, vp, C.POINTER(C.c_int), vp, _Z, vp]),
+    "sg_write_seg_json": (_I, [C.c_char_p, vp, vp, _I, _I]),
     "sg_edgeconv_ws_bytes": (_Z, [_I]),
     "sg_edgeconv_forward": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_gcn_ws_bytes": (_Z, [_I, _I, _I]),

@@ -229,3 +229,55 @@ def write_reference_tree(root: str, scenes, label_style: str = "manual") -> None
         d = os.path.join(base, "adj", "mesh", "resampled", sc.name)
         os.makedirs(d, exist_ok=True)
         torch.save(torch.from_numpy(sc.adj), os.path.join(d, sc.name + ".adj.pth"))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Raw-scan side: what dataset/scannet/util.py reads from a ScanNet scan -- the mesh
+# (`_vh_clean_2.ply`: vertices xyz + rgb, triangle faces) and the over-segmentation (`segs.json: segIndices`).
+# ---------------------------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class RawScan:
+    name: str
+    xyz: np.ndarray          # [V,3] float32 (PLY property type)
+    rgb: np.ndarray          # [V,3] uint8
+    faces: np.ndarray        # [F,3] int32 vertex ids (a few degenerate: repeated ids)
+    seg_indices: np.ndarray  # [V]   int32 raw segment ids (non-contiguous, like ScanNet's)
+    perm: np.ndarray         # [V]   int64 the permutation `generate_pointcloud_pth` draws with torch.randperm
+
+
+def make_raw_scan(grid_w: int, grid_h: int, seed: int, *, name: Optional[str] = None, dup_frac: float = 0.02,
+                  degenerate_faces: int = 16, cell: int = 7) -> RawScan:
+    """A jittered, wavy W x H vertex lattice triangulated with two faces per cell, plus `dup_frac` duplicated
+    vertices (same coordinates, referenced by extra faces: coincident vertices give exact distance ties) and a few
+    degenerate faces (`get_adj_from_mesh` drops their zero-length edges, util.py:783).  Segments are cell x cell
+    vertex blocks with ids 7*b + 3 (np.unique has to compact them)."""
+    w, h = int(grid_w), int(grid_h)
+    v0 = w * h
+    gx, gy = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    u = uniform01(seed, 40, 3 * v0).reshape(v0, 3).astype(np.float64)
+    x = gx.reshape(-1) * 0.04 + (u[:, 0] - 0.5) * 0.02
+    y = gy.reshape(-1) * 0.04 + (u[:, 1] - 0.5) * 0.02
+    z = 0.3 * np.sin(x * 1.7) * np.cos(y * 1.3) + (u[:, 2] - 0.5) * 0.01
+    xyz = np.stack([x, y, z], 1).astype(np.float32)
+    rgb = (uniform01(seed, 41, 3 * v0) * 256).astype(np.int64).clip(0, 255).astype(np.uint8).reshape(v0, 3)
+    vid = np.arange(v0, dtype=np.int64).reshape(h, w)
+    a, b, c, d = vid[:-1, :-1].reshape(-1), vid[:-1, 1:].reshape(-1), vid[1:, :-1].reshape(-1), vid[1:, 1:].reshape(-1)
+    faces = np.concatenate([np.stack([a, b, c], 1), np.stack([b, d, c], 1)], 0)
+    seg = ((gy.reshape(-1).astype(np.int64) // cell) * ((w + cell - 1) // cell) + gx.reshape(-1).astype(np.int64) // cell) * 7 + 3
+    ndup = int(v0 * dup_frac)
+    if ndup:
+        src = randint(seed, 42, ndup, v0)
+        xyz = np.concatenate([xyz, xyz[src]], 0)
+        rgb = np.concatenate([rgb, rgb[src]], 0)
+        seg = np.concatenate([seg, seg[src]], 0)
+        # every duplicate is wired into the mesh by one face with two of its original's neighbours
+        nb1 = np.minimum(src + 1, v0 - 1)
+        nb2 = np.minimum(src + w, v0 - 1)
+        faces = np.concatenate([faces, np.stack([v0 + np.arange(ndup), nb1, nb2], 1)], 0)
+    v = xyz.shape[0]
+    if degenerate_faces:
+        p = randint(seed, 43, 2 * degenerate_faces, v).reshape(-1, 2)
+        faces = np.concatenate([faces, np.stack([p[:, 0], p[:, 0], p[:, 1]], 1), np.stack([p[:1, 0], p[:1, 0], p[:1, 0]], 1)], 0)
+    forder = np.argsort(splitmix64(seed, 44, faces.shape[0]), kind="stable")          # faces in no particular order
+    perm = np.argsort(splitmix64(seed, 45, v), kind="stable").astype(np.int64)
+    return RawScan(name or f"scan{seed:04d}_00", xyz, rgb, faces[forder].astype(np.int32), seg.astype(np.int32), perm)
