@@ -14,4 +14,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_sol
 # 3. HBM traffic: separate PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -- python3 $R/tools/time_scene.py 150000 1500 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -- python3 $R/tools/time_scene.py 150000 1500 > /dev/null 2>&1
+# 4. stress scene (BASELINE.json configs[4]): 500k points / 5k segments, one scene at a time
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stress_stats -- python3 $R/tools/time_scene.py 500000 5000 > $R/gpurun_out/${TAG}_stress_stats.log 2>&1
+# 5. SQ counters per kernel (instruction mix, issue / wait split): one PMC pass, kernel-trace only
+bash $R/tools/pmc_kernel.sh ${TAG}_pmc_sq > $R/gpurun_out/${TAG}_pmc_sq.txt 2>&1
 tail -1 $R/gpurun_out/${TAG}_bench_stats.log | cut -c1-200

@@ -24,7 +24,7 @@ def stats(src, dst, title):
 
 
 bench = stats(f"{tag}_bench_stats", f"{tag}_bench_kernel_stats.csv",
-              "python bench.py --no-cpu-baseline --no-files (8 scenes x 6 steps, 4 pipelines in flight), 150k/1.5k scenes")
+              "python bench.py --no-cpu-baseline --no-files (8 scenes per step, 4 pipelines in flight), 150k/1.5k scenes")
 solo = stats(f"{tag}_solo_stats", f"{tag}_single_stream_kernel_stats.csv", "tools/time_scene.py 150000 1500 (one scene at a time, 6 forwards)")
 
 traffic = collections.defaultdict(dict)
@@ -53,6 +53,13 @@ json.dump(out, open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1, 
 line = [l for l in open(os.path.join(G, f"{tag}_bench_stats.log")).read().splitlines() if l.startswith('{"metric"')][-1]
 with open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w") as o:
     o.write(line + "\n")
+sq = os.path.join(G, f"{tag}_pmc_sq.txt")
+if os.path.exists(sq):
+    lines = [l for l in open(sq).read().splitlines() if " per wave" in l or "| per wave" in l]
+    with open(os.path.join(P, f"{tag}_sq_counters.txt"), "w") as o:
+        o.write("# rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
+                "SQ_ACTIVE_INST_ANY -- python3 tools/time_scene.py 150000 1500\n# averages per launch; wave-cycles = 4 x SQ_WAVE_CYCLES / waves\n")
+        o.write("\n".join(lines) + "\n")
 print("top kernels (bench, avg us | solo avg us):")
 for k in list(bench)[:8]:
     print("  %-28s %9.1f | %9.1f" % (k, bench[k], solo.get(k, float("nan"))))
