@@ -304,3 +304,33 @@ def test_unusual_segmentations_match_oracle(weight_sets, n, s, seed):
         nm = hip.LABEL_NAMES[i]
         assert np.array_equal(res.labels[i], ref["labels"][nm].astype(np.int32)), nm
     assert np.array_equal(res.iou_sem, ref["metrics"][0]) and np.array_equal(res.iou_ins, ref["metrics"][1])
+
+
+FUZZ = [  # (points, segments, seed, generator kwargs, mode): shapes the fixtures do not cover, oracle computed on the spot
+    (3000, 60, 123, dict(min_seg=2), "ins_infer"),
+    (2500, 120, 124, dict(min_seg=1), "ins_infer"),                                   # 2-point segments
+    (5000, 25, 125, dict(dup_frac=0.1, raw_vertices=6000), "ins_infer"),              # 10 % duplicates, V != N
+    (4000, 16, 126, dict(knn_edges=3), "ins_infer"),                                  # sparse graph, few big segments
+    (6000, 300, 127, dict(min_seg=1, knn_edges=10), "ins_infer"),                     # dense graph, tiny segments
+    (3500, 70, 128, dict(dup_frac=0.3), "ins_infer"),                                 # 30 % duplicates: many exact ties
+    (8000, 90, 129, dict(island_radius=0.9), "ins_infer"),                            # unlabeled island -> FPS-1024 fallback
+    (3000, 60, 130, dict(min_seg=2), "sem_infer"),
+    (5000, 25, 131, dict(dup_frac=0.1, raw_vertices=4000), "sem_infer"),              # V < N
+    (9000, 45, 132, dict(raw_vertices=9500), "ins_infer"),
+]
+
+
+@pytest.mark.parametrize("n,s,seed,kw,mode", FUZZ, ids=[f"{c[0]}x{c[1]}-{c[2]}-{c[4][:3]}" for c in FUZZ])
+def test_odd_scenes_match_oracle(weight_sets, n, s, seed, kw, mode):
+    from oracle import cpu_ref
+    from seggroup_amd import hip, synthetic
+    scene = synthetic.make_scene(n, s, seed, **kw)
+    res, _, _ = _run(scene, weight_sets[mode], mode)
+    ref = cpu_ref.forward_scene(scene, weight_sets[mode], mode)
+    nvec = 14 if mode == "ins_infer" else 6
+    assert res.trace[:len(ref["trace"])] == ref["trace"]
+    for i in range(nvec):
+        nm = hip.LABEL_NAMES[i]
+        assert np.array_equal(res.labels[i], ref["labels"][nm].astype(np.int32)), nm
+    assert np.array_equal(res.iou_sem, ref["metrics"][0]) and np.array_equal(res.iou_ins, ref["metrics"][1])
+    assert bool(res.stalled) == bool(ref["stalled"])
