@@ -62,8 +62,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="distinct scenes per GPU per step")
-    ap.add_argument("--inflight", type=int, default=4, help="pipelines (HIP streams) per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="distinct scenes per GPU per step")
+    ap.add_argument("--inflight", type=int, default=8, help="pipelines (HIP streams) per GPU")
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--segments", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
