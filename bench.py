@@ -48,10 +48,10 @@ def kernel_model(n_points: int, k: int = 20):
     return {
         # name: (stages, launches per scene, bound, units per launch, unit, peak, scale)
         # S2X = MLP3's conv1' -> conv2 + BN2 statistics + max over k (its single evaluation); S1X = the same for MLP2's
-        # one layer; S1 = MLP3's conv1 statistics pass (the stage times include the ~20 us one-block BN fold)
+        # one layer (the stage times include the ~20 us one-block BN fold).  MLP3's inner BN statistics come from
+        # k_edge_moments (VALU; stage l3.edgeconv.stats1), which has no MFMA work to price.
         "k_edgeconv<S2X>": (["l3.edgeconv.stats2"], 1, "mfma", c12, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
         "k_edgeconv<S1X>": (["l2.edgeconv.stats1"], 1, "mfma", c1, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
-        "k_edgeconv<S1>": (["l3.edgeconv.stats1"], 1, "mfma", c1, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
         # kNN: reads [N,4] f32, writes [N,20] i32 (VALU-bound brute force inside clusters; HBM is its nominal roof)
         "k_cluster_knn_sorted": (["l2.knn", "l3.knn"], 2, "hbm", 96.0 * n, "GB/s", HBM_PEAK_GBS, 1e9),
     }

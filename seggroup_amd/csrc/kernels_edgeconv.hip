@@ -27,9 +27,10 @@
 // the sign of gamma -- known before the statistics are.  The sign is folded into the weight ROWS while
 // they are staged in LDS (negation commutes exactly with an fma chain), so the pass that accumulates the
 // statistics of y' = sgn(gamma)*y also keeps  E = max_j y'_j  per (point, channel); a one-pass element-wise
-// epilogue then applies  LReLU(|a|*E + b').  MLP2 is therefore ONE MFMA pass (S1X) and MLP3 two (S1 -> S2X),
-// 44 GFLOP executed per scene for 39.4 GFLOP of single-evaluation work, instead of 2 and 3 passes (82 GFLOP)
-// or materialising the 768 MB [N,20,64] tensor.
+// epilogue then applies  LReLU(|a|*E + b').  The INNER BatchNorm of MLP3 needs conv1's statistics before conv2 can
+// run; conv1 is linear, so they follow from the first and second moments of the 18-channel edge features
+// (k_edge_moments: VALU only, no MFMA pass).  MLP2 and MLP3 are therefore ONE MFMA pass each (S1X, S2X): the 38.4 GFLOP
+// of a single evaluation, instead of 2 and 3 passes (82 GFLOP) or materialising the 768 MB [N,20,64] tensor.
 // Per-block fp64 partial sums are combined in fixed order by a one-block finalize kernel, so the
 // result is bit-reproducible run to run.
 #include "sg_common.h"
@@ -38,7 +39,7 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-enum { S1 = 0, S1X = 1, S2X = 2 };     // conv1 statistics | conv1 statistics + extremum | conv1' -> conv2 statistics + extremum
+enum { S1X = 1, S2X = 2 };     // conv1 statistics + extremum (MLP2) | conv1' -> conv2 statistics + extremum (MLP3)
 
 constexpr int kWaves = 4;
 
@@ -60,7 +61,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
                                                           float* __restrict__ ext, double* __restrict__ partial) {
     __shared__ Lds lds;
     constexpr bool kTwo = MODE == S2X;
-    constexpr bool kExt = MODE == S1X || MODE == S2X;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
 
@@ -110,12 +110,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
         f32x16 best[2];
 #pragma unroll
         for (int q = 0; q < 32; ++q) { stat_s[q] = 0.f; stat_q[q] = 0.f; }
-        if (kExt) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) best[t][q] = -INFINITY;
-        }
+            for (int q = 0; q < 16; ++q) best[t][q] = -INFINITY;
 
         const int32_t* krow = knn + (size_t)ptc * K;
         // software pipeline: the next slot's neighbour row is requested before this slot's MFMAs start
@@ -181,7 +179,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
                         const float y = acc1[t][q] * vmask;
                         stat_s[16 * t + q] += y;
                         stat_q[16 * t + q] = __builtin_fmaf(y, y, stat_q[16 * t + q]);
-                        if (kExt) best[t][q] = fmaxf(best[t][q], acc1[t][q]);
+                        best[t][q] = fmaxf(best[t][q], acc1[t][q]);
                     }
             } else {
                 // LeakyReLU(BN1(.)) in place -> B operand of conv2
@@ -234,7 +232,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
                 lds.acc[wave][64 + ch] += (double)v;
             }
         }
-        if (kExt && valid) {
+        if (valid) {
             // E = max_j y'_j : 4 consecutive channels per float4 store
             float* orow = ext + (size_t)pt * 64;
 #pragma unroll
@@ -256,13 +254,136 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
     }
 }
 
-// fixed-order reduction of the per-block partials -> folded weights w' = a*w and shift = beta - a*mean.
+// Batch statistics of conv1's output WITHOUT evaluating it (the inner BN of MLP3): y = W1 e is linear, so
+//   mean_c = w_c . E[e]      E[y_c^2] = w_c^T E[e e^T] w_c
+// and with e = [d, x_i], d = x_j - x_i, the 18 + 171 moments split into per-point terms and one per-slot term:
+//   sum_j e      = [a, K x_i]                         a = sum_j d_j
+//   sum_j e e^T  = [[D, a x_i^T], [x_i a^T, K x_i x_i^T]]   D = sum_j d_j d_j^T   (45 products per slot)
+// One point per lane: 63 VALU instructions per neighbour slot instead of 18 MFMAs per 32 points (~10x cheaper; under
+// the bench's load the MFMA statistics pass took 0.35 ms per scene).  Layout of the 189 partial sums per block:
+// [0,9) a | [9,18) K x_i | [18,63) D upper triangle | [63,144) a x_i^T row-major | [144,189) K x_i x_i^T upper triangle.
+constexpr int kMom = 189;
+
+__global__ __launch_bounds__(256) void k_edge_moments(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
+                                                      double* __restrict__ partial) {
+    __shared__ double red[4][kMom];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pt = blockIdx.x * 256 + tid;
+    const bool valid = pt < N;
+    float a[9], D[45], xi[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { a[k] = 0.f; xi[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 45; ++k) D[k] = 0.f;
+    if (valid) {
+        const float4* xr = reinterpret_cast<const float4*>(x9m + (size_t)pt * 12);
+        const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
+        xi[0] = q0.x; xi[1] = q0.y; xi[2] = q0.z; xi[3] = q0.w; xi[4] = q1.x; xi[5] = q1.y; xi[6] = q1.z; xi[7] = q1.w; xi[8] = q2.x;
+        const int32_t* krow = knn + (size_t)pt * K;
+        int nb = krow[0];
+        const float4* xp = reinterpret_cast<const float4*>(x9m + (size_t)nb * 12);
+        float4 p0 = xp[0], p1 = xp[1], p2 = xp[2];
+        for (int j = 0; j < K; ++j) {
+            const float4 n0 = p0, n1 = p1, n2 = p2;
+            if (j + 1 < K) {
+                nb = krow[j + 1];
+                const float4* xq = reinterpret_cast<const float4*>(x9m + (size_t)nb * 12);
+                p0 = xq[0]; p1 = xq[1]; p2 = xq[2];
+            }
+            const float d[9] = {n0.x - xi[0], n0.y - xi[1], n0.z - xi[2], n0.w - xi[3], n1.x - xi[4],
+                                n1.y - xi[5], n1.z - xi[6], n1.w - xi[7], n2.x - xi[8]};
+            int t = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                a[k] += d[k];
+#pragma unroll
+                for (int l = k; l < 9; ++l) { D[t] = __builtin_fmaf(d[k], d[l], D[t]); ++t; }
+            }
+        }
+    }
+    const float Kf = valid ? (float)K : 0.f;
+    // wave sums in fp32 over a fixed shuffle tree (as the MFMA statistics passes do), then doubles: the four waves
+    // in fixed order, the blocks in fixed order in k_bn_fold_moments
+    auto wsum = [&](float v, int slot) {
+        float s = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[wave][slot] = (double)s;
+    };
+    int t = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wsum(a[k], k);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wsum(Kf * xi[k], 9 + k);
+#pragma unroll
+    for (int k = 0; k < 45; ++k) wsum(D[k], 18 + k);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int l = 0; l < 9; ++l) wsum(a[k] * xi[l], 63 + 9 * k + l);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int l = k; l < 9; ++l) { wsum(Kf * xi[k] * xi[l], 144 + t); ++t; }
+    __syncthreads();
+    if (tid < kMom) partial[(size_t)blockIdx.x * kMom + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+// moments -> folded conv1 weights and shift (one block; fixed-order sum of the per-block partials)
+__global__ __launch_bounds__(1024) void k_bn_fold_moments(const double* __restrict__ partial, int nblocks, double rows,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift) {
+    __shared__ double part[4][256];
+    __shared__ double tot[kMom];
+    __shared__ double mu[18], M[18][18];
+    const int v = threadIdx.x & 255, g = threadIdx.x >> 8;
+    // eight independent chains per thread keep eight loads in flight (one chain = one L2 round trip per add)
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (v < kMom) {
+        int b = g;
+        for (; b + 28 < nblocks; b += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += partial[(size_t)(b + 4 * u) * kMom + v];
+        }
+        for (; b < nblocks; b += 4) acc[0] += partial[(size_t)b * kMom + v];
+    }
+    part[g][v] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (threadIdx.x < kMom) tot[threadIdx.x] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 18) mu[threadIdx.x] = tot[threadIdx.x] / rows;
+    if (threadIdx.x < 324) {
+        const int k = threadIdx.x / 18, l = threadIdx.x % 18;
+        auto tri = [](int i, int j) { return i * 9 - i * (i - 1) / 2 + (j - i); };       // upper-triangle index, i <= j < 9
+        double m;
+        if (k < 9 && l < 9) m = tot[18 + (k <= l ? tri(k, l) : tri(l, k))];
+        else if (k < 9) m = tot[63 + 9 * k + (l - 9)];
+        else if (l < 9) m = tot[63 + 9 * l + (k - 9)];
+        else m = tot[144 + (k <= l ? tri(k - 9, l - 9) : tri(l - 9, k - 9))];
+        M[k][l] = m / rows;
+    }
+    __syncthreads();
+    const int ch = threadIdx.x & 63;
+    double mean = 0.0, ey2 = 0.0;
+    for (int k = 0; k < 18; ++k) {
+        const double wk = (double)w[ch * 18 + k];
+        mean += wk * mu[k];
+        double r = 0.0;
+        for (int l = 0; l < 18; ++l) r += (double)w[ch * 18 + l] * M[k][l];
+        ey2 += wk * r;
+    }
+    const double var = ey2 - mean * mean;
+    const double a = (double)gamma[ch] / sqrt(var + 1e-5);
+    for (int k = threadIdx.x >> 6; k < 18; k += 16) w_folded[ch * 18 + k] = (float)(a * (double)w[ch * 18 + k]);
+    if (threadIdx.x < 64) shift[ch] = (float)((double)beta[ch] - a * mean);
+}
+
+// last layer of an MLP: fixed-order reduction of the per-block partials -> |a| = |gamma| / sqrt(var + eps) and the shift.
 // 1024 threads: thread (value v = tid & 127, lane group g = tid >> 7) sums blocks g, g+8, g+16, ... and the
 // eight group sums are added in a fixed order, so the result does not depend on scheduling.
 __global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ partial, int nblocks, double rows,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  const float* __restrict__ w, int kin, float* __restrict__ w_folded,
-                                                  float* __restrict__ shift) {
+                                                  float* __restrict__ a_out, float* __restrict__ shift) {
     __shared__ double part[8][128];
     __shared__ double tot[128];
     const int v = threadIdx.x & 127, g = threadIdx.x >> 7;
@@ -285,21 +406,14 @@ __global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ par
         tot[threadIdx.x] = t;
     }
     __syncthreads();
-    const int ch = threadIdx.x & 63;
-    if (w) {
-        // inner layer: folded weights + shift
-        const double mean = tot[ch] / rows;
-        const double var = tot[64 + ch] / rows - mean * mean;
-        const double a = (double)gamma[ch] / sqrt(var + 1e-5);
-        for (int k = threadIdx.x >> 6; k < kin; k += 16) w_folded[ch * kin + k] = (float)(a * (double)w[ch * kin + k]);
-        if (threadIdx.x < 64) shift[ch] = (float)((double)beta[ch] - a * mean);
-    } else if (threadIdx.x < 64) {
-        // last layer: the statistics are those of y' = sgn(gamma)*y (mean' = sgn*mean, same variance), so
-        // a*y + (beta - a*mean) == |a|*y' + (beta - |a|*mean'):  w_folded[0..64) = |a|, shift = beta - |a|*mean'
+    if (threadIdx.x < 64) {
+        // the statistics are those of y' = sgn(gamma)*y (mean' = sgn*mean, same variance), so
+        // a*y + (beta - a*mean) == |a|*y' + (beta - |a|*mean')
+        const int ch = threadIdx.x;
         const double mean = tot[ch] / rows;
         const double var = tot[64 + ch] / rows - mean * mean;
         const double a = fabs((double)gamma[ch]) / sqrt(var + 1e-5);
-        w_folded[ch] = (float)a;
+        a_out[ch] = (float)a;
         shift[ch] = (float)((double)beta[ch] - a * mean);
     }
 }
@@ -334,7 +448,7 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     if (N == 0) return SG_OK;
     const int nblocks = sg::cdiv(sg::cdiv(N, 32), kWaves);
     sg::Carver cv(d_ws, ws_bytes);
-    double* partial = cv.take<double>((size_t)nblocks * 128);
+    double* partial = cv.take<double>(std::max((size_t)nblocks * 128, (size_t)sg::cdiv(N, 256) * kMom));
     float* fold = cv.take<float>(64 * 18 + 64 + 64 * 64 + 64);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_edgeconv_forward: workspace too small (%zu < %zu)", ws_bytes, sg_edgeconv_ws_bytes(N));
     float* w1f = fold;
@@ -348,16 +462,17 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     const int egrid = (int)std::min<size_t>((n4 + 255) / 256, 2048);
     if (layers == 1) {
         k_edgeconv<S1X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, d_g1, d_out, partial);
-        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, nullptr, 0, w1f, sh1);
+        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, w1f, sh1);
         if (mark) mark(0);
         k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w1f, sh1);
         if (mark) mark(1);
     } else {
-        k_edgeconv<S1><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, nullptr, partial);
-        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, d_w1, 18, w1f, sh1);
+        const int mblocks = sg::cdiv(N, 256);
+        k_edge_moments<<<mblocks, 256, 0, st>>>(d_x9m, d_knn, N, k, partial);
+        k_bn_fold_moments<<<1, 1024, 0, st>>>(partial, mblocks, rows, d_g1, d_b1, d_w1, w1f, sh1);
         if (mark) mark(0);
         k_edgeconv<S2X, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, d_w2, d_g2, d_out, partial);
-        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, nullptr, 0, w2f, sh2);
+        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, w2f, sh2);
         if (mark) mark(1);
         k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w2f, sh2);
         if (mark) mark(2);
@@ -372,7 +487,8 @@ extern "C" {
 
 size_t sg_edgeconv_ws_bytes(int N) {
     const size_t nblocks = (size_t)sg::cdiv(sg::cdiv(std::max(N, 1), 32), kWaves);
-    return sg::align_up(nblocks * 128 * 8) + sg::align_up((64 * 18 + 64 + 64 * 64 + 64) * 4);
+    const size_t mblocks = (size_t)sg::cdiv(std::max(N, 1), 256);
+    return sg::align_up(std::max(nblocks * 128, mblocks * 189) * 8) + sg::align_up((64 * 18 + 64 + 64 * 64 + 64) * 4);
 }
 
 int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,

@@ -43,8 +43,9 @@ int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_memb
                     int ch_out, int transform, float* d_samples, int32_t* d_sel, void* d_ws, size_t ws_bytes, void* stream,
                     int max_n);
 
-// internal variant of sg_edgeconv_forward: `mark(i)` is called after pass i (0 = STATS1+fold, 1 = STATS2+fold
-// or FINAL1, 2 = FINAL2) so the pipeline can time the passes separately (kernels_edgeconv.hip)
+// internal variant of sg_edgeconv_forward: `mark(i)` is called after step i so the pipeline can time the steps
+// separately (kernels_edgeconv.hip).  layers == 1: 0 = S1X + fold, 1 = epilogue.  layers == 2: 0 = edge-feature
+// moments + fold, 1 = S2X + fold, 2 = epilogue.
 int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
                             const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
                             size_t ws_bytes, void* stream, const std::function<void(int)>& mark);

@@ -73,7 +73,7 @@ if sf:
     E0 = 3.57 * N
     model = {   # kernel: (bound, algorithmic units per launch, note)   -- DESIGN.md section 4
         "k_edgeconv<2, true>": ("mfma", 2 * k * N * (18 * 64 + 64 * 64), "MLP3 conv1'->conv2 + BN2 statistics + max (S2X)"),
-        "k_edgeconv<0, false>": ("mfma", 2 * k * N * 18 * 64, "MLP3 conv1 BN statistics pass (S1)"),
+        "k_edge_moments": ("hbm", (80 + 48 * k) * N, "MLP3 inner-BN statistics from edge-feature moments (gather-latency-bound)"),
         "k_edgeconv<1, false>": ("mfma", 2 * k * N * 18 * 64, "MLP2 conv + BN statistics + max (S1X)"),
         "k_cluster_knn_sorted<20, 1>": ("hbm", 96 * N, "in-cluster kNN-20 (VALU/latency-bound; HBM is the nominal roof)"),
         "k_segment_max64": ("hbm", 260 * N, "per-cluster max of [N,64]"),
