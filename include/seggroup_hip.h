@@ -178,6 +178,23 @@ int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, c
                           const int32_t* d_cl_seg_off, const int32_t* d_order, const int32_t* d_dst,
                           const int32_t* d_seg_off, const int32_t* d_seg_chunk_off, const float* d_segbox,
                           const float* d_chunk_box, const int32_t* d_slot_of_pos, int k, int pos0, int32_t* d_knn, void* stream);
+/* Seeded variant for a layer whose clusters are unions of the clusters of the PREVIOUS kNN layer (model.py:829 after
+ * 788: the score of a pair depends on raw coordinates only and union() appends whole member lists, so a query's
+ * previous list is the exact top k inside its former cluster).  sg_knn_seed_points turns the previous table (rows and
+ * entries = member positions of that layer, d_members = its position -> point map) into d_seed [N,k] indexed by and
+ * holding POINT ids.  sg_cluster_knn_seeded = sg_cluster_knn_sorted with one wave per tile that starts every query
+ * from its seeds (d_members / d_pos_of_point: THIS layer's maps, d_data the raw [N,6] cloud) and skips the chunks of
+ * segments whose former cluster (d_seg_prevcl[S]) is the query's own; d_seg_prevcl = -1 marks segments of former
+ * clusters with <= k points, which have no kNN list (model.py:516-518).  Same table as every other variant. */
+int sg_knn_seed_points(const int32_t* d_knn, const int32_t* d_members, int N, int k, int32_t* d_seed, void* stream);
+int sg_cluster_knn_seeded(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off,
+                          const int32_t* d_tile_cl, const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T,
+                          const int32_t* d_cl_seg_off, const int32_t* d_order, const int32_t* d_dst,
+                          const int32_t* d_seg_off, const int32_t* d_seg_chunk_off, const float* d_segbox,
+                          const float* d_chunk_box, const int32_t* d_slot_of_pos, const int32_t* d_seed,
+                          const int32_t* d_seg_prevcl, const int32_t* d_members, const int32_t* d_pos_of_point,
+                          const float* d_data, int k, int pos0, int32_t* d_knn, void* stream);
+
 /* Two-pass kernel over a cluster-ordered chunk table (same tables once more; variant 0 of sg_knn_set_variant:
  * faster on 500k-point scenes and on large segments, on par with the one-pass kernel at 150k / 1.5k).  Per layer the host provides d_slot_chunk0[S+1] (exclusive prefix, in cluster slot order, of the
  * 32-point chunk counts of the segments d_order[slot]), d_cl_chunk_off[C+1] (= slot_chunk0 at each cluster's first
@@ -195,10 +212,12 @@ int sg_cluster_knn_2pass(const float* d_sxyzw, const int32_t* d_smpos, int N, co
                          int k, int pos0, int32_t* d_knn, void* stream);
 /* Which in-cluster kNN kernel sg_pipeline_forward uses for a layer of T tiles, and how many waves per tile
  * sg_cluster_knn_sorted launches (all variants give the same table; the GPU tests compare them):
- *   -1  by tile count (default): one-pass with 1 wave per tile when T >= 2048 tiles fill the GPU, else 2 or 4 waves
+ *   -1  by tile count (default): 8 when T >= 2048 tiles fill the GPU, else one-pass with 2 or 4 waves per tile
  *    0  two-pass (sg_cluster_knn_2pass)
  *    1 | 2 | 4  one-pass (sg_cluster_knn_sorted) with that many waves per 64-query tile: a shorter critical path per
  *       tile, but every wave warms up its own top-k list
+ *    8  one-pass, 1 wave per tile, seeded from the previous kNN layer where there is one (sg_cluster_knn_seeded;
+ *       sg_pipeline_forward only: layer 3 starts from layer 2's table)
  * Process-wide; returns the previous setting.  Meant for tests and measurements. */
 int sg_knn_set_variant(int variant);
 

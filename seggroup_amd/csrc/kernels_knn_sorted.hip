@@ -23,7 +23,7 @@ namespace {
 using namespace sgknn;
 
 constexpr int kChunkPts = 32;
-constexpr int kBufS = 20;
+constexpr int kBufS = 20;          // append slots per lane (two-pass kernel; the one-pass kernel picks its own)
 constexpr int kQuadS = 4;
 constexpr int kSlotBatch = 128;
 
@@ -113,21 +113,37 @@ __device__ unsigned long long g_knn5_stats[16];
 // slices shorten a tile's critical path but every slice warms up its own top-K list: at 150k points one tile costs
 // 124 list insertions per query with 4 slices and about half of that with 1, and a launch with >= 2048 tiles fills
 // the GPU without slicing (bench: 584 -> 670 scenes/s at 4 -> 1 slices; the host picks by tile count).
-template <int K, int kSlices>
+//
+// kSeeded (one wave per tile only): the clusters of this layer are unions of the clusters the PREVIOUS kNN layer ran
+// on, the score of a pair depends on the two points' raw coordinates only, and union() appends whole member lists
+// (model.py:191), so the relative member order -- the tie rule -- inside a former cluster is unchanged.  A query's
+// previous list therefore IS the exact top K among the candidates of its former cluster: the kernel starts from it
+// (scores recomputed by the same formula, indices mapped to this layer's member positions), with an already tight
+// threshold, and skips every chunk whose segment belongs to the query's former cluster.  Former clusters of <= K
+// points have no kNN list (model.py:516-518 pads them): their segments carry seg_prevcl = -1, their queries start empty
+// and nobody skips them.
+template <int K, int kSlices, bool kSeeded = false>
 __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     const float4* __restrict__ sxyzw, const int32_t* __restrict__ smpos, const int32_t* __restrict__ cl_off,
     const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi,
     const int32_t* __restrict__ cl_seg_off, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off, const float* __restrict__ segbox,
-    const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg) {
-    static_assert(kBufS >= K, "the merge area aliases the append buffers");
+    const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg,
+    const int32_t* __restrict__ seed = nullptr, const int32_t* __restrict__ seg_prevcl = nullptr, const int32_t* __restrict__ members = nullptr,
+    const int32_t* __restrict__ pos_of_point = nullptr, const float* __restrict__ data = nullptr) {
+    static_assert(!kSeeded || kSlices == 1, "seeding is built for one wave per tile");
+    // LDS per wave decides how many tiles a CU keeps in flight, and this kernel waits on memory ~45 % of the time:
+    // one wave per tile needs neither the merge area (>= K slots per lane) nor a 128-entry descriptor batch
+    constexpr int kBufS = kSlices == 1 ? 12 : 20;
+    constexpr int kSlotBatch = kSlices == 1 ? 32 : 128;
+    static_assert(kSlices == 1 || kBufS >= K, "the merge area aliases the append buffers");
     __shared__ float4 slab[kSlices][kChunkPts + kQuadS];
     __shared__ int slab_i[kSlices][kChunkPts + kQuadS];
     __shared__ unsigned long long buf[kBufS][64 * kSlices];     // append buffers; later lists[slice][K][64]
     __shared__ unsigned int thr_pub[kSlices][64];             // score part of each slice's 20th best
     __shared__ unsigned int thr5_pub[kSlices][64];            // score part of each slice's (K / kSlices)-th best
     __shared__ float chunkbox_lds[kSlices][64];
-    __shared__ int st_m[kSlotBatch], st_c0[kSlotBatch], st_d[kSlotBatch];
+    __shared__ int st_m[kSlotBatch], st_c0[kSlotBatch], st_d[kSlotBatch], st_pc[kSlotBatch];
     __shared__ __attribute__((aligned(16))) float st_box[kSlotBatch][8];
     const int t = blockIdx.x;
     const int c = tile_cl[t];
@@ -149,6 +165,21 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
 #pragma unroll
     for (int j = 0; j < K; ++j) kv[j] = 0ull;
     unsigned long long thr = active ? 0ull : ~0ull;          // idle lanes never accept
+    int myprev = -1;                                          // former cluster whose candidates are already in kv
+    if (kSeeded && active) {
+        myprev = seg_prevcl[order[slot_of_pos[myrow]]];
+        if (myprev >= 0) {
+            const int32_t* sp = seed + (size_t)members[myrow] * K;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int p = sp[j];
+                const float* row = data + (size_t)p * 6;
+                const float x = row[0], y = row[1], z = row[2];
+                kv[j] = make_key(score4(me, make_float4(x, y, z, (x * x + y * y) + z * z)), pos_of_point[p] - clo);
+            }
+            thr = kv[K - 1];
+        }
+    }
     thr_pub[wave][lane] = (unsigned int)(thr >> 32);
     thr5_pub[wave][lane] = 0u;
     int cnt = 0;
@@ -184,11 +215,12 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
             thr5_pub[wave][lane] = (unsigned int)(kv[K / kSlices - 1] >> 32);
         }
     };
+    bool ok = true;                                           // seeded: false while the segment at hand belongs to my former cluster
     // one 32-point chunk: sorted positions [p0, p0 + m)
     auto scan_chunk = [&](const float* bx, int p0, int m) {
         const unsigned long long use = best_thr();
         if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[6], 1ull);
-        if (!__any(make_key(box_score_bound(me, bx), 0) >= use)) return;
+        if (!__any(ok && make_key(box_score_bound(me, bx), 0) >= use)) return;
         if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[5], 1ull);
         __builtin_amdgcn_wave_barrier();
         if (lane < kChunkPts + kQuadS) {
@@ -201,7 +233,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
 #pragma unroll
             for (int u = 0; u < kQuadS; ++u) {
                 const unsigned long long key = make_key(score4(me, cw[i + u]), ci[i + u]);
-                if (key > use && key > thr) {
+                if (ok && key > use && key > thr) {
                     buf[cnt][tid] = key;
                     ++cnt;
                 }
@@ -221,11 +253,12 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     // takes it.  The segment's chunk boxes are staged 8 at a time through a wave-private LDS strip (one coalesced
     // load instead of one dependent global load per chunk).
     float* cbx = &chunkbox_lds[wave][0];
-    auto scan_segment = [&](int sg_m, int sg_c0, int d, const float* sbox, int& item) {
+    auto scan_segment = [&](int sg_m, int sg_c0, int d, const float* sbox, int pc, int& item) {
         const int nch = (sg_m + kChunkPts - 1) / kChunkPts;
         const unsigned long long use = best_thr();
+        if (kSeeded) ok = pc < 0 || pc != myprev;
         if ((dbg & 32) && lane == 0 && wave == 0) atomicAdd(&g_knn5_stats[7], 1ull);
-        if (!__any(make_key(box_score_bound(me, sbox), 0) >= use)) { item += nch; return; }
+        if (!__any(ok && make_key(box_score_bound(me, sbox), 0) >= use)) { item += nch; return; }
         for (int j0 = 0; j0 < nch; j0 += 8) {
             const int nb = min(8, nch - j0);
             __builtin_amdgcn_wave_barrier();
@@ -246,7 +279,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
         float sbox[8];
 #pragma unroll
         for (int k = 0; k < 7; ++k) sbox[k] = segbox[(size_t)sg * 8 + k];
-        scan_segment(seg_off[sg + 1] - seg_off[sg], seg_chunk_off[sg], dst[slot], sbox, item);
+        scan_segment(seg_off[sg + 1] - seg_off[sg], seg_chunk_off[sg], dst[slot], sbox, kSeeded ? seg_prevcl[sg] : -1, item);
     }
     drain();
     const unsigned long long t1 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -263,35 +296,44 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
             st_m[e] = seg_off[sg + 1] - seg_off[sg];
             st_c0[e] = seg_chunk_off[sg];
             st_d[e] = dst[slot];
+            if (kSeeded) st_pc[e] = seg_prevcl[sg];
             const float4* bp = reinterpret_cast<const float4*>(segbox + (size_t)sg * 8);
             reinterpret_cast<float4*>(&st_box[e][0])[0] = bp[0];
             reinterpret_cast<float4*>(&st_box[e][0])[1] = bp[1];
         }
         __syncthreads();
-        for (int i = 0; i < nb; ++i) scan_segment(st_m[i], st_c0[i], st_d[i], &st_box[i][0], item);
+        for (int i = 0; i < nb; ++i) scan_segment(st_m[i], st_c0[i], st_d[i], &st_box[i][0], kSeeded ? st_pc[i] : -1, item);
     }
     drain();
     const unsigned long long t3 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
-    __syncthreads();                                          // every wave is done with its append buffer
-    unsigned long long* lists = &buf[0][0];
+    if (kSlices == 1) {
+        if (active) {
+            int32_t* o = knn + (size_t)myrow * K;
 #pragma unroll
-    for (int j = 0; j < K; ++j) lists[((size_t)wave * K + j) * 64 + lane] = kv[j];
-    __syncthreads();
-    if (wave == 0 && active) {
-        int p[kSlices];
-        unsigned long long h[kSlices];
-#pragma unroll
-        for (int w = 0; w < kSlices; ++w) { p[w] = 0; h[w] = lists[((size_t)w * K) * 64 + lane]; }
-        int32_t* o = knn + (size_t)myrow * K;
-        for (int j = 0; j < K; ++j) {
-            int bw = 0;
-            unsigned long long bk = h[0];
-#pragma unroll
-            for (int w = 1; w < kSlices; ++w) if (h[w] > bk) { bk = h[w]; bw = w; }
-            o[j] = clo + key_index(bk);
-#pragma unroll
-            for (int w = 0; w < kSlices; ++w)
-                if (w == bw) { ++p[w]; h[w] = p[w] < K ? lists[((size_t)w * K + p[w]) * 64 + lane] : 0ull; }
+            for (int j = 0; j < K; ++j) o[j] = clo + key_index(kv[j]);
+        }
+    } else {
+        __syncthreads();                                          // every wave is done with its append buffer
+        unsigned long long* lists = &buf[0][0];
+    #pragma unroll
+        for (int j = 0; j < K; ++j) lists[((size_t)wave * K + j) * 64 + lane] = kv[j];
+        __syncthreads();
+        if (wave == 0 && active) {
+            int p[kSlices];
+            unsigned long long h[kSlices];
+    #pragma unroll
+            for (int w = 0; w < kSlices; ++w) { p[w] = 0; h[w] = lists[((size_t)w * K) * 64 + lane]; }
+            int32_t* o = knn + (size_t)myrow * K;
+            for (int j = 0; j < K; ++j) {
+                int bw = 0;
+                unsigned long long bk = h[0];
+    #pragma unroll
+                for (int w = 1; w < kSlices; ++w) if (h[w] > bk) { bk = h[w]; bw = w; }
+                o[j] = clo + key_index(bk);
+    #pragma unroll
+                for (int w = 0; w < kSlices; ++w)
+                    if (w == bw) { ++p[w]; h[w] = p[w] < K ? lists[((size_t)w * K + p[w]) * 64 + lane] : 0ull; }
+            }
         }
     }
     if ((dbg & 16) && lane == 0) {
@@ -304,6 +346,14 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     }
 }
 
+
+// kNN table of one layer (rows and entries = member positions) -> rows and entries = point ids, for seeding the next layer
+__global__ void k_knn_seed_points(const int32_t* __restrict__ knn, const int32_t* __restrict__ members, int N, int K,
+                                  int32_t* __restrict__ seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * K) return;
+    seed[(size_t)members[i / K] * K + i % K] = members[knn[i]];
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Two-pass kernel over a cluster-ordered chunk table, one wave per 64-query tile (sg_knn_set_variant(0); faster than
@@ -530,10 +580,11 @@ static int g_knn_variant = getenv("SG_KNN_SLICES") ? atoi(getenv("SG_KNN_SLICES"
 //   500k pts / 5k segs     one-pass x1 0.70 + 1.10   two-pass 0.59 + 1.06
 //   150k pts / 100 segs    one-pass x1 1.27 + 1.42   two-pass 1.13 + 1.23
 // and the same bench throughput for x1 and two-pass (650-690 scenes/s).  Default: one wave per tile once the launch
-// fills the GPU; sg_knn_set_variant(0) selects the two-pass kernel.
+// fills the GPU, seeded from the previous kNN layer where there is one (8); sg_knn_set_variant(0) selects the
+// two-pass kernel, (1) the unseeded one-pass kernel.
 int sg::knn_variant_for(int T) {
     if (g_knn_variant >= 0) return g_knn_variant;
-    return T >= 2048 ? 1 : T >= 1024 ? 2 : 4;
+    return T >= 2048 ? 8 : T >= 1024 ? 2 : 4;
 }
 
 static int g_knn5_dbg = getenv("SG_KNN_DEBUG") ? atoi(getenv("SG_KNN_DEBUG")) : 0;   // profiling knob (16 = counters + cycle stamps)
@@ -600,8 +651,34 @@ int sg_knn_operands(const float* d_data, const int32_t* d_seg_points, const int3
 
 int sg_knn_set_variant(int variant) {
     const int prev = g_knn_variant;
-    g_knn_variant = (variant == 0 || variant == 1 || variant == 2 || variant == 4) ? variant : -1;
+    g_knn_variant = (variant == 0 || variant == 1 || variant == 2 || variant == 4 || variant == 8) ? variant : -1;
     return prev;
+}
+
+int sg_knn_seed_points(const int32_t* d_knn, const int32_t* d_members, int N, int k, int32_t* d_seed, void* stream) {
+    SG_REQUIRE(N >= 0 && k > 0 && d_knn && d_members && d_seed, "sg_knn_seed_points: bad arguments");
+    if (N == 0) return SG_OK;
+    k_knn_seed_points<<<sg::cdiv((long long)N * k, 256), 256, 0, sg::as_stream(stream)>>>(d_knn, d_members, N, k, d_seed);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_cluster_knn_seeded(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off, const int32_t* d_tile_cl,
+                          const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T, const int32_t* d_cl_seg_off,
+                          const int32_t* d_order, const int32_t* d_dst, const int32_t* d_seg_off, const int32_t* d_seg_chunk_off,
+                          const float* d_segbox, const float* d_chunk_box, const int32_t* d_slot_of_pos, const int32_t* d_seed,
+                          const int32_t* d_seg_prevcl, const int32_t* d_members, const int32_t* d_pos_of_point, const float* d_data,
+                          int k, int pos0, int32_t* d_knn, void* stream) {
+    SG_REQUIRE(N >= 0 && T >= 0 && d_knn && d_sxyzw && d_smpos && d_seed && d_seg_prevcl && d_members && d_pos_of_point && d_data,
+               "sg_cluster_knn_seeded: bad arguments");
+    if (k != 20) return sg::fail(SG_EUNSUP, "sg_cluster_knn_seeded: only k == 20 is built (model.py:788,829), got %d", k);
+    if (T == 0) return SG_OK;
+    k_cluster_knn_sorted<20, 1, true><<<T, 64, 0, sg::as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(d_sxyzw), d_smpos, d_cl_off, d_tile_cl, d_tile_lo, d_tile_hi, d_cl_seg_off, d_order, d_dst,
+        d_seg_off, d_seg_chunk_off, d_segbox, d_chunk_box, d_slot_of_pos, pos0, d_knn, g_knn5_dbg, d_seed, d_seg_prevcl, d_members,
+        d_pos_of_point, d_data);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
 }
 
 int sg_knn_chunk_table(const int32_t* d_order, const int32_t* d_dst, const int32_t* d_seg_off, const int32_t* d_seg_chunk_off,

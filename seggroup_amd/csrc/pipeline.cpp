@@ -63,7 +63,7 @@ struct sg_pipeline {
 
     // device work buffers
     DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_center, ws_eval, ws_sort;
-    DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, slot_of_pos, sperm, smpos, seg_chunk_off, knn, desc, tables, labels;
+    DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, slot_of_pos, sperm, smpos, seg_chunk_off, knn, knn_seed, desc, tables, labels;
     DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf, segbox, chunk_box, chunk_table;
 
     // pinned host staging
@@ -100,7 +100,7 @@ int freeze_layer(const sg_partition* part, int S, LayerDesc& L) {
 // Device descriptor block of one layer, carved from ONE pinned buffer and shipped in ONE H2D copy.
 struct DescOffsets {
     size_t order, dst, cl, cl_pt_off, cl_seg_off, tile_cl, tile_lo, tile_hi, cl_tile_off, goff, gidx, adj, rowptr, col, eid,
-        slot_chunk0, cl_chunk_off, tile_chunk0, total;
+        slot_chunk0, cl_chunk_off, tile_chunk0, seg_prevcl, total;
 };
 
 }  // namespace
@@ -180,8 +180,8 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->ws_eval, sg_eval_ws_bytes(maxS + 2));
     D(pl->adj1, 2 * maxE1); D(pl->count, 4);
     D(pl->members, N); D(pl->pos_of_point, N); D(pl->cluster_of_pos, N); D(pl->slot_of_pos, N);
-    D(pl->knn, N * 20);
-    D(pl->desc, 11 * S + 16 + 4 * T + 2 * maxE1 + 4 * maxE1 + 96);
+    D(pl->knn, N * 20); D(pl->knn_seed, N * 20);
+    D(pl->desc, 12 * S + 16 + 4 * T + 2 * maxE1 + 4 * maxE1 + 96);
     D(pl->tables, SG_NUM_LABEL_VECTORS * S); D(pl->labels, SG_NUM_LABEL_VECTORS * V);
     D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
     D(pl->feat1, S * 128); D(pl->featA, S * 256); D(pl->featB, S * 256);
@@ -315,6 +315,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
         int feat_prev_stride = 128, feat_prev_dim = 128;
         float* cat = pl->featA.p;
         float* gcn_out = pl->featB.p;
+        bool have_seed = false;
         for (int layer = 0; layer < 2; ++layer) {
             const int C = Lnew.C, Dcat = feat_prev_dim + 64;
             const int sb = 4 + 6 * layer;                 // stage index base
@@ -331,7 +332,15 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             const int T = (int)tile_cl.size();
             // cluster-ordered chunk table of the two-pass kNN: chunk numbers per slot / cluster, and per tile the
             // (cluster-relative) chunk that holds its first sorted position
-            const int knn_variant = sg::knn_variant_for(T);
+            int knn_variant = sg::knn_variant_for(T);
+            // seeded (8): layer 3 starts from layer 2's table; a former cluster of <= 20 points has no kNN list (-1)
+            const bool seeded = knn_variant == 8 && layer == 1 && have_seed;
+            if (knn_variant == 8) knn_variant = 1;
+            std::vector<int32_t> seg_prevcl(seeded ? S : 0);
+            for (int sg = 0; seeded && sg < S; ++sg) {
+                const int pc = Lcur.cl_of_seg[sg];
+                seg_prevcl[sg] = Lcur.cl_pt_off[pc + 1] - Lcur.cl_pt_off[pc] > 20 ? pc : -1;
+            }
             std::vector<int32_t> slot_chunk0(S + 1, 0), cl_chunk_off(C + 1, 0), tile_chunk0(T, 0);
             if (knn_variant == 0) {
                 for (int i = 0; i < S; ++i) slot_chunk0[i + 1] = slot_chunk0[i] + (sc->h_seg_size[Lnew.order[i]] + 31) / 32;
@@ -377,6 +386,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             o.order = put(Lnew.order, S); o.dst = put(Lnew.dst, S); o.cl = put(cl_of_order, S); o.cl_pt_off = put(Lnew.cl_pt_off, C + 1);
             o.cl_seg_off = put(Lnew.cl_seg_off, C + 1);
             o.tile_cl = put(tile_cl, T); o.tile_lo = put(tile_lo, T); o.tile_hi = put(tile_hi, T); o.cl_tile_off = put(cl_tile_off, C + 1);
+            o.seg_prevcl = put(seg_prevcl, seg_prevcl.size());
             o.slot_chunk0 = put(slot_chunk0, S + 1); o.cl_chunk_off = put(cl_chunk_off, C + 1); o.tile_chunk0 = put(tile_chunk0, T);
             o.goff = put(goff, C + 1); o.gidx = put(gidx, Lcur.C); o.adj = put(adj, 2 * (size_t)E);
             o.rowptr = put(rowptr, C + 1); o.col = put(col, 2 * (size_t)E); o.eid = put(eid, 2 * (size_t)E);
@@ -402,10 +412,19 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                                             dd + o.slot_chunk0, pl->chunk_table.p, stv));
                 PL_CHECK(sg_cluster_knn_2pass(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi,
                                               dd + o.tile_chunk0, T, dd + o.cl_chunk_off, pl->chunk_table.p, 20, pos0, pl->knn.p, stv));
+            } else if (seeded) {
+                PL_CHECK(sg_cluster_knn_seeded(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
+                                               dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->segbox.p,
+                                               pl->chunk_box.p, pl->slot_of_pos.p, pl->knn_seed.p, dd + o.seg_prevcl, pl->members.p,
+                                               pl->pos_of_point.p, sc->d_data, 20, pos0, pl->knn.p, stv));
             } else {
                 PL_CHECK(sg_cluster_knn_sorted(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
                                                dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->segbox.p,
                                                pl->chunk_box.p, pl->slot_of_pos.p, 20, pos0, pl->knn.p, stv));
+            }
+            if (layer == 0) {                              // the next kNN layer may start from this table
+                PL_CHECK(sg_knn_seed_points(pl->knn.p, pl->members.p, N, 20, pl->knn_seed.p, stv));
+                have_seed = true;
             }
             pl->mark(sb + 2);
             // sub-pass marks: the last pass is marked with the stage id itself, so "lN.edgeconv" keeps meaning the

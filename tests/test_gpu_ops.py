@@ -465,3 +465,90 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         assert np.array_equal(a, e_), f"{name}/{target}: {int(np.any(a != e_, axis=1).sum())} rows differ between brute force and two-pass"
         ref = O.cluster_knn(sc.data[:, :3], L, 20)[members]
         assert np.array_equal(members[a], ref)
+
+
+def _knn_layer_setup(lib, torch, hip, sc, L):
+    """Device arrays of one layer for the sorted kNN kernels + the brute-force table (member-position entries)."""
+    members, off = _layer_arrays(L)
+    N, S = sc.num_points, sc.num_segments
+    order, dst, cso = [], [], [0]
+    for c, m in enumerate(L.members):
+        segs = sc.seg[m]
+        starts = np.concatenate([[0], np.nonzero(np.diff(segs))[0] + 1])
+        order += segs[starts].tolist()
+        dst += (off[c] + starts).tolist()
+        cso.append(len(order))
+    segorder = np.argsort(sc.seg, kind="stable").astype(np.int32)
+    seg_off = np.concatenate([[0], np.cumsum(np.bincount(sc.seg, minlength=S))]).astype(np.int32)
+    tc, lo, hi, cto = _tiles(off)
+    tc4, lo4, hi4, _ = _tiles(off, 64)
+    pos_of_point = np.empty(N, np.int32); pos_of_point[members] = np.arange(N, dtype=np.int32)
+    slot_of_pos = np.repeat(np.arange(S), np.diff(np.concatenate([np.asarray(dst), [N]]))).astype(np.int32)
+    chunk_off = np.concatenate([[0], np.cumsum((np.diff(seg_off) + 31) // 32)]).astype(np.int32)
+    d = {k: _up(torch, np.asarray(v, np.int32)) for k, v in dict(members=members, off=off, tc=tc, lo=lo, hi=hi, cto=cto, order=order, dst=dst,
+                                                                  cso=cso, segpts=segorder, segoff=seg_off, tc4=tc4, lo4=lo4, hi4=hi4,
+                                                                  pos_of_point=pos_of_point, slot=slot_of_pos, co=chunk_off, sop=sc.seg).items()}
+    d["data"] = _up(torch, sc.data)
+    x9m = torch.zeros(N, 12, device="cuda:0"); xyzw = torch.zeros(N, 4, device="cuda:0")
+    ws = _ws(torch, lib.sg_center_ws_bytes(len(tc), L.count))
+    hip.check(lib.sg_center_clusters(d["data"].data_ptr(), N, d["members"].data_ptr(), d["off"].data_ptr(), L.count, d["tc"].data_ptr(),
+                                     d["lo"].data_ptr(), d["hi"].data_ptr(), len(tc), d["cto"].data_ptr(), x9m.data_ptr(), xyzw.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), None))
+    brute = torch.zeros(N, 20, dtype=torch.int32, device="cuda:0")
+    hip.check(lib.sg_cluster_knn(xyzw.data_ptr(), N, d["off"].data_ptr(), d["tc"].data_ptr(), d["lo"].data_ptr(), d["hi"].data_ptr(), len(tc), 20,
+                                 int(pos_of_point[0]), brute.data_ptr(), None))
+    box = torch.zeros(S, 8, device="cuda:0")
+    hip.check(lib.sg_segment_boxes(d["data"].data_ptr(), d["segpts"].data_ptr(), d["segoff"].data_ptr(), S, box.data_ptr(), None))
+    sperm = torch.zeros(N, dtype=torch.int32, device="cuda:0")
+    cbox = torch.zeros(int(chunk_off[-1]) + 1, 8, device="cuda:0")
+    wss = _ws(torch, lib.sg_spatial_sort_ws_bytes(N))
+    hip.check(lib.sg_segment_spatial_sort(d["data"].data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), d["sop"].data_ptr(), S,
+                                          box.data_ptr(), d["co"].data_ptr(), sperm.data_ptr(), cbox.data_ptr(), wss.data_ptr(), wss.numel(), None))
+    sxyzw = torch.zeros(N, 4, device="cuda:0"); smpos = torch.zeros(N, dtype=torch.int32, device="cuda:0")
+    hip.check(lib.sg_knn_operands(d["data"].data_ptr(), d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S, d["order"].data_ptr(),
+                                  d["dst"].data_ptr(), sxyzw.data_ptr(), smpos.data_ptr(), None))
+    d.update(box=box, cbox=cbox, sxyzw=sxyzw, smpos=smpos, brute=brute, pos0=int(pos_of_point[0]), nt4=len(tc4), members_np=members, off_np=off)
+    return d
+
+
+@pytest.mark.parametrize("name,fine,coarse", [("small_20k", 40, 6), ("tiny_dup_4k", 12, 3), ("small_20k", 150, 40)])
+def test_seeded_knn_equals_bruteforce(env, golden_index, name, fine, coarse):
+    """sg_knn_seed_points + sg_cluster_knn_seeded: the coarse layer's clusters are unions of the fine layer's (more unions
+    on the SAME partition), every query starts from its fine-layer list and skips its former cluster's chunks; the table
+    must equal the coarse layer's brute-force table, duplicates and former clusters of <= 20 points included."""
+    lib, torch, hip = env
+    sc = make_fixture_scene(golden_index, name)
+    part, Lf = _semantic_inputs(sc, fine)
+    f = _knn_layer_setup(lib, torch, hip, sc, Lf)
+    N, S = sc.num_points, sc.num_segments
+    seed = torch.full((N, 20), -1, dtype=torch.int32, device="cuda:0")
+    hip.check(lib.sg_knn_seed_points(f["brute"].data_ptr(), f["members"].data_ptr(), N, 20, seed.data_ptr(), None))
+    sd = seed.cpu().numpy()
+    fb = f["brute"].cpu().numpy()
+    assert np.array_equal(sd[f["members_np"]], f["members_np"][fb])           # rows and entries are point ids now
+    # the fine layer's cluster of every segment, -1 where it has no kNN list
+    fine_sizes = np.diff(f["off_np"])
+    cl_of_seg = np.empty(S, np.int64)
+    for c, m in enumerate(Lf.members):
+        cl_of_seg[np.unique(sc.seg[m])] = c
+    seg_prevcl = np.where(fine_sizes[cl_of_seg] > 20, cl_of_seg, -1).astype(np.int32)
+    assert (seg_prevcl >= 0).any()
+    # coarser layer: keep merging the same partition
+    import oracle.cpu_ref as O
+    rng = np.random.default_rng(10)
+    while len(part.roots()) > coarse:
+        r = part.roots()
+        a, b = rng.choice(len(r), 2, replace=False)
+        part.ins[r[a]] = -1
+        part.union(r[a], r[b])
+    Lc = O.Layer(part)
+    c = _knn_layer_setup(lib, torch, hip, sc, Lc)
+    d_prev = _up(torch, seg_prevcl)
+    out = torch.full((N, 20), -7, dtype=torch.int32, device="cuda:0")
+    hip.check(lib.sg_cluster_knn_seeded(c["sxyzw"].data_ptr(), c["smpos"].data_ptr(), N, c["off"].data_ptr(), c["tc4"].data_ptr(),
+                                        c["lo4"].data_ptr(), c["hi4"].data_ptr(), c["nt4"], c["cso"].data_ptr(), c["order"].data_ptr(),
+                                        c["dst"].data_ptr(), c["segoff"].data_ptr(), c["co"].data_ptr(), c["box"].data_ptr(), c["cbox"].data_ptr(),
+                                        c["slot"].data_ptr(), seed.data_ptr(), d_prev.data_ptr(), c["members"].data_ptr(),
+                                        c["pos_of_point"].data_ptr(), c["data"].data_ptr(), 20, c["pos0"], out.data_ptr(), None))
+    a_, b_ = c["brute"].cpu().numpy(), out.cpu().numpy()
+    assert np.array_equal(a_, b_), f"{int(np.any(a_ != b_, axis=1).sum())} rows differ between brute force and seeded"

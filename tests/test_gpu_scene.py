@@ -125,10 +125,11 @@ def test_150k_scene_matches_reference_digests_and_oracle(golden_index, weight_se
     assert np.array_equal(res.iou_sem, g["ins.metric.0"]) and np.array_equal(res.iou_ins, g["ins.metric.1"])
 
 
-@pytest.mark.parametrize("variant", [0, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
 def test_150k_scene_labels_do_not_depend_on_the_knn_kernel(golden_index, weight_sets, variant):
-    """The pipeline's alternative in-cluster kNN kernels (two-pass over the chunk table; 2 / 4 waves per tile) give
-    the reference's labels as well (the default at this size is one wave per tile, covered above)."""
+    """The pipeline's alternative in-cluster kNN kernels (two-pass over the chunk table; 1 / 2 / 4 waves per tile, none
+    of them seeded) give the reference's labels as well (the default at this size, covered above, is one wave per tile
+    with layer 3 seeded from layer 2's table)."""
     from seggroup_amd import hip
     name = "scene_150k"
     scene = make_fixture_scene(golden_index, name)
