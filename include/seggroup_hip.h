@@ -115,7 +115,8 @@ int sg_edge_distance(const float* d_feat, int feat_stride, int D, const int32_t*
 int sg_group_max_rows(const float* d_rows, int row_stride, int D, const int32_t* d_goff, const int32_t* d_gidx,
                       int G, float* d_out, int out_stride, void* stream);
 
-/* a10 point->cluster max (model.py:793,834): rows are in member order, clusters are contiguous ranges */
+/* a10 point->cluster max (model.py:793,834): rows are in member order, i.e. clusters are contiguous ranges and
+ * d_cluster_of_pos is non-decreasing along the rows (sg_gather_members produces exactly that) */
 int sg_segment_max(const float* d_rows, int N, int D, const int32_t* d_cluster_of_pos,
                    float* d_out, int out_stride, int C, void* stream);
 
