@@ -24,7 +24,7 @@ def stats(src, dst, title):
 
 
 bench = stats(f"{tag}_bench_stats", f"{tag}_bench_kernel_stats.csv",
-              "python bench.py --no-cpu-baseline --no-files (16 scenes per step, 8 pipelines in flight), 150k/1.5k scenes")
+              "python bench.py --no-cpu-baseline --no-files (128 scenes per step, 16 pipelines in flight), 150k/1.5k scenes")
 solo = stats(f"{tag}_solo_stats", f"{tag}_single_stream_kernel_stats.csv", "tools/time_scene.py 150000 1500 (one scene at a time, 6 forwards)")
 
 traffic = collections.defaultdict(dict)
