@@ -102,7 +102,8 @@ def main():
     scenes = [DeviceScene.from_synthetic(s, device=dev) for s in host_scenes]
     gen_s = time.time() - t0
     from seggroup_amd.model import BatchRunner
-    runner = BatchRunner(W, scenes, inflight=args.inflight, device=dev)
+    # timing level 1: HIP events only around the modelled kernels (every stage = ~25 events per scene = ~6 % of the throughput)
+    runner = BatchRunner(W, scenes, inflight=args.inflight, device=dev, timing=1)
     acc = {"iou_sem": np.zeros(80), "iou_ins": np.zeros(80), "acc": np.zeros(4), "n": 0}
 
     def step(record=True):
@@ -170,7 +171,7 @@ def main():
                     "stage_ms": {k_: round(v, 4) for k_, v in mean_ms.items()}}
         # the same kernels with ONE scene in flight (outside the timed region): with `inflight` streams sharing the GPU a
         # launch's duration says how long it shared the machine, not how well it uses it
-        solo_runner = BatchRunner(W, scenes[:4], inflight=1, device=dev)
+        solo_runner = BatchRunner(W, scenes[:4], inflight=1, device=dev, timing=1)
         solo_runner.run(scenes[:2], hip.MODE_INS_INFER)
         solo_runner.reset_stage_stats()
         solo_runner.run(scenes[:4], hip.MODE_INS_INFER)

@@ -172,6 +172,12 @@ size_t sg_spatial_sort_ws_bytes(int N);
 int sg_segment_spatial_sort(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off,
                             const int32_t* d_seg_of_point, int S, const float* d_segbox, const int32_t* d_seg_chunk_off,
                             int32_t* d_sperm, float* d_chunk_box, void* d_ws, size_t ws_bytes, void* stream);
+/* sg_segment_boxes + sg_segment_spatial_sort in ONE launch when the largest segment (max_seg points, known to the
+ * host) fits a block's LDS (2048 points); otherwise exactly those two calls (d_ws as for sg_segment_spatial_sort,
+ * unused on the fast path).  Identical outputs: d_segbox [S,8], d_sperm [N], d_chunk_box. */
+int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off,
+                          const int32_t* d_seg_of_point, int S, const int32_t* d_seg_chunk_off, int max_seg, float* d_segbox,
+                          int32_t* d_sperm, float* d_chunk_box, void* d_ws, size_t ws_bytes, void* stream);
 int sg_knn_operands(const float* d_data, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, float* d_sxyzw, int32_t* d_smpos, void* stream);
 int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off,
@@ -402,6 +408,10 @@ int sg_batch_forward(sg_pipeline* const* pipes, int npipes, const sg_scene* scen
 /* per-stage device time of the last forward, in milliseconds (HIP events on the pipeline's stream);
  * names via sg_pipeline_stage_name(i), count returned. */
 int sg_pipeline_stage_times(const sg_pipeline* pl, float* h_ms, int capacity);
+/* How many HIP events a forward records for sg_pipeline_stage_times: 2 (default) one after every stage, 1 only around
+ * the in-cluster kNN and the EdgeConv passes (the other stages read 0), 0 none.  With many pipelines in flight the
+ * ~25 events of level 2 cost ~6 % of the throughput.  Returns the previous level. */
+int sg_pipeline_set_timing(sg_pipeline* pl, int level);
 const char* sg_pipeline_stage_name(int i);
 
 /* =============================================================================================

@@ -57,6 +57,28 @@ __global__ void k_gcn_fc(const float* __restrict__ agg, int S, int D, const floa
 
 }  // namespace
 
+namespace sg {
+
+// d_wt = W^T ([k][o]); workspace as sg_gcn_forward (its transpose slot stays unused)
+int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, const int32_t* d_rowptr, const int32_t* d_col,
+                   const int32_t* d_eid, const float* d_wt, float alpha, float* d_out, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(S >= 0 && D > 0 && D <= 256 && E >= 0 && d_ws, "sg_gcn_forward: bad arguments (D=%d must be <= 256)", D);
+    if (S == 0) return SG_OK;
+    sg::Carver cv(d_ws, ws_bytes);
+    float* dist = cv.take<float>(std::max(E, 1));
+    float* agg = cv.take<float>((size_t)S * D);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_gcn_forward: workspace too small (%zu < %zu)", ws_bytes, sg_gcn_ws_bytes(S, D, E));
+    hipStream_t st = sg::as_stream(stream);
+    int rc = sg_edge_distance(d_x, D, D, d_adj, E, dist, stream);
+    if (rc) return rc;
+    k_gcn_aggregate<<<S, 64 * sg::cdiv(D, 64), 0, st>>>(d_x, D, d_rowptr, d_col, d_eid, dist, alpha, agg);
+    k_gcn_fc<<<sg::cdiv(S, kRows), 256, 0, st>>>(agg, S, D, d_wt, d_out);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // namespace sg
+
 extern "C" {
 
 size_t sg_gcn_ws_bytes(int S, int D, int E) {
@@ -68,18 +90,12 @@ int sg_gcn_forward(const float* d_x, int S, int D, const int32_t* d_adj, int E, 
     SG_REQUIRE(S >= 0 && D > 0 && D <= 256 && E >= 0 && d_ws, "sg_gcn_forward: bad arguments (D=%d must be <= 256)", D);
     if (S == 0) return SG_OK;
     sg::Carver cv(d_ws, ws_bytes);
-    float* dist = cv.take<float>(std::max(E, 1));
-    float* agg = cv.take<float>((size_t)S * D);
+    (void)cv.take<float>(std::max(E, 1));
+    (void)cv.take<float>((size_t)S * D);
     float* wt = cv.take<float>((size_t)D * D);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_gcn_forward: workspace too small (%zu < %zu)", ws_bytes, sg_gcn_ws_bytes(S, D, E));
-    hipStream_t st = sg::as_stream(stream);
-    int rc = sg_edge_distance(d_x, D, D, d_adj, E, dist, stream);
-    if (rc) return rc;
-    k_transpose<<<sg::cdiv(D * D, 256), 256, 0, st>>>(d_w, D, wt);
-    k_gcn_aggregate<<<S, 64 * sg::cdiv(D, 64), 0, st>>>(d_x, D, d_rowptr, d_col, d_eid, dist, alpha, agg);
-    k_gcn_fc<<<sg::cdiv(S, kRows), 256, 0, st>>>(agg, S, D, wt, d_out);
-    SG_LAUNCH_CHECK();
-    return SG_OK;
+    k_transpose<<<sg::cdiv(D * D, 256), 256, 0, sg::as_stream(stream)>>>(d_w, D, wt);
+    return sg::gcn_forward_wt(d_x, S, D, d_adj, E, d_rowptr, d_col, d_eid, wt, alpha, d_out, d_ws, ws_bytes, stream);
 }
 
 }  // extern "C"

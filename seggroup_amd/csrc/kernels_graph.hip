@@ -152,8 +152,10 @@ __global__ void k_edge_distance(const float* __restrict__ feat, int stride, int 
 // ------------------------------------------------------------------------------------------------
 // a10: aggregate_cluster_feature (model.py:278-288)
 // ------------------------------------------------------------------------------------------------
+// `fill_cols` further columns of every output row are set to -inf: the pipeline's next writer of those rows is the
+// atomic point->cluster max, which then needs no fill launch of its own
 __global__ void k_group_max_rows(const float* __restrict__ rows, int row_stride, int D, const int32_t* __restrict__ goff,
-                                 const int32_t* __restrict__ gidx, float* __restrict__ out, int out_stride) {
+                                 const int32_t* __restrict__ gidx, float* __restrict__ out, int out_stride, int fill_cols) {
     const int g = blockIdx.x;
     const int lo = goff[g], hi = goff[g + 1];
     for (int k = threadIdx.x; k < D; k += blockDim.x) {
@@ -161,6 +163,7 @@ __global__ void k_group_max_rows(const float* __restrict__ rows, int row_stride,
         for (int i = lo; i < hi; ++i) m = fmaxf(m, rows[(size_t)gidx[i] * row_stride + k]);
         out[(size_t)g * out_stride + k] = m;
     }
+    for (int k = threadIdx.x; k < fill_cols; k += blockDim.x) out[(size_t)g * out_stride + D + k] = -INFINITY;
 }
 
 __device__ inline void atomic_max_float(float* addr, float v) {
@@ -324,6 +327,27 @@ __global__ void k_eval_first_sem(const int32_t* __restrict__ sem_pred, int max_i
 }  // namespace
 
 // ================================================================================================
+namespace sg {
+
+int group_max_rows_fill(const float* d_rows, int row_stride, int D, const int32_t* d_goff, const int32_t* d_gidx, int G, float* d_out,
+                        int out_stride, int fill_cols, void* stream) {
+    if (G == 0) return SG_OK;
+    k_group_max_rows<<<G, 64 * ((std::min(D, 256) + 63) / 64), 0, sg::as_stream(stream)>>>(d_rows, row_stride, D, d_goff, d_gidx, d_out,
+                                                                                           out_stride, fill_cols);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+// d_out's 64 columns already hold -inf (or earlier maxima)
+int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_of_pos, float* d_out, int out_stride, void* stream) {
+    if (N == 0) return SG_OK;
+    k_segment_max64<<<sg::cdiv(N, kRowsPerBlock), 256, 0, sg::as_stream(stream)>>>(d_rows, N, d_cluster_of_pos, d_out, out_stride);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // namespace sg
+
 extern "C" {
 
 size_t sg_contract_ws_bytes(int S) {
@@ -381,21 +405,15 @@ int sg_group_max_rows(const float* d_rows, int row_stride, int D, const int32_t*
                       float* d_out, int out_stride, void* stream) {
     SG_REQUIRE(G >= 0 && D > 0, "sg_group_max_rows: bad arguments");
     if (G == 0) return SG_OK;
-    k_group_max_rows<<<G, 64 * ((std::min(D, 256) + 63) / 64), 0, sg::as_stream(stream)>>>(d_rows, row_stride, D, d_goff, d_gidx,
-                                                                                           d_out, out_stride);
-    SG_LAUNCH_CHECK();
-    return SG_OK;
+    return sg::group_max_rows_fill(d_rows, row_stride, D, d_goff, d_gidx, G, d_out, out_stride, 0, stream);
 }
 
 int sg_segment_max(const float* d_rows, int N, int D, const int32_t* d_cluster_of_pos, float* d_out, int out_stride, int C,
                    void* stream) {
     SG_REQUIRE(D == 64, "sg_segment_max: only D == 64 rows are supported (got %d)", D);
     if (N == 0 || C == 0) return SG_OK;
-    hipStream_t st = sg::as_stream(stream);
-    k_fill_rows<<<std::min(sg::cdiv((long long)C * 64, 256), 1024), 256, 0, st>>>(d_out, C, 64, out_stride, -INFINITY);
-    k_segment_max64<<<sg::cdiv(N, kRowsPerBlock), 256, 0, st>>>(d_rows, N, d_cluster_of_pos, d_out, out_stride);
-    SG_LAUNCH_CHECK();
-    return SG_OK;
+    k_fill_rows<<<std::min(sg::cdiv((long long)C * 64, 256), 1024), 256, 0, sg::as_stream(stream)>>>(d_out, C, 64, out_stride, -INFINITY);
+    return sg::segment_max_prefilled(d_rows, N, d_cluster_of_pos, d_out, out_stride, stream);
 }
 
 int sg_export_labels(const int32_t* d_unmap, int V, const int32_t* d_seg_of_point, int N, const int32_t* d_tables, int T,

@@ -88,6 +88,102 @@ __global__ __launch_bounds__(64) void k_chunk_boxes(const float* __restrict__ da
     }
 }
 
+// One launch for what sg_segment_boxes + k_morton_keys + the device radix sort (9 launches) + k_chunk_boxes do, for scenes
+// whose largest segment has <= kSortCap points: block s owns segment s, computes its box, sorts (morton30 << 32 | local
+// index) in LDS with a bitonic network -- the local index in the low bits reproduces the radix sort's stable order exactly
+// -- and boxes its 32-point chunks.  At ~1000 scenes/s the pipelines issue ~100k runtime calls per second, so launches
+// saved are throughput.
+constexpr int kSortCap = 2048;
+__global__ __launch_bounds__(256) void k_segment_sort_boxes(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                                                            const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
+                                                            float* __restrict__ segbox, int32_t* __restrict__ sperm,
+                                                            float* __restrict__ chunk_box) {
+    __shared__ unsigned long long key[kSortCap];
+    __shared__ float red[4][8];
+    __shared__ float bx[8];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = seg_off[s], n = seg_off[s + 1] - lo;
+    // 1. segment box {min xyz, max xyz, max |p|^2}
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, xx = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float* r = data + (size_t)seg_points[lo + i] * 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], r[k]); mx[k] = fmaxf(mx[k], r[k]); }
+        xx = fmaxf(xx, (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+        xx = fmaxf(xx, __shfl_xor(xx, o));
+    }
+    if (lane == 0) { red[wave][0] = mn[0]; red[wave][1] = mn[1]; red[wave][2] = mn[2]; red[wave][3] = mx[0]; red[wave][4] = mx[1]; red[wave][5] = mx[2]; red[wave][6] = xx; }
+    __syncthreads();
+    if (tid < 7) {
+        float v = red[0][tid];
+        for (int w = 1; w < 4; ++w) v = tid < 3 ? fminf(v, red[w][tid]) : fmaxf(v, red[w][tid]);
+        bx[tid] = v;
+        segbox[(size_t)s * 8 + tid] = v;
+    }
+    if (tid == 7) segbox[(size_t)s * 8 + 7] = 0.f;
+    __syncthreads();
+    // 2. keys (same quantisation as k_morton_keys), padded to a power of two with ~0
+    int m2 = 64;
+    while (m2 < n) m2 <<= 1;
+    for (int i = tid; i < m2; i += 256) {
+        unsigned long long kk = ~0ull;
+        if (i < n) {
+            const float* r = data + (size_t)seg_points[lo + i] * 6;
+            unsigned int q[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float ext = bx[3 + k] - bx[k];
+                const float t = ext > 0.f ? (r[k] - bx[k]) / ext : 0.f;
+                q[k] = (unsigned int)fminf(fmaxf(t * 1023.f, 0.f), 1023.f);
+            }
+            const unsigned int m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+            kk = ((unsigned long long)m << 32) | (unsigned int)i;
+        }
+        key[i] = kk;
+    }
+    __syncthreads();
+    // 3. bitonic sort, ascending
+    for (int k = 2; k <= m2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (m2 >> 1); t += 256) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                const unsigned long long a = key[i], b = key[p];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { key[i] = b; key[p] = a; }
+            }
+            __syncthreads();
+        }
+    // 4. sorted position -> index into the segment CSR
+    for (int r = tid; r < n; r += 256) sperm[lo + r] = lo + (int)(key[r] & 0xffffffffull);
+    // 5. boxes of the 32-point chunks (two per wave step)
+    const int c0 = seg_chunk_off[s], half = lane >> 5, l = lane & 31;
+    for (int j = 2 * wave + half; j * kChunkPts < n; j += 8) {
+        const int t = j * kChunkPts + l;
+        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY}, cxx = 0.f;
+        if (t < n) {
+            const float* r = data + (size_t)seg_points[lo + (int)(key[t] & 0xffffffffull)] * 6;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { cmn[k] = r[k]; cmx[k] = r[k]; }
+            cxx = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { cmn[k] = fminf(cmn[k], __shfl_xor(cmn[k], o)); cmx[k] = fmaxf(cmx[k], __shfl_xor(cmx[k], o)); }
+            cxx = fmaxf(cxx, __shfl_xor(cxx, o));
+        }
+        if (l == 0) {
+            float* b = chunk_box + (size_t)(c0 + j) * 8;
+            b[0] = cmn[0]; b[1] = cmn[1]; b[2] = cmn[2]; b[3] = cmx[0]; b[4] = cmx[1]; b[5] = cmx[2]; b[6] = cxx; b[7] = 0.f;
+        }
+    }
+}
+
 // per layer: block i = i-th segment in member order; writes the operand and the member position in SORTED order
 __global__ void k_knn_operands(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
                                const int32_t* __restrict__ seg_off, const int32_t* __restrict__ sperm,
@@ -635,6 +731,22 @@ int sg_segment_spatial_sort(const float* d_data, int N, const int32_t* d_seg_poi
     SG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, temp, dk, dv, N, 0, 32 + seg_bits, st));
     SG_HIP(hipMemcpyAsync(d_sperm, dv.Current(), (size_t)N * 4, hipMemcpyDeviceToDevice, st));
     k_chunk_boxes<<<S, 64, 0, st>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_sperm, d_chunk_box);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off,
+                          const int32_t* d_seg_of_point, int S, const int32_t* d_seg_chunk_off, int max_seg, float* d_segbox,
+                          int32_t* d_sperm, float* d_chunk_box, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(N >= 0 && S >= 0 && max_seg >= 0 && d_segbox && d_sperm && d_chunk_box, "sg_segment_sort_boxes: bad arguments");
+    if (N == 0 || S == 0) return SG_OK;
+    if (max_seg > kSortCap) {                                  // a segment does not fit one block's LDS: library sort
+        int rc = sg_segment_boxes(d_data, d_seg_points, d_seg_off, S, d_segbox, stream);
+        if (rc) return rc;
+        return sg_segment_spatial_sort(d_data, N, d_seg_points, d_seg_off, d_seg_of_point, S, d_segbox, d_seg_chunk_off, d_sperm, d_chunk_box,
+                                       d_ws, ws_bytes, stream);
+    }
+    k_segment_sort_boxes<<<S, 256, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_segbox, d_sperm, d_chunk_box);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

@@ -59,7 +59,7 @@ struct sg_pipeline {
 
     // weights (device)
     DevBuf<float> w;   // all parameters, offsets below
-    size_t o_m1w, o_m1g, o_m1b, o_m2w, o_m2g, o_m2b, o_g2, o_m3w1, o_m3g1, o_m3b1, o_m3w2, o_m3g2, o_m3b2, o_g3;
+    size_t o_m1w, o_m1g, o_m1b, o_m2w, o_m2g, o_m2b, o_g2, o_m3w1, o_m3g1, o_m3b1, o_m3w2, o_m3g2, o_m3b2, o_g3, o_g2t, o_g3t;
 
     // device work buffers
     DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_center, ws_eval, ws_sort;
@@ -75,7 +75,18 @@ struct sg_pipeline {
     int n_ev = 0;
     float stage_ms[kNumStages];
 
+    // stage timing (sg_pipeline_set_timing): 2 = an event after every stage, 1 = only around the in-cluster kNN and the
+    // EdgeConv passes (what bench.py's roofline needs: ~10 instead of ~25 events per scene, which cost ~6 % of the
+    // throughput with 16 pipelines in flight), 0 = none
+    int timing = 2;
+    static bool kernel_stage(int stage) { return stage == 6 || stage == 12 || (stage >= 19 && stage <= 23); }
+    void mark_kernel_start() {                                // level 1: the event a timed kernel stage is measured from
+        if (timing == 1) record(-1);
+    }
     void mark(int stage) {
+        if (timing == 2 || (timing == 1 && kernel_stage(stage))) record(stage);
+    }
+    void record(int stage) {
         if (n_ev < kNumEvents) {
             (void)hipEventRecord(ev[n_ev], stream);
             ev_stage[n_ev] = stage;
@@ -113,6 +124,13 @@ int sg_pipeline_stage_times(const sg_pipeline* pl, float* h_ms, int capacity) {
     if (!pl || !h_ms) return sg::fail(SG_EINVAL, "sg_pipeline_stage_times: null argument");
     for (int i = 0; i < kNumStages && i < capacity; ++i) h_ms[i] = pl->stage_ms[i];
     return kNumStages;
+}
+
+int sg_pipeline_set_timing(sg_pipeline* pl, int level) {
+    if (!pl || level < 0 || level > 2) return sg::fail(SG_EINVAL, "sg_pipeline_set_timing: bad arguments");
+    const int prev = pl->timing;
+    pl->timing = level;
+    return prev;
 }
 
 size_t sg_pipeline_device_bytes(const sg_pipeline* pl) { return pl ? pl->dev_bytes : 0; }
@@ -155,6 +173,7 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     pl->o_m3w1 = slot(64 * 18); pl->o_m3g1 = slot(64); pl->o_m3b1 = slot(64);
     pl->o_m3w2 = slot(64 * 64); pl->o_m3g2 = slot(64); pl->o_m3b2 = slot(64);
     pl->o_g3 = slot(256 * 256);
+    pl->o_g2t = slot(192 * 192); pl->o_g3t = slot(256 * 256);        // W^T of the two GCN layers (k_gcn_fc reads [k][o])
     D(pl->w, off);
     if (!bad) {
         std::vector<float> hw(off, 0.f);
@@ -165,6 +184,11 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
         put(pl->o_m3w1, wt->mlp3_w1, 64 * 18); put(pl->o_m3g1, wt->mlp3_g1, 64); put(pl->o_m3b1, wt->mlp3_b1, 64);
         put(pl->o_m3w2, wt->mlp3_w2, 64 * 64); put(pl->o_m3g2, wt->mlp3_g2, 64); put(pl->o_m3b2, wt->mlp3_b2, 64);
         put(pl->o_g3, wt->gcn3_w, 256 * 256);
+        auto put_t = [&](size_t o, const float* src, int D) {
+            if (!src) { bad = 1; return; }
+            for (int r = 0; r < D; ++r) for (int k = 0; k < D; ++k) hw[o + (size_t)k * D + r] = src[(size_t)r * D + k];
+        };
+        put_t(pl->o_g2t, wt->gcn2_w, 192); put_t(pl->o_g3t, wt->gcn3_w, 256);
         if (bad) { sg::fail(SG_EINVAL, "sg_pipeline_create: null weight pointer"); return nullptr; }
         if (hipMemcpy(pl->w.p, hw.data(), off * 4, hipMemcpyHostToDevice) != hipSuccess) { sg::fail(SG_EHIP, "weight upload failed"); return nullptr; }
     }
@@ -241,15 +265,15 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     for (int s = 0; s < S; ++s) max_seg = std::max(max_seg, sc->h_seg_size[s]);
     PL_CHECK(sg::fps_sample_hint(sc->d_data, N, 6, sc->d_seg_points, sc->d_seg_off, S, 64, 6, 1, pl->samples.p, nullptr, pl->ws_fps.p,
                                  pl->ws_fps.n, stv, max_seg));
-    PL_CHECK(sg_segment_boxes(sc->d_data, sc->d_seg_points, sc->d_seg_off, S, pl->segbox.p, stv));
     if (mode == SG_MODE_INS_INFER) {
-        // once per scene: Morton order inside every over-segment + boxes of its 32-point chunks (kNN pruning)
+        // once per scene: segment boxes, Morton order inside every over-segment + boxes of its 32-point chunks (kNN
+        // pruning) -- one launch unless a segment exceeds a block's LDS
         int32_t* co = pl->h_chunk_off.p;
         co[0] = 0;
         for (int s = 0; s < S; ++s) co[s + 1] = co[s] + (sc->h_seg_size[s] + 31) / 32;
         PL_HIP(hipMemcpyAsync(pl->seg_chunk_off.p, co, (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
-        PL_CHECK(sg_segment_spatial_sort(sc->d_data, N, sc->d_seg_points, sc->d_seg_off, sc->d_seg_of_point, S, pl->segbox.p,
-                                         pl->seg_chunk_off.p, pl->sperm.p, pl->chunk_box.p, pl->ws_sort.p, pl->ws_sort.n, stv));
+        PL_CHECK(sg_segment_sort_boxes(sc->d_data, N, sc->d_seg_points, sc->d_seg_off, sc->d_seg_of_point, S, pl->seg_chunk_off.p, max_seg,
+                                       pl->segbox.p, pl->sperm.p, pl->chunk_box.p, pl->ws_sort.p, pl->ws_sort.n, stv));
     }
     pl->mark(1);
     PL_CHECK(sg_mlp1_forward(pl->samples.p, S, W + pl->o_m1w, W + pl->o_m1g, W + pl->o_m1b, pl->feat1.p, 128, pl->ws_mlp1.p,
@@ -397,7 +421,8 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
 
             PL_CHECK(sg_gather_members(sc->d_seg_points, sc->d_seg_off, S, dd + o.order, dd + o.dst, dd + o.cl, pl->members.p,
                                        pl->pos_of_point.p, pl->cluster_of_pos.p, pl->slot_of_pos.p, stv));
-            PL_CHECK(sg_group_max_rows(feat_prev, feat_prev_stride, feat_prev_dim, dd + o.goff, dd + o.gidx, C, cat, Dcat, stv));
+            // + -inf into the 64 columns the point->cluster max fills below
+            PL_CHECK(sg::group_max_rows_fill(feat_prev, feat_prev_stride, feat_prev_dim, dd + o.goff, dd + o.gidx, C, cat, Dcat, 64, stv));
             pl->mark(sb + 0);
             PL_CHECK(sg_center_clusters(sc->d_data, N, pl->members.p, dd + o.cl_pt_off, C, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi,
                                         T, dd + o.cl_tile_off, pl->x9m.p, pl->xyzw.p, pl->ws_center.p, pl->ws_center.n, stv));
@@ -405,6 +430,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             // point 0 is the first member of segment 0; its member-order position is that segment's dst
             int pos0 = 0;
             for (int i = 0; i < S; ++i) if (Lnew.order[i] == 0) { pos0 = Lnew.dst[i]; break; }
+            pl->mark_kernel_start();
             PL_CHECK(sg_knn_operands(sc->d_data, sc->d_seg_points, sc->d_seg_off, pl->sperm.p, S, dd + o.order, dd + o.dst, pl->xyzw.p,
                                      pl->smpos.p, stv));
             if (knn_variant == 0) {
@@ -438,9 +464,9 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                 PL_CHECK(sg::edgeconv_forward_marked(pl->x9m.p, pl->knn.p, N, 20, 2, W + pl->o_m3w1, W + pl->o_m3g1, W + pl->o_m3b1,
                                                      W + pl->o_m3w2, W + pl->o_m3g2, W + pl->o_m3b2, pl->pf.p, pl->ws_edge.p,
                                                      pl->ws_edge.n, stv, mark_pass));
-            PL_CHECK(sg_segment_max(pl->pf.p, N, 64, pl->cluster_of_pos.p, cat + feat_prev_dim, Dcat, C, stv));
+            PL_CHECK(sg::segment_max_prefilled(pl->pf.p, N, pl->cluster_of_pos.p, cat + feat_prev_dim, Dcat, stv));
             pl->mark(sb + 4);
-            PL_CHECK(sg_gcn_forward(cat, C, Dcat, dd + o.adj, E, dd + o.rowptr, dd + o.col, dd + o.eid, W + (layer == 0 ? pl->o_g2 : pl->o_g3),
+            PL_CHECK(sg::gcn_forward_wt(cat, C, Dcat, dd + o.adj, E, dd + o.rowptr, dd + o.col, dd + o.eid, W + (layer == 0 ? pl->o_g2t : pl->o_g3t),
                                     0.125f, gcn_out, pl->ws_gcn.p, pl->ws_gcn.n, stv));
             PL_CHECK(sg_edge_distance(gcn_out, Dcat, Dcat, dd + o.adj, E, pl->dist.p, stv));
             PL_HIP(hipMemcpyAsync(pl->h_dist.p, pl->dist.p, (size_t)E * 4, hipMemcpyDeviceToHost, st));

@@ -50,6 +50,14 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
                             const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
                             size_t ws_bytes, void* stream, const std::function<void(int)>& mark);
 
+// pipeline-internal forms that save launches (kernels_graph.hip, kernels_gcn.hip): group max that also pre-fills the
+// columns the point->cluster max writes next; that max without its own fill; GCN with the weight already transposed
+int group_max_rows_fill(const float* d_rows, int row_stride, int D, const int32_t* d_goff, const int32_t* d_gidx, int G, float* d_out,
+                        int out_stride, int fill_cols, void* stream);
+int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_of_pos, float* d_out, int out_stride, void* stream);
+int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, const int32_t* d_rowptr, const int32_t* d_col,
+                   const int32_t* d_eid, const float* d_wt, float alpha, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     "sg_segment_spatial_sort": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_knn_operands": (_I, [vp, vp, vp, vp, _I, vp, vp, vp, vp, vp]),
     "sg_cluster_knn_sorted": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
+    "sg_segment_sort_boxes": (_I, [vp, _I, vp, vp, vp, _I, vp, _I, vp, vp, vp, vp, _Z, vp]),
     "sg_knn_set_variant": (_I, [_I]),
     "sg_knn_seed_points": (_I, [vp, vp, _I, _I, vp, vp]),
     "sg_cluster_knn_seeded": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
@@ -116,6 +117,7 @@ SIGNATURES = {
     "sg_pipeline_forward": (_I, [vp, vp, _I, vp, vp]),
     "sg_batch_forward": (_I, [vp, _I, vp, _I, _I, vp, vp, vp, vp, _I]),
     "sg_pipeline_stage_times": (_I, [vp, vp, _I]),
+    "sg_pipeline_set_timing": (_I, [vp, _I]),
     "sg_pipeline_stage_name": (C.c_char_p, [_I]),
     "sg_write_label_txt": (_I, [C.c_char_p, vp, _I]),
     "sg_write_label_npy": (_I, [C.c_char_p, vp, _I]),

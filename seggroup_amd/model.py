@@ -152,6 +152,10 @@ class Pipeline:
         lab = self.labels.numpy().reshape(-1)[:hip.NUM_LABEL_VECTORS * sc.V].reshape(hip.NUM_LABEL_VECTORS, sc.V)
         return SceneResult(lab, nvec, res)
 
+    def set_timing(self, level: int) -> int:
+        """0 = no stage-timing events, 1 = only around the kNN / EdgeConv kernels, 2 = every stage (default)."""
+        return self.lib.sg_pipeline_set_timing(self.handle, int(level))
+
     def stage_times(self) -> Dict[str, float]:
         buf = (C.c_float * 32)()
         n = self.lib.sg_pipeline_stage_times(self.handle, buf, 32)
@@ -176,7 +180,8 @@ class BatchRunner:
     """Several scenes in flight on one GPU: `inflight` pipelines (one HIP stream each) driven by native host
     threads inside `sg_batch_forward` -- no Python between a scene's kernels."""
 
-    def __init__(self, w: Dict[str, np.ndarray], scenes: List[DeviceScene], inflight: int = 4, device=None, min_caps=None):
+    def __init__(self, w: Dict[str, np.ndarray], scenes: List[DeviceScene], inflight: int = 4, device=None, min_caps=None,
+                 timing: int = 2):
         dev = torch.device(device if device is not None else scenes[0].device)
         caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
         if min_caps is not None:                    # regrowing: never shrink below the previous capacities
@@ -184,6 +189,8 @@ class BatchRunner:
         self.lib = hip.lib()
         self.device = dev
         self.pipes = [Pipeline(w, *caps, stream=torch.cuda.Stream(device=dev), device=dev) for _ in range(inflight)]
+        for p in self.pipes:
+            p.set_timing(timing)
         self._handles = (C.c_void_p * inflight)(*[p.handle for p in self.pipes])
         self.max_v = caps[3]
         self._labels = None

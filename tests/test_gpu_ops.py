@@ -422,6 +422,15 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         hip.check(lib.sg_segment_spatial_sort(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), d_sop.data_ptr(), S,
                                               box.data_ptr(), d_co.data_ptr(), sperm.data_ptr(), cbox.data_ptr(), wss.data_ptr(),
                                               wss.numel(), None))
+        # the single-launch form (segment box + Morton sort in LDS + chunk boxes) gives the same three arrays bit for bit
+        box2 = torch.full((S, 8), 7.0, device="cuda:0"); sperm2 = torch.full((N,), -1, dtype=torch.int32, device="cuda:0")
+        cbox2 = torch.zeros_like(cbox)
+        for max_seg in (int(np.diff(seg_off).max()), 1 << 20):      # fits a block / forces the library-sort fallback
+            box2.fill_(7.0); sperm2.fill_(-1); cbox2.zero_()
+            hip.check(lib.sg_segment_sort_boxes(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), d_sop.data_ptr(), S,
+                                                d_co.data_ptr(), max_seg, box2.data_ptr(), sperm2.data_ptr(), cbox2.data_ptr(), wss.data_ptr(),
+                                                wss.numel(), None))
+            assert torch.equal(box2, box) and torch.equal(sperm2, sperm) and torch.equal(cbox2, cbox), max_seg
         sp = sperm.cpu().numpy()
         for s_ in (0, S - 1):      # a permutation of the segment's CSR range
             assert sorted(sp[seg_off[s_]:seg_off[s_ + 1]].tolist()) == list(range(seg_off[s_], seg_off[s_ + 1]))
