@@ -441,10 +441,22 @@ __global__ __launch_bounds__(256) void k_bn_lrelu_apply(float* __restrict__ e, s
 
 namespace sg {
 
+// the epilogue alone: d_dst = LReLU(|a| * d_e + b') (debug taps of the pipeline, which otherwise fuses it into the segment max)
+int edgeconv_apply(const float* d_e, int N, const float* d_a, const float* d_shift, float* d_dst, void* stream) {
+    if (N == 0) return SG_OK;
+    hipStream_t st = sg::as_stream(stream);
+    if (d_dst != d_e) SG_HIP(hipMemcpyAsync(d_dst, d_e, (size_t)N * 64 * 4, hipMemcpyDeviceToDevice, st));
+    const size_t n4 = (size_t)N * 16;
+    k_bn_lrelu_apply<<<(int)std::min<size_t>((n4 + 255) / 256, 2048), 256, 0, st>>>(d_dst, n4, d_a, d_shift);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
 int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
                             const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
-                            size_t ws_bytes, void* stream, const std::function<void(int)>& mark) {
+                            size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine) {
     SG_REQUIRE(N >= 0 && k > 0 && (layers == 1 || layers == 2) && d_ws, "sg_edgeconv_forward: bad arguments");
+    if (d_affine) { d_affine[0] = nullptr; d_affine[1] = nullptr; }
     if (N == 0) return SG_OK;
     const int nblocks = sg::cdiv(sg::cdiv(N, 32), kWaves);
     sg::Carver cv(d_ws, ws_bytes);
@@ -464,7 +476,8 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
         k_edgeconv<S1X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, d_g1, d_out, partial);
         k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, w1f, sh1);
         if (mark) mark(0);
-        k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w1f, sh1);
+        if (d_affine) { d_affine[0] = w1f; d_affine[1] = sh1; }        // the caller applies LReLU(|a| E + b') where it consumes E
+        else k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w1f, sh1);
         if (mark) mark(1);
     } else {
         const int mblocks = sg::cdiv(N, 256);
@@ -474,7 +487,8 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
         k_edgeconv<S2X, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, d_w2, d_g2, d_out, partial);
         k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, w2f, sh2);
         if (mark) mark(1);
-        k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w2f, sh2);
+        if (d_affine) { d_affine[0] = w2f; d_affine[1] = sh2; }
+        else k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w2f, sh2);
         if (mark) mark(2);
     }
     SG_LAUNCH_CHECK();
@@ -495,7 +509,7 @@ int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, 
                         const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
                         size_t ws_bytes, void* stream) {
     return sg::edgeconv_forward_marked(d_x9m, d_knn, N, k, layers, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, d_out, d_ws, ws_bytes, stream,
-                                       nullptr);
+                                       nullptr, nullptr);
 }
 
 }  // extern "C"

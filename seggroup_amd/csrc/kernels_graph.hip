@@ -189,8 +189,11 @@ __global__ void k_fill_rows(float* __restrict__ p, int rows, int cols, int strid
 // step -- 1,172 waves, 87 % of their cycles in s_waitcnt, 0.8 TB/s; per-thread flushes at this granularity drown in
 // contended float-max atomics instead.)
 constexpr int kRowsPerBlock = 64;
+// a != nullptr: the rows are EdgeConv's pre-activation maxima E and every element is first mapped to LReLU(a_c * E + b_c)
+// (the same fmaf + fmaxf as k_bn_lrelu_apply), which saves that kernel's launch and a read + write of the [N,64] array.
 __global__ __launch_bounds__(256) void k_segment_max64(const float* __restrict__ rows, int N, const int32_t* __restrict__ cluster_of_pos,
-                                                       float* __restrict__ out, int out_stride) {
+                                                       float* __restrict__ out, int out_stride, const float* __restrict__ a,
+                                                       const float* __restrict__ shift) {
     constexpr int kIter = kRowsPerBlock / 16;
     __shared__ float4 red[16][16];
     const int qi = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -202,6 +205,17 @@ __global__ __launch_bounds__(256) void k_segment_max64(const float* __restrict__
         const int r = r0 + 16 * i;
         c[i] = r < N ? cluster_of_pos[r] : -1;
         v[i] = r < N ? *reinterpret_cast<const float4*>(rows + (size_t)r * 64 + qi * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (a) {
+        const float4 a4 = *reinterpret_cast<const float4*>(a + qi * 4), s4 = *reinterpret_cast<const float4*>(shift + qi * 4);
+#pragma unroll
+        for (int i = 0; i < kIter; ++i) {
+            float y;
+            y = __builtin_fmaf(a4.x, v[i].x, s4.x); v[i].x = fmaxf(y, 0.2f * y);
+            y = __builtin_fmaf(a4.y, v[i].y, s4.y); v[i].y = fmaxf(y, 0.2f * y);
+            y = __builtin_fmaf(a4.z, v[i].z, s4.z); v[i].z = fmaxf(y, 0.2f * y);
+            y = __builtin_fmaf(a4.w, v[i].w, s4.w); v[i].w = fmaxf(y, 0.2f * y);
+        }
     }
     const int c_first = cluster_of_pos[b0], c_last = cluster_of_pos[min(b0 + kRowsPerBlock, N) - 1];
     for (int cl = c_first; cl <= c_last; ++cl) {
@@ -339,9 +353,11 @@ int group_max_rows_fill(const float* d_rows, int row_stride, int D, const int32_
 }
 
 // d_out's 64 columns already hold -inf (or earlier maxima)
-int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_of_pos, float* d_out, int out_stride, void* stream) {
+int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_of_pos, float* d_out, int out_stride, void* stream,
+                          const float* d_a, const float* d_shift) {
     if (N == 0) return SG_OK;
-    k_segment_max64<<<sg::cdiv(N, kRowsPerBlock), 256, 0, sg::as_stream(stream)>>>(d_rows, N, d_cluster_of_pos, d_out, out_stride);
+    k_segment_max64<<<sg::cdiv(N, kRowsPerBlock), 256, 0, sg::as_stream(stream)>>>(d_rows, N, d_cluster_of_pos, d_out, out_stride, d_a,
+                                                                                   d_shift);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

@@ -457,14 +457,16 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             // time of the LAST pass here and the reporting side adds the sub-passes up (see sg_pipeline_stage_times)
             const int sub0 = layer == 0 ? 19 : 21;
             auto mark_pass = [&](int i) { pl->mark(sub0 + i); };
+            // pf = pre-activation maxima; the last BN + LeakyReLU is applied inside the segment max (affine[0..1] = |a|, b')
+            const float* affine[2];
             if (layer == 0)
                 PL_CHECK(sg::edgeconv_forward_marked(pl->x9m.p, pl->knn.p, N, 20, 1, W + pl->o_m2w, W + pl->o_m2g, W + pl->o_m2b, nullptr,
-                                                     nullptr, nullptr, pl->pf.p, pl->ws_edge.p, pl->ws_edge.n, stv, mark_pass));
+                                                     nullptr, nullptr, pl->pf.p, pl->ws_edge.p, pl->ws_edge.n, stv, mark_pass, affine));
             else
                 PL_CHECK(sg::edgeconv_forward_marked(pl->x9m.p, pl->knn.p, N, 20, 2, W + pl->o_m3w1, W + pl->o_m3g1, W + pl->o_m3b1,
                                                      W + pl->o_m3w2, W + pl->o_m3g2, W + pl->o_m3b2, pl->pf.p, pl->ws_edge.p,
-                                                     pl->ws_edge.n, stv, mark_pass));
-            PL_CHECK(sg::segment_max_prefilled(pl->pf.p, N, pl->cluster_of_pos.p, cat + feat_prev_dim, Dcat, stv));
+                                                     pl->ws_edge.n, stv, mark_pass, affine));
+            PL_CHECK(sg::segment_max_prefilled(pl->pf.p, N, pl->cluster_of_pos.p, cat + feat_prev_dim, Dcat, stv, affine[0], affine[1]));
             pl->mark(sb + 4);
             PL_CHECK(sg::gcn_forward_wt(cat, C, Dcat, dd + o.adj, E, dd + o.rowptr, dd + o.col, dd + o.eid, W + (layer == 0 ? pl->o_g2t : pl->o_g3t),
                                     0.125f, gcn_out, pl->ws_gcn.p, pl->ws_gcn.n, stv));
@@ -473,7 +475,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             if (layer == 1 || (dbg && dbg->h_gcn[layer]))
                 PL_HIP(hipMemcpyAsync(pl->h_feat.p, gcn_out, (size_t)C * Dcat * 4, hipMemcpyDeviceToHost, st));
             if (dbg) {
-                if (dbg->d_pointfeat[layer]) PL_HIP(hipMemcpyAsync(dbg->d_pointfeat[layer], pl->pf.p, (size_t)N * 64 * 4, hipMemcpyDeviceToDevice, st));
+                if (dbg->d_pointfeat[layer]) PL_CHECK(sg::edgeconv_apply(pl->pf.p, N, affine[0], affine[1], dbg->d_pointfeat[layer], stv));
                 if (dbg->d_knn[layer]) PL_HIP(hipMemcpyAsync(dbg->d_knn[layer], pl->knn.p, (size_t)N * 20 * 4, hipMemcpyDeviceToDevice, st));
                 if (dbg->d_members[layer]) PL_HIP(hipMemcpyAsync(dbg->d_members[layer], pl->members.p, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
             }

@@ -48,13 +48,18 @@ int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_memb
 // moments + fold, 1 = S2X + fold, 2 = epilogue.
 int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
                             const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
-                            size_t ws_bytes, void* stream, const std::function<void(int)>& mark);
+                            size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine);
+// d_affine != nullptr: the last BatchNorm + LeakyReLU is NOT applied; d_out holds E = max_k sgn(gamma) y_k and
+// d_affine[0..1] receive the device pointers of |a| [64] and b' [64] (inside d_ws) for a consumer that applies
+// LReLU(|a| E + b') itself (segment_max_prefilled does); edgeconv_apply is the epilogue on its own.
+int edgeconv_apply(const float* d_e, int N, const float* d_a, const float* d_shift, float* d_dst, void* stream);
 
 // pipeline-internal forms that save launches (kernels_graph.hip, kernels_gcn.hip): group max that also pre-fills the
 // columns the point->cluster max writes next; that max without its own fill; GCN with the weight already transposed
 int group_max_rows_fill(const float* d_rows, int row_stride, int D, const int32_t* d_goff, const int32_t* d_gidx, int G, float* d_out,
                         int out_stride, int fill_cols, void* stream);
-int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_of_pos, float* d_out, int out_stride, void* stream);
+int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_of_pos, float* d_out, int out_stride, void* stream,
+                          const float* d_a = nullptr, const float* d_shift = nullptr);     // rows -> LReLU(a * row + shift) first
 int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, const int32_t* d_rowptr, const int32_t* d_col,
                    const int32_t* d_eid, const float* d_wt, float alpha, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
 
