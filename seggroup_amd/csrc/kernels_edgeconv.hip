@@ -9,6 +9,9 @@
 // This is the only dense contraction on the hot path and it is MFMA-bound (39 GFLOP/scene, ~280
 // flop/B): it runs on v_mfma_f32_32x32x2_f32 (exact fp32, bit-equal to an fmaf chain).
 //
+// The x_i half of the edge feature does not depend on the neighbour: its contribution to conv1 (plus the folded shift) is
+// evaluated once per point and seeds every slot's accumulator, so a slot costs 10 + 64 MFMAs (MLP3) or 10 (MLP2), not 18 + 64 / 18.
+//
 // Mapping (one wave = one tile of 32 points, loop over the k=20 neighbour slots):
 //   D^T[ch][row] = sum_k W[ch][k] * E[row][k]:  A operand = weights (M = 32 channels per tile, two
 //   tiles), B operand = edge features (N = 32 rows).  Lane l holds row (l & 31) and k-parity (l >> 5);
@@ -48,7 +51,9 @@ __device__ inline int acc_channel(int tile, int reg, int half) { return 32 * til
 
 struct Lds {
     // A fragments, four MFMA steps per ds_read_b128 (conflict-free: consecutive lanes, 16 B each)
-    float4 a1[2][3][64];     // conv1: a1[t][s>>2][lane][s&3] = W1[32t + (lane&31)][2s + (lane>>5)], s < 9 (steps 9..11 unused)
+    // conv1, split by input half (e = [d, x_i], d = x_j - x_i): five K=2 steps each, k = 2s + (lane>>5) < 9 (k = 9: zero)
+    float4 a1d[2][2][64];    // a1d[t][s>>2][lane][s&3] = W1[32t + (lane&31)][k]        the d columns, used every neighbour slot
+    float4 a1x[2][2][64];    // a1x[t][s>>2][lane][s&3] = W1[32t + (lane&31)][9 + k]    the x_i columns, used once per point
     float4 a2[2][8][64];     // conv2: a2[ot][st>>2][lane][st&3] = W2[32ot + (lane&31)][acc_channel(st>>4, st&15, lane>>5)]
     float sh1r[2][2][16];    // folded BN1 shift in accumulator-register order: sh1r[tile][half][reg] (b128 reads)
     double acc[kWaves][128]; // per-wave statistics: [0,64) sum, [64,128) sum of squares
@@ -65,13 +70,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
     const int r = lane & 31, half = lane >> 5;
 
     // the last layer's rows carry the sign of its BN gamma (see the header): y' = sgn(gamma) * y exactly
-    for (int i = tid; i < 2 * 3 * 64; i += 64 * kWaves) (&lds.a1[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    for (int i = tid; i < 2 * 9 * 64; i += 64 * kWaves) {
-        const int l = i & 63, s = (i >> 6) % 9, t = i / (9 * 64);
-        const int ch = 32 * t + (l & 31);
-        const float v = w1[ch * 18 + 2 * s + (l >> 5)];
-        (&lds.a1[t][s >> 2][l].x)[s & 3] = (MODE == S1X && gamma_last[ch] < 0.f) ? -v : v;
+    for (int i = tid; i < 2 * 2 * 8 * 64; i += 64 * kWaves) {       // [part][t][step 0..7][lane]; steps 5..7 and k = 9 stay zero
+        const int l = i & 63, s = (i >> 6) & 7, t = (i >> 9) & 1, part = i >> 10;
+        const int ch = 32 * t + (l & 31), k = 2 * s + (l >> 5);
+        float v = (s < 5 && k < 9) ? w1[ch * 18 + 9 * part + k] : 0.f;
+        if (MODE == S1X && gamma_last[ch] < 0.f) v = -v;
+        (&(part ? lds.a1x : lds.a1d)[t][s >> 2][l].x)[s & 3] = v;
     }
     if (kTwo) {
         for (int i = tid; i < 2 * 32 * 64; i += 64 * kWaves) {
@@ -99,12 +103,39 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
         const float4* xr = reinterpret_cast<const float4*>(x9m + (size_t)ptc * 12);
         const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
         const float xi[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
-        // B operand of conv1, k = 2s + half.  e[0..8] = x_j - x_i, e[9..17] = x_i
-        float b[9];
-        b[5] = half ? xi[2] : xi[1];
-        b[6] = half ? xi[4] : xi[3];
-        b[7] = half ? xi[6] : xi[5];
-        b[8] = half ? xi[8] : xi[7];
+        // B operands, k = 2s + half: the x_i half of the edge feature is the same for all K neighbours of a point, so its
+        // contribution W1[:, 9:18] x_i (+ the folded BN1 shift) is evaluated ONCE into `base` and every slot's accumulator
+        // starts from it (first MFMA: C = base, D = acc1) -- 10 instead of 18 conv1 MFMAs per slot
+        const float xsel[5] = {half ? xi[1] : xi[0], half ? xi[3] : xi[2], half ? xi[5] : xi[4], half ? xi[7] : xi[6], half ? 0.f : xi[8]};
+        f32x16 base[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (kTwo) {
+                const float4* sp = reinterpret_cast<const float4*>(&lds.sh1r[t][half][0]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = sp[g];
+                    base[t][4 * g] = v.x; base[t][4 * g + 1] = v.y; base[t][4 * g + 2] = v.z; base[t][4 * g + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) base[t][q] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 2; ++s4) {
+            const float4 wa = lds.a1x[0][s4][lane], wb = lds.a1x[1][s4][lane];
+            const float* pa = &wa.x;
+            const float* pb = &wb.x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s_ = 4 * s4 + u;
+                if (s_ < 5) {
+                    base[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[u], xsel[s_], base[0], 0, 0, 0);
+                    base[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u], xsel[s_], base[1], 0, 0, 0);
+                }
+            }
+        }
 
         float stat_s[32], stat_q[32];
         f32x16 best[2];
@@ -132,44 +163,23 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
                 p0 = xq[0]; p1 = xq[1]; p2 = xq[2];
                 if (j + 2 < K) nb_next = krow[j + 2];
             }
-            const float d[9] = {n0.x - xi[0], n0.y - xi[1], n0.z - xi[2], n0.w - xi[3], n1.x - xi[4],
-                                n1.y - xi[5], n1.z - xi[6], n1.w - xi[7], n2.x - xi[8]};
-            b[0] = half ? d[1] : d[0];
-            b[1] = half ? d[3] : d[2];
-            b[2] = half ? d[5] : d[4];
-            b[3] = half ? d[7] : d[6];
-            b[4] = half ? xi[0] : d[8];
-
-            // accumulator starts at the folded BN1 shift (inner layer) or at zero; re-read from LDS each slot
-            // (8 x ds_read_b128) instead of parking 32 VGPRs on it
+            // d = x_j - x_i for this lane's k = 2s + half
+            const float bd[5] = {(half ? n0.y : n0.x) - xsel[0], (half ? n0.w : n0.z) - xsel[1], (half ? n1.y : n1.x) - xsel[2],
+                                 (half ? n1.w : n1.z) - xsel[3], half ? 0.f : n2.x - xsel[4]};
             f32x16 acc1[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (kTwo) {
-                    const float4* sp = reinterpret_cast<const float4*>(&lds.sh1r[t][half][0]);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 v = sp[g];
-                        acc1[t][4 * g] = v.x; acc1[t][4 * g + 1] = v.y; acc1[t][4 * g + 2] = v.z; acc1[t][4 * g + 3] = v.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) acc1[t][q] = 0.f;
-                }
-            }
-#pragma unroll
-            for (int s4 = 0; s4 < 3; ++s4) {
-                const float4 wa = lds.a1[0][s4][lane], wb = lds.a1[1][s4][lane];
-                const float* pa = &wa.x;
-                const float* pb = &wb.x;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int s = 4 * s4 + u;
-                    if (s < 9) {
-                        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[u], b[s], acc1[0], 0, 0, 0);
-                        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u], b[s], acc1[1], 0, 0, 0);
-                    }
-                }
+            {
+                const float4 wa = lds.a1d[0][0][lane], wb = lds.a1d[1][0][lane];
+                const float wa4 = lds.a1d[0][1][lane].x, wb4 = lds.a1d[1][1][lane].x;
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, bd[0], base[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.x, bd[0], base[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, bd[1], acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.y, bd[1], acc1[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, bd[2], acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.z, bd[2], acc1[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, bd[3], acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.w, bd[3], acc1[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa4, bd[4], acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb4, bd[4], acc1[1], 0, 0, 0);
             }
             if (!kTwo) {
 #pragma unroll
