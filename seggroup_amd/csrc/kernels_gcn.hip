@@ -14,12 +14,30 @@ __global__ void k_transpose(const float* __restrict__ w, int D, float* __restric
     if (i < D * D) wt[(i % D) * D + (i / D)] = w[i];      // wt[k][o] = w[o][k]
 }
 
-// one block per row: agg[i] = (x_i + sum_j s_ij x_j) / (1 + sum_j s_ij)
+// one block per row: agg[i] = (x_i + sum_j s_ij x_j) / (1 + sum_j s_ij),  s_ij = exp(-alpha * dist_e).
+// The distances of the row's edges are computed here, wave per edge, exactly as k_edge_distance does (same per-lane fp64
+// accumulation over k = lane, lane + 64, ..., same shuffle tree, orientation (a - b + 1e-6) from the edge list): an edge is
+// evaluated by both of its rows, to the same bits, which is cheaper than a launch of its own in front of this kernel.
 __global__ void k_gcn_aggregate(const float* __restrict__ x, int D, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                const int32_t* __restrict__ eid, const float* __restrict__ dist, float alpha,
+                                const int32_t* __restrict__ eid, const int32_t* __restrict__ adj, float* __restrict__ dist, float alpha,
                                 float* __restrict__ agg) {
     const int i = blockIdx.x;
     const int lo = rowptr[i], hi = rowptr[i + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int e = lo + wave; e < hi; e += nw) {
+        const int id = eid[e];
+        const float* a = x + (size_t)adj[2 * id] * D;
+        const float* b = x + (size_t)adj[2 * id + 1] * D;
+        double acc = 0.0;
+        for (int k = lane; k < D; k += 64) {
+            const double d = (double)a[k] - (double)b[k] + 1e-6;
+            acc = fma(d, d, acc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) dist[id] = (float)sqrt(acc);
+    }
+    __syncthreads();                                        // this block's own stores to dist[] are visible to it
     double rowsum = 1.0;
     for (int e = lo; e < hi; ++e) rowsum += exp(-(double)dist[eid[e]] * (double)alpha);
     for (int k = threadIdx.x; k < D; k += blockDim.x) {
@@ -69,9 +87,7 @@ int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, 
     float* agg = cv.take<float>((size_t)S * D);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_gcn_forward: workspace too small (%zu < %zu)", ws_bytes, sg_gcn_ws_bytes(S, D, E));
     hipStream_t st = sg::as_stream(stream);
-    int rc = sg_edge_distance(d_x, D, D, d_adj, E, dist, stream);
-    if (rc) return rc;
-    k_gcn_aggregate<<<S, 64 * sg::cdiv(D, 64), 0, st>>>(d_x, D, d_rowptr, d_col, d_eid, dist, alpha, agg);
+    k_gcn_aggregate<<<S, 64 * sg::cdiv(D, 64), 0, st>>>(d_x, D, d_rowptr, d_col, d_eid, d_adj, dist, alpha, agg);
     k_gcn_fc<<<sg::cdiv(S, kRows), 256, 0, st>>>(agg, S, D, d_wt, d_out);
     SG_LAUNCH_CHECK();
     return SG_OK;
