@@ -174,10 +174,18 @@ int sg_segment_spatial_sort(const float* d_data, int N, const int32_t* d_seg_poi
                             int32_t* d_sperm, float* d_chunk_box, void* d_ws, size_t ws_bytes, void* stream);
 /* sg_segment_boxes + sg_segment_spatial_sort in ONE launch when the largest segment (max_seg points, known to the
  * host) fits a block's LDS (2048 points); otherwise exactly those two calls (d_ws as for sg_segment_spatial_sort,
- * unused on the fast path).  Identical outputs: d_segbox [S,8], d_sperm [N], d_chunk_box. */
+ * unused on the fast path).  Identical outputs: d_segbox [S,8], d_sperm [N], d_chunk_box.  d_seg_sums (may be NULL):
+ * [S,3] double, the sum of every segment's xyz -- layer-invariant, so the host can form any cluster's centroid from it. */
 int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off,
                           const int32_t* d_seg_of_point, int S, const int32_t* d_seg_chunk_off, int max_seg, float* d_segbox,
-                          int32_t* d_sperm, float* d_chunk_box, void* d_ws, size_t ws_bytes, void* stream);
+                          int32_t* d_sperm, float* d_chunk_box, double* d_seg_sums, void* d_ws, size_t ws_bytes, void* stream);
+/* One launch for what sg_gather_members + sg_center_clusters + sg_knn_operands produce for a layer (same arrays, same
+ * bits): d_cl[i] = cluster of the i-th segment in member order, d_cl_mean [C,3] = the clusters' centroids as fp32
+ * (= (float)(sum of the members' xyz in double / count), e.g. from sg_segment_sort_boxes' d_seg_sums). */
+int sg_layer_layout(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
+                    const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl, const float* d_cl_mean, int32_t* d_members,
+                    int32_t* d_pos_of_point, int32_t* d_cluster_of_pos, int32_t* d_slot_of_pos, float* d_x9m, float* d_sxyzw,
+                    int32_t* d_smpos, void* stream);
 int sg_knn_operands(const float* d_data, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, float* d_sxyzw, int32_t* d_smpos, void* stream);
 int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off,

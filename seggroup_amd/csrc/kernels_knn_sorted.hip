@@ -97,18 +97,20 @@ constexpr int kSortCap = 2048;
 __global__ __launch_bounds__(256) void k_segment_sort_boxes(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
                                                             const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
                                                             float* __restrict__ segbox, int32_t* __restrict__ sperm,
-                                                            float* __restrict__ chunk_box) {
+                                                            float* __restrict__ chunk_box, double* __restrict__ seg_sums) {
     __shared__ unsigned long long key[kSortCap];
     __shared__ float red[4][8];
+    __shared__ double dred[4][3];
     __shared__ float bx[8];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = seg_off[s], n = seg_off[s + 1] - lo;
     // 1. segment box {min xyz, max xyz, max |p|^2}
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, xx = 0.f;
+    double sm[3] = {0.0, 0.0, 0.0};                          // coordinate sums: the host builds cluster centroids from them
     for (int i = tid; i < n; i += 256) {
         const float* r = data + (size_t)seg_points[lo + i] * 6;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], r[k]); mx[k] = fmaxf(mx[k], r[k]); }
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], r[k]); mx[k] = fmaxf(mx[k], r[k]); sm[k] += (double)r[k]; }
         xx = fmaxf(xx, (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
     }
 #pragma unroll
@@ -116,6 +118,13 @@ __global__ __launch_bounds__(256) void k_segment_sort_boxes(const float* __restr
 #pragma unroll
         for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
         xx = fmaxf(xx, __shfl_xor(xx, o));
+    }
+    if (seg_sums) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sm[k] += __shfl_xor(sm[k], o);
+        if (lane == 0) { dred[wave][0] = sm[0]; dred[wave][1] = sm[1]; dred[wave][2] = sm[2]; }
     }
     if (lane == 0) { red[wave][0] = mn[0]; red[wave][1] = mn[1]; red[wave][2] = mn[2]; red[wave][3] = mx[0]; red[wave][4] = mx[1]; red[wave][5] = mx[2]; red[wave][6] = xx; }
     __syncthreads();
@@ -126,6 +135,7 @@ __global__ __launch_bounds__(256) void k_segment_sort_boxes(const float* __restr
         segbox[(size_t)s * 8 + tid] = v;
     }
     if (tid == 7) segbox[(size_t)s * 8 + 7] = 0.f;
+    if (seg_sums && tid >= 8 && tid < 11) seg_sums[(size_t)s * 3 + (tid - 8)] = ((dred[0][tid - 8] + dred[1][tid - 8]) + dred[2][tid - 8]) + dred[3][tid - 8];
     __syncthreads();
     // 2. keys (same quantisation as k_morton_keys), padded to a power of two with ~0
     int m2 = 64;
@@ -181,6 +191,58 @@ __global__ __launch_bounds__(256) void k_segment_sort_boxes(const float* __restr
             float* b = chunk_box + (size_t)(c0 + j) * 8;
             b[0] = cmn[0]; b[1] = cmn[1]; b[2] = cmn[2]; b[3] = cmx[0]; b[4] = cmx[1]; b[5] = cmx[2]; b[6] = cxx; b[7] = 0.f;
         }
+    }
+}
+
+// coordinate sums of every segment (the library-sort fallback of sg_segment_sort_boxes; same values as the fused kernel's)
+__global__ __launch_bounds__(256) void k_segment_sums(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                                                      const int32_t* __restrict__ seg_off, double* __restrict__ seg_sums) {
+    __shared__ double dred[4][3];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = seg_off[s], n = seg_off[s + 1] - lo;
+    double sm[3] = {0.0, 0.0, 0.0};
+    for (int i = tid; i < n; i += 256) {
+        const float* r = data + (size_t)seg_points[lo + i] * 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sm[k] += (double)r[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sm[k] += __shfl_xor(sm[k], o);
+    if (lane == 0) { dred[wave][0] = sm[0]; dred[wave][1] = sm[1]; dred[wave][2] = sm[2]; }
+    __syncthreads();
+    if (tid < 3) seg_sums[(size_t)s * 3 + tid] = ((dred[0][tid] + dred[1][tid]) + dred[2][tid]) + dred[3][tid];
+}
+
+// Everything a layer needs laid out per point, in ONE launch (block i = i-th segment in member order): the member arrays
+// of sg_gather_members, the centred rows of sg_center_clusters (the cluster centroids come in, the host sums the
+// per-segment coordinate sums of the sort kernel) and the sorted kNN operands of sg_knn_operands.
+__global__ void k_layer_layout(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
+                               const int32_t* __restrict__ sperm, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
+                               const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
+                               int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
+                               float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos) {
+    const int i = blockIdx.x;
+    const int s = order[i];
+    const int lo = seg_off[s], n = seg_off[s + 1] - lo, d = dst[i], c = cl[i];
+    const float mx = cl_mean[3 * c], my = cl_mean[3 * c + 1], mz = cl_mean[3 * c + 2];
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        const int p = seg_points[lo + r];
+        members[d + r] = p;
+        pos_of_point[p] = d + r;
+        cluster_of_pos[d + r] = c;
+        slot_of_pos[d + r] = i;
+        const float* row = data + (size_t)p * 6;
+        const float x = row[0], y = row[1], z = row[2];
+        float4* o = reinterpret_cast<float4*>(x9m + (size_t)(d + r) * 12);
+        o[0] = make_float4(x, y, z, row[3]);
+        o[1] = make_float4(row[4], row[5], x - mx, y - my);
+        o[2] = make_float4(z - mz, 0.f, 0.f, 0.f);
+        const int ci = sperm[lo + r];                          // r-th point of the segment in Morton order
+        const float* q = data + (size_t)seg_points[ci] * 6;
+        sxyzw[d + r] = make_float4(q[0], q[1], q[2], (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);     // torch.sum(x**2, dim=1)
+        smpos[d + r] = d + (ci - lo);
     }
 }
 
@@ -735,18 +797,34 @@ int sg_segment_spatial_sort(const float* d_data, int N, const int32_t* d_seg_poi
     return SG_OK;
 }
 
+int sg_layer_layout(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
+                    const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl, const float* d_cl_mean, int32_t* d_members,
+                    int32_t* d_pos_of_point, int32_t* d_cluster_of_pos, int32_t* d_slot_of_pos, float* d_x9m, float* d_sxyzw,
+                    int32_t* d_smpos, void* stream) {
+    SG_REQUIRE(N >= 0 && S >= 0 && d_sperm && d_cl_mean && d_members && d_pos_of_point && d_cluster_of_pos && d_slot_of_pos && d_x9m &&
+                   d_sxyzw && d_smpos, "sg_layer_layout: bad arguments");
+    if (S == 0) return SG_OK;
+    k_layer_layout<<<S, 128, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_sperm, d_order, d_dst, d_cl, d_cl_mean, d_members,
+                                                        d_pos_of_point, d_cluster_of_pos, d_slot_of_pos, d_x9m,
+                                                        reinterpret_cast<float4*>(d_sxyzw), d_smpos);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
 int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off,
                           const int32_t* d_seg_of_point, int S, const int32_t* d_seg_chunk_off, int max_seg, float* d_segbox,
-                          int32_t* d_sperm, float* d_chunk_box, void* d_ws, size_t ws_bytes, void* stream) {
+                          int32_t* d_sperm, float* d_chunk_box, double* d_seg_sums, void* d_ws, size_t ws_bytes, void* stream) {
     SG_REQUIRE(N >= 0 && S >= 0 && max_seg >= 0 && d_segbox && d_sperm && d_chunk_box, "sg_segment_sort_boxes: bad arguments");
     if (N == 0 || S == 0) return SG_OK;
     if (max_seg > kSortCap) {                                  // a segment does not fit one block's LDS: library sort
         int rc = sg_segment_boxes(d_data, d_seg_points, d_seg_off, S, d_segbox, stream);
         if (rc) return rc;
+        if (d_seg_sums) k_segment_sums<<<S, 256, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_seg_sums);
         return sg_segment_spatial_sort(d_data, N, d_seg_points, d_seg_off, d_seg_of_point, S, d_segbox, d_seg_chunk_off, d_sperm, d_chunk_box,
                                        d_ws, ws_bytes, stream);
     }
-    k_segment_sort_boxes<<<S, 256, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_segbox, d_sperm, d_chunk_box);
+    k_segment_sort_boxes<<<S, 256, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_segbox, d_sperm, d_chunk_box,
+                                                               d_seg_sums);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

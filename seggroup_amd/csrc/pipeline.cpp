@@ -62,13 +62,15 @@ struct sg_pipeline {
     size_t o_m1w, o_m1g, o_m1b, o_m2w, o_m2g, o_m2b, o_g2, o_m3w1, o_m3g1, o_m3b1, o_m3w2, o_m3g2, o_m3b2, o_g3, o_g2t, o_g3t;
 
     // device work buffers
-    DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_center, ws_eval, ws_sort;
+    DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_eval, ws_sort;
     DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, slot_of_pos, sperm, smpos, seg_chunk_off, knn, knn_seed, desc, tables, labels;
     DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf, segbox, chunk_box, chunk_table;
 
     // pinned host staging
     PinBuf<int32_t> h_adj, h_desc, h_tables, h_count, h_chunk_off;
     PinBuf<float> h_dist, h_feat, h_samples;
+    DevBuf<double> seg_sums;          // [S,3] coordinate sums of every over-segment (layer-invariant)
+    PinBuf<double> h_seg_sums;
 
     hipEvent_t ev[kNumEvents];
     int ev_stage[kNumEvents];
@@ -110,8 +112,8 @@ int freeze_layer(const sg_partition* part, int S, LayerDesc& L) {
 
 // Device descriptor block of one layer, carved from ONE pinned buffer and shipped in ONE H2D copy.
 struct DescOffsets {
-    size_t order, dst, cl, cl_pt_off, cl_seg_off, tile_cl, tile_lo, tile_hi, cl_tile_off, goff, gidx, adj, rowptr, col, eid,
-        slot_chunk0, cl_chunk_off, tile_chunk0, seg_prevcl, total;
+    size_t order, dst, cl, cl_pt_off, cl_seg_off, tile_cl, tile_lo, tile_hi, goff, gidx, adj, rowptr, col, eid,
+        slot_chunk0, cl_chunk_off, tile_chunk0, seg_prevcl, cl_mean, total;
 };
 
 }  // namespace
@@ -200,16 +202,15 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->ws_mlp1, sg_mlp1_ws_bytes(maxS));
     D(pl->ws_edge, sg_edgeconv_ws_bytes(maxN));
     D(pl->ws_gcn, sg_gcn_ws_bytes(maxS, 256, (int)maxE1));
-    D(pl->ws_center, sg_center_ws_bytes((int)T, maxS));
     D(pl->ws_eval, sg_eval_ws_bytes(maxS + 2));
     D(pl->adj1, 2 * maxE1); D(pl->count, 4);
     D(pl->members, N); D(pl->pos_of_point, N); D(pl->cluster_of_pos, N); D(pl->slot_of_pos, N);
     D(pl->knn, N * 20); D(pl->knn_seed, N * 20);
-    D(pl->desc, 12 * S + 16 + 4 * T + 2 * maxE1 + 4 * maxE1 + 96);
+    D(pl->desc, 15 * S + 16 + 4 * T + 2 * maxE1 + 4 * maxE1 + 128);
     D(pl->tables, SG_NUM_LABEL_VECTORS * S); D(pl->labels, SG_NUM_LABEL_VECTORS * V);
     D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
     D(pl->feat1, S * 128); D(pl->featA, S * 256); D(pl->featB, S * 256);
-    D(pl->segbox, S * 8); D(pl->chunk_box, (N / 32 + S + 1) * 8); D(pl->chunk_table, (N / 32 + S + 1) * 8); D(pl->sperm, N); D(pl->smpos, N); D(pl->seg_chunk_off, S + 1);
+    D(pl->seg_sums, S * 3); P(pl->h_seg_sums, S * 3); D(pl->segbox, S * 8); D(pl->chunk_box, (N / 32 + S + 1) * 8); D(pl->chunk_table, (N / 32 + S + 1) * 8); D(pl->sperm, N); D(pl->smpos, N); D(pl->seg_chunk_off, S + 1);
     D(pl->ws_sort, sg_spatial_sort_ws_bytes(maxN)); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64);
     P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4); P(pl->h_chunk_off, S + 1);
     P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
@@ -273,7 +274,8 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
         for (int s = 0; s < S; ++s) co[s + 1] = co[s] + (sc->h_seg_size[s] + 31) / 32;
         PL_HIP(hipMemcpyAsync(pl->seg_chunk_off.p, co, (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
         PL_CHECK(sg_segment_sort_boxes(sc->d_data, N, sc->d_seg_points, sc->d_seg_off, sc->d_seg_of_point, S, pl->seg_chunk_off.p, max_seg,
-                                       pl->segbox.p, pl->sperm.p, pl->chunk_box.p, pl->ws_sort.p, pl->ws_sort.n, stv));
+                                       pl->segbox.p, pl->sperm.p, pl->chunk_box.p, pl->seg_sums.p, pl->ws_sort.p, pl->ws_sort.n, stv));
+        PL_HIP(hipMemcpyAsync(pl->h_seg_sums.p, pl->seg_sums.p, (size_t)S * 3 * 8, hipMemcpyDeviceToHost, st));     // ready at the sync below
     }
     pl->mark(1);
     PL_CHECK(sg_mlp1_forward(pl->samples.p, S, W + pl->o_m1w, W + pl->o_m1g, W + pl->o_m1b, pl->feat1.p, 128, pl->ws_mlp1.p,
@@ -387,6 +389,19 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                 for (int j = 0; j < Lcur.C; ++j) gidx[fill[Lnew.cl_of_seg[Lcur.root[j]]]++] = j;
             }
             for (int i = 0; i < S; ++i) cl_of_order[i] = Lnew.cl_of_seg[Lnew.order[i]];
+            // cluster centroids (combine_centralized_pointcloud, model.py:429-436) from the per-segment coordinate sums:
+            // the sum is carried in double, so its grouping does not show in the fp32 result
+            std::vector<int32_t> cl_mean_bits(3 * (size_t)C);
+            for (int c = 0; c < C; ++c) {
+                double sx = 0.0, sy = 0.0, sz = 0.0;
+                for (int i = Lnew.cl_seg_off[c]; i < Lnew.cl_seg_off[c + 1]; ++i) {
+                    const double* q = pl->h_seg_sums.p + 3 * (size_t)Lnew.order[i];
+                    sx += q[0]; sy += q[1]; sz += q[2];
+                }
+                const double cnt = (double)(Lnew.cl_pt_off[c + 1] - Lnew.cl_pt_off[c]);
+                const float m[3] = {(float)(sx / cnt), (float)(sy / cnt), (float)(sz / cnt)};
+                std::memcpy(&cl_mean_bits[3 * (size_t)c], m, 12);
+            }
             // symmetric CSR of the cluster graph
             std::vector<int32_t> rowptr(C + 1, 0), col(2 * (size_t)E), eid(2 * (size_t)E);
             for (int e = 0; e < E; ++e) { ++rowptr[adj[2 * e] + 1]; ++rowptr[adj[2 * e + 1] + 1]; }
@@ -409,8 +424,9 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             };
             o.order = put(Lnew.order, S); o.dst = put(Lnew.dst, S); o.cl = put(cl_of_order, S); o.cl_pt_off = put(Lnew.cl_pt_off, C + 1);
             o.cl_seg_off = put(Lnew.cl_seg_off, C + 1);
-            o.tile_cl = put(tile_cl, T); o.tile_lo = put(tile_lo, T); o.tile_hi = put(tile_hi, T); o.cl_tile_off = put(cl_tile_off, C + 1);
+            o.tile_cl = put(tile_cl, T); o.tile_lo = put(tile_lo, T); o.tile_hi = put(tile_hi, T);
             o.seg_prevcl = put(seg_prevcl, seg_prevcl.size());
+            o.cl_mean = put(cl_mean_bits, cl_mean_bits.size());
             o.slot_chunk0 = put(slot_chunk0, S + 1); o.cl_chunk_off = put(cl_chunk_off, C + 1); o.tile_chunk0 = put(tile_chunk0, T);
             o.goff = put(goff, C + 1); o.gidx = put(gidx, Lcur.C); o.adj = put(adj, 2 * (size_t)E);
             o.rowptr = put(rowptr, C + 1); o.col = put(col, 2 * (size_t)E); o.eid = put(eid, 2 * (size_t)E);
@@ -419,20 +435,18 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             PL_HIP(hipMemcpyAsync(pl->desc.p, pl->h_desc.p, o.total * 4, hipMemcpyHostToDevice, st));
             const int32_t* dd = pl->desc.p;
 
-            PL_CHECK(sg_gather_members(sc->d_seg_points, sc->d_seg_off, S, dd + o.order, dd + o.dst, dd + o.cl, pl->members.p,
-                                       pl->pos_of_point.p, pl->cluster_of_pos.p, pl->slot_of_pos.p, stv));
+            // member arrays + centred rows + sorted kNN operands of the layer: one launch
+            PL_CHECK(sg_layer_layout(sc->d_data, N, sc->d_seg_points, sc->d_seg_off, pl->sperm.p, S, dd + o.order, dd + o.dst, dd + o.cl,
+                                     reinterpret_cast<const float*>(dd + o.cl_mean), pl->members.p, pl->pos_of_point.p, pl->cluster_of_pos.p,
+                                     pl->slot_of_pos.p, pl->x9m.p, pl->xyzw.p, pl->smpos.p, stv));
             // + -inf into the 64 columns the point->cluster max fills below
             PL_CHECK(sg::group_max_rows_fill(feat_prev, feat_prev_stride, feat_prev_dim, dd + o.goff, dd + o.gidx, C, cat, Dcat, 64, stv));
             pl->mark(sb + 0);
-            PL_CHECK(sg_center_clusters(sc->d_data, N, pl->members.p, dd + o.cl_pt_off, C, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi,
-                                        T, dd + o.cl_tile_off, pl->x9m.p, pl->xyzw.p, pl->ws_center.p, pl->ws_center.n, stv));
-            pl->mark(sb + 1);
+            pl->mark(sb + 1);                              // (centring is part of the layout kernel now)
             // point 0 is the first member of segment 0; its member-order position is that segment's dst
             int pos0 = 0;
             for (int i = 0; i < S; ++i) if (Lnew.order[i] == 0) { pos0 = Lnew.dst[i]; break; }
             pl->mark_kernel_start();
-            PL_CHECK(sg_knn_operands(sc->d_data, sc->d_seg_points, sc->d_seg_off, pl->sperm.p, S, dd + o.order, dd + o.dst, pl->xyzw.p,
-                                     pl->smpos.p, stv));
             if (knn_variant == 0) {
                 PL_CHECK(sg_knn_chunk_table(dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->chunk_box.p, S,
                                             dd + o.slot_chunk0, pl->chunk_table.p, stv));

@@ -77,7 +77,8 @@ SIGNATURES = {
     "sg_segment_spatial_sort": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_knn_operands": (_I, [vp, vp, vp, vp, _I, vp, vp, vp, vp, vp]),
     "sg_cluster_knn_sorted": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
-    "sg_segment_sort_boxes": (_I, [vp, _I, vp, vp, vp, _I, vp, _I, vp, vp, vp, vp, _Z, vp]),
+    "sg_segment_sort_boxes": (_I, [vp, _I, vp, vp, vp, _I, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),
+    "sg_layer_layout": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "sg_knn_set_variant": (_I, [_I]),
     "sg_knn_seed_points": (_I, [vp, vp, _I, _I, vp, vp]),
     "sg_cluster_knn_seeded": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),

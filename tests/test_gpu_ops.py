@@ -427,10 +427,13 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         cbox2 = torch.zeros_like(cbox)
         for max_seg in (int(np.diff(seg_off).max()), 1 << 20):      # fits a block / forces the library-sort fallback
             box2.fill_(7.0); sperm2.fill_(-1); cbox2.zero_()
+            sums = torch.zeros(S, 3, dtype=torch.float64, device="cuda:0")
             hip.check(lib.sg_segment_sort_boxes(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), d_sop.data_ptr(), S,
-                                                d_co.data_ptr(), max_seg, box2.data_ptr(), sperm2.data_ptr(), cbox2.data_ptr(), wss.data_ptr(),
-                                                wss.numel(), None))
+                                                d_co.data_ptr(), max_seg, box2.data_ptr(), sperm2.data_ptr(), cbox2.data_ptr(), sums.data_ptr(),
+                                                wss.data_ptr(), wss.numel(), None))
             assert torch.equal(box2, box) and torch.equal(sperm2, sperm) and torch.equal(cbox2, cbox), max_seg
+            want_sums = np.stack([np.bincount(sc.seg, weights=sc.data[:, k_].astype(np.float64), minlength=S) for k_ in range(3)], 1)
+            assert np.allclose(sums.cpu().numpy(), want_sums, rtol=1e-13, atol=1e-9)
         sp = sperm.cpu().numpy()
         for s_ in (0, S - 1):      # a permutation of the segment's CSR range
             assert sorted(sp[seg_off[s_]:seg_off[s_ + 1]].tolist()) == list(range(seg_off[s_], seg_off[s_ + 1]))
@@ -439,6 +442,26 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         hip.check(lib.sg_knn_operands(d_data.data_ptr(), d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S,
                                       d["order"].data_ptr(), d["dst"].data_ptr(), sxyzw.data_ptr(), smpos.data_ptr(), None))
         assert sorted(smpos.cpu().numpy().tolist()) == list(range(N))
+        # sg_layer_layout = gather_members + center_clusters + knn_operands in one launch: the same arrays, bit for bit,
+        # with the cluster centroids formed on the host from the per-segment coordinate sums
+        hs = sums.cpu().numpy()
+        cl_of_slot = np.repeat(np.arange(L.count), np.diff(cso)).astype(np.int32)
+        mean = np.zeros((L.count, 3), np.float32)
+        for c_ in range(L.count):
+            mean[c_] = (hs[np.asarray(order)[cso[c_]:cso[c_ + 1]]].sum(0) / float(off[c_ + 1] - off[c_])).astype(np.float32)
+        lay = dict(members=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"), pop=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"),
+                   cop=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"), sop=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"),
+                   x9m=torch.full((N, 12), 7.0, device="cuda:0"), sx=torch.zeros(N, 4, device="cuda:0"),
+                   sm=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"))
+        d_cls, d_mean = _up(torch, cl_of_slot), _up(torch, mean)
+        hip.check(lib.sg_layer_layout(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S,
+                                      d["order"].data_ptr(), d["dst"].data_ptr(), d_cls.data_ptr(), d_mean.data_ptr(), lay["members"].data_ptr(),
+                                      lay["pop"].data_ptr(), lay["cop"].data_ptr(), lay["sop"].data_ptr(), lay["x9m"].data_ptr(),
+                                      lay["sx"].data_ptr(), lay["sm"].data_ptr(), None))
+        assert np.array_equal(lay["members"].cpu().numpy(), members) and np.array_equal(lay["pop"].cpu().numpy(), pos_of_point)
+        assert np.array_equal(lay["cop"].cpu().numpy(), np.repeat(np.arange(L.count), np.diff(off)))
+        assert np.array_equal(lay["sop"].cpu().numpy(), slot_of_pos)
+        assert torch.equal(lay["x9m"], x9m) and torch.equal(lay["sx"], sxyzw) and torch.equal(lay["sm"], smpos)
         for variant in (1, 2, 4, -1):        # one-pass with 1 / 2 / 4 waves per tile | the default choice
             prev = lib.sg_knn_set_variant(variant)
             k_sorted = torch.full((N, 20), -7, dtype=torch.int32, device="cuda:0")
