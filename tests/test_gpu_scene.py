@@ -335,3 +335,31 @@ def test_odd_scenes_match_oracle(weight_sets, n, s, seed, kw, mode):
         assert np.array_equal(res.labels[i], ref["labels"][nm].astype(np.int32)), nm
     assert np.array_equal(res.iou_sem, ref["metrics"][0]) and np.array_equal(res.iou_ins, ref["metrics"][1])
     assert bool(res.stalled) == bool(ref["stalled"])
+
+
+def test_stage_timing_levels(golden_index, weight_sets):
+    """sg_pipeline_set_timing: 2 = an event after every stage, 1 = only around the in-cluster kNN and the EdgeConv passes
+    (what bench.py records), 0 = none; the labels do not depend on it."""
+    from seggroup_amd import hip
+    from seggroup_amd.model import Pipeline
+    from seggroup_amd.scene import DeviceScene
+    sc = DeviceScene.from_synthetic(make_fixture_scene(golden_index, "small_20k"), device="cuda:0")
+    pipe = Pipeline(weight_sets["ins_infer"], sc.N, sc.S, sc.E0, sc.V, device="cuda:0")
+    kernel_stages = {"l2.knn", "l3.knn", "l2.edgeconv", "l3.edgeconv", "l2.edgeconv.stats1", "l2.edgeconv.final", "l3.edgeconv.stats1",
+                     "l3.edgeconv.stats2", "l3.edgeconv.final"}
+    labels = {}
+    for level in (2, 1, 0):
+        assert pipe.set_timing(level) in (0, 1, 2)
+        res = pipe.forward(sc, hip.MODE_INS_INFER)
+        labels[level] = res.labels.copy()
+        st = pipe.stage_times()
+        nonzero = {k for k, v in st.items() if v > 0}
+        if level == 2:
+            assert {"contract_edges", "fps64", "mlp1", "export", "evaluate", "l2.knn", "l3.edgeconv"} <= nonzero
+        elif level == 1:
+            assert nonzero and nonzero <= kernel_stages and {"l2.knn", "l3.knn", "l3.edgeconv.stats2"} <= nonzero
+        else:
+            assert not nonzero
+    assert np.array_equal(labels[2], labels[1]) and np.array_equal(labels[2], labels[0])
+    assert pipe.lib.sg_pipeline_set_timing(pipe.handle, 7) < 0
+    pipe.close()
