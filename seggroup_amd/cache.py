@@ -119,8 +119,58 @@ def pack_scene(root: str, scene_name: str, label_style: str = "manual", force: b
     return path
 
 
+_tls = __import__("threading").local()
+
+
+def _pinned(nbytes: int):
+    """A per-thread pinned staging buffer (grown on demand): loader threads reuse theirs for every scene."""
+    import torch
+    buf = getattr(_tls, "pinned", None)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 24), dtype=torch.uint8).pin_memory()
+        _tls.pinned = buf
+    return buf
+
+
 def load_pack(path: str, device="cuda"):
-    """Pack -> DeviceScene (each array uploaded once from the memory map)."""
+    """Pack -> DeviceScene with ONE host-to-device copy: the file is read into a pinned buffer, uploaded as one blob, and
+    the device arrays are typed views into it (every array starts on a 64-byte boundary of the file)."""
+    import torch
     from .scene import DeviceScene
-    p = read_pack(path)
-    return DeviceScene.from_staged({k: p[k] for k in ARRAYS}, name=p["name"], device=device)
+    with open(path, "rb") as f:
+        if f.read(8) != MAGIC:
+            raise ValueError(f"{path}: not a SegGroup scene pack")
+        (hlen,) = struct.unpack("<I", f.read(4))
+        hdr = json.loads(f.read(hlen).decode())
+        base = 12 + hlen
+        size = os.fstat(f.fileno()).st_size - base
+        pin = _pinned(size)
+        view = pin.numpy()[:size]
+        got = f.readinto(memoryview(view))
+        if got != size:
+            raise ValueError(f"{path}: truncated pack")
+    dev = torch.device(device)
+    blob = torch.empty(size, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        stream = getattr(_tls, "stream", None)
+        if stream is None or stream.device != dev:
+            stream = _tls.stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            blob.copy_(pin[:size], non_blocking=True)
+        # the four small per-segment host arrays are copied out of the staging buffer before it is reused
+        host = {}
+        for k in ("seg_first", "seg_size", "seg_ins", "seg_sem"):
+            dt, shape, off = hdr["arrays"][k]
+            n = int(np.prod(shape)) * np.dtype(dt).itemsize
+            host[k] = view[off:off + n].view(np.dtype(dt)).reshape(shape).copy()
+        stream.synchronize()                                  # the pinned buffer is free again, the blob is complete
+    tdt = {"<f4": torch.float32, "<i4": torch.int32, "<i8": torch.int64}
+    arrays = {}
+    for k in ARRAYS:
+        dt, shape, off = hdr["arrays"][k]
+        if k in host:
+            arrays[k] = host[k]
+        else:
+            n = int(np.prod(shape)) * np.dtype(dt).itemsize
+            arrays[k] = blob[off:off + n].view(tdt[dt]).view(*shape)
+    return DeviceScene.from_staged(arrays, name=hdr["name"], device=dev)

@@ -19,6 +19,9 @@ Launch:  python -m seggroup_amd.infer -n EXP --ins_infer            (spawns one 
 """
 from __future__ import annotations
 
+import os as _os
+# one hardware queue per in-flight pipeline; must be set before the HIP runtime initialises (see bench.py)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import argparse
 import os
 import sys
@@ -52,8 +55,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--world-size', type=int, default=0, help='processes to spawn (default: one per visible GPU)')
     p.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL on ROCm)')
     p.add_argument('--port', type=int, default=2344, help='rendezvous port on 127.0.0.1 (reference: 2344)')
-    p.add_argument('--batch', type=int, default=8, help='scenes per batch in the packed fast path (0 = the per-scene SegModel.forward loop)')
-    p.add_argument('--inflight', type=int, default=4, help='pipelines (HIP streams) per GPU in the packed fast path')
+    p.add_argument('--batch', type=int, default=64, help='scenes per batch in the packed fast path (0 = the per-scene SegModel.forward loop)')
+    p.add_argument('--inflight', type=int, default=16, help='pipelines (HIP streams) per GPU in the packed fast path')
     p.add_argument('--no-cache', action='store_true', help='do not build / use packed scene files (dataset/scannet/cache/...)')
     return p
 
@@ -235,7 +238,7 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
             caps = [runner.pipes[0].caps] if runner is not None else []
             if runner is not None:
                 runner.close()
-            runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps[0] if caps else None)
+            runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps[0] if caps else None, timing=0)
         res = runner.run(scenes, mode, writer=writer, out_dirs=[model.output_root(s_.name) for s_ in scenes], formats=formats)
         for r in res:
             acc.add(r.iou_sem, r.iou_ins, r.acc)

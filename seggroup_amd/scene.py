@@ -61,7 +61,8 @@ class DeviceScene:
         self.h_seg_sem = np.ascontiguousarray(a["seg_sem"], dtype=np.int32)
         dev = torch.device(device)
         self.device = dev
-        up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev, non_blocking=False)
+        # device tensors pass through (views into a scene pack's blob); host arrays are uploaded
+        up = lambda x: x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x)).to(dev, non_blocking=False)
         self.d_data = up(a["data"])
         self.d_adj = up(a["adj"])
         self.d_seg_of_point = up(a["seg_of_point"])

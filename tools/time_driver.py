@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=4)
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--skip-loop", action="store_true", help="skip the per-scene loop legs (7 scenes/s: slow for many scenes)")
     a = ap.parse_args()
 
     import torch
@@ -54,9 +55,11 @@ def main():
             return time.time() - t, r
 
         out = {"scenes": a.scenes, "points": a.points, "out_format": a.out_format, "tree_build_s": round(gen_s, 1)}
-        run(["--batch", "0"])                                  # warm-up: HIP context, page cache
-        t, r0 = run(["--batch", "0"])
-        out["per_scene_loop"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
+        r0 = None
+        if not a.skip_loop:
+            run(["--batch", "0"])                              # warm-up: HIP context, page cache
+            t, r0 = run(["--batch", "0"])
+            out["per_scene_loop"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
         fast = ["--batch", str(a.batch), "--inflight", str(a.inflight)]
         t, r1 = run(fast)
         out["packed_cold"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
@@ -64,7 +67,8 @@ def main():
         out["packed_warm"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
         t, r3 = run(fast)
         out["packed_warm_2"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
-        out["summaries_equal"] = all(repr(r0[k]) == repr(r2[k]) for k in r0 if k != "elapsed_s")
+        ref = r0 if r0 is not None else r1
+        out["summaries_equal"] = all(repr(ref[k]) == repr(r2[k]) for k in ref if k != "elapsed_s")
         nfiles = sum(len(f) for _, _, f in os.walk(os.path.join(root, "results")))
         out["files_written"] = nfiles
         print(json.dumps(out))
