@@ -166,24 +166,41 @@ int sg_partition_group_nearby(sg_partition* p, const int32_t* h_root, int C, con
 int sg_partition_contract(const sg_partition* p, const int32_t* h_root_old, const int32_t* h_adj, int E,
                           const uint8_t* h_keep, int32_t* h_adj_out) {
     if (!p || (E > 0 && (!h_root_old || !h_adj || !h_adj_out))) return sg::fail(SG_EINVAL, "sg_partition_contract: null input");
-    std::vector<int32_t> num;
-    p->numbering(num);
-    std::vector<uint64_t> keys;
-    keys.reserve(E);
+    // update_adj (model.py:291-302): map both endpoints to the current numbering, drop loops, order each pair, then
+    // unique rows in lexicographic order.  Endpoints are < C <= S, so two stable counting passes (by b, then by a) sort
+    // the pairs in O(E + C) -- a comparison sort of the ~10k first-layer edges was the largest host cost of a forward.
+    thread_local std::vector<int32_t> num, pa, pb, qa, qb, cnt;
+    const int C = p->numbering(num);
+    pa.clear(); pb.clear();
     for (int e = 0; e < E; ++e) {
         if (h_keep && !h_keep[e]) continue;
         int32_t a = num[p->owner[h_root_old[h_adj[2 * e]]]], b = num[p->owner[h_root_old[h_adj[2 * e + 1]]]];
         if (a == b) continue;
         if (a > b) std::swap(a, b);
-        keys.push_back(((uint64_t)(uint32_t)a << 32) | (uint32_t)b);
+        pa.push_back(a); pb.push_back(b);
     }
-    std::sort(keys.begin(), keys.end());
-    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-    for (size_t i = 0; i < keys.size(); ++i) {
-        h_adj_out[2 * i] = (int32_t)(keys[i] >> 32);
-        h_adj_out[2 * i + 1] = (int32_t)(keys[i] & 0xffffffffu);
+    const size_t n = pa.size();
+    qa.resize(n); qb.resize(n);
+    auto pass = [&](const std::vector<int32_t>& key, const std::vector<int32_t>& ia, const std::vector<int32_t>& ib,
+                    std::vector<int32_t>& oa, std::vector<int32_t>& ob) {
+        cnt.assign((size_t)C + 1, 0);
+        for (size_t i = 0; i < n; ++i) ++cnt[key[i] + 1];
+        for (int c = 0; c < C; ++c) cnt[c + 1] += cnt[c];
+        for (size_t i = 0; i < n; ++i) {
+            const int at = cnt[key[i]]++;
+            oa[at] = ia[i]; ob[at] = ib[i];
+        }
+    };
+    pass(pb, pa, pb, qa, qb);          // by second endpoint
+    pass(qa, qa, qb, pa, pb);          // stable by first endpoint: lexicographic
+    int out = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (i && pa[i] == pa[i - 1] && pb[i] == pb[i - 1]) continue;
+        h_adj_out[2 * out] = pa[i];
+        h_adj_out[2 * out + 1] = pb[i];
+        ++out;
     }
-    return (int)keys.size();
+    return out;
 }
 
 static float pair_distance(const float* a, const float* b, int D) {   // calculate_distance, model.py:269-274

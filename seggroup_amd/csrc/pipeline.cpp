@@ -7,6 +7,7 @@
 // after the FPS-1024 fallback, and at the end (3-5 synchronisations).  Several pipelines on distinct
 // streams (one per in-flight scene) overlap their host phases with each other's kernels.
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <memory>
 #include <mutex>
@@ -98,6 +99,12 @@ struct sg_pipeline {
 };
 
 namespace {
+
+// SG_HOST_PROFILE=1: wall time of sg_pipeline_forward split into 'blocked in hipStreamSynchronize' and the rest (host work +
+// launches), printed per sg_batch_forward call -- a development aid
+std::atomic<long long> g_prof_total_ns{0}, g_prof_sync_ns{0}, g_prof_scenes{0}, g_prof_sec[8];
+const char* const kProfSec[8] = {"setup+launch0", "regroup", "label tables", "descriptors", "layer launches", "final clustering", "export+eval", "other"};
+const bool g_host_profile = getenv("SG_HOST_PROFILE") != nullptr;
 
 struct LayerDesc {               // host view of one frozen numbering + what the device needs for it
     int C = 0, T = 0;
@@ -219,6 +226,14 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     return pl.release();
 }
 
+static hipError_t timed_sync(hipStream_t st) {
+    if (!g_host_profile) return hipStreamSynchronize(st);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipStreamSynchronize(st);
+    g_prof_sync_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return e;
+}
+
 #define PL_CHECK(call) do { int rc__ = (call); if (rc__ < 0) { sg_partition_destroy(part); return rc__; } } while (0)
 #define PL_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { sg_partition_destroy(part); \
     return sg::fail(SG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); } } while (0)
@@ -233,6 +248,23 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                pl->maxN, pl->maxS, pl->maxE, pl->maxV);
     SG_REQUIRE(out->h_labels, "sg_pipeline_forward: out->h_labels is null");
     SG_HIP(hipSetDevice(pl->device));                     // the calling thread may be a fresh worker thread
+    struct ProfScope {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~ProfScope() {
+            if (!g_host_profile) return;
+            g_prof_total_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            ++g_prof_scenes;
+        }
+    } prof_scope;
+    auto prof_last = std::chrono::steady_clock::now();
+    long long prof_sync_seen = g_host_profile ? 0 : 0;
+    (void)prof_sync_seen;
+    auto lap = [&](int sec) {                                // host-profile: time since the previous lap goes to section `sec` (< 0: dropped)
+        if (!g_host_profile) return;
+        const auto now = std::chrono::steady_clock::now();
+        if (sec >= 0) g_prof_sec[sec] += std::chrono::duration_cast<std::chrono::nanoseconds>(now - prof_last).count();
+        prof_last = now;
+    };
     hipStream_t st = pl->stream;
     void* stv = (void*)st;
     const float* W = pl->w.p;
@@ -281,7 +313,9 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     PL_CHECK(sg_mlp1_forward(pl->samples.p, S, W + pl->o_m1w, W + pl->o_m1g, W + pl->o_m1b, pl->feat1.p, 128, pl->ws_mlp1.p,
                              pl->ws_mlp1.n, stv));
     pl->mark(2);
-    PL_HIP(hipStreamSynchronize(st));
+    lap(0);
+    PL_HIP(timed_sync(st));
+    lap(-1);
     int E1 = pl->h_count.p[0];
     if (E1 > cap1) { sg_partition_destroy(part); return sg::fail(SG_ENOMEM, "adjacency capacity exceeded (%d > %d)", E1, cap1); }
     PL_CHECK(sg_edge_distance(pl->feat1.p, 128, 128, pl->adj1.p, E1, pl->dist.p, stv));
@@ -297,7 +331,9 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     freeze_layer(part, S, Lcur);                          // layer 1: every segment its own cluster
     out->trace[0] = Lcur.C;
     PL_CHECK(tables_for(0, true));                        // layer_1.{seg,ins,sem}
-    PL_HIP(hipStreamSynchronize(st));
+    lap(2);
+    PL_HIP(timed_sync(st));
+    lap(-1);
 
     std::vector<int32_t> adj(pl->h_adj.p, pl->h_adj.p + 2 * (size_t)E1), adj_next;
     std::vector<uint8_t> connected, keep;
@@ -328,8 +364,10 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     };
 
     PL_CHECK(regroup(mode == SG_MODE_SEM_INFER ? 3.0f : 6.0f));
+    lap(1);
     out->trace[1] = Lnew.C;
     PL_CHECK(tables_for(3, true));                        // layer_2.*
+    lap(2);
     tap_adj(1, adj, E);
 
     int n_tables = 6;
@@ -432,6 +470,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             o.rowptr = put(rowptr, C + 1); o.col = put(col, 2 * (size_t)E); o.eid = put(eid, 2 * (size_t)E);
             o.total = cur;
             if (o.total > pl->desc.n) { sg_partition_destroy(part); return sg::fail(SG_ENOMEM, "descriptor buffer too small"); }
+            lap(3);
             PL_HIP(hipMemcpyAsync(pl->desc.p, pl->h_desc.p, o.total * 4, hipMemcpyHostToDevice, st));
             const int32_t* dd = pl->desc.p;
 
@@ -494,15 +533,19 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                 if (dbg->d_members[layer]) PL_HIP(hipMemcpyAsync(dbg->d_members[layer], pl->members.p, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
             }
             pl->mark(sb + 5);
-            PL_HIP(hipStreamSynchronize(st));
+            lap(4);
+            PL_HIP(timed_sync(st));
+            lap(-1);
             if (dbg && dbg->h_gcn[layer]) std::copy(pl->h_feat.p, pl->h_feat.p + (size_t)C * Dcat, dbg->h_gcn[layer]);
             tap_dist(1 + layer, E);
 
             // ---- grouping on the GCN features (model.py:802-815 / 843-856) ----
             Lcur = Lnew;
             PL_CHECK(regroup(2.0f));
+            lap(1);
             out->trace[2 + layer] = Lnew.C;
             PL_CHECK(tables_for(6 + 3 * layer, true));    // layer_3.* / layer_4.*
+            lap(2);
             tap_adj(2 + layer, adj, E);
             // next layer: previous features = this GCN output (featB); its concat goes to featA again and its
             // GCN output back into featB -- safe, the stream runs group_max_rows(featB -> featA) before gcn writes featB
@@ -548,7 +591,9 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                                          pl->ws_fps.p, pl->ws_fps.n, stv, max_cl));
             PL_HIP(hipMemcpyAsync(pl->h_samples.p, pl->samples_big.p, (size_t)L5.C * 1024 * 3 * 4, hipMemcpyDeviceToHost, st));
             pl->mark(16);
-            PL_HIP(hipStreamSynchronize(st));
+            lap(5);
+            PL_HIP(timed_sync(st));
+            lap(-1);
             PL_CHECK(sg_partition_unlabeled_fallback(part, L5.root.data(), L5.C, pl->h_samples.p, 1024));
             out->used_fallback = 1;
         }
@@ -566,7 +611,9 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     PL_CHECK(sg_evaluate(sc->d_gt, pl->labels.p + (size_t)sem_row * V, pl->labels.p + (size_t)ins_row * V, V, max_ins, out->iou_sem,
                          out->iou_ins, out->acc, pl->ws_eval.p, pl->ws_eval.n, stv));
     pl->mark(18);
-    PL_HIP(hipStreamSynchronize(st));
+    lap(6);
+    PL_HIP(timed_sync(st));
+    lap(-1);
     sg_partition_destroy(part);
     part = nullptr;
 
@@ -629,6 +676,14 @@ int sg_batch_forward(sg_pipeline* const* pipes, int npipes, const sg_scene* scen
     for (int w = 1; w < nt; ++w) th.emplace_back(worker, w);
     worker(0);
     for (auto& t : th) t.join();
+    if (g_host_profile && g_prof_scenes.load() > 0) {
+        const double n = (double)g_prof_scenes.exchange(0);
+        const double tot = g_prof_total_ns.exchange(0) / n * 1e-6, syn = g_prof_sync_ns.exchange(0) / n * 1e-6;
+        fprintf(stderr, "[sg host profile] %d scenes on %d pipelines: forward %.3f ms per scene = %.3f ms blocked in stream syncs + %.3f ms host work / launches:",
+                (int)n, npipes, tot, syn, tot - syn);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.3f", kProfSec[i], g_prof_sec[i].exchange(0) / n * 1e-6);
+        fprintf(stderr, "\n");
+    }
     if (h_stage_ms_sum)
         for (int k = 0; k < kNumStages; ++k) h_stage_ms_sum[k] += sums[k];
     if (first_err.load() != 0) return sg::fail(first_err.load(), "sg_batch_forward: %s", msg.c_str());
