@@ -15,27 +15,32 @@ __global__ void k_transpose(const float* __restrict__ w, int D, float* __restric
 }
 
 // one block per row: agg[i] = (x_i + sum_j s_ij x_j) / (1 + sum_j s_ij),  s_ij = exp(-alpha * dist_e).
-// The distances of the row's edges are computed here, wave per edge, exactly as k_edge_distance does (same per-lane fp64
-// accumulation over k = lane, lane + 64, ..., same shuffle tree, orientation (a - b + 1e-6) from the edge list): an edge is
-// evaluated by both of its rows, to the same bits, which is cheaper than a launch of its own in front of this kernel.
+// The distances of the row's edges are computed here (fp64 accumulation as in k_edge_distance, orientation (a - b + 1e-6)
+// from the edge list, 16 lanes per edge): an edge is evaluated by both of its rows, by the same code and therefore to the
+// same bits, which is cheaper than a launch of its own in front of this kernel.
 __global__ void k_gcn_aggregate(const float* __restrict__ x, int D, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                 const int32_t* __restrict__ eid, const int32_t* __restrict__ adj, float* __restrict__ dist, float alpha,
                                 float* __restrict__ agg) {
     const int i = blockIdx.x;
     const int lo = rowptr[i], hi = rowptr[i + 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int e = lo + wave; e < hi; e += nw) {
-        const int id = eid[e];
-        const float* a = x + (size_t)adj[2 * id] * D;
-        const float* b = x + (size_t)adj[2 * id + 1] * D;
+    // 16 lanes per edge: a hub cluster has 100+ edges and one edge per wave made it the kernel's tail
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4, ng = blockDim.x >> 4;
+    for (int e0 = lo; e0 < hi; e0 += ng) {
+        const int e = e0 + grp;
         double acc = 0.0;
-        for (int k = lane; k < D; k += 64) {
-            const double d = (double)a[k] - (double)b[k] + 1e-6;
-            acc = fma(d, d, acc);
+        int id = 0;
+        if (e < hi) {
+            id = eid[e];
+            const float* a = x + (size_t)adj[2 * id] * D;
+            const float* b = x + (size_t)adj[2 * id + 1] * D;
+            for (int k = sub; k < D; k += 16) {
+                const double d = (double)a[k] - (double)b[k] + 1e-6;
+                acc = fma(d, d, acc);
+            }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) dist[id] = (float)sqrt(acc);
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (e < hi && sub == 0) dist[id] = (float)sqrt(acc);
     }
     __syncthreads();                                        // this block's own stores to dist[] are visible to it
     double rowsum = 1.0;

@@ -39,16 +39,22 @@ for name, src in (("FETCH_SIZE", f"{tag}_pmc_fetch"), ("WRITE_SIZE", f"{tag}_pmc
 alias = {"k_edgeconv<2, true>": "k_edgeconv<S2X>", "k_edgeconv<2>": "k_edgeconv<S2X>", "k_edgeconv<0, false>": "k_edgeconv<S1>",
          "k_edgeconv<0>": "k_edgeconv<S1>", "k_edgeconv<1, false>": "k_edgeconv<S1X>", "k_edgeconv<1>": "k_edgeconv<S1X>", "k_cluster_knn_pruned<20>": "k_cluster_knn_pruned", "k_cluster_knn_sorted<20>": "k_cluster_knn_sorted",
          "k_cluster_knn_sorted<20, 1>": "k_cluster_knn_sorted", "k_cluster_knn_sorted<20, 2>": "k_cluster_knn_sorted<2 slices>",
-         "k_cluster_knn_sorted<20, 4>": "k_cluster_knn_sorted<4 slices>"}
+         "k_cluster_knn_sorted<20, 4>": "k_cluster_knn_sorted<4 slices>",
+         # layer 2 (unseeded) and layer 3 (seeded) launches of the same kernel: bench.py prices them together
+         "k_cluster_knn_sorted<20, 1, false>": "k_cluster_knn_sorted", "k_cluster_knn_sorted<20, 1, true>": "k_cluster_knn_sorted"}
 out = {"note": "HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB * 1024 from two separate rocprofv3 --pmc passes over "
                "tools/time_scene.py 150000 1500; on gfx950 FETCH_SIZE can under-count wide coalesced reads by up to 2x "
                "(MI355X_MICROARCH.md, HBM section), so read the fetch side as a lower bound",
        "bytes_per_launch": {}, "fetch_kb": {}, "write_kb": {}}
+merged = collections.defaultdict(list)
 for k, v in traffic.items():
-    name = alias.get(k, k)
-    out["bytes_per_launch"][name] = int((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024)
-    out["fetch_kb"][name] = round(v.get("FETCH_SIZE", 0), 1)
-    out["write_kb"][name] = round(v.get("WRITE_SIZE", 0), 1)
+    merged[alias.get(k, k)].append(v)
+for name, vs in merged.items():                      # several instantiations under one name: the mean per launch
+    f_ = sum(v.get("FETCH_SIZE", 0) for v in vs) / len(vs)
+    w_ = sum(v.get("WRITE_SIZE", 0) for v in vs) / len(vs)
+    out["bytes_per_launch"][name] = int((f_ + w_) * 1024)
+    out["fetch_kb"][name] = round(f_, 1)
+    out["write_kb"][name] = round(w_, 1)
 json.dump(out, open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 line = [l for l in open(os.path.join(G, f"{tag}_bench_stats.log")).read().splitlines() if l.startswith('{"metric"')][-1]
 with open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w") as o:
@@ -75,7 +81,8 @@ if sf:
         "k_edgeconv<2, true>": ("mfma", 2 * k * N * (18 * 64 + 64 * 64), "MLP3 conv1'->conv2 + BN2 statistics + max (S2X)"),
         "k_edge_moments": ("hbm", (80 + 48 * k) * N, "MLP3 inner-BN statistics from edge-feature moments (gather-latency-bound)"),
         "k_edgeconv<1, false>": ("mfma", 2 * k * N * 18 * 64, "MLP2 conv + BN statistics + max (S1X)"),
-        "k_cluster_knn_sorted<20, 1>": ("hbm", 96 * N, "in-cluster kNN-20 (VALU/latency-bound; HBM is the nominal roof)"),
+        "k_cluster_knn_sorted<20, 1, false>": ("hbm", 96 * N, "in-cluster kNN-20, layer 2 (VALU/latency-bound; HBM is the nominal roof)"),
+        "k_cluster_knn_sorted<20, 1, true>": ("hbm", 96 * N, "in-cluster kNN-20, layer 3, seeded from layer 2"),
         "k_segment_max64": ("hbm", 260 * N, "per-cluster max of [N,64]"),
         "k_export": ("hbm", 60 * N, "14 label vectors gather"),
         "k_mark_pairs": ("hbm", 16 * E0, "mesh-edge contraction (bitmap)"),
