@@ -8,7 +8,7 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the SAME command as the bench line (no CPU leg, no file leg: they launch no kernels)
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_bench_stats -- python3 $R/bench.py --no-cpu-baseline --no-files > $R/gpurun_out/${TAG}_bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_bench_stats -- python3 $R/bench.py --no-cpu-baseline --no-files --steps 4 --warmup 1 > $R/gpurun_out/${TAG}_bench_stats.log 2>&1
 # 2. single-stream kernel durations (no inter-stream interference)
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_solo_stats -- python3 $R/tools/time_scene.py 150000 1500 > $R/gpurun_out/${TAG}_solo_stats.log 2>&1
 # 3. HBM traffic: separate PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md)
