@@ -363,3 +363,25 @@ def test_stage_timing_levels(golden_index, weight_sets):
     assert np.array_equal(labels[2], labels[1]) and np.array_equal(labels[2], labels[0])
     assert pipe.lib.sg_pipeline_set_timing(pipe.handle, 7) < 0
     pipe.close()
+
+
+@pytest.mark.parametrize("variant", [8, 0, 1])
+@pytest.mark.parametrize("cfg", [FUZZ[1], FUZZ[2], FUZZ[5], FUZZ[6]], ids=lambda c: f"{c[0]}x{c[1]}-{c[2]}")
+def test_odd_scenes_with_the_large_scene_knn_kernels(weight_sets, cfg, variant):
+    """The kernels the pipeline picks for large layers -- one wave per tile with layer 3 seeded from layer 2's table (8),
+    two-pass over the chunk table (0), unseeded one wave per tile (1) -- forced onto small scenes with 2-point segments,
+    10-30 % duplicated points and an unlabeled island: labels must still equal the oracle's."""
+    from oracle import cpu_ref
+    from seggroup_amd import hip, synthetic
+    n, s, seed, kw, mode = cfg
+    scene = synthetic.make_scene(n, s, seed, **kw)
+    prev = hip.lib().sg_knn_set_variant(variant)
+    try:
+        res, _, _ = _run(scene, weight_sets[mode], mode)
+    finally:
+        hip.lib().sg_knn_set_variant(prev)
+    ref = cpu_ref.forward_scene(scene, weight_sets[mode], mode)
+    assert res.trace == ref["trace"]
+    for i in range(14):
+        nm = hip.LABEL_NAMES[i]
+        assert np.array_equal(res.labels[i], ref["labels"][nm].astype(np.int32)), nm
