@@ -18,21 +18,38 @@ __global__ void k_transpose(const float* __restrict__ w, int D, float* __restric
 // The distances of the row's edges are computed here (fp64 accumulation as in k_edge_distance, orientation (a - b + 1e-6)
 // from the edge list, 16 lanes per edge): an edge is evaluated by both of its rows, by the same code and therefore to the
 // same bits, which is cheaper than a launch of its own in front of this kernel.
+// The row's edge list (edge id, neighbour, the edge's two endpoints) is staged in LDS with two rounds of parallel loads and
+// every edge's weight is evaluated once -- walking rowptr -> eid -> adj -> rows -> dist per edge and per thread was a chain of
+// dependent global round trips (72 us per launch for ~1,000 rows).  Rows with more than kDegCap edges take the direct path.
+constexpr int kDegCap = 256;
 __global__ void k_gcn_aggregate(const float* __restrict__ x, int D, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                 const int32_t* __restrict__ eid, const int32_t* __restrict__ adj, float* __restrict__ dist, float alpha,
                                 float* __restrict__ agg) {
+    __shared__ int s_id[kDegCap], s_col[kDegCap], s_a[kDegCap], s_b[kDegCap];
+    __shared__ double s_w[kDegCap];
     const int i = blockIdx.x;
-    const int lo = rowptr[i], hi = rowptr[i + 1];
+    const int lo = rowptr[i], hi = rowptr[i + 1], deg = hi - lo;
+    const bool staged = deg <= kDegCap;
+    if (staged) {
+        for (int t = threadIdx.x; t < deg; t += blockDim.x) {
+            const int id = eid[lo + t];
+            s_id[t] = id;
+            s_col[t] = col[lo + t];
+            s_a[t] = adj[2 * id];
+            s_b[t] = adj[2 * id + 1];
+        }
+        __syncthreads();
+    }
     // 16 lanes per edge: a hub cluster has 100+ edges and one edge per wave made it the kernel's tail
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4, ng = blockDim.x >> 4;
-    for (int e0 = lo; e0 < hi; e0 += ng) {
-        const int e = e0 + grp;
+    for (int t0 = 0; t0 < deg; t0 += ng) {
+        const int t = t0 + grp;
         double acc = 0.0;
         int id = 0;
-        if (e < hi) {
-            id = eid[e];
-            const float* a = x + (size_t)adj[2 * id] * D;
-            const float* b = x + (size_t)adj[2 * id + 1] * D;
+        if (t < deg) {
+            id = staged ? s_id[t] : eid[lo + t];
+            const float* a = x + (size_t)(staged ? s_a[t] : adj[2 * id]) * D;
+            const float* b = x + (size_t)(staged ? s_b[t] : adj[2 * id + 1]) * D;
             for (int k = sub; k < D; k += 16) {
                 const double d = (double)a[k] - (double)b[k] + 1e-6;
                 acc = fma(d, d, acc);
@@ -40,16 +57,29 @@ __global__ void k_gcn_aggregate(const float* __restrict__ x, int D, const int32_
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (e < hi && sub == 0) dist[id] = (float)sqrt(acc);
+        if (t < deg && sub == 0) {
+            const float df = (float)sqrt(acc);
+            dist[id] = df;
+            if (staged) s_w[t] = exp(-(double)df * (double)alpha);
+        }
     }
-    __syncthreads();                                        // this block's own stores to dist[] are visible to it
+    __syncthreads();                                        // weights in LDS / this block's own stores to dist[] visible to it
     double rowsum = 1.0;
-    for (int e = lo; e < hi; ++e) rowsum += exp(-(double)dist[eid[e]] * (double)alpha);
-    for (int k = threadIdx.x; k < D; k += blockDim.x) {
-        double acc = (double)x[(size_t)i * D + k];
-        for (int e = lo; e < hi; ++e)
-            acc = fma(exp(-(double)dist[eid[e]] * (double)alpha), (double)x[(size_t)col[e] * D + k], acc);
-        agg[(size_t)i * D + k] = (float)(acc / rowsum);
+    if (staged) {
+        for (int t = 0; t < deg; ++t) rowsum += s_w[t];
+        for (int k = threadIdx.x; k < D; k += blockDim.x) {
+            double acc = (double)x[(size_t)i * D + k];
+            for (int t = 0; t < deg; ++t) acc = fma(s_w[t], (double)x[(size_t)s_col[t] * D + k], acc);
+            agg[(size_t)i * D + k] = (float)(acc / rowsum);
+        }
+    } else {
+        for (int e = lo; e < hi; ++e) rowsum += exp(-(double)dist[eid[e]] * (double)alpha);
+        for (int k = threadIdx.x; k < D; k += blockDim.x) {
+            double acc = (double)x[(size_t)i * D + k];
+            for (int e = lo; e < hi; ++e)
+                acc = fma(exp(-(double)dist[eid[e]] * (double)alpha), (double)x[(size_t)col[e] * D + k], acc);
+            agg[(size_t)i * D + k] = (float)(acc / rowsum);
+        }
     }
 }
 
