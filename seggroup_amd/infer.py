@@ -147,6 +147,13 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         scene_list = f.readlines()
 
     dev = None
+    if forward_fn is None and args.batch > 0 and not args.no_cache:
+        # packed fast path: build this rank's missing scene packs in worker processes before this process touches the GPU
+        from . import cache
+        mine_names = [scene_list[i][:-1] for i in scene_indices(len(scene_list), rank, world, args.sampler)]
+        built = cache.build_missing(args.root, mine_names, args.label_style, workers=max(1, int(args.workers)))
+        if built and rank == 0:
+            io.cprint('Built %d scene packs under dataset/scannet/cache/%s' % (built, args.label_style))
     if forward_fn is None:
         from .data import ScanNet
         from .model import SegModel

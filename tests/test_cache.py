@@ -75,6 +75,28 @@ def test_stage_arrays_rejects_inconsistent_input(golden_index):
         cache.stage_arrays(scene.data, scene.weak_label, seg, scene.adj, scene.unmap, scene.gt)
 
 
+def test_missing_packs_are_built_in_worker_processes(tmp_path, golden_index):
+    """cache.build_missing: stale / missing packs only, through the process pool once there are enough of them."""
+    from seggroup_amd import cache, synthetic
+    base = make_fixture_scene(golden_index, "tiny_4k")
+    scenes = [synthetic.Scene(f"scene{i:04d}_00", base.data, base.weak_label, base.seg, base.adj, base.unmap, base.gt) for i in range(10)]
+    root = str(tmp_path)
+    synthetic.write_reference_tree(root, scenes)
+    names = [s.name for s in scenes]
+    assert not cache.is_current(root, names[0])
+    cache.pack_scene(root, names[0])                                  # one is already there
+    assert cache.is_current(root, names[0])
+    assert cache.build_missing(root, names, workers=4) == 9          # >= 8 to do: worker processes
+    assert all(cache.is_current(root, n) for n in names) and cache.build_missing(root, names, workers=4) == 0
+    want = cache.stage_arrays(base.data, base.weak_label, base.seg, base.adj, base.unmap, base.gt)
+    got = cache.read_pack(cache.pack_path(root, names[7]))
+    assert got["name"] == names[7] and all(np.array_equal(got[k], want[k]) for k in cache.ARRAYS)
+    src = cache.source_files(root, names[3])[0]
+    future = time.time() + 5
+    os.utime(src, (future, future))
+    assert not cache.is_current(root, names[3]) and cache.build_missing(root, names, workers=4) == 1     # few: built inline
+
+
 # ---- SURVEY 8f-2: the label files as the three downstream trainers read them ---------------------------------
 
 def _read_like_consumers(path, as_type):
