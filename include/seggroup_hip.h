@@ -210,7 +210,7 @@ int sg_cluster_knn_seeded(const float* d_sxyzw, const int32_t* d_smpos, int N, c
                           const int32_t* d_seg_prevcl, const int32_t* d_members, const int32_t* d_pos_of_point,
                           const float* d_data, int k, int pos0, int32_t* d_knn, void* stream);
 
-/* Two-pass kernel over a cluster-ordered chunk table (same tables once more; variant 0 of sg_knn_set_variant:
+/* Two-pass kernel over a cluster-ordered chunk table (same tables once more; variant 0 of sg_pipeline_set_knn_variant:
  * faster on 500k-point scenes and on large segments, on par with the one-pass kernel at 150k / 1.5k).  Per layer the host provides d_slot_chunk0[S+1] (exclusive prefix, in cluster slot order, of the
  * 32-point chunk counts of the segments d_order[slot]), d_cl_chunk_off[C+1] (= slot_chunk0 at each cluster's first
  * slot) and d_tile_chunk0[T] (cluster-relative number of the chunk holding the tile's first sorted position).
@@ -225,16 +225,15 @@ int sg_cluster_knn_2pass(const float* d_sxyzw, const int32_t* d_smpos, int N, co
                          const int32_t* d_tile_cl, const int32_t* d_tile_lo, const int32_t* d_tile_hi,
                          const int32_t* d_tile_chunk0, int T, const int32_t* d_cl_chunk_off, const float* d_cc,
                          int k, int pos0, int32_t* d_knn, void* stream);
-/* Which in-cluster kNN kernel sg_pipeline_forward uses for a layer of T tiles, and how many waves per tile
- * sg_cluster_knn_sorted launches (all variants give the same table; the GPU tests compare them):
- *   -1  by tile count (default): 8 when T >= 2048 tiles fill the GPU, else one-pass with 2 or 4 waves per tile
- *    0  two-pass (sg_cluster_knn_2pass)
- *    1 | 2 | 4  one-pass (sg_cluster_knn_sorted) with that many waves per 64-query tile: a shorter critical path per
- *       tile, but every wave warms up its own top-k list
- *    8  one-pass, 1 wave per tile, seeded from the previous kNN layer where there is one (sg_cluster_knn_seeded;
- *       sg_pipeline_forward only: layer 3 starts from layer 2's table)
- * Process-wide; returns the previous setting.  Meant for tests and measurements. */
-int sg_knn_set_variant(int variant);
+/* sg_cluster_knn_sorted with an explicit number of waves per 64-query tile (1, 2 or 4; anything else = by tile count:
+ * 1 when T >= 2048 tiles fill the GPU, else 2 or 4).  More waves shorten a tile's critical path, but every wave warms
+ * up its own top-k list.  Same table for every choice (the GPU tests compare them). */
+int sg_cluster_knn_sorted_w(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off,
+                            const int32_t* d_tile_cl, const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T,
+                            const int32_t* d_cl_seg_off, const int32_t* d_order, const int32_t* d_dst,
+                            const int32_t* d_seg_off, const int32_t* d_seg_chunk_off, const float* d_segbox,
+                            const float* d_chunk_box, const int32_t* d_slot_of_pos, int k, int pos0, int waves_per_tile,
+                            int32_t* d_knn, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a13  get_graph_feature2 + MLP2 / MLP3 (model.py:83-138): edge features [x_j - x_i, x_i] over the
@@ -420,6 +419,15 @@ int sg_pipeline_stage_times(const sg_pipeline* pl, float* h_ms, int capacity);
  * the in-cluster kNN and the EdgeConv passes (the other stages read 0), 0 none.  With many pipelines in flight the
  * ~25 events of level 2 cost ~6 % of the throughput.  Returns the previous level. */
 int sg_pipeline_set_timing(sg_pipeline* pl, int level);
+/* Which in-cluster kNN kernel THIS pipeline uses for a layer of T tiles (all variants give the same table; the GPU
+ * tests compare them).  Per pipeline: the library keeps no process-wide state.
+ *   -1  by tile count (default): 8 when T >= 2048 tiles fill the GPU, else one-pass with 2 or 4 waves per tile
+ *    0  two-pass (sg_cluster_knn_2pass)
+ *    1 | 2 | 4  one-pass (sg_cluster_knn_sorted_w) with that many waves per 64-query tile
+ *    8  one-pass, 1 wave per tile, seeded from the previous kNN layer where there is one (sg_cluster_knn_seeded:
+ *       layer 3 starts from layer 2's table)
+ * Returns the previous setting. */
+int sg_pipeline_set_knn_variant(sg_pipeline* pl, int variant);
 const char* sg_pipeline_stage_name(int i);
 
 /* =============================================================================================
@@ -480,6 +488,16 @@ int sg_segment_lists(const int32_t* d_seg_indices, int V, const int64_t* d_mappe
 /* `.seg.json` exactly as json.dump writes it (util.py:205-220): one list per sampled point, a segment's members at
  * the index of its smallest member, [] elsewhere.  Host arrays of sg_segment_lists (any group order). */
 int sg_write_seg_json(const char* path, const int32_t* h_seg_points, const int32_t* h_seg_off, int G, int Np);
+
+/* =============================================================================================
+ * Readers for the reference's on-disk inputs.  Host only.
+ * ============================================================================================= */
+
+/* `<scene>.seg.json` (model.py:713-714; written by dataset/scannet/util.py:205-220): one JSON list per sampled point,
+ * non-empty iff the point is the first member of an over-segment.  Fills h_seg_of_point[N] with segment numbers (rank
+ * of the segment's first point) and returns the number of segments, or a negative error (malformed JSON, a list that
+ * does not start at its own index, a member out of range / claimed twice, an uncovered point). */
+int sg_parse_seg_json(const char* path, int N, int32_t* h_seg_of_point);
 
 #ifdef __cplusplus
 }

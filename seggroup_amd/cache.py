@@ -104,7 +104,7 @@ def read_pack(path: str) -> Dict[str, object]:
 def pack_scene(root: str, scene_name: str, label_style: str = "manual", force: bool = False) -> str:
     """Build (or reuse) the pack of one scene of the reference's on-disk tree; returns its path."""
     import torch
-    from .scene import seg_from_lists
+    from .scene import seg_from_file
 
     path = pack_path(root, scene_name, label_style)
     src = source_files(root, scene_name, label_style)
@@ -112,8 +112,7 @@ def pack_scene(root: str, scene_name: str, label_style: str = "manual", force: b
         return path
     ld = lambda p: torch.load(p, map_location="cpu")
     data, unmap, weak = ld(src[0]).numpy(), ld(src[1]).numpy(), ld(src[2]).numpy()
-    with open(src[3]) as f:
-        seg = seg_from_lists(json.load(f), data.shape[0])
+    seg = seg_from_file(src[3], data.shape[0])
     gt, adj = ld(src[4]).numpy(), ld(src[5]).numpy()
     write_pack(path, scene_name, stage_arrays(data, weak, seg, adj, unmap, gt))
     return path

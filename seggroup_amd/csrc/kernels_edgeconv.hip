@@ -36,6 +36,12 @@
 // of a single evaluation, instead of 2 and 3 passes (82 GFLOP) or materialising the 768 MB [N,20,64] tensor.
 // Per-block fp64 partial sums are combined in fixed order by a one-block finalize kernel, so the
 // result is bit-reproducible run to run.
+//
+// Conditioning: channels 0..2 of x_i are ABSOLUTE coordinates.  BatchNorm is invariant to a per-channel constant added to
+// its input, so every kernel here evaluates the x_i half of conv1 on x_i - [c, 0] with c = the XYZ of row 0 (any fixed point
+// near the cloud): the statistics (sum y, sum y^2 and the edge-feature moments) are then sums of values of the cloud's
+// extent, not of its distance from the origin, and var = E[y^2] - mean^2 does not cancel for a scan that sits 100 m away
+// from the origin.  The differences d = x_j - x_i are formed from the raw coordinates exactly as the reference does.
 #include "sg_common.h"
 
 namespace {
@@ -107,6 +113,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
         // contribution W1[:, 9:18] x_i (+ the folded BN1 shift) is evaluated ONCE into `base` and every slot's accumulator
         // starts from it (first MFMA: C = base, D = acc1) -- 10 instead of 18 conv1 MFMAs per slot
         const float xsel[5] = {half ? xi[1] : xi[0], half ? xi[3] : xi[2], half ? xi[5] : xi[4], half ? xi[7] : xi[6], half ? 0.f : xi[8]};
+        // the x_i half sees coordinates relative to row 0 (see "Conditioning" in the header); d below uses the raw ones
+        const float xcen[5] = {half ? xi[1] - x9m[1] : xi[0] - x9m[0], half ? xi[3] : xi[2] - x9m[2], xsel[2], xsel[3], xsel[4]};
         f32x16 base[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -131,8 +139,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
             for (int u = 0; u < 4; ++u) {
                 const int s_ = 4 * s4 + u;
                 if (s_ < 5) {
-                    base[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[u], xsel[s_], base[0], 0, 0, 0);
-                    base[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u], xsel[s_], base[1], 0, 0, 0);
+                    base[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[u], xcen[s_], base[0], 0, 0, 0);
+                    base[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u], xcen[s_], base[1], 0, 0, 0);
                 }
             }
         }
@@ -289,6 +297,7 @@ __global__ __launch_bounds__(256) void k_edge_moments(const float* __restrict__ 
         const float4* xr = reinterpret_cast<const float4*>(x9m + (size_t)pt * 12);
         const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
         xi[0] = q0.x; xi[1] = q0.y; xi[2] = q0.z; xi[3] = q0.w; xi[4] = q1.x; xi[5] = q1.y; xi[6] = q1.z; xi[7] = q1.w; xi[8] = q2.x;
+        const float cx = x9m[0], cy = x9m[1], cz = x9m[2];       // moments of [d, x_i - [c, 0]]: see "Conditioning" in the header
         const int32_t* krow = knn + (size_t)pt * K;
         int nb = krow[0];
         const float4* xp = reinterpret_cast<const float4*>(x9m + (size_t)nb * 12);
@@ -310,6 +319,7 @@ __global__ __launch_bounds__(256) void k_edge_moments(const float* __restrict__ 
                 for (int l = k; l < 9; ++l) { D[t] = __builtin_fmaf(d[k], d[l], D[t]); ++t; }
             }
         }
+        xi[0] -= cx; xi[1] -= cy; xi[2] -= cz;                   // d is done with the raw coordinates; the x_i terms are centred
     }
     const float Kf = valid ? (float)K : 0.f;
     // wave sums in fp32 over a fixed shuffle tree (as the MFMA statistics passes do), then doubles: the four waves

@@ -257,8 +257,14 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_pruned(
     const float4* __restrict__ xyzw, const int32_t* __restrict__ cl_off, const int32_t* __restrict__ tile_cl,
     const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi, const int32_t* __restrict__ cl_seg_off,
     const int32_t* __restrict__ order, const int32_t* __restrict__ dst, const int32_t* __restrict__ seg_off,
-    const float* __restrict__ segbox, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg) {
+    const float* __restrict__ segbox, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg_arg) {
     static_assert(kBuf4 >= K, "the merge area aliases the append buffers");
+#ifdef SG_KNN_PROFILE
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;     // release builds: the work counters below fold away (make PROFILE=1 keeps them)
+    (void)dbg_arg;
+#endif
     __shared__ float4 slab[kSlices][64 + kQuad];
     __shared__ unsigned long long buf[kBuf4][64 * kSlices];      // append buffers; later lists[slice][K][64]
     __shared__ unsigned int thr_pub[kSlices][64];             // published score part only: 32-bit LDS stores cannot tear
@@ -471,7 +477,11 @@ int sg_cluster_knn(const float* d_xyzw, int N, const int32_t* d_cl_off, const in
     return SG_OK;
 }
 
+#ifdef SG_KNN_PROFILE
 static int g_knn_dbg = getenv("SG_KNN_DEBUG") ? atoi(getenv("SG_KNN_DEBUG")) : 0;   // profiling knob: 1 no inserts, 2 no scan, 4 stats
+#else
+static constexpr int g_knn_dbg = 0;
+#endif
 
 int sg_segment_boxes(const float* d_data, const int32_t* d_seg_points, const int32_t* d_seg_off, int S, float* d_box, void* stream) {
     SG_REQUIRE(S >= 0 && d_box, "sg_segment_boxes: bad arguments");
@@ -495,6 +505,7 @@ int sg_cluster_knn_pruned(const float* d_xyzw, int N, const int32_t* d_cl_off, c
     return SG_OK;
 }
 
+#ifdef SG_KNN_PROFILE
 int sg_debug_knn_blocktimes(unsigned long long* h_out, int count) {
     SG_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_knn_blocktime), sizeof(unsigned long long) * std::min(count, 8192)));
     unsigned long long* z = new unsigned long long[8192]();
@@ -513,5 +524,7 @@ int sg_debug_knn_stats(unsigned long long* h_out, int reset) {
     }
     return SG_OK;
 }
+
+#endif
 
 }  // extern "C"

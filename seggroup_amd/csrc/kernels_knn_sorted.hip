@@ -22,10 +22,17 @@ namespace {
 
 using namespace sgknn;
 
+// Work counters / cycle stamps of the kNN kernels exist only in profiling builds (make PROFILE=1): in a release build
+// `dbg` folds to 0 at compile time, the statistics code and its device globals disappear, and the library has no
+// process-wide mutable state.
+#ifdef SG_KNN_PROFILE
+constexpr bool kKnnProfile = true;
+#else
+constexpr bool kKnnProfile = false;
+#endif
+
 constexpr int kChunkPts = 32;
-constexpr int kBufS = 20;          // append slots per lane (two-pass kernel; the one-pass kernel picks its own)
 constexpr int kQuadS = 4;
-constexpr int kSlotBatch = 128;
 
 __device__ inline unsigned int spread10(unsigned int v) {      // 10 bits -> every third bit
     v &= 0x3ffu;
@@ -286,10 +293,11 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi,
     const int32_t* __restrict__ cl_seg_off, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off, const float* __restrict__ segbox,
-    const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg,
+    const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg_arg,
     const int32_t* __restrict__ seed = nullptr, const int32_t* __restrict__ seg_prevcl = nullptr, const int32_t* __restrict__ members = nullptr,
     const int32_t* __restrict__ pos_of_point = nullptr, const float* __restrict__ data = nullptr) {
     static_assert(!kSeeded || kSlices == 1, "seeding is built for one wave per tile");
+    const int dbg = kKnnProfile ? dbg_arg : 0;
     // LDS per wave decides how many tiles a CU keeps in flight, and this kernel waits on memory ~45 % of the time:
     // one wave per tile needs neither the merge area (>= K slots per lane) nor a 128-entry descriptor batch
     constexpr int kBufS = kSlices == 1 ? 12 : 20;
@@ -564,7 +572,8 @@ __global__ __launch_bounds__(64) void k_cluster_knn_2pass(
     const float4* __restrict__ sxyzw, const int32_t* __restrict__ smpos, const int32_t* __restrict__ cl_off,
     const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi,
     const int32_t* __restrict__ tile_chunk0, const int32_t* __restrict__ cl_chunk_off, const float4* __restrict__ cc,
-    int pos0, int32_t* __restrict__ knn, int dbg) {
+    int pos0, int32_t* __restrict__ knn, int dbg_arg) {
+    const int dbg = kKnnProfile ? dbg_arg : 0;
     __shared__ float4 cw[kChunkPts + kQuadS];
     __shared__ int ci[kChunkPts + kQuadS];
     constexpr int kBuf2 = 12;                                 // pass 2 appends ~K keys per lane in total; pass 1 gets 2x the slots
@@ -731,31 +740,37 @@ __global__ __launch_bounds__(64) void k_cluster_knn_2pass(
 
 }  // namespace
 
-static int g_knn_variant = getenv("SG_KNN_SLICES") ? atoi(getenv("SG_KNN_SLICES")) : -1;   // see sg_knn_set_variant
 // Which in-cluster kNN kernel the pipeline launches for a layer of T tiles: 0 = two-pass over the chunk table,
-// 1 / 2 / 4 = one-pass with that many waves per tile.  Measured on MI355X (ms per launch, layers 2 + 3, solo):
+// 1 / 2 / 4 = one-pass with that many waves per tile, 8 = one-pass x1 seeded from the previous kNN layer where there is
+// one.  Measured on MI355X (ms per launch, layers 2 + 3, solo):
 //   150k pts / 1.5k segs   one-pass x1 0.36 + 0.46   two-pass 0.38 + 0.50   (x4: 0.32 + 0.50, but 584 vs 670 scenes/s in the bench)
 //   500k pts / 5k segs     one-pass x1 0.70 + 1.10   two-pass 0.59 + 1.06
 //   150k pts / 100 segs    one-pass x1 1.27 + 1.42   two-pass 1.13 + 1.23
-// and the same bench throughput for x1 and two-pass (650-690 scenes/s).  Default: one wave per tile once the launch
-// fills the GPU, seeded from the previous kNN layer where there is one (8); sg_knn_set_variant(0) selects the
-// two-pass kernel, (1) the unseeded one-pass kernel.
-int sg::knn_variant_for(int T) {
-    if (g_knn_variant >= 0) return g_knn_variant;
+// and the same bench throughput for x1 and two-pass (650-690 scenes/s).  Default (override < 0): one wave per tile once
+// the launch fills the GPU, seeded.  `override` is a per-pipeline setting (sg_pipeline_set_knn_variant): the library
+// keeps no process-wide state.
+int sg::knn_variant_for(int T, int override) {
+    if (override == 0 || override == 1 || override == 2 || override == 4 || override == 8) return override;
     return T >= 2048 ? 8 : T >= 1024 ? 2 : 4;
 }
 
+#ifdef SG_KNN_PROFILE
 static int g_knn5_dbg = getenv("SG_KNN_DEBUG") ? atoi(getenv("SG_KNN_DEBUG")) : 0;   // profiling knob (16 = counters + cycle stamps)
+#else
+static constexpr int g_knn5_dbg = 0;
+#endif
 
 extern "C" {
 
-// undocumented profiling aid: copies and clears the sorted-kNN work counters
+#ifdef SG_KNN_PROFILE
+// profiling builds only: copies and clears the sorted-kNN work counters
 int sg_debug_knn5_stats(unsigned long long* h_out) {
     SG_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_knn5_stats), sizeof(unsigned long long) * 16));
     unsigned long long z[16] = {0};
     SG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_knn5_stats), z, sizeof z));
     return SG_OK;
 }
+#endif
 
 size_t sg_spatial_sort_ws_bytes(int N) {
     size_t temp = 0;
@@ -839,12 +854,6 @@ int sg_knn_operands(const float* d_data, const int32_t* d_seg_points, const int3
     return SG_OK;
 }
 
-int sg_knn_set_variant(int variant) {
-    const int prev = g_knn_variant;
-    g_knn_variant = (variant == 0 || variant == 1 || variant == 2 || variant == 4 || variant == 8) ? variant : -1;
-    return prev;
-}
-
 int sg_knn_seed_points(const int32_t* d_knn, const int32_t* d_members, int N, int k, int32_t* d_seed, void* stream) {
     SG_REQUIRE(N >= 0 && k > 0 && d_knn && d_members && d_seed, "sg_knn_seed_points: bad arguments");
     if (N == 0) return SG_OK;
@@ -894,15 +903,15 @@ int sg_cluster_knn_2pass(const float* d_sxyzw, const int32_t* d_smpos, int N, co
     return SG_OK;
 }
 
-int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off, const int32_t* d_tile_cl,
-                          const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T, const int32_t* d_cl_seg_off,
-                          const int32_t* d_order, const int32_t* d_dst, const int32_t* d_seg_off, const int32_t* d_seg_chunk_off,
-                          const float* d_segbox, const float* d_chunk_box, const int32_t* d_slot_of_pos, int k, int pos0,
-                          int32_t* d_knn, void* stream) {
+int sg_cluster_knn_sorted_w(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off, const int32_t* d_tile_cl,
+                            const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T, const int32_t* d_cl_seg_off,
+                            const int32_t* d_order, const int32_t* d_dst, const int32_t* d_seg_off, const int32_t* d_seg_chunk_off,
+                            const float* d_segbox, const float* d_chunk_box, const int32_t* d_slot_of_pos, int k, int pos0,
+                            int waves_per_tile, int32_t* d_knn, void* stream) {
     SG_REQUIRE(N >= 0 && T >= 0 && d_knn && d_sxyzw && d_smpos, "sg_cluster_knn_sorted: bad arguments");
     if (k != 20) return sg::fail(SG_EUNSUP, "sg_cluster_knn_sorted: only k == 20 is built (model.py:788,829), got %d", k);
     if (T == 0) return SG_OK;
-    const int slices = (g_knn_variant == 1 || g_knn_variant == 2 || g_knn_variant == 4) ? g_knn_variant : (T >= 2048 ? 1 : T >= 1024 ? 2 : 4);
+    const int slices = (waves_per_tile == 1 || waves_per_tile == 2 || waves_per_tile == 4) ? waves_per_tile : (T >= 2048 ? 1 : T >= 1024 ? 2 : 4);
 #define SG_KNN_LAUNCH(S)                                                                                                  \
     k_cluster_knn_sorted<20, S><<<T, 64 * S, 0, sg::as_stream(stream)>>>(                                                 \
         reinterpret_cast<const float4*>(d_sxyzw), d_smpos, d_cl_off, d_tile_cl, d_tile_lo, d_tile_hi, d_cl_seg_off, d_order, d_dst, \
@@ -913,6 +922,15 @@ int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, c
 #undef SG_KNN_LAUNCH
     SG_LAUNCH_CHECK();
     return SG_OK;
+}
+
+int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off, const int32_t* d_tile_cl,
+                          const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T, const int32_t* d_cl_seg_off,
+                          const int32_t* d_order, const int32_t* d_dst, const int32_t* d_seg_off, const int32_t* d_seg_chunk_off,
+                          const float* d_segbox, const float* d_chunk_box, const int32_t* d_slot_of_pos, int k, int pos0,
+                          int32_t* d_knn, void* stream) {
+    return sg_cluster_knn_sorted_w(d_sxyzw, d_smpos, N, d_cl_off, d_tile_cl, d_tile_lo, d_tile_hi, T, d_cl_seg_off, d_order, d_dst, d_seg_off,
+                                   d_seg_chunk_off, d_segbox, d_chunk_box, d_slot_of_pos, k, pos0, 0, d_knn, stream);
 }
 
 }  // extern "C"

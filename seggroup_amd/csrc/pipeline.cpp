@@ -82,6 +82,7 @@ struct sg_pipeline {
     // EdgeConv passes (what bench.py's roofline needs: ~10 instead of ~25 events per scene, which cost ~6 % of the
     // throughput with 16 pipelines in flight), 0 = none
     int timing = 2;
+    int knn_variant = -1;        // sg_pipeline_set_knn_variant: < 0 = by tile count
     static bool kernel_stage(int stage) { return stage == 6 || stage == 12 || (stage >= 19 && stage <= 23); }
     void mark_kernel_start() {                                // level 1: the event a timed kernel stage is measured from
         if (timing == 1) record(-1);
@@ -139,6 +140,13 @@ int sg_pipeline_set_timing(sg_pipeline* pl, int level) {
     if (!pl || level < 0 || level > 2) return sg::fail(SG_EINVAL, "sg_pipeline_set_timing: bad arguments");
     const int prev = pl->timing;
     pl->timing = level;
+    return prev;
+}
+
+int sg_pipeline_set_knn_variant(sg_pipeline* pl, int variant) {
+    if (!pl) return sg::fail(SG_EINVAL, "sg_pipeline_set_knn_variant: null pipeline");
+    const int prev = pl->knn_variant;
+    pl->knn_variant = (variant == 0 || variant == 1 || variant == 2 || variant == 4 || variant == 8) ? variant : -1;
     return prev;
 }
 
@@ -350,7 +358,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     auto regroup = [&](float th) -> int {
         connected.assign(std::max(E, 1), 0);
         int rc = sg_partition_group_nearby(part, Lcur.root.data(), Lcur.C, pl->h_dist.p, adj.data(), E, th, connected.data());
-        if (rc == SG_ESTALL) { out->stalled = 1; rc = SG_OK; }
+        if (rc == SG_ESTALL) { out->stalled = 1; rc = SG_OK; sg::err_buf()[0] = 0; }   // downgraded: no stale message stays behind
         if (rc < 0) return rc;
         keep.resize(connected.size());
         for (size_t i = 0; i < connected.size(); ++i) keep[i] = !connected[i];
@@ -396,9 +404,10 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             const int T = (int)tile_cl.size();
             // cluster-ordered chunk table of the two-pass kNN: chunk numbers per slot / cluster, and per tile the
             // (cluster-relative) chunk that holds its first sorted position
-            int knn_variant = sg::knn_variant_for(T);
+            int knn_variant = sg::knn_variant_for(T, pl->knn_variant);
             // seeded (8): layer 3 starts from layer 2's table; a former cluster of <= 20 points has no kNN list (-1)
             const bool seeded = knn_variant == 8 && layer == 1 && have_seed;
+            const int waves_per_tile = pl->knn_variant == 1 || pl->knn_variant == 2 || pl->knn_variant == 4 ? pl->knn_variant : 0;
             if (knn_variant == 8) knn_variant = 1;
             std::vector<int32_t> seg_prevcl(seeded ? S : 0);
             for (int sg = 0; seeded && sg < S; ++sg) {
@@ -497,9 +506,9 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                                                pl->chunk_box.p, pl->slot_of_pos.p, pl->knn_seed.p, dd + o.seg_prevcl, pl->members.p,
                                                pl->pos_of_point.p, sc->d_data, 20, pos0, pl->knn.p, stv));
             } else {
-                PL_CHECK(sg_cluster_knn_sorted(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
-                                               dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->segbox.p,
-                                               pl->chunk_box.p, pl->slot_of_pos.p, 20, pos0, pl->knn.p, stv));
+                PL_CHECK(sg_cluster_knn_sorted_w(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
+                                                 dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->segbox.p,
+                                                 pl->chunk_box.p, pl->slot_of_pos.p, 20, pos0, waves_per_tile, pl->knn.p, stv));
             }
             if (layer == 0) {                              // the next kNN layer may start from this table
                 PL_CHECK(sg_knn_seed_points(pl->knn.p, pl->members.p, N, 20, pl->knn_seed.p, stv));

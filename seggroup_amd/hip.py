@@ -11,6 +11,9 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libseggroup_hip.so")
+# SEGGROUP_HIP_HOST_LIB: a HOST-ONLY build of the library (`make -C seggroup_amd/csrc asan`: grouping engine, writers,
+# parsers under ASan/UBSan).  It has no kernels, so only the host entry points bind; everything else raises on use.
+HOST_LIB_OVERRIDE = os.environ.get("SEGGROUP_HIP_HOST_LIB")
 
 SG_OK, SG_EINVAL, SG_EHIP, SG_ENOMEM, SG_ESTALL, SG_EUNSUP = 0, -1, -2, -3, -4, -5
 MODE_INS_INFER, MODE_SEM_INFER = 0, 1
@@ -79,7 +82,7 @@ SIGNATURES = {
     "sg_cluster_knn_sorted": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
     "sg_segment_sort_boxes": (_I, [vp, _I, vp, vp, vp, _I, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_layer_layout": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "sg_knn_set_variant": (_I, [_I]),
+    "sg_cluster_knn_sorted_w": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, _I, vp, vp]),
     "sg_knn_seed_points": (_I, [vp, vp, _I, _I, vp, vp]),
     "sg_cluster_knn_seeded": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
     "sg_knn_chunk_table": (_I, [vp, vp, vp, vp, vp, _I, vp, vp, vp]),
@@ -93,6 +96,7 @@ SIGNATURES = {
     "sg_segment_lists_ws_bytes": (_Z, [_I, _I]),
     "sg_segment_lists": (_I, [vp, _I, vp, _I, vp, vp, vp, C.POINTER(C.c_int), vp, _Z, vp]),
     "sg_write_seg_json": (_I, [C.c_char_p, vp, vp, _I, _I]),
+    "sg_parse_seg_json": (_I, [C.c_char_p, _I, vp]),
     "sg_edgeconv_ws_bytes": (_Z, [_I]),
     "sg_edgeconv_forward": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_gcn_ws_bytes": (_Z, [_I, _I, _I]),
@@ -119,6 +123,7 @@ SIGNATURES = {
     "sg_batch_forward": (_I, [vp, _I, vp, _I, _I, vp, vp, vp, vp, _I]),
     "sg_pipeline_stage_times": (_I, [vp, vp, _I]),
     "sg_pipeline_set_timing": (_I, [vp, _I]),
+    "sg_pipeline_set_knn_variant": (_I, [vp, _I]),
     "sg_pipeline_stage_name": (C.c_char_p, [_I]),
     "sg_write_label_txt": (_I, [C.c_char_p, vp, _I]),
     "sg_write_label_npy": (_I, [C.c_char_p, vp, _I]),
@@ -165,14 +170,20 @@ def lib() -> C.CDLL:
     """Load (once) and return the shared library; raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = HOST_LIB_OVERRIDE or LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C seggroup_amd/csrc`).  The SegGroup hot path has no CPU fallback.")
         _load_hip_runtime()
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                if HOST_LIB_OVERRIDE:              # host-only sanitizer build: device entry points are absent by design
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = l

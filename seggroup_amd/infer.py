@@ -134,6 +134,17 @@ def final_report(s, io: IOStream) -> None:
         io.cprint('')
 
 
+def load_checkpoint(model, ckpt_path: str) -> None:
+    """`infer.py:112-121`: `last.t7` = {'state_dict': ...} saved from the DDP-wrapped model ('module.' prefix).  Loaded
+    STRICTLY like the reference: a checkpoint of another experiment / with renamed or missing keys must not end up
+    writing pseudo labels from randomly initialised weights."""
+    import torch
+    ckpt = torch.load(ckpt_path, map_location='cpu')
+    sd = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
+    sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
+    model.load_state_dict(sd, strict=True)
+
+
 def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = None, init_dist: bool = True) -> Optional[dict]:
     """One rank's loop.  `forward_fn(scene_index) -> (iou_sem, iou_ins, acc)` replaces the model in the
     CPU (gloo) tests of the driver logic; by default it is SegModel.forward on this rank's GPU."""
@@ -151,7 +162,10 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         # packed fast path: build this rank's missing scene packs in worker processes before this process touches the GPU
         from . import cache
         mine_names = [scene_list[i][:-1] for i in scene_indices(len(scene_list), rank, world, args.sampler)]
-        built = cache.build_missing(args.root, mine_names, args.label_style, workers=max(1, int(args.workers)))
+        # the reference gives every rank workers / ngpus loader processes (infer.py:94); the spawn context (not the order
+        # of calls) is what keeps these children clear of this process's GPU state
+        per_rank = max(1, -(-int(args.workers) // max(world, 1)))
+        built = cache.build_missing(args.root, sorted(set(mine_names)), args.label_style, workers=per_rank)
         if built and rank == 0:
             io.cprint('Built %d scene packs under dataset/scannet/cache/%s' % (built, args.label_style))
     if forward_fn is None:
@@ -168,10 +182,7 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
             if rank == 0:
                 io.cprint('No checkpoint model, please make sure that you use right name in --exp_name')
             raise SystemExit(1)
-        ckpt = torch.load(ckpt_path, map_location='cpu')
-        sd = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
-        sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
-        model.load_state_dict(sd, strict=False)
+        load_checkpoint(model, ckpt_path)
         if rank == 0:
             io.cprint('Load model from ' + ckpt_path)
         model.epoch = 'sem_infer' if args.sem_infer else 'ins_infer'
@@ -236,7 +247,7 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     batches = [names[k:k + args.batch] for k in range(0, len(names), args.batch)]
     pending = [pool.submit(stage, n) for n in batches[0]] if batches else []
     writer = AsyncLabelWriter(threads=max(2, workers))
-    runner, done = None, 0
+    runner, done, stalled = None, 0, []
     w = model.export_weights()
     for bi, batch in enumerate(batches):
         scenes = [f.result() for f in pending]
@@ -247,9 +258,14 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
                 runner.close()
             runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps[0] if caps else None, timing=0)
         res = runner.run(scenes, mode, writer=writer, out_dirs=[model.output_root(s_.name) for s_ in scenes], formats=formats)
-        for r in res:
+        for s_, r in zip(scenes, res):
             acc.add(r.iou_sem, r.iou_ins, r.acc)
             done += 1
+            if r.stalled:
+                # the reference never returns from such a scene (pass 2 of group_nearby_clusters loops forever, model.py:
+                # 228-239); here the sweep that made no progress was the last one -- say so, the labels are still written
+                stalled.append(s_.name)
+                print('[rank %d] %s: a <5-point cluster could not be merged (reference would not terminate); sweep cut short' % (rank, s_.name), flush=True)
             if rank == 0:
                 io.cprint(progress_line(min(done * world, len(scene_list)), len(scene_list), acc.summary()))
     writer.flush()
@@ -257,6 +273,8 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     if runner is not None:
         runner.close()
     pool.shutdown()
+    if stalled and rank == 0:
+        io.cprint('%d scene(s) hit the non-terminating pass-2 case of group_nearby_clusters: %s' % (len(stalled), ' '.join(stalled)))
 
 
 def _spawn_entry(rank, world, args):

@@ -149,7 +149,9 @@ class Pipeline:
         hip.check(rc)
         nvec = 14 if mode == hip.MODE_INS_INFER else 6
         # the C side packs the vectors at stride V of THIS scene (include/seggroup_hip.h, sg_result.h_labels)
-        lab = self.labels.numpy().reshape(-1)[:hip.NUM_LABEL_VECTORS * sc.V].reshape(hip.NUM_LABEL_VECTORS, sc.V)
+        # a private copy: the pinned buffer is overwritten by this pipeline's next forward (SegModel.last_result must not
+        # go stale); BatchRunner.run hands out views instead and documents it
+        lab = self.labels.numpy().reshape(-1)[:hip.NUM_LABEL_VECTORS * sc.V].reshape(hip.NUM_LABEL_VECTORS, sc.V).copy()
         return SceneResult(lab, nvec, res)
 
     def set_timing(self, level: int) -> int:
@@ -201,7 +203,8 @@ class BatchRunner:
     def run(self, scenes: List[DeviceScene], mode: int = hip.MODE_INS_INFER, writer: "Optional[AsyncLabelWriter]" = None,
             out_dirs: Optional[List[str]] = None, formats=("txt", "npy")) -> List[SceneResult]:
         """Forward every scene; with `writer` + `out_dirs` the native threads also hand each scene's label vectors to
-        the writer pool (files appear asynchronously: call writer.flush())."""
+        the writer pool (files appear asynchronously: call writer.flush()).  The returned `labels` arrays are VIEWS into
+        this runner's pinned buffer: valid until the next `run()`; copy what has to outlive it."""
         n = len(scenes)
         if any(not self.pipes[0].fits(s) for s in scenes):
             raise ValueError("BatchRunner.run: a scene exceeds the capacities this runner was created with")
@@ -392,6 +395,9 @@ class SegModel(nn.Module):
                                                  label_style=self.label_style, device=data.device)
             self._scene_cache = {scene_name: sc}          # keep one scene resident, like the reference's per-step load
         res = self.forward_scene(sc, write=True)
+        if res.stalled:
+            print('%s: a <5-point cluster could not be merged (the reference loops forever here, model.py:228-239); sweep cut short'
+                  % scene_name, flush=True)
         dev = data.device
         out = (torch.from_numpy(res.iou_sem).to(dev), torch.from_numpy(res.iou_ins).to(dev), torch.from_numpy(res.acc).to(dev))
         if self.sem_infer or self.ins_infer:

@@ -107,6 +107,17 @@ def to_state_dict(w: Mapping[str, np.ndarray], prefix: str = "module."):
     return sd
 
 
+def to_full_state_dict(w: Mapping[str, np.ndarray], prefix: str = "module."):
+    """A COMPLETE reference checkpoint `state_dict` (all 54 entries of SURVEY.md 8b: BN running statistics and counters,
+    the train-only classifier at its default init) carrying the inference parameters `w` -- what `train.py:216-220` saves
+    and `infer.py:121` loads with strict key matching."""
+    from .model import SegModel
+
+    net = SegModel(exp_name="_ckpt", ins_infer=True, data_root="/nonexistent")
+    net.load_weights(w)
+    return {prefix + k: v.detach().clone() for k, v in net.state_dict().items()}
+
+
 def save_npz(path: str, w: Mapping[str, np.ndarray]) -> None:
     np.savez_compressed(path, **{k.replace(".", "__"): v for k, v in w.items()})
 

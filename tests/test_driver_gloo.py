@@ -70,3 +70,59 @@ def test_two_ranks_equal_one_rank(tmp_path, sampler):
     assert abs(got["acc_sem"] - want["acc_sem"]) < 1e-12
     log = open(os.path.join(root, "checkpoints", "exp", "run_infer.log")).read()
     assert "==> Infer           Instance mIoU:" in log and "Semantic mIoU (20 classes)" in log and "otherfurniture" in log
+
+
+# ---- bench.py: its own reduction and its launcher ---------------------------------------------------------------
+def _bench_reduce_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group(backend="gloo")
+    mine = list(range(rank, 1201, world))                        # bench.py --scenes-total 1201: scene i -> rank i mod W
+    vec = np.zeros(165)
+    for i in mine:
+        s, n_, a = _stub_forward(i)
+        vec[:80] += s.reshape(-1); vec[80:160] += n_.reshape(-1); vec[160:164] += a; vec[164] += 1
+    out = bench.reduce_accumulators(vec, world, "gloo")
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        q.put(out.tolist())
+
+
+def test_bench_reduction_two_ranks_equal_one_rank():
+    """bench.py's end-of-run all-reduce of the 165 float64 accumulators over a 1201-scene shard (configs[3]) at world
+    size 2 (gloo) equals the single-process sums, and every scene is counted exactly once."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_reduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = np.asarray(q.get(timeout=180))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = np.zeros(165)
+    for i in range(1201):
+        s, n_, a = _stub_forward(i)
+        want[:80] += s.reshape(-1); want[80:160] += n_.reshape(-1); want[160:164] += a; want[164] += 1
+    assert got[164] == 1201 and np.array_equal(got[:160], want[:160]) and np.allclose(got[160:164], want[160:164], rtol=0, atol=1e-9)
+
+
+def test_bench_refuses_a_multi_gpu_label_without_the_gpus():
+    """`python bench.py --gpus 2` on a box with fewer than 2 HIP devices must fail loudly (round-1 bug: it measured one GPU
+    and printed n_gpus: 1); and a rank whose WORLD_SIZE disagrees with --gpus must refuse as well."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with < 2 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2 and "only" in r.stderr and '{"metric"' not in r.stdout
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and '{"metric"' not in r.stdout

@@ -462,14 +462,12 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         assert np.array_equal(lay["cop"].cpu().numpy(), np.repeat(np.arange(L.count), np.diff(off)))
         assert np.array_equal(lay["sop"].cpu().numpy(), slot_of_pos)
         assert torch.equal(lay["x9m"], x9m) and torch.equal(lay["sx"], sxyzw) and torch.equal(lay["sm"], smpos)
-        for variant in (1, 2, 4, -1):        # one-pass with 1 / 2 / 4 waves per tile | the default choice
-            prev = lib.sg_knn_set_variant(variant)
+        for variant in (1, 2, 4, 0):        # one-pass with 1 / 2 / 4 waves per tile | 0: chosen by tile count
             k_sorted = torch.full((N, 20), -7, dtype=torch.int32, device="cuda:0")
-            hip.check(lib.sg_cluster_knn_sorted(sxyzw.data_ptr(), smpos.data_ptr(), N, d["off"].data_ptr(), d4[0].data_ptr(), d4[1].data_ptr(),
-                                                d4[2].data_ptr(), len(tc4), d["cso"].data_ptr(), d["order"].data_ptr(), d["dst"].data_ptr(),
-                                                d["segoff"].data_ptr(), d_co.data_ptr(), box.data_ptr(), cbox.data_ptr(), d_slot.data_ptr(), 20,
-                                                int(pos_of_point[0]), k_sorted.data_ptr(), None))
-            lib.sg_knn_set_variant(prev)
+            hip.check(lib.sg_cluster_knn_sorted_w(sxyzw.data_ptr(), smpos.data_ptr(), N, d["off"].data_ptr(), d4[0].data_ptr(), d4[1].data_ptr(),
+                                                  d4[2].data_ptr(), len(tc4), d["cso"].data_ptr(), d["order"].data_ptr(), d["dst"].data_ptr(),
+                                                  d["segoff"].data_ptr(), d_co.data_ptr(), box.data_ptr(), cbox.data_ptr(), d_slot.data_ptr(), 20,
+                                                  int(pos_of_point[0]), variant, k_sorted.data_ptr(), None))
             c_ = k_sorted.cpu().numpy()
             assert np.array_equal(a, c_), f"{name}/{target}/variant {variant}: {int(np.any(a != c_, axis=1).sum())} rows differ between brute force and sorted"
         # two-pass kernel over the cluster-ordered chunk table (host side of the table as in pipeline.cpp)

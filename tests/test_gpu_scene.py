@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 FLOAT_TOL = 1e-4
 
 
-def _run(scene, w, mode_name, debug=False):
+def _run(scene, w, mode_name, debug=False, knn_variant=None):
     import ctypes as C
     import torch
     from seggroup_amd import hip
@@ -24,6 +24,8 @@ def _run(scene, w, mode_name, debug=False):
     net.epoch = mode_name
     ds = DeviceScene.from_synthetic(scene, device="cuda:0")
     pipe = net.pipeline_for(ds)
+    if knn_variant is not None:                     # per-pipeline setting: the library keeps no process-wide knob
+        pipe.lib.sg_pipeline_set_knn_variant(pipe.handle, knn_variant)
     taps = {}
     dbg = None
     if debug:
@@ -133,11 +135,7 @@ def test_150k_scene_labels_do_not_depend_on_the_knn_kernel(golden_index, weight_
     from seggroup_amd import hip
     name = "scene_150k"
     scene = make_fixture_scene(golden_index, name)
-    prev = hip.lib().sg_knn_set_variant(variant)
-    try:
-        res, _, _ = _run(scene, weight_sets["ins_infer"], "ins_infer")
-    finally:
-        hip.lib().sg_knn_set_variant(prev)
+    res, _, _ = _run(scene, weight_sets["ins_infer"], "ins_infer", knn_variant=variant)
     e = golden_index[name]["ins_infer"]
     assert res.trace[1:5] == e["nclusters"]
     for i in range(14):
@@ -190,7 +188,7 @@ def test_dropin_forward_and_driver_write_reference_files(tmp_path, golden_index,
     os_mod = __import__("os")
     ck = os_mod.path.join(root, "checkpoints", "exp", "models")
     os_mod.makedirs(ck)
-    torch.save({"epoch": 6, "state_dict": weights.to_state_dict(weight_sets["ins_infer"]), "optimizer": {}},
+    torch.save({"epoch": 6, "state_dict": weights.to_full_state_dict(weight_sets["ins_infer"]), "optimizer": {}},
                os_mod.path.join(ck, "last.t7"))
     # (1) forward() called exactly like infer.py:150-152 does
     net = SegModel(exp_name="exp", ins_infer=True, data_root=root).to("cuda:0")
@@ -273,7 +271,7 @@ def test_packed_scene_and_fast_driver_match_reference_capture(tmp_path, golden_i
         assert np.array_equal(getattr(a, k), getattr(b, k)), k
     ck = os.path.join(root, "checkpoints", "exp", "models")
     os.makedirs(ck)
-    torch.save({"state_dict": weights.to_state_dict(weight_sets["ins_infer"])}, os.path.join(ck, "last.t7"))
+    torch.save({"state_dict": weights.to_full_state_dict(weight_sets["ins_infer"])}, os.path.join(ck, "last.t7"))
     fast = infer.run_worker(0, 1, infer.build_parser().parse_args(
         ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--batch", "2", "--inflight", "2", "-j", "2"]))
     for sc, n in zip(scenes, names):
@@ -375,13 +373,78 @@ def test_odd_scenes_with_the_large_scene_knn_kernels(weight_sets, cfg, variant):
     from seggroup_amd import hip, synthetic
     n, s, seed, kw, mode = cfg
     scene = synthetic.make_scene(n, s, seed, **kw)
-    prev = hip.lib().sg_knn_set_variant(variant)
-    try:
-        res, _, _ = _run(scene, weight_sets[mode], mode)
-    finally:
-        hip.lib().sg_knn_set_variant(prev)
+    res, _, _ = _run(scene, weight_sets[mode], mode, knn_variant=variant)
     ref = cpu_ref.forward_scene(scene, weight_sets[mode], mode)
     assert res.trace == ref["trace"]
     for i in range(14):
         nm = hip.LABEL_NAMES[i]
         assert np.array_equal(res.labels[i], ref["labels"][nm].astype(np.int32)), nm
+
+
+def _digest(res):
+    h = hashlib.sha256()
+    for i in range(res.n_vectors):
+        h.update(np.ascontiguousarray(res.labels[i]).tobytes())
+    h.update(res.iou_sem.tobytes()); h.update(res.iou_ins.tobytes()); h.update(np.nan_to_num(res.acc, nan=-1.0).tobytes())
+    h.update(np.asarray(res.trace, np.int32).tobytes())
+    return h.hexdigest()
+
+
+def test_batch_of_64_full_size_scenes_through_the_concurrent_path(golden_index, weight_sets):
+    """BASELINE.json configs[2]: 64 distinct 150k-point / 1.5k-segment scenes through the CONCURRENT path (BatchRunner,
+    16 scenes in flight -- what bench.py times), twice.  Every scene's 14 label vectors, metric tensors and cluster trace
+    must equal (i) the same scene through a single default-stream pipeline and (ii), for the `scene_150k` fixture seed that
+    rides in the batch, the digests of the reference capture in tests/golden/index.json.  A race on a shared buffer, a
+    stream-ordering slip or cross-scene state would show here and nowhere in the single-pipeline tests."""
+    from seggroup_amd import hip, synthetic
+    from seggroup_amd.model import BatchRunner, Pipeline
+    from seggroup_amd.scene import DeviceScene
+    W = weight_sets["ins_infer"]
+    fixture = make_fixture_scene(golden_index, "scene_150k")
+    host = [fixture] + [synthetic.make_scene(150000, 1500, 61000 + i) for i in range(63)]
+    scenes = [DeviceScene.from_synthetic(s, device="cuda:0") for s in host]
+    del host
+    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+    solo = Pipeline(W, *caps, device="cuda:0")
+    want = [_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
+    solo.close()
+    assert len(set(want)) == 64                                    # the scenes really are distinct
+    runner = BatchRunner(W, scenes, inflight=16, device="cuda:0", timing=1)
+    for rep in range(2):
+        order = list(range(64)) if rep == 0 else list(range(63, -1, -1))      # second pass: other scene -> slot assignment
+        res = runner.run([scenes[i] for i in order], hip.MODE_INS_INFER)
+        got = [_digest(r) for r in res]
+        bad = [order[j] for j in range(64) if got[j] != want[order[j]]]
+        assert not bad, f"pass {rep}: scenes {bad} differ between the concurrent path and a single pipeline"
+        if rep == 0:
+            e = golden_index["scene_150k"]["ins_infer"]
+            assert res[0].trace[1:5] == e["nclusters"]
+            for i in range(14):
+                nm = hip.LABEL_NAMES[i]
+                assert hashlib.sha256(np.ascontiguousarray(res[0].labels[i]).tobytes()).hexdigest() == e["label_sha"][nm], nm
+    runner.close()
+
+
+def test_scan_far_from_the_origin_matches_oracle(weight_sets):
+    """BatchNorm statistics of EdgeConv are formed from sums of y and y^2 (and, for MLP3's inner BN, from edge-feature
+    moments): with absolute coordinates in the features, var = E[y^2] - mean^2 would cancel for a scan that sits ~100 m from
+    the origin.  The kernels evaluate the x_i half about a point of the cloud (kernels_edgeconv.hip, "Conditioning"): labels
+    must equal the float64 oracle's, point features stay within the north-star tolerance."""
+    import torch
+    from oracle import cpu_ref
+    from seggroup_amd import hip, synthetic
+    scene = synthetic.make_scene(20000, 200, 9100)
+    scene.data[:, 0] += np.float32(103.0)
+    scene.data[:, 1] -= np.float32(87.0)
+    scene.data[:, 2] += np.float32(41.0)
+    res, t, _ = _run(scene, weight_sets["ins_infer"], "ins_infer", debug=True)
+    ref = cpu_ref.forward_scene(scene, weight_sets["ins_infer"], "ins_infer", keep=True)
+    assert res.trace == ref["trace"]
+    for i in range(14):
+        nm = hip.LABEL_NAMES[i]
+        assert np.array_equal(res.labels[i], ref["labels"][nm].astype(np.int32)), nm
+    for i, nm in enumerate(("mlp_2", "mlp_3")):
+        members = t["members"][i].cpu().numpy()
+        pf = np.empty((scene.num_points, 64), np.float32)
+        pf[members] = t["pf"][i].cpu().numpy()
+        assert np.abs(pf - ref["stages"][nm]["point_feat"]).max() < FLOAT_TOL, nm

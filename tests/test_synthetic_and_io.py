@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from conftest import make_fixture_scene
 
@@ -60,3 +61,31 @@ def test_weights_state_dict_contract():
     got = net.export_weights()
     for k in w:
         assert np.array_equal(got[k], w[k])
+
+
+def test_driver_loads_checkpoints_strictly(tmp_path):
+    """infer.py:121 loads `last.t7` with strict key matching; so does the driver here: a complete reference-shaped
+    checkpoint loads, one with a missing or a foreign key is refused instead of silently running on random weights."""
+    import torch
+    from seggroup_amd import infer, weights
+    from seggroup_amd.model import SegModel
+    w = weights.make_weights(5, 2.0, affine_jitter=0.1)
+    full = weights.to_full_state_dict(w)
+    assert len(full) == 54 and all(k.startswith("module.") for k in full)           # SURVEY 8b: 54 entries
+    net = SegModel(exp_name="x", ins_infer=True, data_root="/nonexistent")
+    p = str(tmp_path / "last.t7")
+    torch.save({"epoch": 6, "state_dict": full, "optimizer": {}}, p)
+    infer.load_checkpoint(net, p)
+    got = net.export_weights()
+    for k in w:
+        assert np.array_equal(got[k], w[k])
+    broken = dict(full)
+    del broken["module.gcn_3.fc.weight"]
+    torch.save({"state_dict": broken}, p)
+    with pytest.raises(RuntimeError, match="gcn_3.fc.weight"):
+        infer.load_checkpoint(net, p)
+    foreign = dict(full)
+    foreign["module.mlp_9.conv1.0.weight"] = full["module.mlp_1.conv1.0.weight"]
+    torch.save({"state_dict": foreign}, p)
+    with pytest.raises(RuntimeError, match="mlp_9"):
+        infer.load_checkpoint(net, p)

@@ -43,7 +43,7 @@ def main():
         synthetic.write_reference_tree(root, scenes)
         ck = os.path.join(root, "checkpoints", "exp", "models")
         os.makedirs(ck)
-        torch.save({"state_dict": weights.to_state_dict(weights.make_weights(1, bn1_gamma=2.0))}, os.path.join(ck, "last.t7"))
+        torch.save({"state_dict": weights.to_full_state_dict(weights.make_weights(1, bn1_gamma=2.0))}, os.path.join(ck, "last.t7"))
         gen_s = time.time() - t0
         common = ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--out-format", a.out_format, "-j", str(a.workers)]
 
