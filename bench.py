@@ -73,7 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--scenes-total", type=int, default=0,
                     help="strong scaling: ONE set of this many scenes sharded i mod W over the ranks (configs[3]: 1201); "
                          "a step = one pass over the rank's shard in batches of --batch")
-    ap.add_argument("--inflight", type=int, default=16, help="scenes in flight per GPU")
+    ap.add_argument("--groups", type=int, default=4, help="engine groups per GPU (host thread + HIP stream each)")
+    ap.add_argument("--per-group", type=int, default=8, help="scenes a group advances in lock-step through batched launches")
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--segments", type=int, default=1500)
     ap.add_argument("--seg-profile", default="voronoi", help="synthetic segment-size profile: voronoi (SURVEY 8d recipe) | scannet (heavy-tailed)")
@@ -225,23 +226,36 @@ def main(argv=None):
         pool.shutdown()
     gen_s = time.time() - t_gen
 
-    from seggroup_amd.model import BatchRunner
-    # timing level 1: HIP events only around the modelled kernels (every stage = ~25 events per scene = ~6 % of the throughput)
-    runner = BatchRunner(W, scenes, inflight=args.inflight, device=dev, timing=1)
+    from seggroup_amd.model import Engine
+    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+    # stage timing: a handful of HIP events per batched launch sequence (per group of scenes, not per scene)
+    runner = Engine(W, caps, groups=args.groups, per_group=args.per_group, device=dev, timing=1)
     acc = {"iou_sem": np.zeros(80), "iou_ins": np.zeros(80), "acc": np.zeros(4), "n": 0}
     batches = [scenes[k:k + args.batch] for k in range(0, len(scenes), args.batch)]
 
-    def step(record=True):
-        """One step = every scene of the rank's batch (or shard) through SegModel.forward."""
-        last = None
-        for b in batches:
-            last = runner.run(b, hip.MODE_INS_INFER)
+    def run_steps(k, record=True):
+        """k steps; a step = every scene of the rank's batch (or shard) through SegModel.forward.  Batches are queued one
+        ahead (submit k+1, then wait for k), as a driver with a stream of scenes does: the engine's groups never drain
+        between two batches.  Every batch is waited for and its results consumed inside the call."""
+        last, pending = None, None
+
+        def consume(res):
             if record:
-                for r in last:
+                for r in res:
                     acc["iou_sem"] += r.iou_sem.reshape(-1)
                     acc["iou_ins"] += r.iou_ins.reshape(-1)
                     acc["acc"] += np.nan_to_num(r.acc)
                     acc["n"] += 1
+            return res
+
+        for _ in range(k):
+            for b in batches:
+                t = runner.submit(b, hip.MODE_INS_INFER)
+                if pending is not None:
+                    last = consume(runner.wait(pending))
+                pending = t
+        if pending is not None:
+            last = consume(runner.wait(pending))
         return last
 
     def barrier():
@@ -249,13 +263,11 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(record=False)
+    run_steps(args.warmup, record=False)
     runner.reset_stage_stats()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last_results = step()
+    last_results = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -273,7 +285,6 @@ def main(argv=None):
     batch_digests = [label_digest(last_results[i]) for i in range(n_par)]
     batch_trace0 = list(last_results[0].trace)
     from seggroup_amd.model import Pipeline
-    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
     solo = Pipeline(W, *caps, stream=None, device=dev)
     solo.set_timing(0)
     solo_digests = [label_digest(solo.forward(last_batch[i], hip.MODE_INS_INFER)) for i in range(n_par)]
@@ -306,7 +317,7 @@ def main(argv=None):
         all_k = priced(per_scene)
         # the same kernels with ONE scene in flight (outside the timed region): with several streams sharing the GPU a
         # launch's duration says how long it shared the machine, not how well it uses it
-        solo_runner = BatchRunner(W, scenes[:4], inflight=1, device=dev, timing=1)
+        solo_runner = Engine(W, caps, groups=1, per_group=1, device=dev, timing=1)
         solo_runner.run(scenes[:2], hip.MODE_INS_INFER)
         solo_runner.reset_stage_stats()
         solo_runner.run(scenes[:4], hip.MODE_INS_INFER)
@@ -396,7 +407,8 @@ def main(argv=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if args.scenes_total > 0 else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "mode": "ins_infer", "scenes_per_step_per_gpu": len(scenes), "scenes_in_flight": args.inflight,
+            "config": {"workload": workload, "mode": "ins_infer", "scenes_per_step_per_gpu": len(scenes), "scenes_in_flight": args.groups * args.per_group,
+                       "engine": f"{args.groups} groups x {args.per_group} scenes per batched launch",
                        "seg_profile": args.seg_profile, "weights": "tests/golden/weights_g2.npz", "parallelism": f"scene-parallel x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
             "parity_check": {"scenes_per_rank": n_par, "ranks_equal": parity_all,

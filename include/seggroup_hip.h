@@ -412,6 +412,36 @@ int sg_batch_forward(sg_pipeline* const* pipes, int npipes, const sg_scene* scen
                      sg_result* results, float* h_stage_ms_sum,
                      struct sg_writer* writer, const char* const* out_dirs, int formats);
 
+/* =============================================================================================
+ * Scene engine: SegModel.forward for MANY scenes with the scene index as a grid dimension (infer.py:149-152 loop body,
+ * model.py:684-897).  `groups` persistent host threads (one HIP stream each) pull up to `scenes_per_group` scenes at a
+ * time from a job queue and advance them in lock-step: every kernel is launched ONCE per phase for all scenes of the
+ * group (csrc/engine_ctx.h), with one host->device copy, one device->host copy and one stream synchronisation per
+ * phase; the serial grouping of a group's scenes runs on its thread while the other groups' kernels occupy the GPU.
+ * groups x scenes_per_group scenes are in flight.  Results are bit-identical to sg_pipeline_forward (same kernel
+ * bodies; tests/test_gpu_scene.py).
+ *
+ * sg_engine_submit enqueues `count` scenes and returns a ticket at once (the arrays must stay valid until the ticket
+ * has been waited for; results[i].h_labels as for sg_batch_forward); sg_engine_wait blocks until every scene of the
+ * ticket is done and returns the first error.  A driver keeps the GPU busy across batches by submitting batch k+1
+ * before it waits for batch k.  writer / out_dirs / formats as for sg_batch_forward.
+ * ============================================================================================= */
+typedef struct sg_engine sg_engine;
+sg_engine* sg_engine_create(int max_points, int max_segments, int max_edges, int max_vertices, const sg_weights* w,
+                            int groups, int scenes_per_group);
+void sg_engine_destroy(sg_engine* e);
+int sg_engine_submit(sg_engine* e, const sg_scene* scenes, int count, int mode, sg_result* results,
+                     struct sg_writer* writer, const char* const* out_dirs, int formats);
+int sg_engine_wait(sg_engine* e, int ticket);
+/* 0 = no stage timing (default), 1 | 2 = HIP events around the stages of every batched launch.  Returns the previous level. */
+int sg_engine_set_timing(sg_engine* e, int level);
+/* sg_pipeline_set_knn_variant for every slot (the two-pass kernel, 0, has no batched twin: the seeded kernel runs instead) */
+int sg_engine_set_knn_variant(sg_engine* e, int variant);
+/* accumulated device time per stage (ms; a batched launch counts once, whatever the number of scenes in it) since the
+ * last reset, in sg_pipeline_stage_name order; returns the number of scenes those launches covered */
+long long sg_engine_stage_times(sg_engine* e, double* h_ms_sum, int capacity, int reset);
+size_t sg_engine_device_bytes(const sg_engine* e);
+
 /* per-stage device time of the last forward, in milliseconds (HIP events on the pipeline's stream);
  * names via sg_pipeline_stage_name(i), count returned. */
 int sg_pipeline_stage_times(const sg_pipeline* pl, float* h_ms, int capacity);

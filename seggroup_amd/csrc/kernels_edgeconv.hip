@@ -42,6 +42,7 @@
 // near the cloud): the statistics (sum y, sum y^2 and the edge-feature moments) are then sums of values of the cloud's
 // extent, not of its distance from the origin, and var = E[y^2] - mean^2 does not cancel for a scan that sits 100 m away
 // from the origin.  The differences d = x_j - x_i are formed from the raw coordinates exactly as the reference does.
+#include "engine_ctx.h"
 #include "sg_common.h"
 
 namespace {
@@ -65,11 +66,11 @@ struct Lds {
     double acc[kWaves][128]; // per-wave statistics: [0,64) sum, [64,128) sum of squares
 };
 
-template <int MODE, bool REREAD_A = false>
-__global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
-                                                          const float* __restrict__ w1, const float* __restrict__ shift1,
-                                                          const float* __restrict__ w2, const float* __restrict__ gamma_last,
-                                                          float* __restrict__ ext, double* __restrict__ partial) {
+template <int MODE, bool REREAD_A>
+__device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
+                                              const float* __restrict__ w1, const float* __restrict__ shift1,
+                                              const float* __restrict__ w2, const float* __restrict__ gamma_last,
+                                              float* __restrict__ ext, double* __restrict__ partial, int bid) {
     __shared__ Lds lds;
     constexpr bool kTwo = MODE == S2X;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
     for (int i = tid; i < kWaves * 128; i += 64 * kWaves) (&lds.acc[0][0])[i] = 0.0;
     __syncthreads();
 
-    const int tile = blockIdx.x * kWaves + wave;
+    const int tile = bid * kWaves + wave;
     const int pt = tile * 32 + r;
     const bool valid = pt < N;
     const float vmask = valid ? 1.f : 0.f;
@@ -268,8 +269,23 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) s += lds.acc[w][tid];
-        partial[(size_t)blockIdx.x * 128 + tid] = s;
+        partial[(size_t)bid * 128 + tid] = s;
     }
+}
+template <int MODE, bool REREAD_A = false>
+__global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
+                                                          const float* __restrict__ w1, const float* __restrict__ shift1,
+                                                          const float* __restrict__ w2, const float* __restrict__ gamma_last,
+                                                          float* __restrict__ ext, double* __restrict__ partial) {
+    edgeconv_body<MODE, REREAD_A>(x9m, knn, N, K, w1, shift1, w2, gamma_last, ext, partial, blockIdx.x);
+}
+// S1X: the scene's MLP2 weights as they are; S2X: its folded conv1 (ec_w1f, ec_sh1) + the raw conv2
+template <int MODE, bool REREAD_A>
+__global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.ec_blocks) return;
+    if (MODE == S1X) edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, 20, c.ec_w1, nullptr, nullptr, c.ec_g1, c.pf, c.ec_partial, blockIdx.x);
+    else edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, 20, c.ec_w1f, c.ec_sh1, c.ec_w2, c.ec_g2, c.pf, c.ec_partial, blockIdx.x);
 }
 
 // Batch statistics of conv1's output WITHOUT evaluating it (the inner BN of MLP3): y = W1 e is linear, so
@@ -282,11 +298,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
 // [0,9) a | [9,18) K x_i | [18,63) D upper triangle | [63,144) a x_i^T row-major | [144,189) K x_i x_i^T upper triangle.
 constexpr int kMom = 189;
 
-__global__ __launch_bounds__(256) void k_edge_moments(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
-                                                      double* __restrict__ partial) {
+__device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
+                                                  double* __restrict__ partial, int bid) {
     __shared__ double red[4][kMom];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pt = blockIdx.x * 256 + tid;
+    const int pt = bid * 256 + tid;
     const bool valid = pt < N;
     float a[9], D[45], xi[9];
 #pragma unroll
@@ -346,13 +362,22 @@ __global__ __launch_bounds__(256) void k_edge_moments(const float* __restrict__ 
 #pragma unroll
         for (int l = k; l < 9; ++l) { wsum(Kf * xi[k] * xi[l], 144 + t); ++t; }
     __syncthreads();
-    if (tid < kMom) partial[(size_t)blockIdx.x * kMom + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    if (tid < kMom) partial[(size_t)bid * kMom + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+__global__ __launch_bounds__(256) void k_edge_moments(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
+                                                      double* __restrict__ partial) {
+    edge_moments_body(x9m, knn, N, K, partial, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_edge_moments_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.ec_mblocks) return;
+    edge_moments_body(c.x9m, c.knn, c.N, 20, c.ec_partial, blockIdx.x);
 }
 
 // moments -> folded conv1 weights and shift (one block; fixed-order sum of the per-block partials)
-__global__ __launch_bounds__(1024) void k_bn_fold_moments(const double* __restrict__ partial, int nblocks, double rows,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift) {
+__device__ __forceinline__ void bn_fold_moments_body(const double* __restrict__ partial, int nblocks, double rows,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift) {
     __shared__ double part[4][256];
     __shared__ double tot[kMom];
     __shared__ double mu[18], M[18][18];
@@ -397,13 +422,22 @@ __global__ __launch_bounds__(1024) void k_bn_fold_moments(const double* __restri
     for (int k = threadIdx.x >> 6; k < 18; k += 16) w_folded[ch * 18 + k] = (float)(a * (double)w[ch * 18 + k]);
     if (threadIdx.x < 64) shift[ch] = (float)((double)beta[ch] - a * mean);
 }
+__global__ __launch_bounds__(1024) void k_bn_fold_moments(const double* __restrict__ partial, int nblocks, double rows,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift) {
+    bn_fold_moments_body(partial, nblocks, rows, gamma, beta, w, w_folded, shift);
+}
+__global__ __launch_bounds__(1024) void k_bn_fold_moments_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    bn_fold_moments_body(c.ec_partial, c.ec_mblocks, (double)c.N * 20.0, c.ec_g1, c.ec_b1, c.ec_w1, c.ec_w1f, c.ec_sh1);
+}
 
 // last layer of an MLP: fixed-order reduction of the per-block partials -> |a| = |gamma| / sqrt(var + eps) and the shift.
 // 1024 threads: thread (value v = tid & 127, lane group g = tid >> 7) sums blocks g, g+8, g+16, ... and the
 // eight group sums are added in a fixed order, so the result does not depend on scheduling.
-__global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ partial, int nblocks, double rows,
-                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  float* __restrict__ a_out, float* __restrict__ shift) {
+__device__ __forceinline__ void bn_fold_body(const double* __restrict__ partial, int nblocks, double rows,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             float* __restrict__ a_out, float* __restrict__ shift) {
     __shared__ double part[8][128];
     __shared__ double tot[128];
     const int v = threadIdx.x & 127, g = threadIdx.x >> 7;
@@ -436,6 +470,17 @@ __global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ par
         a_out[ch] = (float)a;
         shift[ch] = (float)((double)beta[ch] - a * mean);
     }
+}
+__global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ partial, int nblocks, double rows,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ a_out, float* __restrict__ shift) {
+    bn_fold_body(partial, nblocks, rows, gamma, beta, a_out, shift);
+}
+// layers == 1: MLP2's only BN (-> ec_w1f = |a|, ec_sh1); layers == 2: MLP3's last BN (-> ec_w2f, ec_sh2)
+__global__ __launch_bounds__(1024) void k_bn_fold_b(const sg::SlotCtx* __restrict__ cx, int layers) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if (layers == 1) bn_fold_body(c.ec_partial, c.ec_blocks, (double)c.N * 20.0, c.ec_g1, c.ec_b1, c.ec_w1f, c.ec_sh1);
+    else bn_fold_body(c.ec_partial, c.ec_blocks, (double)c.N * 20.0, c.ec_g2, c.ec_b2, c.ec_w2f, c.ec_sh2);
 }
 
 // epilogue of the last layer, in place: out = LReLU(|a| * E + b')
@@ -510,6 +555,26 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
         if (d_affine) { d_affine[0] = w2f; d_affine[1] = sh2; }
         else k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w2f, sh2);
         if (mark) mark(2);
+    }
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mark)(void*, int), void* mark_arg, hipStream_t st) {
+    if (bd.nslots == 0 || bd.max_N == 0) return SG_OK;
+    const int nblocks = sg::cdiv(sg::cdiv(bd.max_N, 32), kWaves);
+    const dim3 grid(nblocks, bd.nslots), one(1, bd.nslots);
+    if (layers == 1) {
+        k_edgeconv_b<S1X, false><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
+        k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 1);
+        if (mark) mark(mark_arg, 0);
+    } else {
+        k_edge_moments_b<<<dim3(sg::cdiv(bd.max_N, 256), bd.nslots), 256, 0, st>>>(d_ctx);
+        k_bn_fold_moments_b<<<one, 1024, 0, st>>>(d_ctx);
+        if (mark) mark(mark_arg, 0);
+        k_edgeconv_b<S2X, true><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
+        k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 2);
+        if (mark) mark(mark_arg, 1);
     }
     SG_LAUNCH_CHECK();
     return SG_OK;

@@ -11,6 +11,7 @@
 // (dx2 + dy2) + dz2 -- this translation unit is compiled with -ffp-contract=off so no FMA is formed.
 #include <climits>
 
+#include "engine_ctx.h"
 #include "sg_common.h"
 
 namespace {
@@ -64,13 +65,12 @@ __device__ inline Best fps_pass(const float* X, const float* Y, const float* Z, 
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_fps_sample(const float* __restrict__ data, int N, int ch_in,
-                                                      const int32_t* __restrict__ members, const int32_t* __restrict__ cl_off,
-                                                      int P, int ch_out, int transform, int n_lo, int n_hi, int lds_pts,
-                                                      float* __restrict__ samples, int32_t* __restrict__ sel,
-                                                      float* __restrict__ ws) {
+__device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, int N, int ch_in,
+                                                const int32_t* __restrict__ members, const int32_t* __restrict__ cl_off,
+                                                int P, int ch_out, int transform, int n_lo, int n_hi, int lds_pts,
+                                                float* __restrict__ samples, int32_t* __restrict__ sel,
+                                                float* __restrict__ ws, int c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int c = blockIdx.x;
     const int lo = cl_off[c], n = cl_off[c + 1] - lo;
     if (n < n_lo || n > n_hi || n <= 0) return;
     int* picks = reinterpret_cast<int*>(smem);                       // [P]
@@ -161,6 +161,23 @@ __global__ __launch_bounds__(BLOCK) void k_fps_sample(const float* __restrict__ 
     }
 }
 
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fps_sample(const float* __restrict__ data, int N, int ch_in,
+                                                      const int32_t* __restrict__ members, const int32_t* __restrict__ cl_off,
+                                                      int P, int ch_out, int transform, int n_lo, int n_hi, int lds_pts,
+                                                      float* __restrict__ samples, int32_t* __restrict__ sel,
+                                                      float* __restrict__ ws) {
+    fps_sample_body<BLOCK>(data, N, ch_in, members, cl_off, P, ch_out, transform, n_lo, n_hi, lds_pts, samples, sel, ws, blockIdx.x);
+}
+
+// structural layer of several scenes: FPS-64 over the original over-segments, all six channels, transformed
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fps_sample_b(const sg::SlotCtx* __restrict__ cx, int n_lo, int n_hi, int lds_pts) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.S) return;
+    fps_sample_body<BLOCK>(c.data, c.N, 6, c.seg_points, c.seg_off, 64, 6, 1, n_lo, n_hi, lds_pts, c.samples, nullptr, c.ws_fps, blockIdx.x);
+}
+
 }  // namespace
 
 namespace sg {
@@ -192,6 +209,26 @@ int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_memb
         k_fps_sample<1024><<<C, 1024, head + (size_t)big_pts * 16, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform,
                                                                         kSmallMax + 1, INT_MAX, big_pts, d_samples, d_sel,
                                                                         (float*)d_ws);
+    }
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
+    if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
+    const int P = 64;
+    const size_t head = (size_t)P * 4 + 16 * sizeof(Best);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fps_sample_b<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(head + (size_t)kLdsCap * 16 + 4096 * 4)));
+        attr_set = true;
+    }
+    const int small_pts = std::max(64, std::min(bd.max_seg, kSmallMax));
+    k_fps_sample_b<64><<<dim3(bd.max_S, bd.nslots), 64, head + (size_t)small_pts * 16, st>>>(d_ctx, 1, kSmallMax, small_pts);
+    if (bd.max_seg > kSmallMax) {
+        const int big_pts = std::min(bd.max_seg, kLdsCap);
+        k_fps_sample_b<1024><<<dim3(bd.max_S, bd.nslots), 1024, head + (size_t)big_pts * 16, st>>>(d_ctx, kSmallMax + 1, INT_MAX, big_pts);
     }
     SG_LAUNCH_CHECK();
     return SG_OK;

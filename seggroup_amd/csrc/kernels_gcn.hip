@@ -5,6 +5,7 @@
 // row-normalised product is evaluated over the symmetric CSR built by the host grouping engine.
 // S <= a few thousand and D <= 256: this stage is latency-, not bandwidth-bound; sums are carried in
 // fp64 so the decision distances that follow are as close to exact arithmetic as fp32 features allow.
+#include "engine_ctx.h"
 #include "sg_common.h"
 
 namespace {
@@ -22,12 +23,11 @@ __global__ void k_transpose(const float* __restrict__ w, int D, float* __restric
 // every edge's weight is evaluated once -- walking rowptr -> eid -> adj -> rows -> dist per edge and per thread was a chain of
 // dependent global round trips (72 us per launch for ~1,000 rows).  Rows with more than kDegCap edges take the direct path.
 constexpr int kDegCap = 256;
-__global__ void k_gcn_aggregate(const float* __restrict__ x, int D, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                const int32_t* __restrict__ eid, const int32_t* __restrict__ adj, float* __restrict__ dist, float alpha,
-                                float* __restrict__ agg) {
+__device__ __forceinline__ void gcn_aggregate_body(const float* __restrict__ x, int D, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                   const int32_t* __restrict__ eid, const int32_t* __restrict__ adj, float* __restrict__ dist, float alpha,
+                                                   float* __restrict__ agg, int i) {
     __shared__ int s_id[kDegCap], s_col[kDegCap], s_a[kDegCap], s_b[kDegCap];
     __shared__ double s_w[kDegCap];
-    const int i = blockIdx.x;
     const int lo = rowptr[i], hi = rowptr[i + 1], deg = hi - lo;
     const bool staged = deg <= kDegCap;
     if (staged) {
@@ -82,12 +82,24 @@ __global__ void k_gcn_aggregate(const float* __restrict__ x, int D, const int32_
         }
     }
 }
+__global__ void k_gcn_aggregate(const float* __restrict__ x, int D, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                const int32_t* __restrict__ eid, const int32_t* __restrict__ adj, float* __restrict__ dist, float alpha,
+                                float* __restrict__ agg) {
+    gcn_aggregate_body(x, D, rowptr, col, eid, adj, dist, alpha, agg, blockIdx.x);
+}
+__global__ void k_gcn_aggregate_b(const sg::SlotCtx* __restrict__ cx, float alpha) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.C) return;
+    gcn_aggregate_body(c.cat, c.Dcat, c.rowptr, c.col, c.eid, c.g_adj, c.g_dist, alpha, c.g_agg, blockIdx.x);
+}
 
 constexpr int kRows = 8;
 // out[i][o] = relu(sum_k agg[i][k] * W[o][k]); block = kRows rows, thread o = output column
-__global__ void k_gcn_fc(const float* __restrict__ agg, int S, int D, const float* __restrict__ wt, float* __restrict__ out) {
+// out2 (may be null): a second copy of the result (the engine's outbox)
+__device__ __forceinline__ void gcn_fc_body(const float* __restrict__ agg, int S, int D, const float* __restrict__ wt, float* __restrict__ out,
+                                            float* __restrict__ out2, int bid) {
     __shared__ float rows[kRows][256];
-    const int r0 = blockIdx.x * kRows;
+    const int r0 = bid * kRows;
     for (int i = threadIdx.x; i < kRows * D; i += blockDim.x) {
         const int rr = i / D, k = i % D;
         rows[rr][k] = (r0 + rr < S) ? agg[(size_t)(r0 + rr) * D + k] : 0.f;
@@ -105,7 +117,19 @@ __global__ void k_gcn_fc(const float* __restrict__ agg, int S, int D, const floa
     }
 #pragma unroll
     for (int rr = 0; rr < kRows; ++rr)
-        if (r0 + rr < S) out[(size_t)(r0 + rr) * D + o] = fmaxf((float)acc[rr], 0.f);
+        if (r0 + rr < S) {
+            const float v = fmaxf((float)acc[rr], 0.f);
+            out[(size_t)(r0 + rr) * D + o] = v;
+            if (out2) out2[(size_t)(r0 + rr) * D + o] = v;
+        }
+}
+__global__ void k_gcn_fc(const float* __restrict__ agg, int S, int D, const float* __restrict__ wt, float* __restrict__ out) {
+    gcn_fc_body(agg, S, D, wt, out, nullptr, blockIdx.x);
+}
+__global__ void k_gcn_fc_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x * kRows >= c.C) return;
+    gcn_fc_body(c.g_agg, c.C, c.Dcat, c.g_wt, c.g_out, c.g_out_copy, blockIdx.x);
 }
 
 }  // namespace
@@ -124,6 +148,16 @@ int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, 
     hipStream_t st = sg::as_stream(stream);
     k_gcn_aggregate<<<S, 64 * sg::cdiv(D, 64), 0, st>>>(d_x, D, d_rowptr, d_col, d_eid, d_adj, dist, alpha, agg);
     k_gcn_fc<<<sg::cdiv(S, kRows), 256, 0, st>>>(agg, S, D, d_wt, d_out);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+// every slot of a launch is at the same layer, hence the same feature width (192 | 256); the aggregate kernel writes the
+// edge distances of g_adj into g_dist as a by-product (sg::gcn_forward_wt)
+int b_gcn(const SlotCtx* d_ctx, const BatchDims& bd, float alpha, hipStream_t st) {
+    if (bd.nslots == 0 || bd.max_C == 0) return SG_OK;
+    k_gcn_aggregate_b<<<dim3(bd.max_C, bd.nslots), 256, 0, st>>>(d_ctx, alpha);
+    k_gcn_fc_b<<<dim3(sg::cdiv(bd.max_C, kRows), bd.nslots), 256, 0, st>>>(d_ctx);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

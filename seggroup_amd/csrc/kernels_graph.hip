@@ -1,17 +1,20 @@
 // Graph / label bookkeeping kernels (HBM-bound integer work): point-edge contraction (a3), member
 // gathering (a2/a10), edge distance (a8), row/segment max (a10), label export (a16), metric counts (a17).
+#include "engine_ctx.h"
 #include "sg_common.h"
 
 namespace {
+
+using sg::SlotCtx;
 
 constexpr int kBlock = 256;
 
 // ------------------------------------------------------------------------------------------------
 // a3: update_adj first call (model.py:291-302, 724-733).  One bit per (lo,hi) segment pair.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_mark_pairs(const int64_t* __restrict__ adj, int E, const int32_t* __restrict__ seg, int N, int S,
-                             uint32_t* __restrict__ bitmap) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void mark_pairs_body(const int64_t* __restrict__ adj, int E, const int32_t* __restrict__ seg, int N, int S,
+                                                uint32_t* __restrict__ bitmap, int bid, int nblk) {
+    for (int e = bid * blockDim.x + threadIdx.x; e < E; e += nblk * blockDim.x) {
         // 16-byte coalesced read of one edge row
         const longlong2 row = reinterpret_cast<const longlong2*>(adj)[e];
         const long long a = row.x, b = row.y;
@@ -24,6 +27,14 @@ __global__ void k_mark_pairs(const int64_t* __restrict__ adj, int E, const int32
         uint32_t* w = bitmap + (bit >> 5);
         if ((__builtin_nontemporal_load(w) & mask) == 0) atomicOr(w, mask);   // ~60 edges hit each bit
     }
+}
+__global__ void k_mark_pairs(const int64_t* __restrict__ adj, int E, const int32_t* __restrict__ seg, int N, int S,
+                             uint32_t* __restrict__ bitmap) {
+    mark_pairs_body(adj, E, seg, N, S, bitmap, blockIdx.x, gridDim.x);
+}
+__global__ void k_mark_pairs_b(const SlotCtx* __restrict__ cx) {
+    const SlotCtx& c = cx[blockIdx.y];
+    mark_pairs_body(c.adj0, c.E0, c.seg_of_point, c.N, c.S, c.bitmap, blockIdx.x, gridDim.x);
 }
 
 constexpr int kWordsPerThread = 4;
@@ -51,19 +62,27 @@ __device__ inline int block_exclusive_scan(int v, int* total) {
     return base + incl - v;
 }
 
-__global__ void k_count_bits(const uint32_t* __restrict__ bitmap, size_t words, int* __restrict__ block_count) {
-    const size_t w0 = (size_t)blockIdx.x * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
+__device__ __forceinline__ void count_bits_body(const uint32_t* __restrict__ bitmap, size_t words, int* __restrict__ block_count, int bid) {
+    const size_t w0 = (size_t)bid * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
     int c = 0;
 #pragma unroll
     for (int i = 0; i < kWordsPerThread; ++i)
         if (w0 + i < words) c += __popc(bitmap[w0 + i]);
     int total;
     block_exclusive_scan(c, &total);
-    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+    if (threadIdx.x == 0) block_count[bid] = total;
+}
+__global__ void k_count_bits(const uint32_t* __restrict__ bitmap, size_t words, int* __restrict__ block_count) {
+    count_bits_body(bitmap, words, block_count, blockIdx.x);
+}
+__global__ void k_count_bits_b(const SlotCtx* __restrict__ cx) {
+    const SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.bits_blocks) return;
+    count_bits_body(c.bitmap, (size_t)c.bitmap_words, c.block_count, blockIdx.x);
 }
 
 // single block: exclusive scan of the per-block counts, total -> *out_count
-__global__ void k_scan_blocks(int* __restrict__ block_count, int nblocks, int* __restrict__ out_count) {
+__device__ __forceinline__ void scan_blocks_body(int* __restrict__ block_count, int nblocks, int* __restrict__ out_count) {
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -80,19 +99,30 @@ __global__ void k_scan_blocks(int* __restrict__ block_count, int nblocks, int* _
     }
     if (threadIdx.x == 0) *out_count = carry;
 }
+__global__ void k_scan_blocks(int* __restrict__ block_count, int nblocks, int* __restrict__ out_count) {
+    scan_blocks_body(block_count, nblocks, out_count);
+}
+__global__ void k_scan_blocks_b(const SlotCtx* __restrict__ cx) {
+    const SlotCtx& c = cx[blockIdx.y];
+    scan_blocks_body(c.block_count, c.bits_blocks, c.count);
+}
 
-__global__ void k_emit_pairs(const uint32_t* __restrict__ bitmap, size_t words, const int* __restrict__ block_off, int S,
-                             int32_t* __restrict__ out, int capacity) {
-    const size_t w0 = (size_t)blockIdx.x * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
+// kClear: the words are zeroed as they are read, so the bitmap is all-zero again when the launch ends (the engine's
+// scenes then need no memset launch); out2 (may be null) receives a second copy of the first cap2 rows (the outbox)
+template <bool kClear>
+__device__ __forceinline__ void emit_pairs_body(uint32_t* __restrict__ bitmap, size_t words, const int* __restrict__ block_off, int S,
+                                                int32_t* __restrict__ out, int capacity, int32_t* __restrict__ out2, int cap2, int bid) {
+    const size_t w0 = (size_t)bid * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
     uint32_t w[kWordsPerThread];
     int c = 0;
 #pragma unroll
     for (int i = 0; i < kWordsPerThread; ++i) {
         w[i] = (w0 + i < words) ? bitmap[w0 + i] : 0u;
+        if (kClear && w[i]) bitmap[w0 + i] = 0u;
         c += __popc(w[i]);
     }
     int total;
-    int off = block_off[blockIdx.x] + block_exclusive_scan(c, &total);
+    int off = block_off[bid] + block_exclusive_scan(c, &total);
 #pragma unroll
     for (int i = 0; i < kWordsPerThread; ++i) {
         uint32_t bits = w[i];
@@ -100,13 +130,27 @@ __global__ void k_emit_pairs(const uint32_t* __restrict__ bitmap, size_t words, 
             const int b = __ffs(bits) - 1;
             bits &= bits - 1;
             const unsigned long long bit = ((unsigned long long)(w0 + i) << 5) + b;
+            const int32_t lo = (int32_t)(bit / (unsigned)S), hi = (int32_t)(bit % (unsigned)S);
             if (off < capacity) {
-                out[2 * off] = (int32_t)(bit / (unsigned)S);
-                out[2 * off + 1] = (int32_t)(bit % (unsigned)S);
+                out[2 * off] = lo;
+                out[2 * off + 1] = hi;
+            }
+            if (out2 && off < cap2) {
+                out2[2 * off] = lo;
+                out2[2 * off + 1] = hi;
             }
             ++off;
         }
     }
+}
+__global__ void k_emit_pairs(uint32_t* __restrict__ bitmap, size_t words, const int* __restrict__ block_off, int S,
+                             int32_t* __restrict__ out, int capacity) {
+    emit_pairs_body<false>(bitmap, words, block_off, S, out, capacity, nullptr, 0, blockIdx.x);
+}
+__global__ void k_emit_pairs_b(const SlotCtx* __restrict__ cx) {
+    const SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.bits_blocks) return;
+    emit_pairs_body<true>(c.bitmap, (size_t)c.bitmap_words, c.block_count, c.S, c.adj1, c.cap1, c.adj1_out, c.out_rows, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -132,11 +176,9 @@ __global__ void k_gather_members(const int32_t* __restrict__ seg_points, const i
 // ------------------------------------------------------------------------------------------------
 // a8: calculate_distance (model.py:269-274).  One wave per edge, fp64 accumulation.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_edge_distance(const float* __restrict__ feat, int stride, int D, const int32_t* __restrict__ adj, int E,
-                                float* __restrict__ dist) {
+__device__ __forceinline__ void edge_distance_one(const float* __restrict__ feat, int stride, int D, const int32_t* __restrict__ adj, int e,
+                                                  float* __restrict__ dist, float* __restrict__ dist2, int cap2) {
     const int lane = threadIdx.x & 63;
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (e >= E) return;
     const float* a = feat + (size_t)adj[2 * e] * stride;
     const float* b = feat + (size_t)adj[2 * e + 1] * stride;
     double acc = 0.0;
@@ -146,7 +188,25 @@ __global__ void k_edge_distance(const float* __restrict__ feat, int stride, int 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) dist[e] = (float)sqrt(acc);
+    if (lane == 0) {
+        const float v = (float)sqrt(acc);
+        dist[e] = v;
+        if (dist2 && e < cap2) dist2[e] = v;
+    }
+}
+__global__ void k_edge_distance(const float* __restrict__ feat, int stride, int D, const int32_t* __restrict__ adj, int E,
+                                float* __restrict__ dist) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (e >= E) return;
+    edge_distance_one(feat, stride, D, adj, e, dist, nullptr, 0);
+}
+// wave-stride over the edges: the edge count may live on the device (the contraction of the same phase produced it)
+__global__ void k_edge_distance_b(const SlotCtx* __restrict__ cx) {
+    const SlotCtx& c = cx[blockIdx.y];
+    const int E = c.dist_E_dev ? min(*c.dist_E_dev, c.cap1) : c.dist_E;
+    const int wpb = blockDim.x >> 6;
+    for (int e = blockIdx.x * wpb + (threadIdx.x >> 6); e < E; e += gridDim.x * wpb)
+        edge_distance_one(c.dist_feat, c.dist_stride, c.dist_D, c.dist_adj, e, c.dist, c.dist_copy, c.dist_copy_rows);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -154,9 +214,8 @@ __global__ void k_edge_distance(const float* __restrict__ feat, int stride, int 
 // ------------------------------------------------------------------------------------------------
 // `fill_cols` further columns of every output row are set to -inf: the pipeline's next writer of those rows is the
 // atomic point->cluster max, which then needs no fill launch of its own
-__global__ void k_group_max_rows(const float* __restrict__ rows, int row_stride, int D, const int32_t* __restrict__ goff,
-                                 const int32_t* __restrict__ gidx, float* __restrict__ out, int out_stride, int fill_cols) {
-    const int g = blockIdx.x;
+__device__ __forceinline__ void group_max_rows_body(const float* __restrict__ rows, int row_stride, int D, const int32_t* __restrict__ goff,
+                                                    const int32_t* __restrict__ gidx, float* __restrict__ out, int out_stride, int fill_cols, int g) {
     const int lo = goff[g], hi = goff[g + 1];
     for (int k = threadIdx.x; k < D; k += blockDim.x) {
         float m = -INFINITY;
@@ -164,6 +223,15 @@ __global__ void k_group_max_rows(const float* __restrict__ rows, int row_stride,
         out[(size_t)g * out_stride + k] = m;
     }
     for (int k = threadIdx.x; k < fill_cols; k += blockDim.x) out[(size_t)g * out_stride + D + k] = -INFINITY;
+}
+__global__ void k_group_max_rows(const float* __restrict__ rows, int row_stride, int D, const int32_t* __restrict__ goff,
+                                 const int32_t* __restrict__ gidx, float* __restrict__ out, int out_stride, int fill_cols) {
+    group_max_rows_body(rows, row_stride, D, goff, gidx, out, out_stride, fill_cols, blockIdx.x);
+}
+__global__ void k_group_max_rows_b(const SlotCtx* __restrict__ cx) {
+    const SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.C) return;
+    group_max_rows_body(c.gm_rows, c.gm_stride, c.gm_D, c.goff, c.gidx, c.cat, c.Dcat, 64, blockIdx.x);
 }
 
 __device__ inline void atomic_max_float(float* addr, float v) {
@@ -191,13 +259,13 @@ __global__ void k_fill_rows(float* __restrict__ p, int rows, int cols, int strid
 constexpr int kRowsPerBlock = 64;
 // a != nullptr: the rows are EdgeConv's pre-activation maxima E and every element is first mapped to LReLU(a_c * E + b_c)
 // (the same fmaf + fmaxf as k_bn_lrelu_apply), which saves that kernel's launch and a read + write of the [N,64] array.
-__global__ __launch_bounds__(256) void k_segment_max64(const float* __restrict__ rows, int N, const int32_t* __restrict__ cluster_of_pos,
-                                                       float* __restrict__ out, int out_stride, const float* __restrict__ a,
-                                                       const float* __restrict__ shift) {
+__device__ __forceinline__ void segment_max64_body(const float* __restrict__ rows, int N, const int32_t* __restrict__ cluster_of_pos,
+                                                   float* __restrict__ out, int out_stride, const float* __restrict__ a,
+                                                   const float* __restrict__ shift, int bid) {
     constexpr int kIter = kRowsPerBlock / 16;
     __shared__ float4 red[16][16];
     const int qi = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int b0 = blockIdx.x * kRowsPerBlock, r0 = b0 + rl;
+    const int b0 = bid * kRowsPerBlock, r0 = b0 + rl;
     float4 v[kIter];
     int c[kIter];
 #pragma unroll
@@ -235,17 +303,40 @@ __global__ __launch_bounds__(256) void k_segment_max64(const float* __restrict__
         }
     }
 }
+__global__ __launch_bounds__(256) void k_segment_max64(const float* __restrict__ rows, int N, const int32_t* __restrict__ cluster_of_pos,
+                                                       float* __restrict__ out, int out_stride, const float* __restrict__ a,
+                                                       const float* __restrict__ shift) {
+    segment_max64_body(rows, N, cluster_of_pos, out, out_stride, a, shift, blockIdx.x);
+}
+// layers selects which folded affine of the EdgeConv applies (MLP2: w1f/sh1 hold |a|, b'; MLP3: w2f/sh2)
+__global__ __launch_bounds__(256) void k_segment_max64_b(const SlotCtx* __restrict__ cx, int layers) {
+    const SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x * kRowsPerBlock >= c.N) return;
+    segment_max64_body(c.pf, c.N, c.cluster_of_pos, c.cat + c.gm_D, c.Dcat, layers == 1 ? c.ec_w1f : c.ec_w2f, layers == 1 ? c.ec_sh1 : c.ec_sh2,
+                       blockIdx.x);
+}
 
 // ------------------------------------------------------------------------------------------------
 // a16: label export gather (model.py:525-605)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_export(const int32_t* __restrict__ unmap, int V, const int32_t* __restrict__ seg_of_point, int N,
-                         const int32_t* __restrict__ tables, int T, int S, int32_t* __restrict__ out) {
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void export_body(const int32_t* __restrict__ unmap, int V, const int32_t* __restrict__ seg_of_point, int N,
+                                            const int32_t* __restrict__ tables, int T, int S, int32_t* __restrict__ out, int bid, int nblk) {
+    for (int v = bid * blockDim.x + threadIdx.x; v < V; v += nblk * blockDim.x) {
         const int p = unmap[v];
         const int s = (p >= 0 && p < N) ? seg_of_point[p] : -1;
         for (int t = 0; t < T; ++t) out[(size_t)t * V + v] = (s >= 0 && s < S) ? tables[(size_t)t * S + s] : -1;
     }
+}
+__global__ void k_export(const int32_t* __restrict__ unmap, int V, const int32_t* __restrict__ seg_of_point, int N,
+                         const int32_t* __restrict__ tables, int T, int S, int32_t* __restrict__ out) {
+    export_body(unmap, V, seg_of_point, N, tables, T, S, out, blockIdx.x, gridDim.x);
+}
+// also resets the metric counters the evaluate kernels of the same phase accumulate into (saves two memset launches)
+__global__ void k_export_b(const SlotCtx* __restrict__ cx) {
+    const SlotCtx& c = cx[blockIdx.y];
+    const int n0 = 128 + 3 * c.max_ins, n1 = n0 + c.max_ins;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += gridDim.x * blockDim.x) c.cnt[i] = i < n0 ? 0u : 0xffffffffu;
+    export_body(c.unmap, c.V, c.seg_of_point, c.N, c.tables, c.n_tables, c.S, c.labels, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -268,9 +359,9 @@ __device__ inline bool in_ins_valid(int c) {   // INS_VALID_CLASS_IDS (model.py:
 // histograms for the 3x40 semantic bins and -- when they fit (max_ins <= kInsLds) -- for the four
 // per-instance arrays, flushed once per block: no hot global atomics.
 constexpr int kInsLds = 2048;
-__global__ __launch_bounds__(256) void k_eval_counts(const int32_t* __restrict__ gt, const int32_t* __restrict__ sem_pred,
-                                                     const int32_t* __restrict__ ins_pred, int V, int max_ins,
-                                                     uint32_t* __restrict__ cnt) {
+__device__ __forceinline__ void eval_counts_body(const int32_t* __restrict__ gt, const int32_t* __restrict__ sem_pred,
+                                                 const int32_t* __restrict__ ins_pred, int V, int max_ins,
+                                                 uint32_t* __restrict__ cnt, int bid, int nblk) {
     extern __shared__ uint32_t dyn[];                       // [4 * max_ins] when max_ins <= kInsLds
     __shared__ uint32_t h[128];
     const bool lds_ins = max_ins <= kInsLds;
@@ -287,7 +378,7 @@ __global__ __launch_bounds__(256) void k_eval_counts(const int32_t* __restrict__
     uint32_t* ins_b = lds_ins ? dyn + 2 * max_ins : g_b;
     uint32_t* first = lds_ins ? dyn + 3 * max_ins : g_f;
     uint32_t sc[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x) {
+    for (int v = bid * blockDim.x + threadIdx.x; v < V; v += nblk * blockDim.x) {
         const int2 g = reinterpret_cast<const int2*>(gt)[v];
         const int st = g.x, it = g.y;
         if (st == 0) continue;                                   // valid_idxs (model.py:615)
@@ -327,15 +418,32 @@ __global__ __launch_bounds__(256) void k_eval_counts(const int32_t* __restrict__
             if (dyn[3 * max_ins + i] != 0xffffffffu) atomicMin(&g_f[i], dyn[3 * max_ins + i]);
         }
 }
+__global__ __launch_bounds__(256) void k_eval_counts(const int32_t* __restrict__ gt, const int32_t* __restrict__ sem_pred,
+                                                     const int32_t* __restrict__ ins_pred, int V, int max_ins,
+                                                     uint32_t* __restrict__ cnt) {
+    eval_counts_body(gt, sem_pred, ins_pred, V, max_ins, cnt, blockIdx.x, gridDim.x);
+}
+// dynamic LDS is sized for the launch's largest max_ins; a scene whose own max_ins fits uses the LDS histograms
+__global__ __launch_bounds__(256) void k_eval_counts_b(const SlotCtx* __restrict__ cx) {
+    const SlotCtx& c = cx[blockIdx.y];
+    eval_counts_body(c.gt, c.labels + (size_t)c.sem_row * c.V, c.labels + (size_t)c.ins_row * c.V, c.V, c.max_ins, c.cnt, blockIdx.x, gridDim.x);
+}
 
 // semantic prediction at the first valid vertex of every predicted instance (model.py:636)
-__global__ void k_eval_first_sem(const int32_t* __restrict__ sem_pred, int max_ins, uint32_t* __restrict__ cnt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void eval_first_sem_body(const int32_t* __restrict__ sem_pred, int max_ins, uint32_t* __restrict__ cnt, int bid) {
+    const int i = bid * blockDim.x + threadIdx.x;
     if (i >= max_ins) return;
     const uint32_t* ins_p = cnt + 128;
     const uint32_t* first = ins_p + 3 * (size_t)max_ins;
     uint32_t* fsem = cnt + 128 + 4 * (size_t)max_ins;
     fsem[i] = ins_p[i] ? (uint32_t)sem_pred[first[i]] : 0xffffffffu;
+}
+__global__ void k_eval_first_sem(const int32_t* __restrict__ sem_pred, int max_ins, uint32_t* __restrict__ cnt) {
+    eval_first_sem_body(sem_pred, max_ins, cnt, blockIdx.x);
+}
+__global__ void k_eval_first_sem_b(const SlotCtx* __restrict__ cx) {
+    const SlotCtx& c = cx[blockIdx.y];
+    eval_first_sem_body(c.labels + (size_t)c.sem_row * c.V, c.max_ins, c.cnt, blockIdx.x);
 }
 
 }  // namespace
@@ -360,6 +468,75 @@ int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_o
                                                                                    d_shift);
     SG_LAUNCH_CHECK();
     return SG_OK;
+}
+
+// ---- batched launches (engine.cpp) ----
+int b_contract(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
+    if (bd.nslots == 0) return SG_OK;
+    const dim3 gy(1, bd.nslots);
+    if (bd.max_E0 > 0) k_mark_pairs_b<<<dim3(std::min(sg::cdiv(bd.max_E0, kBlock), 1024), bd.nslots), kBlock, 0, st>>>(d_ctx);
+    k_count_bits_b<<<dim3(bd.max_bits_blocks, bd.nslots), kBlock, 0, st>>>(d_ctx);
+    k_scan_blocks_b<<<gy, kBlock, 0, st>>>(d_ctx);
+    k_emit_pairs_b<<<dim3(bd.max_bits_blocks, bd.nslots), kBlock, 0, st>>>(d_ctx);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int b_edge_distance(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
+    if (bd.nslots == 0) return SG_OK;
+    const int blocks = std::max(1, std::min(sg::cdiv(std::max(bd.max_E, 1), 4), 512));
+    k_edge_distance_b<<<dim3(blocks, bd.nslots), 256, 0, st>>>(d_ctx);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int b_group_max_fill(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
+    if (bd.nslots == 0 || bd.max_C == 0) return SG_OK;
+    k_group_max_rows_b<<<dim3(bd.max_C, bd.nslots), 256, 0, st>>>(d_ctx);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int b_segment_max(const SlotCtx* d_ctx, const BatchDims& bd, int layers, hipStream_t st) {
+    if (bd.nslots == 0 || bd.max_N == 0) return SG_OK;
+    k_segment_max64_b<<<dim3(sg::cdiv(bd.max_N, kRowsPerBlock), bd.nslots), 256, 0, st>>>(d_ctx, layers);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int b_export_eval(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
+    if (bd.nslots == 0) return SG_OK;
+    k_export_b<<<dim3(std::max(1, std::min(sg::cdiv(bd.max_V, 256), 1024)), bd.nslots), 256, 0, st>>>(d_ctx);
+    const size_t dyn = (size_t)std::min(std::max(bd.max_ins, 1), kInsLds) * 16;     // every scene with max_ins <= kInsLds fits
+    k_eval_counts_b<<<dim3(std::max(1, std::min(sg::cdiv(bd.max_V, 1024), 256)), bd.nslots), 256, dyn, st>>>(d_ctx);
+    k_eval_first_sem_b<<<dim3(sg::cdiv(std::max(bd.max_ins, 1), 256), bd.nslots), 256, 0, st>>>(d_ctx);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+void eval_finish(const uint32_t* h, int max_ins, float* h_iou_sem, float* h_iou_ins, float* h_acc) {
+    const uint32_t* ins_p = h + 128;
+    const uint32_t* ins_t = ins_p + max_ins;
+    const uint32_t* ins_b = ins_t + max_ins;
+    const int32_t* first_sem = reinterpret_cast<const int32_t*>(ins_b + 2 * (size_t)max_ins);
+    for (int c = 0; c < 40; ++c) {
+        h_iou_sem[c] = (float)h[80 + c];                                  // I (model.py:626)
+        h_iou_sem[40 + c] = (float)(h[c] + h[40 + c] - h[80 + c]);        // U (model.py:627)
+    }
+    for (int c = 0; c < 80; ++c) h_iou_ins[c] = 0.f;
+    for (int i = 0; i < max_ins; ++i) {                                   // model.py:633-639
+        if (!ins_p[i]) continue;
+        int slot = first_sem[i] - 1;
+        if (slot < 0) slot += 40;                                         // Python negative index wrap
+        if (slot < 0 || slot >= 40) continue;
+        h_iou_ins[slot] += (float)ins_b[i];
+        h_iou_ins[40 + slot] += (float)(ins_p[i] + ins_t[i] - ins_b[i]);
+    }
+    auto ratio = [](uint32_t a, uint32_t b) { return b ? (float)((double)a / (double)b) : NAN; };
+    h_acc[0] = ratio(h[121], h[120]);
+    h_acc[1] = ratio(h[122], h[120]);
+    h_acc[2] = ratio(h[124], h[123]);
+    h_acc[3] = ratio(h[126], h[125]);
 }
 
 }  // namespace sg
@@ -461,28 +638,7 @@ int sg_evaluate(const int32_t* d_gt, const int32_t* d_sem_pred, const int32_t* d
     std::vector<uint32_t> h(n);
     SG_HIP(hipMemcpyAsync(h.data(), cnt, n * 4, hipMemcpyDeviceToHost, st));
     SG_HIP(hipStreamSynchronize(st));
-    const uint32_t* ins_p = h.data() + 128;
-    const uint32_t* ins_t = ins_p + max_ins;
-    const uint32_t* ins_b = ins_t + max_ins;
-    const int32_t* first_sem = reinterpret_cast<const int32_t*>(ins_b + 2 * (size_t)max_ins);
-    for (int c = 0; c < 40; ++c) {
-        h_iou_sem[c] = (float)h[80 + c];                                  // I (model.py:626)
-        h_iou_sem[40 + c] = (float)(h[c] + h[40 + c] - h[80 + c]);        // U (model.py:627)
-    }
-    for (int c = 0; c < 80; ++c) h_iou_ins[c] = 0.f;
-    for (int i = 0; i < max_ins; ++i) {                                   // model.py:633-639
-        if (!ins_p[i]) continue;
-        int slot = first_sem[i] - 1;
-        if (slot < 0) slot += 40;                                         // Python negative index wrap
-        if (slot < 0 || slot >= 40) continue;
-        h_iou_ins[slot] += (float)ins_b[i];
-        h_iou_ins[40 + slot] += (float)(ins_p[i] + ins_t[i] - ins_b[i]);
-    }
-    auto ratio = [](uint32_t a, uint32_t b) { return b ? (float)((double)a / (double)b) : NAN; };
-    h_acc[0] = ratio(h[121], h[120]);
-    h_acc[1] = ratio(h[122], h[120]);
-    h_acc[2] = ratio(h[124], h[123]);
-    h_acc[3] = ratio(h[126], h[125]);
+    sg::eval_finish(h.data(), max_ins, h_iou_sem, h_iou_ins, h_acc);
     return SG_OK;
 }
 

@@ -15,6 +15,7 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include "engine_ctx.h"
 #include "knn_device.h"
 #include "sg_common.h"
 
@@ -101,15 +102,15 @@ __global__ __launch_bounds__(64) void k_chunk_boxes(const float* __restrict__ da
 // -- and boxes its 32-point chunks.  At ~1000 scenes/s the pipelines issue ~100k runtime calls per second, so launches
 // saved are throughput.
 constexpr int kSortCap = 2048;
-__global__ __launch_bounds__(256) void k_segment_sort_boxes(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
-                                                            const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
-                                                            float* __restrict__ segbox, int32_t* __restrict__ sperm,
-                                                            float* __restrict__ chunk_box, double* __restrict__ seg_sums) {
+__device__ __forceinline__ void segment_sort_boxes_body(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                                                        const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
+                                                        float* __restrict__ segbox, int32_t* __restrict__ sperm,
+                                                        float* __restrict__ chunk_box, double* __restrict__ seg_sums, int s) {
     __shared__ unsigned long long key[kSortCap];
     __shared__ float red[4][8];
     __shared__ double dred[4][3];
     __shared__ float bx[8];
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = seg_off[s], n = seg_off[s + 1] - lo;
     // 1. segment box {min xyz, max xyz, max |p|^2}
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, xx = 0.f;
@@ -200,6 +201,17 @@ __global__ __launch_bounds__(256) void k_segment_sort_boxes(const float* __restr
         }
     }
 }
+__global__ __launch_bounds__(256) void k_segment_sort_boxes(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                                                            const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
+                                                            float* __restrict__ segbox, int32_t* __restrict__ sperm,
+                                                            float* __restrict__ chunk_box, double* __restrict__ seg_sums) {
+    segment_sort_boxes_body(data, seg_points, seg_off, seg_chunk_off, segbox, sperm, chunk_box, seg_sums, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_segment_sort_boxes_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.S) return;
+    segment_sort_boxes_body(c.data, c.seg_points, c.seg_off, c.seg_chunk_off, c.segbox, c.sperm, c.chunk_box, c.seg_sums, blockIdx.x);
+}
 
 // coordinate sums of every segment (the library-sort fallback of sg_segment_sort_boxes; same values as the fused kernel's)
 __global__ __launch_bounds__(256) void k_segment_sums(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
@@ -225,12 +237,11 @@ __global__ __launch_bounds__(256) void k_segment_sums(const float* __restrict__ 
 // Everything a layer needs laid out per point, in ONE launch (block i = i-th segment in member order): the member arrays
 // of sg_gather_members, the centred rows of sg_center_clusters (the cluster centroids come in, the host sums the
 // per-segment coordinate sums of the sort kernel) and the sorted kNN operands of sg_knn_operands.
-__global__ void k_layer_layout(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
-                               const int32_t* __restrict__ sperm, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
-                               const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
-                               int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
-                               float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos) {
-    const int i = blockIdx.x;
+__device__ __forceinline__ void layer_layout_body(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
+                                                  const int32_t* __restrict__ sperm, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
+                                                  const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
+                                                  int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
+                                                  float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos, int i) {
     const int s = order[i];
     const int lo = seg_off[s], n = seg_off[s + 1] - lo, d = dst[i], c = cl[i];
     const float mx = cl_mean[3 * c], my = cl_mean[3 * c + 1], mz = cl_mean[3 * c + 2];
@@ -251,6 +262,20 @@ __global__ void k_layer_layout(const float* __restrict__ data, const int32_t* __
         sxyzw[d + r] = make_float4(q[0], q[1], q[2], (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);     // torch.sum(x**2, dim=1)
         smpos[d + r] = d + (ci - lo);
     }
+}
+__global__ void k_layer_layout(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
+                               const int32_t* __restrict__ sperm, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
+                               const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
+                               int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
+                               float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos) {
+    layer_layout_body(data, seg_points, seg_off, sperm, order, dst, cl, cl_mean, members, pos_of_point, cluster_of_pos, slot_of_pos, x9m, sxyzw,
+                      smpos, blockIdx.x);
+}
+__global__ void k_layer_layout_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.S) return;
+    layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, c.pos_of_point, c.cluster_of_pos,
+                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, blockIdx.x);
 }
 
 // per layer: block i = i-th segment in member order; writes the operand and the member position in SORTED order
@@ -287,15 +312,15 @@ __device__ unsigned long long g_knn5_stats[16];
 // threshold, and skips every chunk whose segment belongs to the query's former cluster.  Former clusters of <= K
 // points have no kNN list (model.py:516-518 pads them): their segments carry seg_prevcl = -1, their queries start empty
 // and nobody skips them.
-template <int K, int kSlices, bool kSeeded = false>
-__global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
+template <int K, int kSlices, bool kSeeded>
+__device__ __forceinline__ void cluster_knn_sorted_body(
     const float4* __restrict__ sxyzw, const int32_t* __restrict__ smpos, const int32_t* __restrict__ cl_off,
     const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi,
     const int32_t* __restrict__ cl_seg_off, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off, const float* __restrict__ segbox,
     const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg_arg,
-    const int32_t* __restrict__ seed = nullptr, const int32_t* __restrict__ seg_prevcl = nullptr, const int32_t* __restrict__ members = nullptr,
-    const int32_t* __restrict__ pos_of_point = nullptr, const float* __restrict__ data = nullptr) {
+    const int32_t* __restrict__ seed, const int32_t* __restrict__ seg_prevcl, const int32_t* __restrict__ members,
+    const int32_t* __restrict__ pos_of_point, const float* __restrict__ data, int t) {
     static_assert(!kSeeded || kSlices == 1, "seeding is built for one wave per tile");
     const int dbg = kKnnProfile ? dbg_arg : 0;
     // LDS per wave decides how many tiles a CU keeps in flight, and this kernel waits on memory ~45 % of the time:
@@ -311,7 +336,6 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     __shared__ float chunkbox_lds[kSlices][64];
     __shared__ int st_m[kSlotBatch], st_c0[kSlotBatch], st_d[kSlotBatch], st_pc[kSlotBatch];
     __shared__ __attribute__((aligned(16))) float st_box[kSlotBatch][8];
-    const int t = blockIdx.x;
     const int c = tile_cl[t];
     const int clo = cl_off[c], n = cl_off[c + 1] - clo;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -511,6 +535,27 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
         atomicAdd(&g_knn5_stats[4], t4 - t3);
     }
 }
+template <int K, int kSlices, bool kSeeded = false>
+__global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
+    const float4* __restrict__ sxyzw, const int32_t* __restrict__ smpos, const int32_t* __restrict__ cl_off,
+    const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi,
+    const int32_t* __restrict__ cl_seg_off, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
+    const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off, const float* __restrict__ segbox,
+    const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg_arg,
+    const int32_t* __restrict__ seed = nullptr, const int32_t* __restrict__ seg_prevcl = nullptr, const int32_t* __restrict__ members = nullptr,
+    const int32_t* __restrict__ pos_of_point = nullptr, const float* __restrict__ data = nullptr) {
+    cluster_knn_sorted_body<K, kSlices, kSeeded>(sxyzw, smpos, cl_off, tile_cl, tile_lo, tile_hi, cl_seg_off, order, dst, seg_off, seg_chunk_off,
+                                                 segbox, chunk_box, slot_of_pos, pos0, knn, dbg_arg, seed, seg_prevcl, members, pos_of_point, data,
+                                                 blockIdx.x);
+}
+template <int K, int kSlices, bool kSeeded>
+__global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.T) return;
+    cluster_knn_sorted_body<K, kSlices, kSeeded>(c.sxyzw, c.smpos, c.cl_pt_off, c.tile_cl, c.tile_lo, c.tile_hi, c.cl_seg_off, c.order, c.dst,
+                                                 c.seg_off, c.seg_chunk_off, c.segbox, c.chunk_box, c.slot_of_pos, c.pos0, c.knn, 0, c.knn_seed,
+                                                 c.seg_prevcl, c.members, c.pos_of_point, c.data, blockIdx.x);
+}
 
 
 // kNN table of one layer (rows and entries = member positions) -> rows and entries = point ids, for seeding the next layer
@@ -519,6 +564,12 @@ __global__ void k_knn_seed_points(const int32_t* __restrict__ knn, const int32_t
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * K) return;
     seed[(size_t)members[i / K] * K + i % K] = members[knn[i]];
+}
+__global__ void k_knn_seed_points_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.N * 20) return;
+    c.knn_seed[(size_t)c.members[i / 20] * 20 + i % 20] = c.members[c.knn[i]];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -753,6 +804,47 @@ int sg::knn_variant_for(int T, int override) {
     if (override == 0 || override == 1 || override == 2 || override == 4 || override == 8) return override;
     return T >= 2048 ? 8 : T >= 1024 ? 2 : 4;
 }
+
+namespace sg {
+
+// the over-segments of every slot must fit the one-launch LDS sort (max_seg <= sort cap); the engine routes scenes with
+// larger segments through the single-scene library-sort path
+bool sort_boxes_fits_lds(int max_seg) { return max_seg <= kSortCap; }
+
+int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
+    if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
+    if (bd.max_seg > kSortCap) return sg::fail(SG_EUNSUP, "b_sort_boxes: a segment of %d points exceeds the LDS sort (%d)", bd.max_seg, kSortCap);
+    k_segment_sort_boxes_b<<<dim3(bd.max_S, bd.nslots), 256, 0, st>>>(d_ctx);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int b_layer_layout(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
+    if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
+    k_layer_layout_b<<<dim3(bd.max_S, bd.nslots), 128, 0, st>>>(d_ctx);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int b_cluster_knn(const SlotCtx* d_ctx, const BatchDims& bd, int waves_per_tile, bool seeded, hipStream_t st) {
+    if (bd.nslots == 0 || bd.max_T == 0) return SG_OK;
+    const dim3 grid(bd.max_T, bd.nslots);
+    if (seeded) k_cluster_knn_sorted_b<20, 1, true><<<grid, 64, 0, st>>>(d_ctx);
+    else if (waves_per_tile == 1) k_cluster_knn_sorted_b<20, 1, false><<<grid, 64, 0, st>>>(d_ctx);
+    else if (waves_per_tile == 2) k_cluster_knn_sorted_b<20, 2, false><<<grid, 128, 0, st>>>(d_ctx);
+    else k_cluster_knn_sorted_b<20, 4, false><<<grid, 256, 0, st>>>(d_ctx);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int b_knn_seed_points(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
+    if (bd.nslots == 0 || bd.max_N == 0) return SG_OK;
+    k_knn_seed_points_b<<<dim3(sg::cdiv((long long)bd.max_N * 20, 256), bd.nslots), 256, 0, st>>>(d_ctx);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // namespace sg
 
 #ifdef SG_KNN_PROFILE
 static int g_knn5_dbg = getenv("SG_KNN_DEBUG") ? atoi(getenv("SG_KNN_DEBUG")) : 0;   // profiling knob (16 = counters + cycle stamps)

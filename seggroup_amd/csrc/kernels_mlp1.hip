@@ -10,6 +10,7 @@
 //                           (the conv is linear, so they follow from the 6x6 input moments), folded into
 //                           w' = a*w, b' = beta - a*mean;
 //   3. k_mlp1_apply       : conv + affine + LeakyReLU + max_k, then wave-reduced max/mean over the lanes.
+#include "engine_ctx.h"
 #include "sg_common.h"
 
 namespace {
@@ -25,9 +26,9 @@ __device__ inline float knn_score(float xq, float yq, float zq, float xxq, float
 
 __device__ inline float sqnorm3(float x, float y, float z) { return (x * x + y * y) + z * z; }
 
-__global__ __launch_bounds__(64) void k_mlp1_knn_moments(const float* __restrict__ samples, uint8_t* __restrict__ knn,
-                                                         double* __restrict__ partial) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void mlp1_knn_moments_body(const float* __restrict__ samples, uint8_t* __restrict__ knn,
+                                                      double* __restrict__ partial, int c) {
+    const int lane = threadIdx.x;
     const float* row = samples + ((size_t)c * 64 + lane) * 6;
     float f[6];
 #pragma unroll
@@ -91,12 +92,21 @@ __global__ __launch_bounds__(64) void k_mlp1_knn_moments(const float* __restrict
         if (lane == 0) partial[(size_t)c * 27 + q] = v;
     }
 }
+__global__ __launch_bounds__(64) void k_mlp1_knn_moments(const float* __restrict__ samples, uint8_t* __restrict__ knn,
+                                                         double* __restrict__ partial) {
+    mlp1_knn_moments_body(samples, knn, partial, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_mlp1_knn_moments_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.S) return;
+    mlp1_knn_moments_body(c.samples, c.m1_knn, c.m1_partial, blockIdx.x);
+}
 
 // one block of 27 x 32 threads: value q is summed by 32 lanes over clusters l, l+32, ... and the lane sums are
 // combined by a fixed shuffle tree (reproducible); then thread c < 64 derives channel c's folded affine
-__global__ __launch_bounds__(27 * 32) void k_mlp1_finalize(const double* __restrict__ partial, int C, const float* __restrict__ w,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ folded) {
+__device__ __forceinline__ void mlp1_finalize_body(const double* __restrict__ partial, int C, const float* __restrict__ w,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float* __restrict__ folded) {
     __shared__ double mom[27];
     {
         const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
@@ -122,10 +132,20 @@ __global__ __launch_bounds__(27 * 32) void k_mlp1_finalize(const double* __restr
     for (int k = 0; k < 6; ++k) folded[ch * 6 + k] = (float)(a_ * (double)w[ch * 6 + k]);
     folded[384 + ch] = (float)((double)beta[ch] - a_ * mean);
 }
+__global__ __launch_bounds__(27 * 32) void k_mlp1_finalize(const double* __restrict__ partial, int C, const float* __restrict__ w,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ folded) {
+    mlp1_finalize_body(partial, C, w, gamma, beta, folded);
+}
+__global__ __launch_bounds__(27 * 32) void k_mlp1_finalize_b(const sg::SlotCtx* __restrict__ cx, const float* __restrict__ w,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    mlp1_finalize_body(c.m1_partial, c.S, w, gamma, beta, c.m1_folded);
+}
 
-__global__ __launch_bounds__(64) void k_mlp1_apply(const float* __restrict__ samples, const uint8_t* __restrict__ knn,
-                                                   const float* __restrict__ folded, float* __restrict__ feat, int feat_stride) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void mlp1_apply_body(const float* __restrict__ samples, const uint8_t* __restrict__ knn,
+                                                const float* __restrict__ folded, float* __restrict__ feat, int feat_stride, int c) {
+    const int lane = threadIdx.x;
     const float* row = samples + ((size_t)c * 64 + lane) * 6;
     float f[6];
 #pragma unroll
@@ -167,8 +187,30 @@ __global__ __launch_bounds__(64) void k_mlp1_apply(const float* __restrict__ sam
         if (lane == 0) { out[ch] = mx; out[64 + ch] = (float)(sm / 64.0); }    // model.py:77-79
     }
 }
+__global__ __launch_bounds__(64) void k_mlp1_apply(const float* __restrict__ samples, const uint8_t* __restrict__ knn,
+                                                   const float* __restrict__ folded, float* __restrict__ feat, int feat_stride) {
+    mlp1_apply_body(samples, knn, folded, feat, feat_stride, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_mlp1_apply_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.S) return;
+    mlp1_apply_body(c.samples, c.m1_knn, c.m1_folded, c.feat1, 128, blockIdx.x);
+}
 
 }  // namespace
+
+namespace sg {
+
+int b_mlp1(const SlotCtx* d_ctx, const float* d_w, const float* d_g, const float* d_b, const BatchDims& bd, hipStream_t st) {
+    if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
+    k_mlp1_knn_moments_b<<<dim3(bd.max_S, bd.nslots), 64, 0, st>>>(d_ctx);
+    k_mlp1_finalize_b<<<dim3(1, bd.nslots), 27 * 32, 0, st>>>(d_ctx, d_w, d_g, d_b);
+    k_mlp1_apply_b<<<dim3(bd.max_S, bd.nslots), 64, 0, st>>>(d_ctx);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // namespace sg
 
 extern "C" {
 

@@ -1,0 +1,107 @@
+// Private layout of sg_pipeline (shared by pipeline.cpp, the single-scene path, and engine.cpp, which drives several
+// pipelines' buffers with batched launches).  Not part of the C ABI.
+#pragma once
+#include "sg_common.h"
+
+namespace sgp {
+
+constexpr int kNumEvents = 48;
+static const char* const kStageNames[] = {"contract_edges", "fps64", "mlp1", "dist1+d2h",
+                             "l2.gather", "l2.center", "l2.knn", "l2.edgeconv", "l2.segmax", "l2.gcn+dist",
+                             "l3.gather", "l3.center", "l3.knn", "l3.edgeconv", "l3.segmax", "l3.gcn+dist",
+                             "fallback_fps1024", "export", "evaluate",
+                             // sub-passes of the two EdgeConv stages (their sum is l2.edgeconv / l3.edgeconv)
+                             "l2.edgeconv.stats1", "l2.edgeconv.final", "l3.edgeconv.stats1", "l3.edgeconv.stats2",
+                             "l3.edgeconv.final"};
+constexpr int kNumStages = sizeof(kStageNames) / sizeof(kStageNames[0]);
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        n = count ? count : 1;
+        return hipMalloc((void**)&p, n * sizeof(T)) == hipSuccess ? 0 : -1;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        n = count ? count : 1;
+        return hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault) == hipSuccess ? 0 : -1;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
+}  // namespace sgp
+
+struct sg_pipeline {
+    int maxN = 0, maxS = 0, maxE = 0, maxV = 0, maxT = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t dev_bytes = 0, pin_bytes = 0;
+
+    // weights (device)
+    sgp::DevBuf<float> w;   // all parameters, offsets below
+    size_t o_m1w, o_m1g, o_m1b, o_m2w, o_m2g, o_m2b, o_g2, o_m3w1, o_m3g1, o_m3b1, o_m3w2, o_m3g2, o_m3b2, o_g3, o_g2t, o_g3t;
+
+    // device work buffers
+    sgp::DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_eval, ws_sort;
+    sgp::DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, slot_of_pos, sperm, smpos, seg_chunk_off, knn, knn_seed, desc, tables, labels;
+    sgp::DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf, segbox, chunk_box, chunk_table;
+
+    // pinned host staging
+    sgp::PinBuf<int32_t> h_adj, h_desc, h_tables, h_count, h_chunk_off;
+    sgp::PinBuf<float> h_dist, h_feat, h_samples;
+    sgp::DevBuf<double> seg_sums;          // [S,3] coordinate sums of every over-segment (layer-invariant)
+    sgp::PinBuf<double> h_seg_sums;
+
+    hipEvent_t ev[sgp::kNumEvents];
+    int ev_stage[sgp::kNumEvents];
+    int n_ev = 0;
+    float stage_ms[sgp::kNumStages];
+
+    // stage timing (sg_pipeline_set_timing): 2 = an event after every stage, 1 = only around the in-cluster kNN and the
+    // EdgeConv passes (what bench.py's roofline needs: ~10 instead of ~25 events per scene, which cost ~6 % of the
+    // throughput with 16 pipelines in flight), 0 = none
+    int timing = 2;
+    int knn_variant = -1;        // sg_pipeline_set_knn_variant: < 0 = by tile count
+    static bool kernel_stage(int stage) { return stage == 6 || stage == 12 || (stage >= 19 && stage <= 23); }
+    void mark_kernel_start() {                                // level 1: the event a timed kernel stage is measured from
+        if (timing == 1) record(-1);
+    }
+    void mark(int stage) {
+        if (timing == 2 || (timing == 1 && kernel_stage(stage))) record(stage);
+    }
+    void record(int stage) {
+        if (n_ev < sgp::kNumEvents) {
+            (void)hipEventRecord(ev[n_ev], stream);
+            ev_stage[n_ev] = stage;
+            ++n_ev;
+        }
+    }
+};
+
+namespace sgp {
+
+struct LayerDesc {               // host view of one frozen numbering + what the device needs for it
+    int C = 0, T = 0;
+    std::vector<int32_t> root, cl_of_seg, order, cl_seg_off, cl_pt_off, dst;
+};
+
+inline int freeze_layer(const sg_partition* part, int S, LayerDesc& L) {
+    L.root.resize(S); L.cl_of_seg.resize(S); L.order.resize(S); L.cl_seg_off.resize(S + 1); L.cl_pt_off.resize(S + 1); L.dst.resize(S);
+    L.C = sg_partition_layer(part, L.root.data(), L.cl_of_seg.data(), L.order.data(), L.cl_seg_off.data(), L.cl_pt_off.data(), L.dst.data());
+    return L.C;
+}
+
+// Device descriptor block of one layer, carved from ONE pinned buffer and shipped in ONE H2D copy.
+struct DescOffsets {
+    size_t order, dst, cl, cl_pt_off, cl_seg_off, tile_cl, tile_lo, tile_hi, goff, gidx, adj, rowptr, col, eid,
+        slot_chunk0, cl_chunk_off, tile_chunk0, seg_prevcl, cl_mean, total;
+};
+
+}  // namespace sgp

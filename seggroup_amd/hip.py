@@ -121,6 +121,14 @@ SIGNATURES = {
     "sg_pipeline_device_bytes": (_Z, [vp]),
     "sg_pipeline_forward": (_I, [vp, vp, _I, vp, vp]),
     "sg_batch_forward": (_I, [vp, _I, vp, _I, _I, vp, vp, vp, vp, _I]),
+    "sg_engine_create": (vp, [_I, _I, _I, _I, vp, _I, _I]),
+    "sg_engine_destroy": (None, [vp]),
+    "sg_engine_submit": (_I, [vp, vp, _I, _I, vp, vp, vp, _I]),
+    "sg_engine_wait": (_I, [vp, _I]),
+    "sg_engine_set_timing": (_I, [vp, _I]),
+    "sg_engine_set_knn_variant": (_I, [vp, _I]),
+    "sg_engine_stage_times": (C.c_longlong, [vp, vp, _I, _I]),
+    "sg_engine_device_bytes": (_Z, [vp]),
     "sg_pipeline_stage_times": (_I, [vp, vp, _I]),
     "sg_pipeline_set_timing": (_I, [vp, _I]),
     "sg_pipeline_set_knn_variant": (_I, [vp, _I]),

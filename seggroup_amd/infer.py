@@ -56,7 +56,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL on ROCm)')
     p.add_argument('--port', type=int, default=2344, help='rendezvous port on 127.0.0.1 (reference: 2344)')
     p.add_argument('--batch', type=int, default=64, help='scenes per batch in the packed fast path (0 = the per-scene SegModel.forward loop)')
-    p.add_argument('--inflight', type=int, default=16, help='pipelines (HIP streams) per GPU in the packed fast path')
+    p.add_argument('--inflight', type=int, default=32, help='scenes in flight per GPU in the packed fast path (engine groups of 8)')
     p.add_argument('--no-cache', action='store_true', help='do not build / use packed scene files (dataset/scannet/cache/...)')
     return p
 
@@ -252,11 +252,11 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     for bi, batch in enumerate(batches):
         scenes = [f.result() for f in pending]
         pending = [pool.submit(stage, n) for n in batches[bi + 1]] if bi + 1 < len(batches) else []
-        if runner is None or any(not runner.pipes[0].fits(s_) for s_ in scenes):
-            caps = [runner.pipes[0].caps] if runner is not None else []
+        if runner is None or any(not runner.fits(s_) for s_ in scenes):
+            caps = runner.caps if runner is not None else None
             if runner is not None:
                 runner.close()
-            runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps[0] if caps else None, timing=0)
+            runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps, timing=0)
         res = runner.run(scenes, mode, writer=writer, out_dirs=[model.output_root(s_.name) for s_ in scenes], formats=formats)
         for s_, r in zip(scenes, res):
             acc.add(r.iou_sem, r.iou_ins, r.acc)

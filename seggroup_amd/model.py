@@ -121,15 +121,7 @@ class Pipeline:
         self.device = torch.device(device if device is not None else "cuda")
         self.stream = stream
         self.caps = (max_points, max_segments, max_edges, max_vertices)
-        self._keep = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in w.items()}
-        k = self._keep
-        cw = hip.Weights(
-            mlp1_w=k["mlp_1.conv1.0.weight"].ctypes.data, mlp1_g=k["mlp_1.bn1.weight"].ctypes.data, mlp1_b=k["mlp_1.bn1.bias"].ctypes.data,
-            mlp2_w=k["mlp_2.conv1.0.weight"].ctypes.data, mlp2_g=k["mlp_2.bn1.weight"].ctypes.data, mlp2_b=k["mlp_2.bn1.bias"].ctypes.data,
-            gcn2_w=k["gcn_2.fc.weight"].ctypes.data,
-            mlp3_w1=k["mlp_3.conv1.0.weight"].ctypes.data, mlp3_g1=k["mlp_3.bn1.weight"].ctypes.data, mlp3_b1=k["mlp_3.bn1.bias"].ctypes.data,
-            mlp3_w2=k["mlp_3.conv2.0.weight"].ctypes.data, mlp3_g2=k["mlp_3.bn2.weight"].ctypes.data, mlp3_b2=k["mlp_3.bn2.bias"].ctypes.data,
-            gcn3_w=k["gcn_3.fc.weight"].ctypes.data)
+        cw, self._keep = _c_weights(w)
         with torch.cuda.device(self.device):
             sp = stream.cuda_stream if stream is not None else None
             self.handle = self.lib.sg_pipeline_create(max_points, max_segments, max_edges, max_vertices, C.byref(cw), sp)
@@ -178,42 +170,66 @@ class Pipeline:
             pass
 
 
-class BatchRunner:
-    """Several scenes in flight on one GPU: `inflight` pipelines (one HIP stream each) driven by native host
-    threads inside `sg_batch_forward` -- no Python between a scene's kernels."""
+def _c_weights(w: Dict[str, np.ndarray]):
+    k = {n: np.ascontiguousarray(v, dtype=np.float32) for n, v in w.items()}
+    cw = hip.Weights(
+        mlp1_w=k["mlp_1.conv1.0.weight"].ctypes.data, mlp1_g=k["mlp_1.bn1.weight"].ctypes.data, mlp1_b=k["mlp_1.bn1.bias"].ctypes.data,
+        mlp2_w=k["mlp_2.conv1.0.weight"].ctypes.data, mlp2_g=k["mlp_2.bn1.weight"].ctypes.data, mlp2_b=k["mlp_2.bn1.bias"].ctypes.data,
+        gcn2_w=k["gcn_2.fc.weight"].ctypes.data,
+        mlp3_w1=k["mlp_3.conv1.0.weight"].ctypes.data, mlp3_g1=k["mlp_3.bn1.weight"].ctypes.data, mlp3_b1=k["mlp_3.bn1.bias"].ctypes.data,
+        mlp3_w2=k["mlp_3.conv2.0.weight"].ctypes.data, mlp3_g2=k["mlp_3.bn2.weight"].ctypes.data, mlp3_b2=k["mlp_3.bn2.bias"].ctypes.data,
+        gcn3_w=k["gcn_3.fc.weight"].ctypes.data)
+    return cw, k
 
-    def __init__(self, w: Dict[str, np.ndarray], scenes: List[DeviceScene], inflight: int = 4, device=None, min_caps=None,
-                 timing: int = 2):
-        dev = torch.device(device if device is not None else scenes[0].device)
-        caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
-        if min_caps is not None:                    # regrowing: never shrink below the previous capacities
-            caps = tuple(max(a, b) for a, b in zip(caps, min_caps))
+
+class Ticket:
+    """One submitted batch: keeps the ctypes arrays alive until `Engine.wait` and names the label buffer it fills."""
+
+    def __init__(self, tid, scenes, c_scenes, c_res, c_dirs, labels, mode):
+        self.id, self.scenes, self.c_scenes, self.c_res, self.c_dirs, self.labels, self.mode = tid, scenes, c_scenes, c_res, c_dirs, labels, mode
+
+
+class Engine:
+    """The scene engine (`sg_engine_*`, csrc/engine.cpp): `groups` native host threads, each advancing up to `per_group`
+    scenes in lock-step with ONE launch per kernel and phase for all of them (scene index = grid.y).  `submit()` returns at
+    once, `wait()` blocks: a driver that submits batch k+1 before waiting for batch k keeps the GPU busy across batches.
+
+    Label vectors of a waited ticket are VIEWS into one of two pinned buffers used alternately: they stay valid until the
+    second `submit()` after theirs."""
+
+    def __init__(self, w: Dict[str, np.ndarray], caps, groups: int = 4, per_group: int = 8, device=None, timing: int = 0):
+        hip.require_device()
         self.lib = hip.lib()
-        self.device = dev
-        self.pipes = [Pipeline(w, *caps, stream=torch.cuda.Stream(device=dev), device=dev) for _ in range(inflight)]
-        for p in self.pipes:
-            p.set_timing(timing)
-        self._handles = (C.c_void_p * inflight)(*[p.handle for p in self.pipes])
-        self.max_v = caps[3]
-        self._labels = None
-        self._nstage = len(self.pipes[0].stage_times())
-        self.stage_sum = (C.c_float * 32)()
-        self.stage_count = 0
+        self.device = torch.device(device if device is not None else "cuda")
+        self.caps = tuple(int(c) for c in caps)
+        self.groups, self.per_group = int(groups), int(per_group)
+        cw, self._keep = _c_weights(w)
+        with torch.cuda.device(self.device):
+            self.handle = self.lib.sg_engine_create(*self.caps, C.byref(cw), self.groups, self.per_group)
+        if not self.handle:
+            raise hip.SgError(hip.SG_EHIP, self.lib.sg_last_error().decode())
+        self.lib.sg_engine_set_timing(self.handle, int(timing))
+        self._labels = [None, None]
+        self._turn = 0
+        self._names = [self.lib.sg_pipeline_stage_name(i).decode() for i in range(32) if self.lib.sg_pipeline_stage_name(i)]
 
-    def run(self, scenes: List[DeviceScene], mode: int = hip.MODE_INS_INFER, writer: "Optional[AsyncLabelWriter]" = None,
-            out_dirs: Optional[List[str]] = None, formats=("txt", "npy")) -> List[SceneResult]:
-        """Forward every scene; with `writer` + `out_dirs` the native threads also hand each scene's label vectors to
-        the writer pool (files appear asynchronously: call writer.flush()).  The returned `labels` arrays are VIEWS into
-        this runner's pinned buffer: valid until the next `run()`; copy what has to outlive it."""
+    def fits(self, sc: DeviceScene) -> bool:
+        return sc.N <= self.caps[0] and sc.S <= self.caps[1] and sc.E0 <= self.caps[2] and sc.V <= self.caps[3]
+
+    def submit(self, scenes: List[DeviceScene], mode: int = hip.MODE_INS_INFER, writer: "Optional[AsyncLabelWriter]" = None,
+               out_dirs: Optional[List[str]] = None, formats=("txt", "npy")) -> Ticket:
         n = len(scenes)
-        if any(not self.pipes[0].fits(s) for s in scenes):
-            raise ValueError("BatchRunner.run: a scene exceeds the capacities this runner was created with")
-        if self._labels is None or self._labels.shape[0] < n:
-            self._labels = torch.empty((n, hip.NUM_LABEL_VECTORS, self.max_v), dtype=torch.int32).pin_memory()
+        if any(not self.fits(s) for s in scenes):
+            raise ValueError("Engine.submit: a scene exceeds the capacities this engine was created with")
+        slot = self._turn
+        self._turn ^= 1
+        buf = self._labels[slot]
+        if buf is None or buf.shape[0] < n:
+            buf = self._labels[slot] = torch.empty((max(n, 1), hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32).pin_memory()
         c_scenes = (hip.Scene * n)(*[s.c_struct for s in scenes])
         c_res = (hip.Result * n)()
         for i in range(n):
-            c_res[i].h_labels = self._labels[i].data_ptr()
+            c_res[i].h_labels = buf[i].data_ptr()
         c_dirs, wh, fm = None, None, 0
         if writer is not None and out_dirs is not None:
             for d_ in out_dirs:
@@ -222,26 +238,63 @@ class BatchRunner:
             wh = writer.handle
             fm = (1 if "txt" in formats else 0) | (2 if "npy" in formats else 0)
         with torch.cuda.device(self.device):
-            rc = self.lib.sg_batch_forward(self._handles, len(self.pipes), c_scenes, n, mode, c_res, self.stage_sum, wh, c_dirs, fm)
-        hip.check(rc)
-        self.stage_count += n
-        nvec = 14 if mode == hip.MODE_INS_INFER else 6
-        lab = self._labels.numpy()
+            tid = self.lib.sg_engine_submit(self.handle, c_scenes, n, mode, c_res, wh, c_dirs, fm)
+        hip.check(tid)
+        return Ticket(tid, list(scenes), c_scenes, c_res, c_dirs, buf, mode)
+
+    def wait(self, t: Ticket) -> List[SceneResult]:
+        hip.check(self.lib.sg_engine_wait(self.handle, t.id))
+        nvec = 14 if t.mode == hip.MODE_INS_INFER else 6
+        lab = t.labels.numpy()
         nv = hip.NUM_LABEL_VECTORS                  # scene i's vectors are packed at stride V_i inside its slot
-        return [SceneResult(lab[i].reshape(-1)[:nv * scenes[i].V].reshape(nv, scenes[i].V), nvec, c_res[i]) for i in range(n)]
+        return [SceneResult(lab[i].reshape(-1)[:nv * s.V].reshape(nv, s.V), nvec, t.c_res[i]) for i, s in enumerate(t.scenes)]
+
+    def run(self, scenes: List[DeviceScene], mode: int = hip.MODE_INS_INFER, writer: "Optional[AsyncLabelWriter]" = None,
+            out_dirs: Optional[List[str]] = None, formats=("txt", "npy")) -> List[SceneResult]:
+        """Forward every scene; with `writer` + `out_dirs` the native threads also hand each scene's label vectors to
+        the writer pool (files appear asynchronously: call writer.flush())."""
+        return self.wait(self.submit(scenes, mode, writer, out_dirs, formats))
+
+    def set_knn_variant(self, variant: int) -> int:
+        return self.lib.sg_engine_set_knn_variant(self.handle, int(variant))
 
     def mean_stage_ms(self) -> Dict[str, float]:
-        names = [self.lib.sg_pipeline_stage_name(i).decode() for i in range(self._nstage)]
-        return {nm: float(self.stage_sum[i]) / max(self.stage_count, 1) for i, nm in enumerate(names)}
+        """Device time per stage and SCENE: the duration of every batched launch divided by the scenes it covered."""
+        buf = (C.c_double * 32)()
+        n = self.lib.sg_engine_stage_times(self.handle, buf, 32, 0)
+        return {nm: float(buf[i]) / max(int(n), 1) for i, nm in enumerate(self._names)}
 
     def reset_stage_stats(self):
-        for i in range(32):
-            self.stage_sum[i] = 0.0
-        self.stage_count = 0
+        self.lib.sg_engine_stage_times(self.handle, None, 0, 1)
+
+    def device_bytes(self) -> int:
+        return int(self.lib.sg_engine_device_bytes(self.handle))
 
     def close(self):
-        for p in self.pipes:
-            p.close()
+        if getattr(self, "handle", None):
+            self.lib.sg_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchRunner(Engine):
+    """`inflight` scenes in flight on one GPU: the engine with capacities taken from a list of scenes (the driver's and
+    the tests' entry point).  inflight >= 16 runs inflight // 8 groups of 8 scenes."""
+
+    def __init__(self, w: Dict[str, np.ndarray], scenes: List[DeviceScene], inflight: int = 4, device=None, min_caps=None,
+                 timing: int = 0, per_group: Optional[int] = None):
+        dev = torch.device(device if device is not None else scenes[0].device)
+        caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+        if min_caps is not None:                    # regrowing: never shrink below the previous capacities
+            caps = tuple(max(a, b) for a, b in zip(caps, min_caps))
+        if per_group is None:
+            per_group = min(8, max(1, inflight // 2))
+        super().__init__(w, caps, groups=max(1, inflight // per_group), per_group=per_group, device=dev, timing=timing)
 
 
 class AsyncLabelWriter:

@@ -238,16 +238,68 @@ def test_pipeline_larger_than_scene_and_ragged_batches(golden_index, weight_sets
         for i in range(14):
             assert np.array_equal(res.labels[i], g[f"ins.label.{hip.LABEL_NAMES[i]}"].astype(np.int32)), (n, i)
     big.close()
-    runner = BatchRunner(w, scenes, inflight=3, device="cuda:0")
-    for _ in range(2):
-        out = runner.run(scenes, hip.MODE_INS_INFER)
-        for n, sc, res in zip(names, scenes, out):
-            g = load_golden(n)
-            assert res.labels.shape == (14, sc.V)
-            for i in range(14):
-                assert np.array_equal(res.labels[i], g[f"ins.label.{hip.LABEL_NAMES[i]}"].astype(np.int32)), (n, i)
-            assert np.array_equal(res.iou_ins, g["ins.metric.1"])
+    # the engine: groups of scenes of DIFFERENT sizes advance in lock-step through batched launches (grid.y = scene); one
+    # of them needs the FPS-1024 fallback, which runs for that scene alone
+    for inflight, per_group in ((3, 1), (4, 4), (8, 3), (2, 2)):
+        runner = BatchRunner(w, scenes, inflight=inflight, per_group=per_group, device="cuda:0")
+        for _ in range(2):
+            out = runner.run(scenes, hip.MODE_INS_INFER)
+            for n, sc, res in zip(names, scenes, out):
+                g = load_golden(n)
+                assert res.labels.shape == (14, sc.V)
+                for i in range(14):
+                    assert np.array_equal(res.labels[i], g[f"ins.label.{hip.LABEL_NAMES[i]}"].astype(np.int32)), (n, i, inflight, per_group)
+                assert np.array_equal(res.iou_ins, g["ins.metric.1"]) and np.array_equal(res.iou_sem, g["ins.metric.0"])
+                assert res.used_fallback == (n == "island_20k")
+        runner.close()
+    # sem_infer through the engine (returns after the structural layer: 6 label vectors)
+    ws = weight_sets["sem_infer"]
+    runner = BatchRunner(ws, scenes, inflight=4, per_group=2, device="cuda:0")
+    out = runner.run(scenes, hip.MODE_SEM_INFER)
+    for n, sc, res in zip(names, scenes, out):
+        g = load_golden(n)
+        assert res.n_vectors == 6
+        for i in range(6):
+            assert np.array_equal(res.labels[i], g[f"sem.label.{hip.LABEL_NAMES[i]}"].astype(np.int32)), (n, i)
+        assert np.array_equal(res.iou_sem, g["sem.metric.0"]) and np.array_equal(res.iou_ins, g["sem.metric.1"])
     runner.close()
+
+
+def test_engine_pipelined_tickets_odd_scenes_and_errors(weight_sets):
+    """Engine vs single pipeline on scenes the fixtures do not cover -- 2-point segments, duplicates, V != N, an island, a
+    segment too large for the one-launch LDS sort (library-sort path inside a batched phase) -- with two tickets in flight
+    (submit, submit, wait, wait); then a scene that exceeds the engine's capacity must fail its ticket cleanly and leave the
+    engine usable."""
+    import torch
+    from seggroup_amd import hip, synthetic
+    from seggroup_amd.model import BatchRunner, Pipeline
+    from seggroup_amd.scene import DeviceScene
+    W = weight_sets["ins_infer"]
+    host = [synthetic.make_scene(n, s, seed, **kw) for n, s, seed, kw, mode in FUZZ if mode == "ins_infer"]
+    host.append(synthetic.make_scene(30000, 6, 140, min_seg=4))                # ~5,000-point segments: beyond the LDS sort cap
+    scenes = [DeviceScene.from_synthetic(h, device="cuda:0") for h in host]
+    assert max(int(s.h_seg_size.max()) for s in scenes) > 2048
+    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+    solo = Pipeline(W, *caps, device="cuda:0")
+    want = [_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
+    solo.close()
+    eng = BatchRunner(W, scenes, inflight=6, per_group=3, device="cuda:0", timing=1)
+    a, b = scenes[:5], scenes[5:]
+    t1 = eng.submit(a, hip.MODE_INS_INFER)
+    t2 = eng.submit(b, hip.MODE_INS_INFER)
+    got = [_digest(r) for r in eng.wait(t1)] + [_digest(r) for r in eng.wait(t2)]
+    assert got == want
+    ms = eng.mean_stage_ms()
+    assert ms["l2.knn"] > 0 and ms["l3.edgeconv.stats2"] > 0
+    # capacity violation: the ticket fails, nothing hangs, the next ticket is fine
+    big = DeviceScene.from_synthetic(synthetic.make_scene(caps[0] + 5000, 50, 141), device="cuda:0")
+    eng2 = BatchRunner(W, scenes[:2], inflight=2, per_group=2, device="cuda:0")
+    c_ok = eng2.submit(scenes[:2], hip.MODE_INS_INFER)
+    assert [_digest(r) for r in eng2.wait(c_ok)] == want[:2]
+    with pytest.raises(ValueError):
+        eng2.submit([big], hip.MODE_INS_INFER)
+    assert [_digest(r) for r in eng2.run(scenes[:2], hip.MODE_INS_INFER)] == want[:2]
+    eng.close(); eng2.close()
 
 
 def test_packed_scene_and_fast_driver_match_reference_capture(tmp_path, golden_index, weight_sets):
@@ -391,8 +443,8 @@ def _digest(res):
 
 
 def test_batch_of_64_full_size_scenes_through_the_concurrent_path(golden_index, weight_sets):
-    """BASELINE.json configs[2]: 64 distinct 150k-point / 1.5k-segment scenes through the CONCURRENT path (BatchRunner,
-    16 scenes in flight -- what bench.py times), twice.  Every scene's 14 label vectors, metric tensors and cluster trace
+    """BASELINE.json configs[2]: 64 distinct 150k-point / 1.5k-segment scenes through the CONCURRENT path (the scene engine,
+    4 groups x 8 scenes advancing through batched launches -- what bench.py times), twice.  Every scene's 14 label vectors, metric tensors and cluster trace
     must equal (i) the same scene through a single default-stream pipeline and (ii), for the `scene_150k` fixture seed that
     rides in the batch, the digests of the reference capture in tests/golden/index.json.  A race on a shared buffer, a
     stream-ordering slip or cross-scene state would show here and nowhere in the single-pipeline tests."""
@@ -409,7 +461,7 @@ def test_batch_of_64_full_size_scenes_through_the_concurrent_path(golden_index, 
     want = [_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
     solo.close()
     assert len(set(want)) == 64                                    # the scenes really are distinct
-    runner = BatchRunner(W, scenes, inflight=16, device="cuda:0", timing=1)
+    runner = BatchRunner(W, scenes, inflight=32, device="cuda:0", timing=1)        # the engine: 4 groups x 8 scenes in lock-step
     for rep in range(2):
         order = list(range(64)) if rep == 0 else list(range(63, -1, -1))      # second pass: other scene -> slot assignment
         res = runner.run([scenes[i] for i in order], hip.MODE_INS_INFER)
