@@ -73,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--scenes-total", type=int, default=0,
                     help="strong scaling: ONE set of this many scenes sharded i mod W over the ranks (configs[3]: 1201); "
                          "a step = one pass over the rank's shard in batches of --batch")
-    ap.add_argument("--groups", type=int, default=4, help="engine groups per GPU (host thread + HIP stream each)")
+    ap.add_argument("--groups", type=int, default=6, help="engine groups per GPU (host thread + HIP stream each)")
     ap.add_argument("--per-group", type=int, default=8, help="scenes a group advances in lock-step through batched launches")
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--segments", type=int, default=1500)
@@ -234,10 +234,10 @@ def main(argv=None):
     batches = [scenes[k:k + args.batch] for k in range(0, len(scenes), args.batch)]
 
     def run_steps(k, record=True):
-        """k steps; a step = every scene of the rank's batch (or shard) through SegModel.forward.  Batches are queued one
-        ahead (submit k+1, then wait for k), as a driver with a stream of scenes does: the engine's groups never drain
+        """k steps; a step = every scene of the rank's batch (or shard) through SegModel.forward.  Batches are queued two
+        ahead (submit k+2, then wait for k), as a driver with a stream of scenes does: the engine's groups never drain
         between two batches.  Every batch is waited for and its results consumed inside the call."""
-        last, pending = None, None
+        last, pending = None, []
 
         def consume(res):
             if record:
@@ -250,12 +250,11 @@ def main(argv=None):
 
         for _ in range(k):
             for b in batches:
-                t = runner.submit(b, hip.MODE_INS_INFER)
-                if pending is not None:
-                    last = consume(runner.wait(pending))
-                pending = t
-        if pending is not None:
-            last = consume(runner.wait(pending))
+                pending.append(runner.submit(b, hip.MODE_INS_INFER))
+                if len(pending) > 2:
+                    last = consume(runner.wait(pending.pop(0)))
+        while pending:
+            last = consume(runner.wait(pending.pop(0)))
         return last
 
     def barrier():
@@ -263,6 +262,7 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    runner.profile(enable=True)
     run_steps(args.warmup, record=False)
     runner.reset_stage_stats()
     barrier()
@@ -270,6 +270,7 @@ def main(argv=None):
     last_results = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    engine_profile = {k_: round(v, 3) for k_, v in runner.profile().items()}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -416,6 +417,7 @@ def main(argv=None):
                                      "== the same scenes through one default-stream pipeline"},
             "with_label_files_scenes_per_s": with_files or None,
             "pseudo_label_mIoU": {"semantic": round(miou_sem, 4), "instance": round(miou_ins, 4), "scenes": int(vec[164])},
+            "engine_profile": engine_profile,
             "cluster_trace_scene0": batch_trace0, "scene_generation_s": round(gen_s, 1),
         }
         print(json.dumps(out), flush=True)

@@ -441,6 +441,9 @@ int sg_engine_set_knn_variant(sg_engine* e, int variant);
  * last reset, in sg_pipeline_stage_name order; returns the number of scenes those launches covered */
 long long sg_engine_stage_times(sg_engine* e, double* h_ms_sum, int capacity, int reset);
 size_t sg_engine_device_bytes(const sg_engine* e);
+/* development aid: wall time of the group threads since the last reset -- out[0] super-steps, [1] scenes, [2] ms inside
+ * super-steps, [3] of which blocked in stream synchronisation, [4] ms waiting for work; enable != 0 turns the accounting on */
+int sg_engine_profile(sg_engine* e, double* out, int reset, int enable);
 
 /* per-stage device time of the last forward, in milliseconds (HIP events on the pipeline's stream);
  * names via sg_pipeline_stage_name(i), count returned. */

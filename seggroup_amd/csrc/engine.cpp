@@ -20,6 +20,7 @@
 // sg_engine_submit() returns at once, so a driver can queue the next batch before the previous one has drained.
 // Kernel bodies are shared with the single-scene path, so results are bit-identical to sg_pipeline_forward (tested).
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <deque>
@@ -38,6 +39,19 @@ using sg::BatchDims;
 using sg::SlotCtx;
 
 constexpr int kMaxGroupEvents = 24;
+
+// SG_ENGINE_PROFILE=1: wall time of the group threads split into host work (grouping, descriptors, launch calls), time
+// blocked in hipStreamSynchronize and time idle waiting for work; printed by sg_engine_destroy -- a development aid
+bool g_profile = getenv("SG_ENGINE_PROFILE") != nullptr;
+thread_local long long tl_ns_sync = 0;
+inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline hipError_t timed_sync(hipStream_t st) {
+    if (!g_profile) return hipStreamSynchronize(st);
+    const long long t0 = now_ns();
+    const hipError_t e = hipStreamSynchronize(st);
+    tl_ns_sync += now_ns() - t0;
+    return e;
+}
 const char* const kLabelNames[SG_NUM_LABEL_VECTORS] = {"layer_1.seg", "layer_1.ins", "layer_1.sem", "layer_2.seg", "layer_2.ins",
                                                        "layer_2.sem", "layer_3.seg", "layer_3.ins", "layer_3.sem", "layer_4.seg",
                                                        "layer_4.ins", "layer_4.sem", "final.ins", "final.sem"};
@@ -99,6 +113,7 @@ struct Run {
     bool dist_in_outbox = true;
     std::vector<float> big_dist;               // rare: more edges than the outbox holds
     std::vector<double> seg_sums;              // [S,3] kept for the cluster centroids of both layers
+    std::vector<int32_t> chunk_off;            // [S+1] first 32-point chunk of every segment (re-shipped with every phase's parameters)
     // fixed carve of the slot's workspaces
     uint32_t* bitmap = nullptr;
     int* block_count = nullptr;
@@ -149,7 +164,10 @@ struct sg_engine {
     std::condition_variable cv_work, cv_done;
     std::deque<std::shared_ptr<Job>> jobs;
     int next_id = 0;
+    int idle_groups = 0;                  // groups waiting for work (under mu)
     bool stop = false;
+
+    std::atomic<long long> ns_sync{0}, ns_step{0}, ns_idle{0}, n_steps{0}, n_step_scenes{0};     // SG_ENGINE_PROFILE
 
     std::mutex mu_times;
     double stage_ms_sum[kNumStages] = {0};
@@ -232,13 +250,13 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
         r.o_dist = box.take<float>((size_t)r.out_rows, &c.dist1_out);
         c.samples = pl->samples.p; c.ws_fps = reinterpret_cast<float*>(pl->ws_fps.p);
         if (mode == SG_MODE_INS_INFER) {
+            r.chunk_off.resize((size_t)S + 1);
+            r.chunk_off[0] = 0;
+            for (int s = 0; s < S; ++s) r.chunk_off[s + 1] = r.chunk_off[s] + (sc->h_seg_size[s] + 31) / 32;
             int32_t* d_co = nullptr;
             int32_t* co = par.take<int32_t>((size_t)S + 1, &d_co);
-            if (co) {
-                co[0] = 0;
-                for (int s = 0; s < S; ++s) co[s + 1] = co[s] + (sc->h_seg_size[s] + 31) / 32;
-            }
-            c.seg_chunk_off = d_co;
+            if (co) std::memcpy(co, r.chunk_off.data(), ((size_t)S + 1) * 4);
+            c.seg_chunk_off = d_co;                               // lives in THIS phase's parameter block only
             c.segbox = pl->segbox.p; c.sperm = pl->sperm.p; c.chunk_box = pl->chunk_box.p;
             lds_sort = lds_sort && sg::sort_boxes_fits_lds(r.max_seg);
         }
@@ -274,7 +292,7 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
     EG_CHECK(sg::b_edge_distance(d_ctx, bd, stream));
     EG_HIP(hipMemcpyAsync(box.h, box.d, box.used, hipMemcpyDeviceToHost, stream));
     mark(3);
-    EG_HIP(hipStreamSynchronize(stream));
+    EG_HIP(timed_sync(stream));
 
     // ---- host: layer 1 tables, structural grouping, layer 2 tables ----
     for (int i = 0; i < n; ++i) {
@@ -288,7 +306,7 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
             r.big_dist.resize(E1);
             EG_HIP(hipMemcpyAsync(r.adj.data(), r.pl->adj1.p, (size_t)E1 * 8, hipMemcpyDeviceToHost, stream));
             EG_HIP(hipMemcpyAsync(r.big_dist.data(), r.pl->dist.p, (size_t)E1 * 4, hipMemcpyDeviceToHost, stream));
-            EG_HIP(hipStreamSynchronize(stream));
+            EG_HIP(timed_sync(stream));
             h_dist = r.big_dist.data();
         } else {
             r.adj.assign(r.o_adj1, r.o_adj1 + 2 * (size_t)E1);
@@ -350,6 +368,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
         }
         tiles_total += T;
         c.order = put(Ln.order.data(), S); c.dst = put(Ln.dst.data(), S);
+        c.seg_chunk_off = put(r.chunk_off.data(), (size_t)S + 1);
         tmp.resize(S);
         for (int k = 0; k < S; ++k) tmp[k] = Ln.cl_of_seg[Ln.order[k]];
         c.cl = put(tmp.data(), S);
@@ -468,7 +487,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
         }
     }
     mark(sb + 5);
-    EG_HIP(hipStreamSynchronize(stream));
+    EG_HIP(timed_sync(stream));
 
     // ---- host: grouping on the GCN features (model.py:802-815 / 843-856) ----
     for (int i = 0; i < n; ++i) {
@@ -531,7 +550,7 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
                 EG_CHECK(sg::fps_sample_hint(sc->d_data, sc->N, 6, pl->members.p, dd + o_off, L5.C, 1024, 3, 0, pl->samples_big.p, nullptr,
                                              pl->ws_fps.p, pl->ws_fps.n, (void*)stream, max_cl));
                 EG_HIP(hipMemcpyAsync(pl->h_samples.p, pl->samples_big.p, (size_t)L5.C * 1024 * 3 * 4, hipMemcpyDeviceToHost, stream));
-                EG_HIP(hipStreamSynchronize(stream));
+                EG_HIP(timed_sync(stream));
                 EG_CHECK(sg_partition_unlabeled_fallback(r.part, L5.root.data(), L5.C, pl->h_samples.p, 1024));
                 r.out->used_fallback = 1;
             }
@@ -567,7 +586,7 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
     }
     EG_HIP(hipMemcpyAsync(box.h, box.d, box.used, hipMemcpyDeviceToHost, stream));
     mark(18);
-    EG_HIP(hipStreamSynchronize(stream));
+    EG_HIP(timed_sync(stream));
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
         sg::eval_finish(r.o_cnt, r.max_ins, r.out->iou_sem, r.out->iou_ins, r.out->acc);
@@ -632,20 +651,29 @@ void sg_engine::Group::loop() {
         std::shared_ptr<Job> job;
         int first = 0, take = 0;
         {
+            const long long t_idle = g_profile ? now_ns() : 0;
             std::unique_lock<std::mutex> lk(eng->mu);
+            ++eng->idle_groups;
             eng->cv_work.wait(lk, [&] {
                 if (eng->stop) return true;
                 for (auto& j : eng->jobs) if (j->next < j->count && j->err == 0) return true;
                 return false;
             });
-            if (eng->stop) return;
+            if (eng->stop) { --eng->idle_groups; return; }
             for (auto& j : eng->jobs) if (j->next < j->count && j->err == 0) { job = j; break; }
-            const int remaining = job->count - job->next;
-            // full groups while there is plenty of work; near the end of a job the rest is spread over all groups
-            take = std::min((int)slots.size(), std::max(1, (remaining + eng->G - 1) / eng->G));
+            // a full group's worth, unless other groups are idle too and the queue is short: then what is queued is shared
+            // with them (start of a run, last scenes of a run) instead of leaving them without work
+            long long queued = 0;
+            for (auto& j : eng->jobs) if (j->err == 0) queued += j->count - j->next;
+            const long long share = (queued + eng->idle_groups - 1) / std::max(eng->idle_groups, 1);
+            take = (int)std::min<long long>(std::min<long long>((long long)slots.size(), job->count - job->next), std::max<long long>(1, share));
+            --eng->idle_groups;
             first = job->next;
             job->next += take;
+            if (g_profile) eng->ns_idle += now_ns() - t_idle;
         }
+        const long long t_step = g_profile ? now_ns() : 0;
+        tl_ns_sync = 0;
         for (int i = 0; i < take; ++i) {
             Run& r = runs[i];
             r.sc = &job->scenes[first + i];
@@ -662,6 +690,7 @@ void sg_engine::Group::loop() {
             else if (!runs[i].out->h_labels) rc = sg::fail(SG_EINVAL, "sg_engine: results[%d].h_labels is null", first + i);
         }
         if (rc >= 0) rc = superstep(runs.data(), take, job->mode, job->writer, job->formats);
+        if (g_profile) { eng->ns_step += now_ns() - t_step; eng->ns_sync += tl_ns_sync; ++eng->n_steps; eng->n_step_scenes += take; }
         {
             std::lock_guard<std::mutex> lk(eng->mu);
             if (rc < 0 && job->err == 0) { job->err = rc; job->msg = sg_last_error(); }
@@ -685,6 +714,12 @@ void sg_engine_destroy(sg_engine* e) {
     }
     e->cv_work.notify_all();
     for (auto& g : e->groups) if (g->th.joinable()) g->th.join();
+    if (g_profile && e->n_steps.load() > 0) {
+        const double n = (double)e->n_steps.load(), sc = (double)e->n_step_scenes.load();
+        const double step = e->ns_step.load() / n * 1e-6, syn = e->ns_sync.load() / n * 1e-6, idle = e->ns_idle.load() / n * 1e-6;
+        fprintf(stderr, "[sg engine profile] %d groups x %d: %.0f super-steps, %.2f scenes each: %.3f ms per super-step = %.3f ms blocked in stream syncs + "
+                "%.3f ms host work / launch calls; %.3f ms idle between super-steps\n", e->G, e->B, n, sc / n, step, syn, step - syn, idle);
+    }
     for (auto& g : e->groups) {
         for (sg_pipeline* p : g->slots) sg_pipeline_destroy(p);
         for (int i = 0; i < kMaxGroupEvents; ++i) if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
@@ -824,6 +859,20 @@ long long sg_engine_stage_times(sg_engine* e, double* h_ms_sum, int capacity, in
         e->scenes_timed = 0;
     }
     return n;
+}
+
+/* development aid: where the group threads' wall time went since the last reset -- out[0] super-steps, [1] scenes, [2] ms
+ * inside super-steps, [3] of which blocked in stream synchronisation, [4] ms waiting for work.  enable != 0 switches the
+ * accounting on (it is off unless SG_ENGINE_PROFILE is set). */
+int sg_engine_profile(sg_engine* e, double* out, int reset, int enable) {
+    if (!e) return sg::fail(SG_EINVAL, "sg_engine_profile: null engine");
+    if (enable) g_profile = true;
+    if (out) {
+        out[0] = (double)e->n_steps.load(); out[1] = (double)e->n_step_scenes.load();
+        out[2] = e->ns_step.load() * 1e-6; out[3] = e->ns_sync.load() * 1e-6; out[4] = e->ns_idle.load() * 1e-6;
+    }
+    if (reset) { e->n_steps = 0; e->n_step_scenes = 0; e->ns_step = 0; e->ns_sync = 0; e->ns_idle = 0; }
+    return SG_OK;
 }
 
 size_t sg_engine_device_bytes(const sg_engine* e) { return e ? e->dev_bytes : 0; }

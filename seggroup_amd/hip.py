@@ -129,6 +129,7 @@ SIGNATURES = {
     "sg_engine_set_knn_variant": (_I, [vp, _I]),
     "sg_engine_stage_times": (C.c_longlong, [vp, vp, _I, _I]),
     "sg_engine_device_bytes": (_Z, [vp]),
+    "sg_engine_profile": (_I, [vp, vp, _I, _I]),
     "sg_pipeline_stage_times": (_I, [vp, vp, _I]),
     "sg_pipeline_set_timing": (_I, [vp, _I]),
     "sg_pipeline_set_knn_variant": (_I, [vp, _I]),

@@ -194,8 +194,8 @@ class Engine:
     scenes in lock-step with ONE launch per kernel and phase for all of them (scene index = grid.y).  `submit()` returns at
     once, `wait()` blocks: a driver that submits batch k+1 before waiting for batch k keeps the GPU busy across batches.
 
-    Label vectors of a waited ticket are VIEWS into one of two pinned buffers used alternately: they stay valid until the
-    second `submit()` after theirs."""
+    Label vectors of a waited ticket are VIEWS into one of `ring` pinned buffers used in turn: they stay valid until the
+    `ring`-th `submit()` after theirs (ring = 3: two tickets can be queued behind the one being consumed)."""
 
     def __init__(self, w: Dict[str, np.ndarray], caps, groups: int = 4, per_group: int = 8, device=None, timing: int = 0):
         hip.require_device()
@@ -209,7 +209,8 @@ class Engine:
         if not self.handle:
             raise hip.SgError(hip.SG_EHIP, self.lib.sg_last_error().decode())
         self.lib.sg_engine_set_timing(self.handle, int(timing))
-        self._labels = [None, None]
+        self.ring = 3
+        self._labels = [None] * self.ring
         self._turn = 0
         self._names = [self.lib.sg_pipeline_stage_name(i).decode() for i in range(32) if self.lib.sg_pipeline_stage_name(i)]
 
@@ -222,10 +223,13 @@ class Engine:
         if any(not self.fits(s) for s in scenes):
             raise ValueError("Engine.submit: a scene exceeds the capacities this engine was created with")
         slot = self._turn
-        self._turn ^= 1
+        self._turn = (self._turn + 1) % self.ring
+        if self._labels[slot] is None or self._labels[slot].shape[0] < n:
+            # pinning hundreds of MB takes ~0.1 s: every ring slot is (re)sized at once, not one per submit
+            for k in range(self.ring):
+                if self._labels[k] is None or self._labels[k].shape[0] < n:
+                    self._labels[k] = torch.empty((max(n, 1), hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32).pin_memory()
         buf = self._labels[slot]
-        if buf is None or buf.shape[0] < n:
-            buf = self._labels[slot] = torch.empty((max(n, 1), hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32).pin_memory()
         c_scenes = (hip.Scene * n)(*[s.c_struct for s in scenes])
         c_res = (hip.Result * n)()
         for i in range(n):
@@ -266,6 +270,15 @@ class Engine:
 
     def reset_stage_stats(self):
         self.lib.sg_engine_stage_times(self.handle, None, 0, 1)
+        self.lib.sg_engine_profile(self.handle, None, 1, 0)
+
+    def profile(self, enable: bool = False) -> Dict[str, float]:
+        """Where the group threads' wall time went since the last reset (development aid)."""
+        out = (C.c_double * 8)()
+        self.lib.sg_engine_profile(self.handle, out, 0, 1 if enable else 0)
+        n = max(out[0], 1.0)
+        return {"super_steps": out[0], "scenes_per_super_step": out[1] / n, "ms_per_super_step": out[2] / n,
+                "ms_blocked_in_sync": out[3] / n, "ms_host_work": (out[2] - out[3]) / n, "ms_idle": out[4] / n}
 
     def device_bytes(self) -> int:
         return int(self.lib.sg_engine_device_bytes(self.handle))
