@@ -110,6 +110,7 @@ struct SlotCtx {
     float* ec_w2f;                     // |a| of the last layer of MLP3
     float* ec_sh2;
     float* pf;                         // [N,64] pre-activation maxima
+    int K;                             // neighbours per point (20); a run-time value on purpose: as a literal the moments kernel unrolls all slots
     int ec_blocks;                     // ceil(ceil(N/32)/4)
     int ec_mblocks;                    // ceil(N/256)
 

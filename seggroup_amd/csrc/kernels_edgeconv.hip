@@ -37,6 +37,19 @@
 // Per-block fp64 partial sums are combined in fixed order by a one-block finalize kernel, so the
 // result is bit-reproducible run to run.
 //
+// conv2 of MLP3 (64 -> 64, 78 % of the stage's flops) runs on the bf16 matrix pipe at fp32 accuracy: the fp32 MFMA issues
+// at the fp32 VECTOR rate (64 cycles per 32x32x2 on a SIMD), v_mfma_f32_32x32x16_bf16 moves 8x the k-depth in half the
+// cycles.  Every fp32 operand is cut EXACTLY into three bf16 pieces by truncation (x = x1 + x2 + x3: 8 + 8 + 8 significand
+// bits; two ANDs and two subtractions per value, the pieces are the high halves of x, x - x1 and x - x1 - x2) and the
+// six products whose weight is >= 2^-16 of the leading one are accumulated in fp32 by the matrix pipe:
+//     w x ~= w1 x1 + (w1 x2 + w2 x1) + (w1 x3 + w2 x2 + w3 x1)        dropped: w2 x3 + w3 x2 + w3 x3 <= 3 * 2^-24 |w x|
+// Each bf16 x bf16 product is exact in fp32, so the result differs from the fp32 fmaf chain only by the order of the fp32
+// additions and the dropped 2^-24 terms: measured against the float64 oracle it is as close as the fp32 MFMA was (~1e-6;
+// tolerance 1e-4).  48 bf16 MFMAs (32 cycles each) + ~180 VALU replace 64 fp32 MFMAs (64 cycles each) per neighbour slot.
+// The accumulator of conv1 is still fed straight back as the B operand: a 16-deep k block of the bf16 MFMA takes 8
+// consecutive accumulator registers of a lane (lanes 0-31: k 0-7, lanes 32-63: k 8-15), and the weights are staged in LDS
+// in exactly that channel order, already split.
+//
 // Conditioning: channels 0..2 of x_i are ABSOLUTE coordinates.  BatchNorm is invariant to a per-channel constant added to
 // its input, so every kernel here evaluates the x_i half of conv1 on x_i - [c, 0] with c = the XYZ of row 0 (any fixed point
 // near the cloud): the statistics (sum y, sum y^2 and the edge-feature moments) are then sums of values of the cloud's
@@ -48,6 +61,8 @@
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 enum { S1X = 1, S2X = 2 };     // conv1 statistics + extremum (MLP2) | conv1' -> conv2 statistics + extremum (MLP3)
 
@@ -61,7 +76,8 @@ struct Lds {
     // conv1, split by input half (e = [d, x_i], d = x_j - x_i): five K=2 steps each, k = 2s + (lane>>5) < 9 (k = 9: zero)
     float4 a1d[2][2][64];    // a1d[t][s>>2][lane][s&3] = W1[32t + (lane&31)][k]        the d columns, used every neighbour slot
     float4 a1x[2][2][64];    // a1x[t][s>>2][lane][s&3] = W1[32t + (lane&31)][9 + k]    the x_i columns, used once per point
-    float4 a2[2][8][64];     // conv2: a2[ot][st>>2][lane][st&3] = W2[32ot + (lane&31)][acc_channel(st>>4, st&15, lane>>5)]
+    // conv2, bf16 pieces: a2b[piece][ot][kb][lane] = 8 bf16 = piece of W2[32ot + (lane&31)][acc_channel(kb>>1, 8(kb&1) + j, lane>>5)], j = 0..7
+    u32x4 a2b[3][2][4][64];
     float sh1r[2][2][16];    // folded BN1 shift in accumulator-register order: sh1r[tile][half][reg] (b128 reads)
     double acc[kWaves][128]; // per-wave statistics: [0,64) sum, [64,128) sum of squares
 };
@@ -85,11 +101,30 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
         (&(part ? lds.a1x : lds.a1d)[t][s >> 2][l].x)[s & 3] = v;
     }
     if (kTwo) {
-        for (int i = tid; i < 2 * 32 * 64; i += 64 * kWaves) {
-            const int l = i & 63, st = (i >> 6) & 31, ot = i >> 11;
+        // one (ot, kb, lane) fragment per iteration: 8 weights, each cut into its three bf16 pieces
+        for (int i = tid; i < 2 * 4 * 64; i += 64 * kWaves) {
+            const int l = i & 63, kb = (i >> 6) & 3, ot = i >> 8;
             const int ch = 32 * ot + (l & 31);
-            const float v = w2[ch * 64 + acc_channel(st >> 4, st & 15, l >> 5)];
-            (&lds.a2[ot][st >> 2][l].x)[st & 3] = gamma_last[ch] < 0.f ? -v : v;
+            const bool neg = gamma_last[ch] < 0.f;
+            unsigned int p1[4], p2[4], p3[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                unsigned int h1[2], h2[2], h3[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float v = w2[ch * 64 + acc_channel(kb >> 1, 8 * (kb & 1) + 2 * jj + u, l >> 5)];
+                    if (neg) v = -v;
+                    const float a = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+                    const float r = v - a;
+                    const float b = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+                    const float c = r - b;
+                    h1[u] = __float_as_uint(a) >> 16; h2[u] = __float_as_uint(b) >> 16; h3[u] = __float_as_uint(c) >> 16;
+                }
+                p1[jj] = h1[0] | (h1[1] << 16); p2[jj] = h2[0] | (h2[1] << 16); p3[jj] = h3[0] | (h3[1] << 16);
+            }
+            lds.a2b[0][ot][kb][l] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+            lds.a2b[1][ot][kb][l] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+            lds.a2b[2][ot][kb][l] = u32x4{p3[0], p3[1], p3[2], p3[3]};
         }
     }
     if (tid < 64) {
@@ -206,26 +241,49 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc1[t][q] = fmaxf(acc1[t][q], 0.2f * acc1[t][q]);
-                // both output tiles at once: two independent accumulator chains interleaved, each A-operand read
-                // (ds_read_b32) feeds one MFMA of either chain
+                // conv2 on the bf16 matrix pipe (see the header): per 16-deep k block the 8 accumulator registers of this lane
+                // are cut into three bf16 pieces each and meet the pre-split weights in six MFMAs per output tile; the two
+                // output tiles are independent accumulator chains, interleaved
                 f32x16 acc2[2];
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc2[ot][q] = 0.f;
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int kb = 0; kb < 4; ++kb) {
+                    unsigned int q1[4], q2[4], q3[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 wa = lds.a2[0][4 * t + g][lane], wb = lds.a2[1][4 * t + g][lane];
-                        const float* pa = &wa.x;
-                        const float* pb = &wb.x;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[u], acc1[t][4 * g + u], acc2[0], 0, 0, 0);
-                            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u], acc1[t][4 * g + u], acc2[1], 0, 0, 0);
-                        }
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float v0 = acc1[kb >> 1][8 * (kb & 1) + 2 * jj], v1 = acc1[kb >> 1][8 * (kb & 1) + 2 * jj + 1];
+                        const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u);
+                        const float r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
+                        const float c0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+                        const float c1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+                        // {low half: high 16 bits of the even value, high half: high 16 bits of the odd value}
+                        q1[jj] = __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);
+                        q2[jj] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                        q3[jj] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
                     }
+                    const bf16x8 x1 = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
+                    const bf16x8 x2 = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+                    const bf16x8 x3 = __builtin_bit_cast(bf16x8, u32x4{q3[0], q3[1], q3[2], q3[3]});
+                    const bf16x8 wa1 = __builtin_bit_cast(bf16x8, lds.a2b[0][0][kb][lane]), wb1 = __builtin_bit_cast(bf16x8, lds.a2b[0][1][kb][lane]);
+                    const bf16x8 wa2 = __builtin_bit_cast(bf16x8, lds.a2b[1][0][kb][lane]), wb2 = __builtin_bit_cast(bf16x8, lds.a2b[1][1][kb][lane]);
+                    const bf16x8 wa3 = __builtin_bit_cast(bf16x8, lds.a2b[2][0][kb][lane]), wb3 = __builtin_bit_cast(bf16x8, lds.a2b[2][1][kb][lane]);
+                    // smallest terms first
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa3, x1, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb3, x1, acc2[1], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2, x2, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb2, x2, acc2[1], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x3, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x3, acc2[1], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2, x1, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb2, x1, acc2[1], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x2, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x2, acc2[1], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x1, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x1, acc2[1], 0, 0, 0);
+                }
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -284,8 +342,8 @@ template <int MODE, bool REREAD_A>
 __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.ec_blocks) return;
-    if (MODE == S1X) edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, 20, c.ec_w1, nullptr, nullptr, c.ec_g1, c.pf, c.ec_partial, blockIdx.x);
-    else edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, 20, c.ec_w1f, c.ec_sh1, c.ec_w2, c.ec_g2, c.pf, c.ec_partial, blockIdx.x);
+    if (MODE == S1X) edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, c.K, c.ec_w1, nullptr, nullptr, c.ec_g1, c.pf, c.ec_partial, blockIdx.x);
+    else edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, c.K, c.ec_w1f, c.ec_sh1, c.ec_w2, c.ec_g2, c.pf, c.ec_partial, blockIdx.x);
 }
 
 // Batch statistics of conv1's output WITHOUT evaluating it (the inner BN of MLP3): y = W1 e is linear, so
@@ -371,7 +429,7 @@ __global__ __launch_bounds__(256) void k_edge_moments(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_edge_moments_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.ec_mblocks) return;
-    edge_moments_body(c.x9m, c.knn, c.N, 20, c.ec_partial, blockIdx.x);
+    edge_moments_body(c.x9m, c.knn, c.N, c.K, c.ec_partial, blockIdx.x);
 }
 
 // moments -> folded conv1 weights and shift (one block; fixed-order sum of the per-block partials)
