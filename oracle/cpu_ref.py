@@ -216,7 +216,13 @@ def sample_clusters(data, layer: Layer, P, transform=True):
         sel[c] = ii
         blk = data[ii].copy()
         if transform:
-            mean = blk[:, :3].astype(np.float64).mean(0).astype(F32)
+            # torch's fp32 `cluster_data[:, :3].mean(0)` (model.py:421): four interleaved accumulators over the rows, added in
+            # order, divided by P (probed against torch 2.10 CPU: bit-equal on every column).  Matters when all samples of a
+            # segment coincide: the reference then normalises the rounding error of this sum, a float64 mean yields 0 / 0.
+            acc = [np.zeros(3, F32) for _ in range(4)]
+            for r in range(P):
+                acc[r & 3] = (acc[r & 3] + blk[r, :3]).astype(F32)
+            mean = ((((acc[0] + acc[1]).astype(F32) + acc[2]).astype(F32) + acc[3]).astype(F32) / F32(P)).astype(F32)
             blk[:, :3] = blk[:, :3] - mean
             with np.errstate(divide="ignore", invalid="ignore"):
                 blk[:, :3] = blk[:, :3] / np.abs(blk[:, :3]).max()

@@ -116,30 +116,36 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
 
     // rows: members tiled rep times, then the picks (model.py:413-420)
     float* out = samples + (size_t)c * P * ch_out;
-    double sx = 0, sy = 0, sz = 0;
     for (int r = tid; r < P; r += BLOCK) {
         const int local = r < rep * n ? r % n : picks[r - rep * n];
         const int p = members[lo + local];
         if (sel) sel[(size_t)c * P + r] = p;
         const float* row = data + (size_t)p * ch_in;
         for (int k = 0; k < ch_out; ++k) out[(size_t)r * ch_out + k] = row[k];
-        sx += row[0]; sy += row[1]; sz += row[2];
     }
     if (!transform) return;
 
-    // model.py:421-423: subtract the mean XYZ of the P rows, divide by the scalar max |XYZ|
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
-    __shared__ double wsum[3][16];
+    // model.py:421-423: subtract the mean XYZ of the P rows, divide by the scalar max |XYZ| -- in torch's fp32 arithmetic.
+    // `cluster_data[:, :3].mean(0)` reduces the [P, 3] view over its outer dimension with FOUR interleaved fp32
+    // accumulators (rows j, j+4, j+8, ... for j = 0..3) that are then added in order, ((a0 + a1) + a2) + a3, and divides by
+    // P (probed against torch 2.10 CPU, 900 / 900 columns bit-equal; a plain or pairwise sum matches ~30-60 %).  The order is
+    // load-bearing: for a segment whose samples all coincide (a 1-point segment tiled 64 times) the reference's output is
+    // the rounding error of this very sum, scaled to O(1) by the division below -- a float64 mean gives 0 / 0 = NaN there
+    // and the NaN spreads through MLP1's batch statistics to every distance of the scene.
+    __shared__ float part4[4][3];
+    __shared__ float mean3[3];
     __shared__ float wmax[16];
-    if constexpr (BLOCK > 64) {
-        if ((tid & 63) == 0) { wsum[0][tid >> 6] = sx; wsum[1][tid >> 6] = sy; wsum[2][tid >> 6] = sz; }
-        __syncthreads();
-        sx = sy = sz = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) { sx += wsum[0][w]; sy += wsum[1][w]; sz += wsum[2][w]; }
+    __syncthreads();                                               // the rows above are visible to the whole block
+    if (tid < 12) {
+        const int j = tid & 3, ch = tid >> 2;
+        float a = 0.f;
+        for (int r = j; r < P; r += 4) a += out[(size_t)r * ch_out + ch];
+        part4[j][ch] = a;
     }
-    const float mx = (float)(sx / P), my = (float)(sy / P), mz = (float)(sz / P);
-    __syncthreads();   // rows written above are re-read below by the same threads only; barrier orders LDS scratch reuse
+    __syncthreads();
+    if (tid < 3) mean3[tid] = (((part4[0][tid] + part4[1][tid]) + part4[2][tid]) + part4[3][tid]) / (float)P;
+    __syncthreads();
+    const float mx = mean3[0], my = mean3[1], mz = mean3[2];
     float amax = 0.f;
     for (int r = tid; r < P; r += BLOCK) {
         float* q = out + (size_t)r * ch_out;

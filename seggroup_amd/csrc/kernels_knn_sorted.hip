@@ -548,8 +548,11 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
                                                  segbox, chunk_box, slot_of_pos, pos0, knn, dbg_arg, seed, seg_prevcl, members, pos_of_point, data,
                                                  blockIdx.x);
 }
+// one wave per tile: these waves wait on memory two thirds of their life (PMC: 35 % issuing).  The seeded kernel gets a
+// fourth resident wave per SIMD by capping it at 128 VGPRs (129 -> 118, no spill: 952 -> 848 us per launch of 8 scenes); a
+// fifth wave for the unseeded one (104 -> 96 VGPRs) costs 10 spilled registers and is slower (973 -> 991 us).
 template <int K, int kSlices, bool kSeeded>
-__global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted_b(const sg::SlotCtx* __restrict__ cx) {
+__global__ __launch_bounds__(64 * kSlices, kSlices == 1 && kSeeded ? 4 : 1) void k_cluster_knn_sorted_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.T) return;
     cluster_knn_sorted_body<K, kSlices, kSeeded>(c.sxyzw, c.smpos, c.cl_pt_off, c.tile_cl, c.tile_lo, c.tile_hi, c.cl_seg_off, c.order, c.dst,

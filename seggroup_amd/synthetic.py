@@ -90,8 +90,11 @@ def _renumber_by_first_point(lab: np.ndarray) -> np.ndarray:
 
 def make_scene(num_points: int = 150000, num_segments: int = 1500, seed: int = 0, *,
                name: Optional[str] = None, knn_edges: int = 6, dup_frac: float = 0.0,
-               raw_vertices: Optional[int] = None, min_seg: int = 6, island_radius: float = 0.0) -> Scene:
+               raw_vertices: Optional[int] = None, min_seg: int = 6, island_radius: float = 0.0,
+               seg_profile: str = "voronoi") -> Scene:
     """Build one synthetic scene.
+
+    seg_profile = "scannet" switches to `make_scannet_scene` (surfaces, heavy-tailed segment sizes, V != N).
 
     dup_frac > 0 overwrites that fraction of points with copies of other points (exact
     duplicates exercise the FPS / kNN tie quirks).
@@ -104,6 +107,10 @@ def make_scene(num_points: int = 150000, num_segments: int = 1500, seed: int = 0
     """
     from scipy.spatial import cKDTree
 
+    if seg_profile == "scannet":
+        return make_scannet_scene(num_points, num_segments, seed, name=name, knn_edges=knn_edges)
+    if seg_profile != "voronoi":
+        raise ValueError(f"unknown seg_profile {seg_profile!r}")
     n, s = int(num_points), int(num_segments)
     u = uniform01(seed, 1, 6 * n).reshape(n, 6)
     data = np.empty((n, 6), dtype=np.float32)
@@ -191,6 +198,159 @@ def make_scene(num_points: int = 150000, num_segments: int = 1500, seed: int = 0
 
     return Scene(name=name or f"scene{seed:04d}_00", data=data, weak_label=weak, seg=seg.astype(np.int32),
                  adj=adj, unmap=unmap, gt=gt)
+
+
+def make_scannet_scene(num_points: int = 150000, num_segments: int = 1500, seed: int = 0, *, name: Optional[str] = None,
+                       knn_edges: int = 6) -> Scene:
+    """A scene shaped like a ScanNet scan rather than like the uniform box of `make_scene` (SURVEY.md 8d calibration):
+
+    * points lie on SURFACES: a floor, four walls and a few hundred small randomly oriented rectangles ("furniture"), with
+      ~1 cm of noise off the plane;
+    * the over-segmentation is heavy-tailed like ScanNet's normal-based segmentor: the floor is 1-2 segments (10k-30k
+      points), every wall 1-2 (3k-8k), the rest of the S segments are Voronoi cells inside the small surfaces (median ~60
+      points);
+    * K ~ S / 47 instances, ~1.3 labelled segments per instance (manual_label.zip statistics);
+    * V != N: even seeds are "sub-sampled" scans (V = 1.2 N raw vertices, several map to one point), odd seeds are "tiled"
+      scans (V = 0.85 N: 15 % of the points are exact duplicates of other points, dataset/scannet/util.py:669-681).
+
+    NumPy + SciPy + the counter-based splitmix64 stream only: the GPU box regenerates identical bytes."""
+    from scipy.spatial import cKDTree
+
+    n, s = int(num_points), int(num_segments)
+    if s < 24 or n < 40 * s // 4:
+        raise ValueError("make_scannet_scene needs >= 24 segments and >= 10 points per segment on average")
+    tiled = bool(seed & 1)
+    n_base = int(n * 0.85) if tiled else n                      # distinct points; a tiled scan repeats some of them
+    # ---- structures: (fraction of the points, number of segments) ----
+    n_small = max(8, s // 6)                                     # small surfaces ("furniture"), ~6 segments each
+    frac = np.concatenate([[0.20], np.full(4, 0.0625), np.full(n_small, 0.55 / n_small)])
+    jitter = 0.5 + uniform01(seed, 2, frac.size).astype(np.float64)
+    frac = frac * jitter
+    frac /= frac.sum()
+    struct = np.searchsorted(np.cumsum(frac), uniform01(seed, 3, n_base).astype(np.float64), side="right").clip(0, frac.size - 1)
+    u = uniform01(seed, 1, 6 * n_base).reshape(n_base, 6).astype(np.float64)
+    xyz = np.empty((n_base, 3), np.float64)
+    noise = (u[:, 2] - 0.5) * 0.02
+    # floor
+    m = struct == 0
+    xyz[m] = np.stack([u[m, 0] * 8.0, u[m, 1] * 6.0, noise[m]], 1)
+    # walls: x = 0, x = 8, y = 0, y = 6
+    for w in range(4):
+        m = struct == 1 + w
+        a, b = u[m, 0], u[m, 1] * 3.0
+        if w < 2:
+            xyz[m] = np.stack([np.full(a.shape, 8.0 * w) + noise[m], a * 6.0, b], 1)
+        else:
+            xyz[m] = np.stack([a * 8.0, np.full(a.shape, 6.0 * (w - 2)) + noise[m], b], 1)
+    # small rectangles: centre, two in-plane axes (random orientation), extents 0.15-1.0 m
+    pr = uniform01(seed, 4, 9 * n_small).reshape(n_small, 9).astype(np.float64)
+    cen = pr[:, :3] * np.array([7.0, 5.0, 2.0]) + np.array([0.5, 0.5, 0.3])
+    e1 = pr[:, 3:6] - 0.5
+    e1 /= np.linalg.norm(e1, axis=1, keepdims=True) + 1e-9
+    tmp = np.cross(e1, np.array([0.0, 0.0, 1.0]))
+    tmp[np.linalg.norm(tmp, axis=1) < 1e-6] = np.array([1.0, 0.0, 0.0])
+    e2 = tmp / np.linalg.norm(tmp, axis=1, keepdims=True)
+    e3 = np.cross(e1, e2)
+    ext = 0.15 + 0.85 * pr[:, 6:8]
+    m = struct >= 5
+    k = struct[m] - 5
+    xyz[m] = (cen[k] + e1[k] * ((u[m, 0] - 0.5) * ext[k, 0])[:, None] + e2[k] * ((u[m, 1] - 0.5) * ext[k, 1])[:, None] + e3[k] * noise[m][:, None])
+    rgb = u[:, 3:] * 2.0 - 1.0
+
+    # ---- over-segmentation: segments per structure, Voronoi cells inside each structure ----
+    counts_struct = np.bincount(struct, minlength=frac.size)
+    segs_struct = np.zeros(frac.size, np.int64)
+    segs_struct[0] = 1 + (seed >> 1) % 2                         # floor: 1-2 segments
+    segs_struct[1:5] = 1 + (splitmix64(seed, 5, 4) % np.uint64(2)).astype(np.int64)
+    rest = s - int(segs_struct[:5].sum())
+    w_small = counts_struct[5:].astype(np.float64)
+    alloc = np.maximum(1, np.floor(w_small / max(w_small.sum(), 1.0) * rest)).astype(np.int64)
+    order_small = np.argsort(-w_small, kind="stable")
+    i = 0
+    while alloc.sum() < rest:
+        alloc[order_small[i % n_small]] += 1; i += 1
+    while alloc.sum() > rest:
+        j = order_small[i % n_small]
+        if alloc[j] > 1:
+            alloc[j] -= 1
+        i += 1
+    segs_struct[5:] = alloc
+    lab = np.full(n_base, -1, np.int64)
+    base = 0
+    for st in range(frac.size):
+        idx = np.nonzero(struct == st)[0]
+        ks = int(min(segs_struct[st], max(idx.size, 1)))
+        if idx.size == 0:
+            continue
+        pick = np.argsort(splitmix64(seed, 1000 + st, idx.size), kind="stable")[:ks]
+        _, cell = cKDTree(xyz[idx[pick]]).query(xyz[idx], k=1)
+        lab[idx] = base + cell
+        base += ks
+    # empty structures / merged cells may leave the count short: split the largest segments until there are s of them
+    lab = np.unique(lab, return_inverse=True)[1]
+    while int(lab.max()) + 1 < s:
+        cnt = np.bincount(lab)
+        big = int(np.argmax(cnt))
+        idx = np.nonzero(lab == big)[0]
+        half = xyz[idx, int(np.argmax(np.ptp(xyz[idx], axis=0)))]
+        lab[idx[half > np.median(half)]] = int(lab.max()) + 1
+    data_base = np.concatenate([xyz, rgb], 1).astype(np.float32)
+
+    # ---- tiled scans: the sampled cloud repeats vertices (exact duplicates, same segment) ----
+    if tiled:
+        src = np.concatenate([np.arange(n_base, dtype=np.int64), randint(seed, 7, n - n_base, n_base)])
+        perm = np.argsort(splitmix64(seed, 8, n), kind="stable")
+        src = src[perm]
+    else:
+        src = np.arange(n, dtype=np.int64)
+    data = data_base[src]
+    seg = _renumber_by_first_point(lab[src])
+    xyz_n = data[:, :3].astype(np.float64)
+
+    # mesh-like adjacency: symmetrised k-NN edges, sorted pairs, unique rows (duplicates are at distance 0 of each other)
+    _, nb = cKDTree(xyz_n).query(xyz_n, k=knn_edges + 1, workers=-1)
+    a = np.repeat(np.arange(n, dtype=np.int64), knn_edges)
+    b = nb[:, 1:].reshape(-1).astype(np.int64)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    keep = lo != hi
+    key = np.unique(lo[keep] * np.int64(n) + hi[keep])
+    adj = np.stack([key // n, key % n], axis=1).astype(np.int64)
+
+    # ---- instances: K ~ S / 47 seeds over segment centroids; ~1.3 labelled segments per instance ----
+    s_real = int(seg.max()) + 1
+    counts = np.bincount(seg, minlength=s_real)
+    cent = np.stack([np.bincount(seg, weights=xyz_n[:, d], minlength=s_real) for d in range(3)], axis=1) / counts[:, None]
+    k_ins = max(2, s_real // 47)
+    ins_seed = np.argsort(splitmix64(seed, 300, s_real), kind="stable")[:k_ins]
+    _, seg_ins = cKDTree(cent[ins_seed]).query(cent, k=1)
+    ins_sem = randint(seed, 400, k_ins, 40)
+    weak = np.full((n, 2), -1, dtype=np.int64)
+    extra = uniform01(seed, 401, k_ins)
+    for k in range(k_ins):
+        segs = np.nonzero(seg_ins == k)[0]
+        if segs.size == 0:
+            continue
+        by_size = segs[np.argsort(-counts[segs], kind="stable")]
+        chosen = by_size[:2] if (extra[k] < 0.3 and by_size.size > 1) else by_size[:1]
+        for sg in chosen:
+            mask = seg == sg
+            weak[mask, 0] = ins_sem[k]
+            weak[mask, 1] = k
+    gt_pts = np.stack([ins_sem[seg_ins[seg]] + 1, seg_ins[seg] + 1], axis=1).astype(np.int64)
+    # ---- raw vertices: sub-sampled scans have more vertices than points, tiled ones fewer ----
+    v = int(n * 1.2) if not tiled else n_base
+    if tiled:
+        # vertex j is base point j; it maps to the LAST sampled copy of itself (generate_pointcloud_pth, util.py:687-689)
+        unmap = np.zeros(v, np.int64)
+        unmap[src] = np.arange(n, dtype=np.int64)
+    else:
+        unmap = randint(seed, 500, v, n)
+        slots = np.argsort(splitmix64(seed, 501, v), kind="stable")[:n]
+        unmap[slots] = np.arange(n, dtype=np.int64)
+    gt = gt_pts[unmap].copy()
+    hole = randint(seed, 600, max(1, v // 50), v)
+    gt[hole] = 0
+    return Scene(name=name or f"scan{seed:04d}_00", data=data, weak_label=weak, seg=seg.astype(np.int32), adj=adj, unmap=unmap, gt=gt)
 
 
 def write_reference_tree(root: str, scenes, label_style: str = "manual") -> None:
