@@ -81,7 +81,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline leg")
     ap.add_argument("--no-files", action="store_true", help="skip the separate with-files measurement")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (batch-128 figure, scannet-profile figure)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra leg (scenes/s on the ScanNet-shaped segment profile)")
+    ap.add_argument("--extra-scannet", type=int, default=16, help="scenes of the ScanNet-shaped profile in the extra leg (rank 0, N = 1)")
     ap.add_argument("--writer-threads", type=int, default=16, help="native writer threads for the with-files leg")
     ap.add_argument("--gen-workers", type=int, default=0, help="scene generator processes (0 = min(16, cores))")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU rehearsals of the reduction)")
@@ -193,6 +194,9 @@ def main(argv=None):
         jobs = [(args.points, args.segments, 40000 + i, args.seg_profile) for i in mine]
     else:
         jobs = [(args.points, args.segments, 30000 + 1000 * rank + i, args.seg_profile) for i in range(args.batch)]
+    n_main = len(jobs)
+    n_extra = 0 if (args.no_extras or world > 1 or args.seg_profile != "voronoi") else max(0, args.extra_scannet)
+    jobs += [(args.points, args.segments, 70100 + i, "scannet") for i in range(n_extra)]
     scene_iter, pool = generate_scenes(jobs, workers)
 
     import torch
@@ -225,9 +229,11 @@ def main(argv=None):
     if pool is not None:
         pool.shutdown()
     gen_s = time.time() - t_gen
+    extra_scenes, scenes = scenes[n_main:], scenes[:n_main]
 
     from seggroup_amd.model import Engine
-    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+    every = scenes + extra_scenes
+    caps = (max(s.N for s in every), max(s.S for s in every), max(s.E0 for s in every), max(s.V for s in every))
     # stage timing: a handful of HIP events per batched launch sequence (per group of scenes, not per scene)
     runner = Engine(W, caps, groups=args.groups, per_group=args.per_group, device=dev, timing=1)
     acc = {"iou_sem": np.zeros(80), "iou_ins": np.zeros(80), "acc": np.zeros(4), "n": 0}
@@ -371,6 +377,33 @@ def main(argv=None):
                     with_files["+".join(fmts)] = round(2 * len(sub) / (time.perf_counter() - t1), 3)
             writer.close()
 
+        extras = {}
+        if extra_scenes:
+            # the same engine on ScanNet-shaped scenes (synthetic.make_scannet_scene: surfaces, 10k-30k-point floor / wall segments,
+            # median segment ~55 points, V != N, every other scene with 15 % duplicated points); each scene checked against a
+            # single pipeline like the main batch
+            runner.run(extra_scenes, hip.MODE_INS_INFER)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps, pend, res_x = 4, [], None
+            for _ in range(reps):                                  # queued two ahead, like the timed loop
+                pend.append(runner.submit(extra_scenes, hip.MODE_INS_INFER))
+                if len(pend) > 2:
+                    res_x = runner.wait(pend.pop(0))
+            while pend:
+                res_x = runner.wait(pend.pop(0))
+            dt = time.perf_counter() - t1
+            solo2 = Pipeline(W, *caps, stream=None, device=dev)
+            solo2.set_timing(0)
+            same_x = all(label_digest(res_x[i]) == label_digest(solo2.forward(extra_scenes[i], hip.MODE_INS_INFER)) for i in range(min(4, len(extra_scenes))))
+            solo2.close()
+            seg_max = max(int(s_.h_seg_size.max()) for s_ in extra_scenes)
+            extras["scannet_profile"] = {"scenes_per_s": round(reps * len(extra_scenes) / dt, 3), "scenes": len(extra_scenes), "largest_segment_points": seg_max,
+                                         "equals_single_pipeline": bool(same_x),
+                                         "cluster_trace_scene0": list(res_x[0].trace)}
+            if not same_x:
+                parity_all = False
+
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_ref
@@ -417,6 +450,7 @@ def main(argv=None):
                                      "== the same scenes through one default-stream pipeline"},
             "with_label_files_scenes_per_s": with_files or None,
             "pseudo_label_mIoU": {"semantic": round(miou_sem, 4), "instance": round(miou_ins, 4), "scenes": int(vec[164])},
+            "extra": extras or None,
             "engine_profile": engine_profile,
             "cluster_trace_scene0": batch_trace0, "scene_generation_s": round(gen_s, 1),
         }

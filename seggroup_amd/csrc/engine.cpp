@@ -214,7 +214,6 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
     SlotCtx* h_ctx = par.take<SlotCtx>(n, &d_ctx);
     BatchDims bd;
     bd.nslots = n;
-    bool lds_sort = true;
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
         sg_pipeline* pl = r.pl;
@@ -258,7 +257,7 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
             if (co) std::memcpy(co, r.chunk_off.data(), ((size_t)S + 1) * 4);
             c.seg_chunk_off = d_co;                               // lives in THIS phase's parameter block only
             c.segbox = pl->segbox.p; c.sperm = pl->sperm.p; c.chunk_box = pl->chunk_box.p;
-            lds_sort = lds_sort && sg::sort_boxes_fits_lds(r.max_seg);
+            c.sort_keys = reinterpret_cast<unsigned long long*>(pl->ws_sort.p);
         }
         c.m1_knn = r.m1_knn; c.m1_partial = r.m1_partial; c.m1_folded = r.m1_folded; c.feat1 = pl->feat1.p;
         c.dist_feat = pl->feat1.p; c.dist_stride = 128; c.dist_D = 128; c.dist_adj = pl->adj1.p; c.dist_E_dev = c.count; c.dist_E = 0;
@@ -276,14 +275,7 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
     mark(0);
     EG_CHECK(sg::b_fps64(d_ctx, bd, stream));
     if (mode == SG_MODE_INS_INFER) {
-        if (lds_sort) EG_CHECK(sg::b_sort_boxes(d_ctx, bd, stream));
-        else                                                      // a segment larger than a block's LDS: library sort, scene by scene
-            for (int i = 0; i < n; ++i) {
-                Run& r = runs_[i];
-                EG_CHECK(sg_segment_sort_boxes(r.sc->d_data, r.sc->N, r.sc->d_seg_points, r.sc->d_seg_off, r.sc->d_seg_of_point, r.sc->S,
-                                               r.ctx.seg_chunk_off, r.max_seg, r.pl->segbox.p, r.pl->sperm.p, r.pl->chunk_box.p, r.ctx.seg_sums,
-                                               r.pl->ws_sort.p, r.pl->ws_sort.n, (void*)stream));
-            }
+        EG_CHECK(sg::b_sort_boxes(d_ctx, bd, stream));
     }
     mark(1);
     sg_pipeline* p0 = runs_[0].pl;

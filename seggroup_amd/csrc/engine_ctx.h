@@ -46,6 +46,7 @@ struct SlotCtx {
     int32_t* sperm;                    // [N]
     float* chunk_box;
     double* seg_sums;                  // outbox [S,3]
+    unsigned long long* sort_keys;     // [2N] scratch of the big-segment sort
 
     // ---- a6/a7: MLP1 ----
     uint8_t* m1_knn;

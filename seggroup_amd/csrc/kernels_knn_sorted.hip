@@ -112,6 +112,7 @@ __device__ __forceinline__ void segment_sort_boxes_body(const float* __restrict_
     __shared__ float bx[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = seg_off[s], n = seg_off[s + 1] - lo;
+    if (n > kSortCap) return;                                  // k_bigseg_sort_boxes' share (block-uniform)
     // 1. segment box {min xyz, max xyz, max |p|^2}
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, xx = 0.f;
     double sm[3] = {0.0, 0.0, 0.0};                          // coordinate sums: the host builds cluster centroids from them
@@ -211,6 +212,186 @@ __global__ __launch_bounds__(256) void k_segment_sort_boxes_b(const sg::SlotCtx*
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.S) return;
     segment_sort_boxes_body(c.data, c.seg_points, c.seg_off, c.seg_chunk_off, c.segbox, c.sperm, c.chunk_box, c.seg_sums, blockIdx.x);
+}
+
+// Segments of more than kSortCap points (floors, walls: 10k-30k points in ScanNet's over-segmentation) -- same outputs,
+// same order (ascending (morton30, index)), one 1024-thread block per segment, no library sort:
+//   1. box + coordinate sums;  2. keys into global scratch + LDS histogram of the TOP 12 Morton bits (16^3 cells);
+//   3. scan, scatter into cell order;  4. consecutive cells are packed greedily into runs of <= kSortCap keys and every
+//   run is sorted in LDS by the full 64-bit key (cells are already in order, so the concatenation is the total order);
+//   5. boxes of the 32-point chunks.  A cell with more than kSortCap points (> 2,048 points in 1/4096 of the segment's
+//   box: massive duplication) is cut into pieces that are sorted one by one -- the order inside such a cell is then not
+//   the full sort, which only loosens the chunk boxes there (the kNN tables do not depend on this order).
+// Blocks whose segment is small exit at once, so the launch covers every segment and needs no list of the big ones.
+constexpr int kBigBlock = 1024, kBins = 4096, kMaxRuns = 2048;
+__device__ __forceinline__ void bigseg_sort_boxes_body(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                                                       const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
+                                                       float* __restrict__ segbox, int32_t* __restrict__ sperm, float* __restrict__ chunk_box,
+                                                       double* __restrict__ seg_sums, unsigned long long* __restrict__ keysA,
+                                                       unsigned long long* __restrict__ keysB, int s) {
+    const int lo = seg_off[s], n = seg_off[s + 1] - lo;
+    if (n <= kSortCap) return;
+    __shared__ unsigned long long key[kSortCap];
+    __shared__ int hist[kBins];
+    __shared__ int run_end[kMaxRuns];
+    __shared__ float red[kBigBlock / 64][8];
+    __shared__ double dred[kBigBlock / 64][3];
+    __shared__ float bx[8];
+    __shared__ int n_runs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kW = kBigBlock / 64;
+    // 1. box + sums
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, xx = 0.f;
+    double sm[3] = {0.0, 0.0, 0.0};
+    for (int i = tid; i < n; i += kBigBlock) {
+        const float* r = data + (size_t)seg_points[lo + i] * 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], r[k]); mx[k] = fmaxf(mx[k], r[k]); sm[k] += (double)r[k]; }
+        xx = fmaxf(xx, (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); sm[k] += __shfl_xor(sm[k], o); }
+        xx = fmaxf(xx, __shfl_xor(xx, o));
+    }
+    if (lane == 0) {
+        red[wave][0] = mn[0]; red[wave][1] = mn[1]; red[wave][2] = mn[2]; red[wave][3] = mx[0]; red[wave][4] = mx[1]; red[wave][5] = mx[2]; red[wave][6] = xx;
+        dred[wave][0] = sm[0]; dred[wave][1] = sm[1]; dred[wave][2] = sm[2];
+    }
+    for (int i = tid; i < kBins; i += kBigBlock) hist[i] = 0;
+    __syncthreads();
+    if (tid < 7) {
+        float v = red[0][tid];
+        for (int w = 1; w < kW; ++w) v = tid < 3 ? fminf(v, red[w][tid]) : fmaxf(v, red[w][tid]);
+        bx[tid] = v;
+        segbox[(size_t)s * 8 + tid] = v;
+    }
+    if (tid == 7) segbox[(size_t)s * 8 + 7] = 0.f;
+    if (seg_sums && tid >= 8 && tid < 11) {
+        // NOTE: the sum is carried in double; its grouping (16 waves here, 4 in the small kernel) does not show in the fp32
+        // centroids the host forms from it
+        double t = 0.0;
+        for (int w = 0; w < kW; ++w) t += dred[w][tid - 8];
+        seg_sums[(size_t)s * 3 + (tid - 8)] = t;
+    }
+    __syncthreads();
+    // 2. keys + histogram of the top 12 bits
+    for (int i = tid; i < n; i += kBigBlock) {
+        const float* r = data + (size_t)seg_points[lo + i] * 6;
+        unsigned int q[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float ext = bx[3 + k] - bx[k];
+            const float t = ext > 0.f ? (r[k] - bx[k]) / ext : 0.f;
+            q[k] = (unsigned int)fminf(fmaxf(t * 1023.f, 0.f), 1023.f);
+        }
+        const unsigned int m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+        keysA[lo + i] = ((unsigned long long)m << 32) | (unsigned int)i;
+        atomicAdd(&hist[m >> 18], 1);
+    }
+    __syncthreads();
+    // 3. exclusive scan of the 4096 counts (4 per thread), runs, scatter cursors
+    {
+        int c[4], sum = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { c[u] = hist[4 * tid + u]; sum += c[u]; }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        __shared__ int wsum[kW];
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        int off = base + incl - sum;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { hist[4 * tid + u] = off; off += c[u]; }      // hist[] now = first position of every cell
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // greedy packing of consecutive cells into runs of <= kSortCap keys (an oversize cell is cut into pieces)
+        int nr = 0, start = 0;
+        for (int b = 0; b < kBins && nr < kMaxRuns - 1; ++b) {
+            const int end = b + 1 < kBins ? hist[b + 1] : n;
+            while (end - start > kSortCap && nr < kMaxRuns - 1) {
+                const int cell_lo = hist[b];
+                if (cell_lo > start) { run_end[nr++] = cell_lo; start = cell_lo; }          // close the run before this cell
+                else { run_end[nr++] = start + kSortCap; start += kSortCap; }                // a piece of an oversize cell
+            }
+        }
+        if (start < n || nr == 0) run_end[nr++] = n;
+        n_runs = nr;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kBigBlock) {
+        const unsigned long long k = keysA[lo + i];
+        const int pos = atomicAdd(&hist[(unsigned int)(k >> 32) >> 18], 1);
+        keysB[lo + pos] = k;
+    }
+    __syncthreads();
+    // 4. sort every run in LDS (bitonic, ascending), emit the sorted positions
+    const int nr = n_runs;
+    int r0 = 0;
+    for (int r = 0; r < nr; ++r) {
+        const int r1 = run_end[r];
+        for (int p0 = r0; p0 < r1; p0 += kSortCap) {              // one piece per run (more only if the run table overflowed)
+            const int m = min(kSortCap, r1 - p0);
+            int m2 = 64;
+            while (m2 < m) m2 <<= 1;
+            for (int i = tid; i < m2; i += kBigBlock) key[i] = i < m ? keysB[lo + p0 + i] : ~0ull;
+            __syncthreads();
+            for (int k = 2; k <= m2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < (m2 >> 1); t += kBigBlock) {
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                        const unsigned long long a = key[i], b = key[p];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { key[i] = b; key[p] = a; }
+                    }
+                    __syncthreads();
+                }
+            for (int i = tid; i < m; i += kBigBlock) sperm[lo + p0 + i] = lo + (int)(key[i] & 0xffffffffull);
+            __syncthreads();
+        }
+        r0 = r1;
+    }
+    // 5. boxes of the 32-point chunks (two per wave step); sperm[] of this segment was written by this block
+    const int c0 = seg_chunk_off[s], half = lane >> 5, l = lane & 31;
+    for (int j = 2 * wave + half; j * kChunkPts < n; j += 2 * kW) {
+        const int t = j * kChunkPts + l;
+        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY}, cxx = 0.f;
+        if (t < n) {
+            const float* r = data + (size_t)seg_points[sperm[lo + t]] * 6;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { cmn[k] = r[k]; cmx[k] = r[k]; }
+            cxx = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { cmn[k] = fminf(cmn[k], __shfl_xor(cmn[k], o)); cmx[k] = fmaxf(cmx[k], __shfl_xor(cmx[k], o)); }
+            cxx = fmaxf(cxx, __shfl_xor(cxx, o));
+        }
+        if (l == 0) {
+            float* b = chunk_box + (size_t)(c0 + j) * 8;
+            b[0] = cmn[0]; b[1] = cmn[1]; b[2] = cmn[2]; b[3] = cmx[0]; b[4] = cmx[1]; b[5] = cmx[2]; b[6] = cxx; b[7] = 0.f;
+        }
+    }
+}
+__global__ __launch_bounds__(kBigBlock) void k_bigseg_sort_boxes(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                                                                 const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
+                                                                 float* __restrict__ segbox, int32_t* __restrict__ sperm,
+                                                                 float* __restrict__ chunk_box, double* __restrict__ seg_sums,
+                                                                 unsigned long long* __restrict__ keysA, unsigned long long* __restrict__ keysB) {
+    bigseg_sort_boxes_body(data, seg_points, seg_off, seg_chunk_off, segbox, sperm, chunk_box, seg_sums, keysA, keysB, blockIdx.x);
+}
+__global__ __launch_bounds__(kBigBlock) void k_bigseg_sort_boxes_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.S) return;
+    bigseg_sort_boxes_body(c.data, c.seg_points, c.seg_off, c.seg_chunk_off, c.segbox, c.sperm, c.chunk_box, c.seg_sums, c.sort_keys,
+                           c.sort_keys + c.N, blockIdx.x);
 }
 
 // coordinate sums of every segment (the library-sort fallback of sg_segment_sort_boxes; same values as the fused kernel's)
@@ -816,8 +997,8 @@ bool sort_boxes_fits_lds(int max_seg) { return max_seg <= kSortCap; }
 
 int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
     if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
-    if (bd.max_seg > kSortCap) return sg::fail(SG_EUNSUP, "b_sort_boxes: a segment of %d points exceeds the LDS sort (%d)", bd.max_seg, kSortCap);
     k_segment_sort_boxes_b<<<dim3(bd.max_S, bd.nslots), 256, 0, st>>>(d_ctx);
+    if (bd.max_seg > kSortCap) k_bigseg_sort_boxes_b<<<dim3(bd.max_S, bd.nslots), kBigBlock, 0, st>>>(d_ctx);     // small segments exit at once
     SG_LAUNCH_CHECK();
     return SG_OK;
 }
@@ -926,15 +1107,14 @@ int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_point
                           int32_t* d_sperm, float* d_chunk_box, double* d_seg_sums, void* d_ws, size_t ws_bytes, void* stream) {
     SG_REQUIRE(N >= 0 && S >= 0 && max_seg >= 0 && d_segbox && d_sperm && d_chunk_box, "sg_segment_sort_boxes: bad arguments");
     if (N == 0 || S == 0) return SG_OK;
-    if (max_seg > kSortCap) {                                  // a segment does not fit one block's LDS: library sort
-        int rc = sg_segment_boxes(d_data, d_seg_points, d_seg_off, S, d_segbox, stream);
-        if (rc) return rc;
-        if (d_seg_sums) k_segment_sums<<<S, 256, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_seg_sums);
-        return sg_segment_spatial_sort(d_data, N, d_seg_points, d_seg_off, d_seg_of_point, S, d_segbox, d_seg_chunk_off, d_sperm, d_chunk_box,
-                                       d_ws, ws_bytes, stream);
-    }
     k_segment_sort_boxes<<<S, 256, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_segbox, d_sperm, d_chunk_box,
                                                                d_seg_sums);
+    if (max_seg > kSortCap) {                                  // segments beyond one block's LDS: cell-bucketed LDS sort, scratch = 2 x N keys
+        if (!d_ws || ws_bytes < (size_t)N * 16) return sg::fail(SG_ENOMEM, "sg_segment_sort_boxes: workspace too small (%zu < %zu)", ws_bytes, (size_t)N * 16);
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(d_ws);
+        k_bigseg_sort_boxes<<<S, kBigBlock, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_segbox, d_sperm,
+                                                                      d_chunk_box, d_seg_sums, keys, keys + N);
+    }
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

@@ -582,3 +582,51 @@ def test_seeded_knn_equals_bruteforce(env, golden_index, name, fine, coarse):
                                         c["pos_of_point"].data_ptr(), c["data"].data_ptr(), 20, c["pos0"], out.data_ptr(), None))
     a_, b_ = c["brute"].cpu().numpy(), out.cpu().numpy()
     assert np.array_equal(a_, b_), f"{int(np.any(a_ != b_, axis=1).sum())} rows differ between brute force and seeded"
+
+
+@pytest.mark.parametrize("cfg", [(30000, 6, 140, dict(min_seg=4)), (60000, 600, 70000, dict(seg_profile="scannet")),
+                                 (60000, 600, 70001, dict(seg_profile="scannet")), (20000, 3, 142, dict(min_seg=4, dup_frac=0.3))],
+                         ids=["5k-point-segments", "scannet-subsampled", "scannet-tiled", "7k-segments-30pct-duplicates"])
+def test_segments_beyond_the_lds_sort_cap(env, cfg):
+    """Over-segments of more than 2,048 points (floors and walls of a real scan: 10k-30k points) are Morton-sorted by
+    k_bigseg_sort_boxes (cells of the top 12 Morton bits, every run of cells sorted in LDS) instead of a library radix
+    sort: segment boxes, sorted order, chunk boxes and coordinate sums must equal the library path's bit for bit."""
+    lib, torch, hip = env
+    from seggroup_amd import synthetic
+    n, s, seed, kw = cfg
+    sc = synthetic.make_scene(n, s, seed, **kw)
+    N, S = sc.num_points, sc.num_segments
+    counts = np.bincount(sc.seg, minlength=S)
+    assert counts.max() > 2048
+    order = np.argsort(sc.seg, kind="stable").astype(np.int32)
+    seg_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    chunk_off = np.concatenate([[0], np.cumsum((counts + 31) // 32)]).astype(np.int32)
+    d_data, d_pts, d_off, d_sop, d_co = (_up(torch, x) for x in (sc.data, order, seg_off, sc.seg, chunk_off))
+    nchunk = int(chunk_off[-1])
+    # library path: boxes, then radix sort of (segment | morton30) pairs, then chunk boxes
+    box = torch.zeros(S, 8, device="cuda:0")
+    hip.check(lib.sg_segment_boxes(d_data.data_ptr(), d_pts.data_ptr(), d_off.data_ptr(), S, box.data_ptr(), None))
+    sperm = torch.zeros(N, dtype=torch.int32, device="cuda:0")
+    cbox = torch.zeros(nchunk + 1, 8, device="cuda:0")
+    wss = _ws(torch, lib.sg_spatial_sort_ws_bytes(N))
+    hip.check(lib.sg_segment_spatial_sort(d_data.data_ptr(), N, d_pts.data_ptr(), d_off.data_ptr(), d_sop.data_ptr(), S, box.data_ptr(),
+                                          d_co.data_ptr(), sperm.data_ptr(), cbox.data_ptr(), wss.data_ptr(), wss.numel(), None))
+    # the pipeline's path
+    box2 = torch.full((S, 8), 7.0, device="cuda:0"); sperm2 = torch.full((N,), -1, dtype=torch.int32, device="cuda:0")
+    cbox2 = torch.zeros_like(cbox); sums = torch.zeros(S, 3, dtype=torch.float64, device="cuda:0")
+    ws2 = _ws(torch, 16 * N)
+    for rep in range(2):                                        # twice: the scratch keeps stale keys from the first run
+        hip.check(lib.sg_segment_sort_boxes(d_data.data_ptr(), N, d_pts.data_ptr(), d_off.data_ptr(), d_sop.data_ptr(), S, d_co.data_ptr(),
+                                            int(counts.max()), box2.data_ptr(), sperm2.data_ptr(), cbox2.data_ptr(), sums.data_ptr(),
+                                            ws2.data_ptr(), ws2.numel(), None))
+        torch.cuda.synchronize()
+        assert torch.equal(box2, box)
+        bad = torch.nonzero(sperm2 != sperm).flatten()
+        assert bad.numel() == 0, f"{bad.numel()} sorted positions differ, first at {int(bad[0])} (segment {int(sc.seg[order[int(bad[0])]])})"
+        assert torch.equal(cbox2[:nchunk], cbox[:nchunk])
+    want = np.stack([np.bincount(sc.seg, weights=sc.data[:, k_].astype(np.float64), minlength=S) for k_ in range(3)], 1)
+    assert np.allclose(sums.cpu().numpy(), want, rtol=1e-13, atol=1e-9)
+    with pytest.raises(hip.SgError):                            # the scratch is checked, not trusted
+        hip.check(lib.sg_segment_sort_boxes(d_data.data_ptr(), N, d_pts.data_ptr(), d_off.data_ptr(), d_sop.data_ptr(), S, d_co.data_ptr(),
+                                            int(counts.max()), box2.data_ptr(), sperm2.data_ptr(), cbox2.data_ptr(), sums.data_ptr(),
+                                            ws2.data_ptr(), 1024, None))
