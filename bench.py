@@ -349,15 +349,19 @@ def main(argv=None):
                                   "flop_per_scene": f_scene},
                     "all_kernels": all_k, "single_stream": solo_k,
                     "stage_ms": {k_: round(v, 4) for k_, v in mean_ms.items() if v > 0}}
-        # VALU roof of the in-cluster kNN: SQ_INSTS_VALU per launch (PMC pass, committed) / (1024 SIMDs x 2.4 GHz / 2 cycles)
-        vi = (pmc.get("valu_insts_per_scene_launch", {}) or {}).get("k_cluster_knn_sorted")
+        # VALU roof of the in-cluster kNN: SQ_INSTS_VALU per scene-launch (PMC pass, committed) / (1024 SIMDs x 2.4 GHz / 2 cycles)
+        vmap = pmc.get("valu_insts_per_scene_launch", {}) or {}
+        vi = sum(vmap.get(k_, 0) for k_ in ("k_cluster_knn_sorted<unseeded>", "k_cluster_knn_sorted<seeded>"))
         if vi and "k_cluster_knn_sorted" in all_k:
-            ms = all_k["k_cluster_knn_sorted"]["ms_per_scene_launch"]
-            sms = solo_k.get("k_cluster_knn_sorted", {}).get("ms_per_scene_launch", 0.0)
-            roofline["knn_valu"] = {"valu_insts_per_scene_launch": vi, "peak_ginst_per_s": VALU_PEAK_GINST,
-                                    "valu_frac": round(vi / (ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
-                                    "valu_frac_single_stream": round(vi / (sms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if sms > 0 else None,
-                                    "source": f"profiles/{PROFILE_TAG}_pmc_kernels.json (SQ_INSTS_VALU, separate PMC pass)"}
+            ms2 = 2.0 * all_k["k_cluster_knn_sorted"]["ms_per_scene_launch"]                       # both launches of a scene
+            sms2 = 2.0 * solo_k.get("k_cluster_knn_sorted", {}).get("ms_per_scene_launch", 0.0)
+            roofline["knn_valu"] = {"valu_insts_per_scene": vi, "peak_ginst_per_s": VALU_PEAK_GINST,
+                                    "valu_frac": round(vi / (ms2 * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
+                                    "valu_frac_single_stream": round(vi / (sms2 * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if sms2 > 0 else None,
+                                    "source": f"profiles/{PROFILE_TAG}_pmc_kernels.json (SQ_INSTS_VALU of the two kNN launches of a scene, separate PMC pass)"}
+        mb = (pmc.get("mfma_busy_share", {}) or {}).get(dom)
+        if mb is not None:
+            roofline["mfma_busy_share_pmc"] = {"value": mb, "source": f"profiles/{PROFILE_TAG}_pmc_kernels.json (SQ_VALU_MFMA_BUSY_CYCLES, solo batched)"}
 
         with_files = {}
         if not args.no_files:

@@ -532,6 +532,12 @@ int sg_write_seg_json(const char* path, const int32_t* h_seg_points, const int32
  * does not start at its own index, a member out of range / claimed twice, an uncovered point). */
 int sg_parse_seg_json(const char* path, int N, int32_t* h_seg_of_point);
 
+/* Segment number per point (ranks of the segments' first points) -> CSR of the over-segmentation (h_seg_points [N] ascending
+ * inside every segment, h_seg_off [S+1]) + h_seg_first [S], h_seg_size [S]: the host side of DisjointSet's initial state
+ * (model.py:712-721) in one counting pass. */
+int sg_stage_segments(const int32_t* h_seg_of_point, int N, int S, int32_t* h_seg_points, int32_t* h_seg_off,
+                      int32_t* h_seg_first, int32_t* h_seg_size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,13 +49,16 @@ def stage_arrays(data, weak_label, seg, adj, unmap, gt) -> Dict[str, np.ndarray]
     if data.shape[1] != 6 or weak_label.shape != (n, 2) or seg.shape != (n,):
         raise ValueError("stage_arrays: inconsistent input shapes")
     s = int(seg.max()) + 1
-    order = np.argsort(seg, kind="stable").astype(np.int32)
-    counts = np.bincount(seg, minlength=s).astype(np.int32)
-    off = np.zeros(s + 1, dtype=np.int32)
-    np.cumsum(counts, out=off[1:])
-    first = order[off[:-1]].astype(np.int32)
-    if s > 1 and not (np.diff(first) > 0).all():
-        raise ValueError("segment numbers must ascend with each segment's first point")
+    # CSR of the over-segmentation + first point / size of every segment: one native counting pass (sg_stage_segments)
+    from . import hip
+    order = np.empty(n, dtype=np.int32)
+    off = np.empty(s + 1, dtype=np.int32)
+    first = np.empty(s, dtype=np.int32)
+    counts = np.empty(s, dtype=np.int32)
+    try:
+        hip.check(hip.lib().sg_stage_segments(seg.ctypes.data, n, s, order.ctypes.data, off.ctypes.data, first.ctypes.data, counts.ctypes.data))
+    except hip.SgError as e:
+        raise ValueError(str(e)) from None
     return dict(data=data, adj=np.ascontiguousarray(np.asarray(adj, dtype=np.int64).reshape(-1, 2)), seg_of_point=seg,
                 seg_points=order, seg_off=off, unmap=np.ascontiguousarray(unmap, dtype=np.int32),
                 gt=np.ascontiguousarray(gt, dtype=np.int32), seg_first=first, seg_size=counts,
@@ -80,7 +83,7 @@ def write_pack(path: str, name: str, arrays: Dict[str, np.ndarray]) -> None:
         f.write(struct.pack("<I", len(hdr) + pad))
         f.write(hdr + b" " * pad)
         for a in blobs:
-            f.write(a.tobytes())
+            f.write(memoryview(a).cast("B"))
             f.write(b"\0" * ((64 - a.nbytes % 64) % 64))
     os.replace(tmp, path)                       # atomic: concurrent ranks may race to build the same pack
 

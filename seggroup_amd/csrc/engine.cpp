@@ -42,7 +42,8 @@ constexpr int kMaxGroupEvents = 24;
 
 // SG_ENGINE_PROFILE=1: wall time of the group threads split into host work (grouping, descriptors, launch calls), time
 // blocked in hipStreamSynchronize and time idle waiting for work; printed by sg_engine_destroy -- a development aid
-bool g_profile = getenv("SG_ENGINE_PROFILE") != nullptr;
+const bool g_profile_print = getenv("SG_ENGINE_PROFILE") != nullptr;     // print at sg_engine_destroy
+bool g_profile = g_profile_print;
 thread_local long long tl_ns_sync = 0;
 inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline hipError_t timed_sync(hipStream_t st) {
@@ -707,7 +708,7 @@ void sg_engine_destroy(sg_engine* e) {
     }
     e->cv_work.notify_all();
     for (auto& g : e->groups) if (g->th.joinable()) g->th.join();
-    if (g_profile && e->n_steps.load() > 0) {
+    if (g_profile_print && e->n_steps.load() > 0) {
         const double n = (double)e->n_steps.load(), sc = (double)e->n_step_scenes.load();
         const double step = e->ns_step.load() / n * 1e-6, syn = e->ns_sync.load() / n * 1e-6, idle = e->ns_idle.load() / n * 1e-6;
         fprintf(stderr, "[sg engine profile] %d groups x %d: %.0f super-steps, %.2f scenes each: %.3f ms per super-step = %.3f ms blocked in stream syncs + "

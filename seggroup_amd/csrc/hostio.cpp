@@ -96,4 +96,29 @@ int sg_parse_seg_json(const char* path, int N, int32_t* h_seg_of_point) {
     return S;
 }
 
+
+// Segment number per point -> the CSR of the over-segmentation (points ascending inside every segment) + per-segment first
+// point and size: one counting pass instead of a stable argsort of N keys (the largest item of scene staging after the JSON
+// parse).  Segment numbers must be the ranks of the segments' first points (what sg_parse_seg_json returns).
+int sg_stage_segments(const int32_t* h_seg_of_point, int N, int S, int32_t* h_seg_points, int32_t* h_seg_off, int32_t* h_seg_first,
+                      int32_t* h_seg_size) {
+    if (!h_seg_of_point || N <= 0 || S <= 0 || !h_seg_points || !h_seg_off || !h_seg_first || !h_seg_size)
+        return sg::fail(SG_EINVAL, "sg_stage_segments: bad arguments");
+    for (int s = 0; s < S; ++s) { h_seg_size[s] = 0; h_seg_first[s] = -1; }
+    for (int i = 0; i < N; ++i) {
+        const int s = h_seg_of_point[i];
+        if (s < 0 || s >= S) return sg::fail(SG_EINVAL, "sg_stage_segments: point %d has segment %d outside [0, %d)", i, s, S);
+        if (h_seg_size[s]++ == 0) h_seg_first[s] = i;
+    }
+    h_seg_off[0] = 0;
+    for (int s = 0; s < S; ++s) {
+        if (h_seg_size[s] == 0) return sg::fail(SG_EINVAL, "sg_stage_segments: segment %d has no points", s);
+        if (s && h_seg_first[s] <= h_seg_first[s - 1]) return sg::fail(SG_EINVAL, "segment numbers must ascend with each segment's first point");
+        h_seg_off[s + 1] = h_seg_off[s] + h_seg_size[s];
+    }
+    std::vector<int32_t> cur(h_seg_off, h_seg_off + S);
+    for (int i = 0; i < N; ++i) h_seg_points[cur[h_seg_of_point[i]]++] = i;
+    return SG_OK;
+}
+
 }  // extern "C"

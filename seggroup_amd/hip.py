@@ -97,6 +97,7 @@ SIGNATURES = {
     "sg_segment_lists": (_I, [vp, _I, vp, _I, vp, vp, vp, C.POINTER(C.c_int), vp, _Z, vp]),
     "sg_write_seg_json": (_I, [C.c_char_p, vp, vp, _I, _I]),
     "sg_parse_seg_json": (_I, [C.c_char_p, _I, vp]),
+    "sg_stage_segments": (_I, [vp, _I, _I, vp, vp, vp, vp]),
     "sg_edgeconv_ws_bytes": (_Z, [_I]),
     "sg_edgeconv_forward": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_gcn_ws_bytes": (_Z, [_I, _I, _I]),

@@ -198,10 +198,11 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
     mine = scene_indices(len(scene_list), rank, world, args.sampler)
     acc = Accumulator()
     t0 = time.time()
-    fast = dev is not None and args.batch > 0 and not args.no_cache
+    fast = dev is not None and args.batch > 0
     if fast:
-        # packed fast path: scene packs are built once, loader threads stage the next batch while the
-        # GPU runs the current one through sg_batch_forward, label files are written by the native writer pool
+        # fast path: loader threads stage the next batch -- from scene packs (built once) or, with
+        # --no-cache, straight from the reference's files (native seg.json parser, no pack written) -- while the GPU runs
+        # the current one through the scene engine; label files are written by the native writer pool
         _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev)
     else:
         for step, i in enumerate(mine):
@@ -241,6 +242,9 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     workers = max(1, int(args.workers))
 
     def stage(name):
+        if args.no_cache:
+            from .scene import DeviceScene
+            return DeviceScene.from_reference_tree(name, root=args.root, label_style=args.label_style, device=dev)
         return cache.load_pack(cache.pack_scene(args.root, name, args.label_style), device=dev)
 
     pool = ThreadPoolExecutor(max_workers=workers)
@@ -249,16 +253,11 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     writer = AsyncLabelWriter(threads=max(2, workers))
     runner, done, stalled = None, 0, []
     w = model.export_weights()
-    for bi, batch in enumerate(batches):
-        scenes = [f.result() for f in pending]
-        pending = [pool.submit(stage, n) for n in batches[bi + 1]] if bi + 1 < len(batches) else []
-        if runner is None or any(not runner.fits(s_) for s_ in scenes):
-            caps = runner.caps if runner is not None else None
-            if runner is not None:
-                runner.close()
-            runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps, timing=0)
-        res = runner.run(scenes, mode, writer=writer, out_dirs=[model.output_root(s_.name) for s_ in scenes], formats=formats)
-        for s_, r in zip(scenes, res):
+    tickets = []
+
+    def consume(t):
+        nonlocal done
+        for s_, r in zip(t.scenes, runner.wait(t)):
             acc.add(r.iou_sem, r.iou_ins, r.acc)
             done += 1
             if r.stalled:
@@ -268,6 +267,23 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
                 print('[rank %d] %s: a <5-point cluster could not be merged (reference would not terminate); sweep cut short' % (rank, s_.name), flush=True)
             if rank == 0:
                 io.cprint(progress_line(min(done * world, len(scene_list)), len(scene_list), acc.summary()))
+
+    for bi, batch in enumerate(batches):
+        scenes = [f.result() for f in pending]
+        pending = [pool.submit(stage, n) for n in batches[bi + 1]] if bi + 1 < len(batches) else []
+        if runner is None or any(not runner.fits(s_) for s_ in scenes):
+            while tickets:                                  # the engine is rebuilt with larger capacities: drain it first
+                consume(tickets.pop(0))
+            caps = runner.caps if runner is not None else None
+            if runner is not None:
+                runner.close()
+            runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps, timing=0)
+        # one batch is queued behind the one in flight: the engine's groups never drain between batches
+        tickets.append(runner.submit(scenes, mode, writer=writer, out_dirs=[model.output_root(s_.name) for s_ in scenes], formats=formats))
+        if len(tickets) > 1:
+            consume(tickets.pop(0))
+    while tickets:
+        consume(tickets.pop(0))
     writer.flush()
     writer.close()
     if runner is not None:

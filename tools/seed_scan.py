@@ -10,6 +10,7 @@ require HIP == oracle digests on every scanned seed (the rule this build defines
 the reference is stable (A == B == oracle).  The file also documents how often the reference is unstable at full size.
 
 usage: python tools/seed_scan.py NAME N S PROFILE SEED [SEED ...]
+       python tools/seed_scan.py --oracle-only [NAME ...]     (re-run only the oracle for the recorded seeds, e.g. after an oracle fix)
 """
 from __future__ import annotations
 
@@ -33,7 +34,33 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def refresh_oracle(names):
+    from oracle import cpu_ref
+    from seggroup_amd import synthetic, weights as W
+    wts = W.load_npz(os.path.join(REPO, "tests", "golden", "weights_g2.npz"))
+    path = os.path.join(REPO, "tests", "golden", "seed_scan.json")
+    book = json.load(open(path))
+    for name in names or list(book):
+        e = book[name]
+        for seed, rec in e["seeds"].items():
+            scene = synthetic.make_scene(e["n"], e["s"], int(seed), name=f"scene{int(seed):05d}_00", **e["kw"])
+            t0 = time.time()
+            o = cpu_ref.forward_scene(scene, wts, "ins_infer")
+            rec["oracle_s"] = round(time.time() - t0, 1)
+            rec["oracle_trace"] = o["trace"]
+            rec["oracle_stalled"] = bool(o["stalled"])
+            rec["oracle_label_sha"] = {k: sha(v.astype(np.int32)) for k, v in o["labels"].items()}
+            if "reference_label_sha" in rec:
+                rec["oracle_equals_B"] = rec["reference_label_sha"] == rec["oracle_label_sha"]
+                if rec.get("labels_A_equal_B"):
+                    rec["oracle_equals_A"] = rec["oracle_equals_B"]
+            print(name, seed, rec["oracle_trace"], "oracle == reference (B):", rec.get("oracle_equals_B"), flush=True)
+            json.dump(book, open(path, "w"), indent=1, sort_keys=True)
+
+
 def main():
+    if sys.argv[1] == "--oracle-only":
+        return refresh_oracle(sys.argv[2:])
     name, n, s, profile = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     seeds = [int(x) for x in sys.argv[5:]]
     resource.setrlimit(resource.RLIMIT_AS, (52 << 30, 52 << 30))       # the reference's [n, n] kNN matrices must not take the box down

@@ -1,109 +1,109 @@
 #!/usr/bin/env python3
-"""gpurun_out/<tag>_* (written by tools/collect_profiles.sh on the GPU box) -> profiles/<tag>_*.{csv,json,md}"""
-import collections, csv, glob, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+"""gpurun_out/<tag>_* (written on the GPU box by tools/prof_engine.sh and tools/pmc_engine.sh) -> profiles/<tag>_*
+
+    python tools/summarise_profiles.py r02
+
+  profiles/<tag>_bench_kernel_stats.csv        rocprofv3 --kernel-trace --stats of the bench's default engine shape
+  profiles/<tag>_solo_batched_kernel_stats.csv the same with ONE group of 8 scenes (batched launches, nothing else on the GPU)
+  profiles/<tag>_pmc_kernels.json              per kernel and SCENE-launch (a batched launch / the scenes in it): VALU instructions,
+                                               MFMA busy share, wave occupancy, HBM bytes (FETCH_SIZE, WRITE_SIZE: separate PMC passes)
+  profiles/<tag>_sq_counters.txt               the SQ counters as a table
+bench.py reads <tag>_pmc_kernels.json for `roofline.traffic` and the kNN's VALU roof.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
+SIMDS = 1024
 
 
 def short(n):
     return n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 
 
-def stats(src, dst, title):
-    f = glob.glob(os.path.join(G, src, "**", "*kernel_stats.csv"), recursive=True)[0]
-    rows = list(csv.DictReader(open(f)))
+def stats(src_dir, dst, title):
+    fs = glob.glob(os.path.join(G, src_dir, "**", "*kernel_stats.csv"), recursive=True)
+    if not fs:
+        return None
+    rows = list(csv.DictReader(open(fs[0])))
     with open(os.path.join(P, dst), "w") as o:
-        o.write(f"# {title}\n# source: rocprofv3 --kernel-trace --stats ({os.path.basename(f)})\n")
+        o.write(f"# {title}\n# source: rocprofv3 --kernel-trace --stats ({os.path.basename(fs[0])})\n")
         o.write("kernel,calls,total_ms,avg_us,min_us,max_us,pct\n")
         for r in rows:
-            o.write("%s,%s,%.3f,%.2f,%.2f,%.2f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
-                    float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+            o.write("%s,%s,%.3f,%.2f,%.2f,%.2f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
+                                                     float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
     return {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
 
 
-bench = stats(f"{tag}_bench_stats", f"{tag}_bench_kernel_stats.csv",
-              "python bench.py --no-cpu-baseline --no-files (128 scenes per step, 16 pipelines in flight), 150k/1.5k scenes")
-solo = stats(f"{tag}_solo_stats", f"{tag}_single_stream_kernel_stats.csv", "tools/time_scene.py 150000 1500 (one scene at a time, 6 forwards)")
+bench = stats("prof_bench", f"{tag}_bench_kernel_stats.csv", "python bench.py --no-cpu-baseline --no-files (default engine shape), 150k/1.5k scenes")
+solo = stats("prof_solo8", f"{tag}_solo_batched_kernel_stats.csv", "python bench.py --groups 1 --per-group 8 --no-cpu-baseline --no-files: one group, 8 scenes per batched launch, nothing else on the GPU")
 
-traffic = collections.defaultdict(dict)
-for name, src in (("FETCH_SIZE", f"{tag}_pmc_fetch"), ("WRITE_SIZE", f"{tag}_pmc_write")):
-    f = glob.glob(os.path.join(G, src, "**", "*counter_collection.csv"), recursive=True)[0]
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == name:
-            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        traffic[k][name] = sum(v) / len(v)
-alias = {"k_edgeconv<2, true>": "k_edgeconv<S2X>", "k_edgeconv<2>": "k_edgeconv<S2X>", "k_edgeconv<0, false>": "k_edgeconv<S1>",
-         "k_edgeconv<0>": "k_edgeconv<S1>", "k_edgeconv<1, false>": "k_edgeconv<S1X>", "k_edgeconv<1>": "k_edgeconv<S1X>", "k_cluster_knn_pruned<20>": "k_cluster_knn_pruned", "k_cluster_knn_sorted<20>": "k_cluster_knn_sorted",
-         "k_cluster_knn_sorted<20, 1>": "k_cluster_knn_sorted", "k_cluster_knn_sorted<20, 2>": "k_cluster_knn_sorted<2 slices>",
-         "k_cluster_knn_sorted<20, 4>": "k_cluster_knn_sorted<4 slices>",
-         # layer 2 (unseeded) and layer 3 (seeded) launches of the same kernel: bench.py prices them together
-         "k_cluster_knn_sorted<20, 1, false>": "k_cluster_knn_sorted", "k_cluster_knn_sorted<20, 1, true>": "k_cluster_knn_sorted"}
-out = {"note": "HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB * 1024 from two separate rocprofv3 --pmc passes over "
-               "tools/time_scene.py 150000 1500; on gfx950 FETCH_SIZE can under-count wide coalesced reads by up to 2x "
-               "(MI355X_MICROARCH.md, HBM section), so read the fetch side as a lower bound",
-       "bytes_per_launch": {}, "fetch_kb": {}, "write_kb": {}}
-merged = collections.defaultdict(list)
-for k, v in traffic.items():
-    merged[alias.get(k, k)].append(v)
-for name, vs in merged.items():                      # several instantiations under one name: the mean per launch
-    f_ = sum(v.get("FETCH_SIZE", 0) for v in vs) / len(vs)
-    w_ = sum(v.get("WRITE_SIZE", 0) for v in vs) / len(vs)
-    out["bytes_per_launch"][name] = int((f_ + w_) * 1024)
-    out["fetch_kb"][name] = round(f_, 1)
-    out["write_kb"][name] = round(w_, 1)
-json.dump(out, open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
-line = [l for l in open(os.path.join(G, f"{tag}_bench_stats.log")).read().splitlines() if l.startswith('{"metric"')][-1]
-with open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w") as o:
-    o.write(line + "\n")
-sq = os.path.join(G, f"{tag}_pmc_sq.txt")
-if os.path.exists(sq):
-    lines = [l for l in open(sq).read().splitlines() if " per wave" in l or "| per wave" in l]
+passes = {}
+for name in ("sq", "mfma", "fetch", "write"):
+    p = os.path.join(G, f"{tag}_pmc_{name}.json")
+    if os.path.exists(p):
+        passes[name] = json.load(open(p))
+if passes:
+    eng = next(iter(passes.values()))["engine"]
+    B = int(eng.split(" x ")[1].split()[0])
+    alias = {"k_edgeconv_b<2, true>": "k_edgeconv<S2X>", "k_edgeconv_b<1, false>": "k_edgeconv<S1X>",
+             "k_cluster_knn_sorted_b<20, 1, false>": "k_cluster_knn_sorted<unseeded>", "k_cluster_knn_sorted_b<20, 1, true>": "k_cluster_knn_sorted<seeded>"}
+    out = {"configuration": f"solo batched: {eng}, python bench.py --steps 2 --warmup 1 under rocprofv3 --pmc (one counter set per pass, --kernel-trace only)",
+           "scenes_per_launch": B,
+           "note": "per SCENE-launch = per batched launch / scenes per launch.  hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024: on gfx950 FETCH_SIZE reports half "
+                   "the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); hbm_bytes_uncorrected uses FETCH_SIZE as reported.  MFMA busy share = "
+                   "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); mean waves per SIMD = 4 x SQ_WAVE_CYCLES / 1024 / kernel cycles.",
+           "valu_insts_per_scene_launch": {}, "hbm_bytes_per_scene_launch": {}, "hbm_bytes_uncorrected_per_scene_launch": {}, "mfma_busy_share": {},
+           "mean_waves_per_simd": {}, "issue_share": {}, "per_kernel_raw": {}}
+    sq, mf = passes.get("sq", {}).get("kernels", {}), passes.get("mfma", {}).get("kernels", {})
+    fe, wr = passes.get("fetch", {}).get("kernels", {}), passes.get("write", {}).get("kernels", {})
+    lines = []
+    for k in sorted(set(sq) | set(mf) | set(fe) | set(wr)):
+        if not k.endswith("_b") and "_b<" not in k:
+            continue                                           # batched kernels only (the single-pipeline parity check runs a few unbatched ones)
+        name = alias.get(k, k)
+        raw = {}
+        for src in (sq, mf, fe, wr):
+            raw.update({n: v for n, v in src.get(k, {}).items() if n != "launches"})
+        out["per_kernel_raw"][name] = {n: round(v, 1) for n, v in raw.items()}
+        if "SQ_INSTS_VALU" in raw:
+            out["valu_insts_per_scene_launch"][name] = round(raw["SQ_INSTS_VALU"] / B)
+        if "FETCH_SIZE" in raw or "WRITE_SIZE" in raw:
+            out["hbm_bytes_per_scene_launch"][name] = int((2 * raw.get("FETCH_SIZE", 0) + raw.get("WRITE_SIZE", 0)) * 1024 / B)
+            out["hbm_bytes_uncorrected_per_scene_launch"][name] = int((raw.get("FETCH_SIZE", 0) + raw.get("WRITE_SIZE", 0)) * 1024 / B)
+        cyc = raw.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        if cyc and "SQ_VALU_MFMA_BUSY_CYCLES" in raw:
+            out["mfma_busy_share"][name] = round(raw["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMDS / cyc, 4)
+        # SQ pass and MFMA pass are different runs: kernel cycles for the occupancy figure come from the MFMA pass's GRBM_GUI_ACTIVE
+        if cyc and "SQ_WAVE_CYCLES" in raw:
+            out["mean_waves_per_simd"][name] = round(4.0 * raw["SQ_WAVE_CYCLES"] / SIMDS / cyc, 2)
+        if raw.get("SQ_WAVE_CYCLES"):
+            out["issue_share"][name] = {"issuing": round(raw.get("SQ_ACTIVE_INST_ANY", 0) / raw["SQ_WAVE_CYCLES"], 3),
+                                        "waiting_s_waitcnt": round(raw.get("SQ_WAIT_ANY", 0) / raw["SQ_WAVE_CYCLES"], 3),
+                                        "issue_stall": round(raw.get("SQ_WAIT_INST_ANY", 0) / raw["SQ_WAVE_CYCLES"], 3)}
+            w = max(raw.get("SQ_WAVES", 1), 1)
+            lines.append("%-40s waves/launch %7d | per wave: VALU %7.0f SALU %6.0f LDS %6.0f | issuing %4.1f%% s_waitcnt %4.1f%% issue-stall %4.1f%%" % (
+                name[:40], w, raw.get("SQ_INSTS_VALU", 0) / w, raw.get("SQ_INSTS_SALU", 0) / w, raw.get("SQ_INSTS_LDS", 0) / w,
+                100 * raw.get("SQ_ACTIVE_INST_ANY", 0) / raw["SQ_WAVE_CYCLES"], 100 * raw.get("SQ_WAIT_ANY", 0) / raw["SQ_WAVE_CYCLES"],
+                100 * raw.get("SQ_WAIT_INST_ANY", 0) / raw["SQ_WAVE_CYCLES"]))
+    json.dump(out, open(os.path.join(P, f"{tag}_pmc_kernels.json"), "w"), indent=1, sort_keys=True)
     with open(os.path.join(P, f"{tag}_sq_counters.txt"), "w") as o:
-        o.write("# rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
-                "SQ_ACTIVE_INST_ANY -- python3 tools/time_scene.py 150000 1500\n# averages per launch; wave-cycles = 4 x SQ_WAVE_CYCLES / waves\n")
+        o.write(f"# {out['configuration']}\n# SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY, averages per batched launch\n")
         o.write("\n".join(lines) + "\n")
-print("top kernels (bench, avg us | solo avg us):")
-for k in list(bench)[:8]:
-    print("  %-28s %9.1f | %9.1f" % (k, bench[k], solo.get(k, float("nan"))))
-
-
-# ---- stress config (BASELINE.json configs[4]): 500k points / 5k segments / 20-NN, rocprof HBM/MFMA roofline report
-sf = glob.glob(os.path.join(G, f"{tag}_stress_stats", "**", "*kernel_stats.csv"), recursive=True)
-if sf:
-    st = stats(f"{tag}_stress_stats", f"{tag}_stress_500k_kernel_stats.csv", "tools/time_scene.py 500000 5000 (one scene at a time, 6 forwards)")
-    N, S, k = 500000.0, 5000.0, 20.0
-    E0 = 3.57 * N
-    model = {   # kernel: (bound, algorithmic units per launch, note)   -- DESIGN.md section 4
-        "k_edgeconv<2, true>": ("mfma", 2 * k * N * (18 * 64 + 64 * 64), "MLP3 conv1'->conv2 + BN2 statistics + max (S2X)"),
-        "k_edge_moments": ("hbm", (80 + 48 * k) * N, "MLP3 inner-BN statistics from edge-feature moments (gather-latency-bound)"),
-        "k_edgeconv<1, false>": ("mfma", 2 * k * N * 18 * 64, "MLP2 conv + BN statistics + max (S1X)"),
-        "k_cluster_knn_sorted<20, 1, false>": ("hbm", 96 * N, "in-cluster kNN-20, layer 2 (VALU/latency-bound; HBM is the nominal roof)"),
-        "k_cluster_knn_sorted<20, 1, true>": ("hbm", 96 * N, "in-cluster kNN-20, layer 3, seeded from layer 2"),
-        "k_segment_max64": ("hbm", 260 * N, "per-cluster max of [N,64]"),
-        "k_export": ("hbm", 60 * N, "14 label vectors gather"),
-        "k_mark_pairs": ("hbm", 16 * E0, "mesh-edge contraction (bitmap)"),
-        "k_center_write": ("hbm", 92 * N, "per-cluster centring, writes x9m + kNN operand"),
-        "k_gather_members": ("hbm", 12 * N, "member lists"),
-    }
-    with open(os.path.join(P, f"{tag}_stress_500k_report.md"), "w") as o:
-        o.write("# Stress scene 500k points / 5k segments / 20-NN graph, 1x MI355X (BASELINE.json configs[4])\n\n")
-        wall = [l for l in open(os.path.join(G, f"{tag}_stress_stats.log")).read().splitlines() if l.startswith("iter 3")]
-        o.write("`rocprofv3 --kernel-trace --stats -- python3 tools/time_scene.py 500000 5000`; " + (wall[0] if wall else "") + "\n\n")
-        o.write("Parity at this size: `tests/test_gpu_scene.py::test_stress_500k_matches_reference_and_oracle_digests` (14 label vectors == reference capture == oracle).\n\n")
-        o.write("| kernel | avg us / launch | algorithmic work / launch | achieved | roof | fraction |\n|---|---|---|---|---|---|\n")
-        for kname, (bound, units, note) in model.items():
-            if kname not in st:
-                continue
-            us = st[kname]
-            if bound == "mfma":
-                ach = units / (us * 1e-6) / 1e12
-                o.write(f"| `{kname}` ({note}) | {us:.1f} | {units/1e9:.1f} GFLOP | {ach:.1f} TFLOP/s | 157.3 TFLOP/s fp32 MFMA | {ach/157.3:.3f} |\n")
-            else:
-                ach = units / (us * 1e-6) / 1e9
-                o.write(f"| `{kname}` ({note}) | {us:.1f} | {units/1e6:.1f} MB | {ach:.0f} GB/s | 8000 GB/s HBM | {ach/8000:.4f} |\n")
-        o.write("\nWhole scene: the path is latency/compute-bound, not HBM-bound (SURVEY.md 8d): ~470 MB of algorithmic HBM traffic per "
-                "500k scene in ~10 ms = 47 GB/s = 0.6 % of the HBM roof; the dense contraction (131 GFLOP per scene) runs on fp32 MFMA.\n")
+    print("pmc: %d kernels" % len(out["per_kernel_raw"]))
+for name, d in (("bench", bench), ("solo batched", solo)):
+    if d:
+        print(name, "top kernels (avg us per launch):")
+        for k in list(d)[:8]:
+            print("   %-44s %9.1f" % (k, d[k]))
+log = os.path.join(G, "prof_bench.log")
+if os.path.exists(log):
+    ls = [l for l in open(log).read().splitlines() if l.startswith('{"metric"')]
+    if ls:
+        open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w").write(ls[-1] + "\n")
