@@ -388,6 +388,11 @@ typedef struct sg_debug {         /* optional taps for stage-level parity tests 
     float*   h_dist[3];             /* HOST distance vectors of the three group_nearby calls            */
     int32_t* h_adj[4];              /* HOST adjacency lists adj_1..adj_4 ([E,2])                         */
     int32_t  n_adj[4];              /* rows written to h_adj[i]                                          */
+    /* train-mode inputs of the classifier tail (model.py:900-914), ins_infer forward only: */
+    float*   h_feat5;               /* HOST [S,256] Feat_5: features of the final clusters                */
+    int32_t* h_ins5;                /* HOST [S] weak instance label of every final cluster (-1 = none)    */
+    int32_t* h_sem5;                /* HOST [S] weak semantic label of every final cluster                */
+    int32_t  n5;                    /* final clusters written                                             */
 } sg_debug;
 
 sg_pipeline* sg_pipeline_create(int max_points, int max_segments, int max_edges, int max_vertices,
@@ -521,6 +526,52 @@ int sg_segment_lists(const int32_t* d_seg_indices, int V, const int64_t* d_mappe
 /* `.seg.json` exactly as json.dump writes it (util.py:205-220): one list per sampled point, a segment's members at
  * the index of its smallest member, [] elsewhere.  Host arrays of sg_segment_lists (any group order). */
 int sg_write_seg_json(const char* path, const int32_t* h_seg_points, const int32_t* h_seg_off, int G, int Np);
+
+/* =============================================================================================
+ * Training step, first slice: the train-mode tail of SegModel.forward + its backward, and the backward
+ * of the three cluster-level operators in front of it.  EdgeConv / BatchNorm2d backward, SGD and the DDP gradient
+ * all-reduce (train.py:96-99,160-170) are the next slice.
+ * ============================================================================================= */
+typedef struct sg_classifier {    /* DEVICE pointers, float32, row-major (model.py:154-166)                         */
+    const float* w1;                /* linear1.weight [128,256] (no bias)                                          */
+    const float* gamma;             /* bn1.weight [128]                                                            */
+    const float* beta;              /* bn1.bias   [128]                                                            */
+    const float* w2;                /* linear2.weight [40,128]                                                     */
+    const float* b2;                /* linear2.bias   [40]                                                         */
+} sg_classifier;
+
+/* model.py:900-932 with Classifier.forward (154-166) and cross_entropy_loss(smoothing=True) (util.py:12-29):
+ *   d_feat5 [C,256]   Feat_5, the final clusters' features
+ *   d_group [C]       instance slot of every final cluster: rank of its weak instance label among the sorted unique labels
+ *                     (np.unique(ins_list), model.py:909; an unlabeled cluster's -1 is a label like any other)
+ *   d_gold  [K]       semantic class of every slot (the first cluster's, model.py:913-914)
+ *   d_keep  [K,128]   dropout keep mask ALREADY scaled by 1 / (1 - p) (0 or 2 for p = 0.5); NULL = no dropout.  The reference
+ *                     draws it from torch's RNG stream; parity is stated with the same mask on both sides.
+ * BatchNorm1d uses batch statistics over the K instances (K < 2: SG_EUNSUP, torch raises ValueError there).
+ * Writes d_loss[2] = {loss_sum, K} (the reference's `loss [1,2]`), optionally d_logits [K,40]; keeps the activations the
+ * backward needs in d_ws (sg_train_tail_ws_bytes). */
+size_t sg_train_tail_ws_bytes(int C, int K);
+int sg_train_tail_forward(const float* d_feat5, int C, const int32_t* d_group, int K, const int32_t* d_gold, const float* d_keep,
+                          const sg_classifier* cls, float* d_logits, float* d_loss, void* d_ws, size_t ws_bytes, void* stream);
+/* gradients of loss = scale * loss_sum (train.py:166: scale = 1 / loss_num) w.r.t. the five classifier tensors and Feat_5
+ * [C,256]; d_ws as left by the forward call of the same scene */
+int sg_train_tail_backward(int C, int K, const int32_t* d_gold, const float* d_keep, const sg_classifier* cls, float scale,
+                           float* d_gw1, float* d_ggamma, float* d_gbeta, float* d_gw2, float* d_gb2, float* d_gfeat5,
+                           void* d_ws, size_t ws_bytes, void* stream);
+
+/* backward of sg_group_max_rows (aggregate_cluster_feature, model.py:278-288): the gradient of a group's maximum goes to its
+ * first maximal row (torch.max), every other row of the group gets 0; d_grows rows of `grow_stride` floats */
+int sg_group_max_rows_backward(const float* d_rows, int row_stride, int D, const int32_t* d_goff, const int32_t* d_gidx, int G,
+                               const float* d_gout, int out_stride, float* d_grows, int grow_stride, void* stream);
+/* backward of sg_segment_max (model.py:793,834): rows [N,D] in member order, cluster c = rows [d_cl_off[c], d_cl_off[c+1]) */
+int sg_segment_max_backward(const float* d_rows, int N, int D, const int32_t* d_cl_off, int C, const float* d_gout, int out_stride,
+                            float* d_grows, void* stream);
+/* backward of sg_gcn_forward, INCLUDING the path through the similarity weights exp(-alpha ||x_a - x_b + 1e-6||) and their
+ * row normalisation (autograd differentiates them in the reference: model.py:262-265,305-309): d_gx [S,D], d_gw [D,D] */
+size_t sg_gcn_backward_ws_bytes(int S, int D, int E);
+int sg_gcn_backward(const float* d_x, int S, int D, const int32_t* d_adj, int E, const int32_t* d_rowptr, const int32_t* d_col,
+                    const int32_t* d_eid, const float* d_w, float alpha, const float* d_gout, float* d_gx, float* d_gw,
+                    void* d_ws, size_t ws_bytes, void* stream);
 
 /* =============================================================================================
  * Readers for the reference's on-disk inputs.  Host only.

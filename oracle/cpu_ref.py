@@ -521,6 +521,38 @@ def group_unlabeled(part: Partition, feat, adj, layer: Layer, data, faithful=Fal
 
 
 # ------------------------------------------------------------------------------------------------
+# 8f-4 (first slice)  train-mode tail: per-instance features -> Classifier -> label-smoothed CE  (model.py:900-932,
+# 154-166; util.py:12-29).  Dropout is PINNED: `keep` [K,128] is the mask already scaled by 1 / (1 - p).
+# ------------------------------------------------------------------------------------------------
+def dropout_keep(K, seed=97):
+    """The pinned dropout mask both sides use: element kept (x2) iff its counter-based uniform is < 0.5."""
+    from seggroup_amd.synthetic import uniform01
+    return np.where(uniform01(seed, int(K), int(K) * 128).reshape(int(K), 128) < 0.5, 2.0, 0.0).astype(F32)
+
+
+def train_tail(feat5, ins5, sem5, Wc, keep=None):
+    """-> dict(loss=[loss_sum, K], logits [K,40], feat6 [K,256], group [C], gold [K]); float64 arithmetic."""
+    ins5 = np.asarray(ins5, dtype=np.int64)
+    ins_gt = np.unique(ins5)                                      # model.py:909 (sorted; -1 is a label like any other)
+    group = np.searchsorted(ins_gt, ins5).astype(np.int32)
+    K = ins_gt.shape[0]
+    feat6 = np.stack([np.asarray(feat5, dtype=np.float64)[group == k].max(axis=0) for k in range(K)])
+    gold = np.array([np.asarray(sem5)[np.nonzero(group == k)[0][0]] for k in range(K)], dtype=np.int64)
+    h = feat6 @ Wc["classifier.linear1.weight"].astype(np.float64).T
+    mean, var = h.mean(0), h.var(0)
+    y = (h - mean) / np.sqrt(var + BN_EPS) * Wc["classifier.bn1.weight"].astype(np.float64) + Wc["classifier.bn1.bias"].astype(np.float64)
+    z = np.maximum(y, LRELU * y)
+    if keep is not None:
+        z = z * np.asarray(keep, dtype=np.float64)
+    logits = z @ Wc["classifier.linear2.weight"].astype(np.float64).T + Wc["classifier.linear2.bias"].astype(np.float64)
+    lse = np.log(np.exp(logits - logits.max(1, keepdims=True)).sum(1, keepdims=True)) + logits.max(1, keepdims=True)
+    logp = logits - lse
+    t = np.full_like(logp, 0.2 / (logp.shape[1] - 1))
+    t[np.arange(K), gold] = 0.8
+    return dict(loss=np.array([-(t * logp).sum(), K], dtype=np.float64), logits=logits, feat6=feat6, group=group, gold=gold)
+
+
+# ------------------------------------------------------------------------------------------------
 # A.13  export  (model.py:525-605)   A.14  metrics  (model.py:608-655)
 # ------------------------------------------------------------------------------------------------
 def export_labels(part: Partition, layer: Layer, unmap, num_points, faithful=False):
@@ -642,6 +674,8 @@ def forward_scene(scene, W, mode="ins_infer", faithful=False, keep=False):
     ins_pred, sem_pred = export("final", L5)
     trace += [L3.count, L4.count, L5.count]
     if keep:
-        st.update(feat4=feat4, adj4=adj4, feat5=feat5, adj5=adj5, root5=part.root.copy())
+        st.update(feat4=feat4, adj4=adj4, feat5=feat5, adj5=adj5, root5=part.root.copy(),
+                  ins5=np.array([part.ins[part.root[r]] for r in L5.unmap], dtype=np.int64),
+                  sem5=np.array([part.sem[part.root[r]] for r in L5.unmap], dtype=np.int64))
     return dict(labels=labels, metrics=evaluate(scene.gt, sem_pred, ins_pred), trace=trace, stages=st,
                 stalled=stalled or s2 or s3)

@@ -510,6 +510,24 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             out->used_fallback = 1;
         }
         out->trace[4] = sg_partition_num_clusters(part);
+        if (dbg && dbg->h_feat5 && dbg->h_ins5 && dbg->h_sem5) {
+            // Feat_5 + the weak labels of the final clusters: what the train-mode tail consumes (model.py:900-914).  After the
+            // FPS-1024 fallback the reference max-aggregates once more into the final numbering (model.py:495-507).
+            LayerDesc L6;
+            const int C6 = freeze_layer(part, S, L6);
+            std::vector<float> f6((size_t)C6 * D4, -INFINITY);
+            for (int j = 0; j < C5; ++j) {
+                float* dstp = &f6[(size_t)L6.cl_of_seg[root5[j]] * D4];
+                const float* src = &feat4[(size_t)j * D4];
+                for (int k = 0; k < D4; ++k) dstp[k] = std::max(dstp[k], src[k]);
+            }
+            std::copy(f6.begin(), f6.end(), dbg->h_feat5);
+            for (int c = 0; c < C6; ++c) {
+                double np_ = 0.0;
+                PL_CHECK(sg_partition_label(part, L6.root[c], &dbg->h_ins5[c], &dbg->h_sem5[c], &np_));
+            }
+            dbg->n5 = C6;
+        }
         PL_CHECK(tables_for(12, false));                  // final.{ins,sem}
         n_tables = 14; ins_row = 12; sem_row = 13;
     }

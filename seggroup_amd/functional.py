@@ -447,6 +447,123 @@ def gcn_forward(X, Edge_adj, fc_weight, alpha=1 / 8):
     return out
 
 
+def _sym_csr(a: np.ndarray, S: int):
+    E = a.shape[0]
+    rowptr = np.zeros(S + 1, dtype=np.int32)
+    np.add.at(rowptr, a[:, 0] + 1, 1)
+    np.add.at(rowptr, a[:, 1] + 1, 1)
+    np.cumsum(rowptr, out=rowptr)
+    fill = rowptr[:-1].copy()
+    col = np.zeros(2 * E, dtype=np.int32)
+    eid = np.zeros(2 * E, dtype=np.int32)
+    for e, (u, v) in enumerate(a):
+        col[fill[u]] = v; eid[fill[u]] = e; fill[u] += 1
+        col[fill[v]] = u; eid[fill[v]] = e; fill[v] += 1
+    return rowptr, col, eid
+
+
+# ------------------------------------------------------------------------------------------------
+# training step, first slice: backward of the cluster-level operators + the classifier tail
+# ------------------------------------------------------------------------------------------------
+def gcn_backward(X, Edge_adj, fc_weight, grad_out, alpha=1 / 8):
+    """Gradients of `gcn_forward` w.r.t. X and fc_weight, including the path through the similarity weights
+    (model.py:262-265,305-309 are differentiated by autograd in the reference)."""
+    _need_cuda(X, "X")
+    lib = hip.lib()
+    S, D = int(X.shape[0]), int(X.shape[1])
+    a = Edge_adj.detach().cpu().numpy().reshape(-1, 2).astype(np.int32)
+    E = a.shape[0]
+    dev = X.device
+    t = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (a,) + _sym_csr(a, S)]
+    x, w, g = X.contiguous().float(), fc_weight.contiguous().float(), grad_out.contiguous().float()
+    gx = torch.empty((S, D), dtype=torch.float32, device=dev)
+    gw = torch.empty((D, D), dtype=torch.float32, device=dev)
+    ws = _ws(lib.sg_gcn_backward_ws_bytes(S, D, E), dev)
+    hip.check(lib.sg_gcn_backward(x.data_ptr(), S, D, t[0].data_ptr(), E, t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), w.data_ptr(),
+                                  C.c_float(alpha), g.data_ptr(), gx.data_ptr(), gw.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return gx, gw
+
+
+def aggregate_cluster_feature_backward(Feat_old, clusters_new: Dict[int, List[int]], grad_new):
+    """Gradient of `aggregate_cluster_feature` (max, model.py:278-288) w.r.t. Feat_old: a group's gradient goes to its first
+    maximal row."""
+    _need_cuda(Feat_old, "Feat_old")
+    lib = hip.lib()
+    dev = Feat_old.device
+    G = len(clusters_new)
+    gidx, goff = _csr([clusters_new[i] for i in range(G)])
+    d_gidx, d_goff = torch.from_numpy(gidx).to(dev), torch.from_numpy(goff).to(dev)
+    rows, g = Feat_old.contiguous().float(), grad_new.contiguous().float()
+    D = int(rows.shape[1])
+    out = torch.zeros_like(rows)
+    hip.check(lib.sg_group_max_rows_backward(rows.data_ptr(), D, D, d_goff.data_ptr(), d_gidx.data_ptr(), G, g.data_ptr(), D, out.data_ptr(), D,
+                                             _stream()))
+    return out
+
+
+def segment_max_backward(rows, cl_off, grad_out):
+    """Gradient of the point -> cluster max (model.py:793,834): rows [N,D] in member order, cluster c = rows
+    [cl_off[c], cl_off[c+1]); grad_out [C,D]."""
+    _need_cuda(rows, "rows")
+    lib = hip.lib()
+    dev = rows.device
+    r, g = rows.contiguous().float(), grad_out.contiguous().float()
+    off = torch.as_tensor(np.asarray(cl_off, dtype=np.int32)).to(dev)
+    N, D, Cn = int(r.shape[0]), int(r.shape[1]), int(off.shape[0]) - 1
+    out = torch.zeros_like(r)
+    hip.check(lib.sg_segment_max_backward(r.data_ptr(), N, D, off.data_ptr(), Cn, g.data_ptr(), D, out.data_ptr(), _stream()))
+    return out
+
+
+class TrainTail:
+    """model.py:900-932: per-instance max feature -> Classifier (154-166) -> label-smoothed cross entropy (util.py:12-29),
+    forward and backward on HIP.  `keep` is the pinned dropout mask [K,128] already scaled by 1 / (1 - p) (None = no dropout)."""
+
+    def __init__(self, feat5, ins5, sem5, classifier: Dict[str, torch.Tensor], keep=None):
+        _need_cuda(feat5, "feat5")
+        self.lib = hip.lib()
+        dev = feat5.device
+        ins5 = np.asarray(ins5, dtype=np.int64)
+        ins_gt = np.unique(ins5)                                       # model.py:909
+        group = np.searchsorted(ins_gt, ins5).astype(np.int32)
+        self.K, self.C = int(ins_gt.shape[0]), int(ins5.shape[0])
+        gold = np.array([np.asarray(sem5)[np.nonzero(group == k)[0][0]] for k in range(self.K)], dtype=np.int32)
+        if gold.min() < 0 or gold.max() >= 40:
+            raise ValueError("TrainTail: a weak semantic label outside 0..39 (scatter in cross_entropy_loss would raise in the reference)")
+        self.feat5 = feat5.contiguous().float()
+        self.group, self.gold = torch.from_numpy(group).to(dev), torch.from_numpy(gold).to(dev)
+        self.keep = None if keep is None else torch.as_tensor(np.asarray(keep, dtype=np.float32)).to(dev).contiguous()
+        self.w = {k: classifier[k].detach().to(dev).contiguous().float() for k in
+                  ("linear1.weight", "bn1.weight", "bn1.bias", "linear2.weight", "linear2.bias")}
+        self.cls = hip.Classifier(w1=self.w["linear1.weight"].data_ptr(), gamma=self.w["bn1.weight"].data_ptr(), beta=self.w["bn1.bias"].data_ptr(),
+                                  w2=self.w["linear2.weight"].data_ptr(), b2=self.w["linear2.bias"].data_ptr())
+        self.ws = _ws(self.lib.sg_train_tail_ws_bytes(self.C, self.K), dev)
+        self.logits = torch.empty((self.K, 40), dtype=torch.float32, device=dev)
+        self.loss = torch.empty(2, dtype=torch.float32, device=dev)
+
+    def forward(self):
+        """-> loss [1,2] = [[loss_sum, K]] like the reference's return value"""
+        hip.check(self.lib.sg_train_tail_forward(self.feat5.data_ptr(), self.C, self.group.data_ptr(), self.K, self.gold.data_ptr(),
+                                                 hip.ptr(self.keep), C.byref(self.cls), self.logits.data_ptr(), self.loss.data_ptr(),
+                                                 self.ws.data_ptr(), self.ws.numel(), _stream()))
+        return self.loss.view(1, 2)
+
+    def backward(self, scale: float = None):
+        """Gradients of scale * loss_sum (default scale = 1 / K: train.py:164-166 on one GPU) -> dict of the five classifier
+        gradients + 'feat5'."""
+        dev = self.feat5.device
+        if scale is None:
+            scale = 1.0 / self.K
+        g = {"linear1.weight": torch.empty((128, 256), device=dev), "bn1.weight": torch.empty(128, device=dev), "bn1.bias": torch.empty(128, device=dev),
+             "linear2.weight": torch.empty((40, 128), device=dev), "linear2.bias": torch.empty(40, device=dev),
+             "feat5": torch.empty((self.C, 256), device=dev)}
+        hip.check(self.lib.sg_train_tail_backward(self.C, self.K, self.gold.data_ptr(), hip.ptr(self.keep), C.byref(self.cls), C.c_float(scale),
+                                                  g["linear1.weight"].data_ptr(), g["bn1.weight"].data_ptr(), g["bn1.bias"].data_ptr(),
+                                                  g["linear2.weight"].data_ptr(), g["linear2.bias"].data_ptr(), g["feat5"].data_ptr(),
+                                                  self.ws.data_ptr(), self.ws.numel(), _stream()))
+        return g
+
+
 # ------------------------------------------------------------------------------------------------
 # export + evaluate
 # ------------------------------------------------------------------------------------------------

@@ -50,9 +50,14 @@ class Result(C.Structure):
                 ("trace", C.c_int32 * 5), ("stalled", C.c_int32), ("used_fallback", C.c_int32)]
 
 
+class Classifier(C.Structure):
+    _fields_ = [(n, vp) for n in ("w1", "gamma", "beta", "w2", "b2")]
+
+
 class Debug(C.Structure):
     _fields_ = [("d_samples1", vp), ("d_feat1", vp), ("d_pointfeat", vp * 2), ("d_knn", vp * 2), ("d_members", vp * 2),
-                ("h_gcn", vp * 2), ("h_dist", vp * 3), ("h_adj", vp * 4), ("n_adj", C.c_int32 * 4)]
+                ("h_gcn", vp * 2), ("h_dist", vp * 3), ("h_adj", vp * 4), ("n_adj", C.c_int32 * 4),
+                ("h_feat5", vp), ("h_ins5", vp), ("h_sem5", vp), ("n5", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/seggroup_hip.h
@@ -96,6 +101,13 @@ SIGNATURES = {
     "sg_segment_lists_ws_bytes": (_Z, [_I, _I]),
     "sg_segment_lists": (_I, [vp, _I, vp, _I, vp, vp, vp, C.POINTER(C.c_int), vp, _Z, vp]),
     "sg_write_seg_json": (_I, [C.c_char_p, vp, vp, _I, _I]),
+    "sg_train_tail_ws_bytes": (_Z, [_I, _I]),
+    "sg_train_tail_forward": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, vp, vp, _Z, vp]),
+    "sg_train_tail_backward": (_I, [_I, _I, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
+    "sg_group_max_rows_backward": (_I, [vp, _I, _I, vp, vp, _I, vp, _I, vp, _I, vp]),
+    "sg_segment_max_backward": (_I, [vp, _I, _I, vp, _I, vp, _I, vp, vp]),
+    "sg_gcn_backward_ws_bytes": (_Z, [_I, _I, _I]),
+    "sg_gcn_backward": (_I, [vp, _I, _I, vp, _I, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, _Z, vp]),
     "sg_parse_seg_json": (_I, [C.c_char_p, _I, vp]),
     "sg_stage_segments": (_I, [vp, _I, _I, vp, vp, vp, vp]),
     "sg_edgeconv_ws_bytes": (_Z, [_I]),

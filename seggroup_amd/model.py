@@ -106,6 +106,7 @@ class SceneResult:
         self.trace = list(res.trace)
         self.stalled = bool(res.stalled)
         self.used_fallback = bool(res.used_fallback)
+        self.feat5 = self.ins5 = self.sem5 = None        # train mode only: Feat_5 [C5,256] + weak labels of the final clusters
 
     def label_dict(self) -> Dict[str, np.ndarray]:
         return {hip.LABEL_NAMES[i]: self.labels[i] for i in range(self.n_vectors)}
@@ -132,9 +133,14 @@ class Pipeline:
     def fits(self, sc: DeviceScene) -> bool:
         return sc.N <= self.caps[0] and sc.S <= self.caps[1] and sc.E0 <= self.caps[2] and sc.V <= self.caps[3]
 
-    def forward(self, sc: DeviceScene, mode: int = hip.MODE_INS_INFER, debug: Optional[hip.Debug] = None) -> SceneResult:
+    def forward(self, sc: DeviceScene, mode: int = hip.MODE_INS_INFER, debug: Optional[hip.Debug] = None, want_feat5: bool = False) -> SceneResult:
         res = hip.Result()
         res.h_labels = self.labels.data_ptr()
+        feat5 = ins5 = sem5 = None
+        if want_feat5 and mode == hip.MODE_INS_INFER:
+            debug = debug if debug is not None else hip.Debug()
+            feat5 = np.zeros((sc.S, 256), np.float32); ins5 = np.zeros(sc.S, np.int32); sem5 = np.zeros(sc.S, np.int32)
+            debug.h_feat5, debug.h_ins5, debug.h_sem5 = feat5.ctypes.data, ins5.ctypes.data, sem5.ctypes.data
         with torch.cuda.device(self.device):
             rc = self.lib.sg_pipeline_forward(self.handle, C.byref(sc.c_struct), mode, C.byref(res),
                                               C.byref(debug) if debug is not None else None)
@@ -144,7 +150,11 @@ class Pipeline:
         # a private copy: the pinned buffer is overwritten by this pipeline's next forward (SegModel.last_result must not
         # go stale); BatchRunner.run hands out views instead and documents it
         lab = self.labels.numpy().reshape(-1)[:hip.NUM_LABEL_VECTORS * sc.V].reshape(hip.NUM_LABEL_VECTORS, sc.V).copy()
-        return SceneResult(lab, nvec, res)
+        out = SceneResult(lab, nvec, res)
+        if feat5 is not None:
+            n5 = int(debug.n5)
+            out.feat5, out.ins5, out.sem5 = feat5[:n5].copy(), ins5[:n5].copy(), sem5[:n5].copy()
+        return out
 
     def set_timing(self, level: int) -> int:
         """0 = no stage-timing events, 1 = only around the kNN / EdgeConv kernels, 2 = every stage (default)."""
@@ -363,8 +373,10 @@ def write_label_files(output_root: str, result: SceneResult, formats=("txt", "np
 class SegModel(nn.Module):
     """Drop-in for the reference `SegModel` (model.py:658-897), inference modes only.
 
-    Training (`epoch` not in {'sem_infer','ins_infer'} with neither infer flag set) is out of scope for
-    this build and raises NotImplementedError after the pseudo labels are exported.
+    With neither infer flag set, `forward` runs the whole ins_infer forward (pseudo labels are exported under
+    `epoch_<n>/` like the reference does) and then the train-mode tail of model.py:900-932 on HIP, returning
+    `(loss[1,2], IoU_sem, IoU_ins, acc)`; `self.last_tail.backward()` gives the classifier / Feat_5 gradients.  The
+    backward through EdgeConv / BatchNorm2d and the optimizer step are the next slice of SURVEY.md 8f-4.
     """
 
     def __init__(self, exp_name='exp', cuda=True, visualize=False, sem_infer=False, ins_infer=False,
@@ -398,6 +410,9 @@ class SegModel(nn.Module):
         self._writer: Optional[AsyncLabelWriter] = None
         self.async_write = True          # label files are written by native threads; flush() waits for them
         self.last_result: Optional[SceneResult] = None
+        self.last_tail = None
+        from .synthetic import uniform01
+        self.dropout_keep = lambda K: np.where(uniform01(97, int(K), int(K) * 128).reshape(int(K), 128) < 0.5, 2.0, 0.0).astype(np.float32)
 
     # -- parameters -> C ABI ----------------------------------------------------------------------
     def export_weights(self) -> Dict[str, np.ndarray]:
@@ -433,7 +448,8 @@ class SegModel(nn.Module):
     def forward_scene(self, sc: DeviceScene, write: bool = True) -> SceneResult:
         """Hot path on a staged scene.  Returns the SceneResult; writes the label files if `write`."""
         with self._lock:
-            res = self.pipeline_for(sc).forward(sc, self.mode())
+            train = not (self.sem_infer or self.ins_infer)
+            res = self.pipeline_for(sc).forward(sc, self.mode(), want_feat5=train)
             if write:
                 if self.async_write:
                     if self._writer is None:
@@ -443,6 +459,17 @@ class SegModel(nn.Module):
                     write_label_files(self.output_root(sc.name), res, self.out_formats)
             self.last_result = res
         return res
+
+    def train_tail(self, sc: DeviceScene, res: SceneResult):
+        """The train-mode tail of this scene (functional.TrainTail) from the Feat_5 tap of the forward just made.  Dropout is
+        PINNED: `self.dropout_keep(K)` -> [K,128] mask of {0, 2}; default = the counter-based mask of
+        `oracle`-independent `synthetic.uniform01(97, K, K * 128) < 0.5`, the one the golden capture used."""
+        if res.feat5 is None:
+            raise RuntimeError("train_tail needs a forward made in train mode (Feat_5 tap)")
+        K = int(np.unique(res.ins5).shape[0])
+        keep = self.dropout_keep(K) if self.dropout_keep is not None else None
+        cls = {k[len("classifier."):]: v for k, v in self.state_dict().items() if k.startswith("classifier.")}
+        return _F.TrainTail(torch.from_numpy(res.feat5).to(sc.device), res.ins5, res.sem5, cls, keep)
 
     def flush(self) -> None:
         """Wait until every label file submitted so far is on disk (raises on the first I/O error)."""
@@ -468,5 +495,9 @@ class SegModel(nn.Module):
         out = (torch.from_numpy(res.iou_sem).to(dev), torch.from_numpy(res.iou_ins).to(dev), torch.from_numpy(res.acc).to(dev))
         if self.sem_infer or self.ins_infer:
             return out
-        raise NotImplementedError("training step (Classifier + loss, model.py:900-932) is out of scope for this build; "
-                                  "pseudo labels and metrics were produced")
+        # train mode (model.py:900-932), first slice of SURVEY.md 8f-4: the classifier tail + label-smoothed cross entropy
+        # run on HIP and `self.last_tail.backward()` yields the gradients of the classifier and of Feat_5; the backward
+        # through EdgeConv / BatchNorm2d (hence an optimizer step over all 147,880 parameters) is the next slice, so the
+        # returned loss carries no autograd graph.
+        self.last_tail = self.train_tail(sc, res)
+        return (self.last_tail.forward(),) + out

@@ -1,0 +1,151 @@
+"""SURVEY.md 8f-4, first slice, on the GPU: the train-mode tail of SegModel.forward against the capture of the real reference
+(tests/golden/train_tail.npz: tools/capture_train.py, dropout pinned), and every backward entry point against torch autograd
+of a float64 restatement of the same operator."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, make_fixture_scene
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _classifier_from_golden(net, g):
+    import torch
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.classifier.")}
+    missing = net.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and not [k for k in sd if k in missing.missing_keys]
+    return {k[len("classifier."):]: v.double() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("name", ["tiny_4k", "tiny_dup_4k", "small_20k", "island_20k"])
+def test_train_mode_forward_matches_reference_capture(golden_index, weight_sets, name):
+    """`SegModel.forward` with neither infer flag set returns `(loss[1,2], IoU_sem, IoU_ins, acc)` like model.py:932; the loss,
+    the logits and the per-instance features equal the reference's (same pinned dropout mask) within the float tolerance, the
+    pseudo labels it exports on the way are the ins_infer ones."""
+    import torch
+    from seggroup_amd import hip
+    from seggroup_amd.model import SegModel
+    from seggroup_amd.scene import DeviceScene
+    g = np.load(os.path.join(GOLDEN, "train_tail.npz"))
+    scene = make_fixture_scene(golden_index, name)
+    net = SegModel(exp_name="t")                       # train mode: neither infer flag
+    net.load_weights(weight_sets["ins_infer"])
+    _classifier_from_golden(net, g)
+    net.epoch = "0"
+    sc = DeviceScene.from_synthetic(scene, device="cuda:0")
+    res = net.forward_scene(sc, write=False)
+    assert res.feat5 is not None and res.feat5.shape[1] == 256 and res.feat5.shape[0] == res.trace[4]
+    tail = net.train_tail(sc, res)
+    loss = tail.forward().cpu().numpy()
+    want = g[f"{name}.loss"]
+    assert loss.shape == (1, 2) and loss[0, 1] == want[0, 1] == tail.K
+    assert abs(loss[0, 0] - want[0, 0]) <= TOL * max(1.0, abs(want[0, 0])), (loss, want)
+    assert np.abs(tail.logits.cpu().numpy() - g[f"{name}.logits"]).max() < TOL
+    # Feat_6 from the tap == the reference's classifier input
+    ins_gt = np.unique(res.ins5)
+    feat6 = np.stack([res.feat5[res.ins5 == i].max(0) for i in ins_gt])
+    assert np.abs(feat6 - g[f"{name}.feat6"]).max() < TOL
+    # the labels written on the way are the inference ones
+    gl = np.load(os.path.join(GOLDEN, name + ".npz"))
+    for i in range(14):
+        assert np.array_equal(res.labels[i], gl[f"ins.label.{hip.LABEL_NAMES[i]}"])
+
+
+def test_train_tail_backward_matches_autograd(golden_index, weight_sets):
+    import torch
+    from oracle import cpu_ref
+    from seggroup_amd.functional import TrainTail
+    g = np.load(os.path.join(GOLDEN, "train_tail.npz"))
+    rng = np.random.default_rng(5)
+    C, K = 37, 9
+    feat5 = rng.normal(size=(C, 256)).astype(np.float32)
+    ins5 = rng.integers(-1, K - 1, C); ins5[:K] = np.arange(-1, K - 1)             # every slot occupied, -1 included
+    sem5 = rng.integers(0, 40, C)
+    cls = {k[len("w.classifier."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.classifier.")}
+    cls["bn1.weight"] = cls["bn1.weight"] + torch.from_numpy(rng.normal(size=128).astype(np.float32)) * 0.3
+    cls["bn1.bias"] = torch.from_numpy(rng.normal(size=128).astype(np.float32)) * 0.2
+    keep = cpu_ref.dropout_keep(K)
+    tail = TrainTail(torch.from_numpy(feat5).cuda(), ins5, sem5, cls, keep)
+    loss = tail.forward().cpu().numpy()
+    got = {k: v.cpu().numpy() for k, v in tail.backward().items()}
+    # float64 torch restatement of model.py:900-932 + util.py:12-29
+    f5 = torch.from_numpy(feat5).double().requires_grad_(True)
+    p = {k: v.double().clone().requires_grad_(True) for k, v in cls.items()}
+    ins_gt = np.unique(ins5)
+    f6 = torch.cat([torch.max(f5[np.nonzero(ins5 == i)[0]], dim=0, keepdim=True)[0] for i in ins_gt])
+    gold = torch.tensor([int(sem5[np.nonzero(ins5 == i)[0][0]]) for i in ins_gt])
+    h = f6 @ p["linear1.weight"].T
+    y = torch.nn.functional.batch_norm(h, None, None, p["bn1.weight"], p["bn1.bias"], True, 0.1, 1e-5)
+    z = torch.nn.functional.leaky_relu(y, 0.2) * torch.from_numpy(keep).double()
+    logits = z @ p["linear2.weight"].T + p["linear2.bias"]
+    one_hot = torch.zeros_like(logits).scatter(1, gold.view(-1, 1), 1)
+    one_hot = one_hot * 0.8 + (1 - one_hot) * 0.2 / 39
+    loss_sum = -(one_hot * torch.log_softmax(logits, dim=1)).sum()
+    assert abs(loss[0, 0] - loss_sum.item()) < TOL * abs(loss_sum.item()) and loss[0, 1] == K
+    (loss_sum / K).backward()
+    for k in cls:
+        w = p[k].grad.numpy()
+        assert np.abs(got[k] - w).max() < TOL * max(1.0, np.abs(w).max()), k
+    assert np.abs(got["feat5"] - f5.grad.numpy()).max() < TOL
+
+
+def test_group_max_and_segment_max_backward():
+    import torch
+    from seggroup_amd.functional import aggregate_cluster_feature_backward, segment_max_backward
+    rng = np.random.default_rng(6)
+    R, D, G = 61, 192, 17
+    rows = rng.normal(size=(R, D)).astype(np.float32)
+    owner = rng.integers(0, G, R); owner[:G] = np.arange(G)
+    rows[owner == 3] = rows[np.nonzero(owner == 3)[0][0]]                       # a group of identical rows: the FIRST one wins
+    groups = {g_: np.nonzero(owner == g_)[0].tolist() for g_ in range(G)}
+    gout = rng.normal(size=(G, D)).astype(np.float32)
+    got = aggregate_cluster_feature_backward(torch.from_numpy(rows).cuda(), groups, torch.from_numpy(gout).cuda()).cpu().numpy()
+    x = torch.from_numpy(rows).double().requires_grad_(True)
+    out = torch.cat([torch.max(x[groups[g_]], dim=0, keepdim=True)[0] for g_ in range(G)])
+    out.backward(torch.from_numpy(gout).double())
+    assert np.array_equal(got, x.grad.numpy().astype(np.float32))
+    # point -> cluster max over contiguous ranges
+    off = np.array([0, 5, 6, 40, 41, 61], np.int32)
+    gout2 = rng.normal(size=(5, D)).astype(np.float32)
+    got2 = segment_max_backward(torch.from_numpy(rows).cuda(), off, torch.from_numpy(gout2).cuda()).cpu().numpy()
+    x = torch.from_numpy(rows).double().requires_grad_(True)
+    out = torch.cat([torch.max(x[off[c]:off[c + 1]], dim=0, keepdim=True)[0] for c in range(5)])
+    out.backward(torch.from_numpy(gout2).double())
+    assert np.array_equal(got2, x.grad.numpy().astype(np.float32))
+
+
+@pytest.mark.parametrize("S,D,E", [(40, 192, 110), (25, 256, 0), (7, 192, 21)])
+def test_gcn_backward_matches_autograd(S, D, E):
+    """The GCN layer's gradients w.r.t. its input features AND through the similarity weights exp(-alpha * dist) and their row
+    normalisation (model.py:262-265, 305-309, 146-151), against autograd of the reference's dense formulation."""
+    import torch
+    from seggroup_amd.functional import gcn_backward, gcn_forward
+    rng = np.random.default_rng(S)
+    X = rng.normal(size=(S, D)).astype(np.float32)
+    W = (rng.normal(size=(D, D)) / np.sqrt(D)).astype(np.float32)
+    pairs = {(min(a, b), max(a, b)) for a, b in rng.integers(0, S, (4 * E + 4, 2)) if a != b}
+    adj = np.array(sorted(pairs)[:E], np.int64).reshape(-1, 2)
+    gout = rng.normal(size=(S, D)).astype(np.float32)
+    alpha = 1 / 8
+    out = gcn_forward(torch.from_numpy(X).cuda(), torch.from_numpy(adj).cuda(), torch.from_numpy(W).cuda(), alpha).cpu().numpy()
+    gx, gw = [t.cpu().numpy() for t in gcn_backward(torch.from_numpy(X).cuda(), torch.from_numpy(adj), torch.from_numpy(W).cuda(),
+                                                     torch.from_numpy(gout).cuda(), alpha)]
+    x = torch.from_numpy(X).double().requires_grad_(True)
+    w = torch.from_numpy(W).double().requires_grad_(True)
+    edge = torch.eye(S, dtype=torch.float64)
+    if adj.shape[0]:
+        a, b = torch.from_numpy(adj[:, 0]), torch.from_numpy(adj[:, 1])
+        dist = torch.sqrt(((x[a] - x[b] + 1e-6) ** 2).sum(1))                    # F.pairwise_distance (model.py:272)
+        sims = torch.exp(-dist * alpha)
+        m = torch.zeros(S, S, dtype=torch.float64)
+        m = m.index_put((a, b), sims).index_put((b, a), sims)
+        edge = edge + m
+    edge = edge / edge.sum(1, keepdim=True)
+    ref = torch.relu((edge @ x) @ w.T)
+    assert np.abs(out - ref.detach().numpy()).max() < TOL
+    ref.backward(torch.from_numpy(gout).double())
+    assert np.abs(gx - x.grad.numpy()).max() < TOL * max(1.0, np.abs(x.grad.numpy()).max())
+    assert np.abs(gw - w.grad.numpy()).max() < TOL * max(1.0, np.abs(w.grad.numpy()).max())

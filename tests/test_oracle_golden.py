@@ -137,3 +137,23 @@ def test_group_nearby_stall_is_detected():
     L = O.Layer(p)
     conn, stalled = O.group_nearby(p, np.array([9.0], np.float32), np.array([[0, 1]]), L, 6)
     assert stalled and not conn[0]
+
+
+@pytest.mark.parametrize("name", ["tiny_4k", "tiny_dup_4k", "small_20k", "island_20k"])
+def test_oracle_train_tail_matches_reference_capture(golden_index, weight_sets, name):
+    """SURVEY 8f-4, first slice: the oracle's restatement of the train-mode tail (model.py:900-932, Classifier, label-smoothed
+    CE) against the capture of the real reference with the same pinned dropout mask (tools/capture_train.py)."""
+    import os
+    from conftest import GOLDEN, make_fixture_scene
+    from oracle import cpu_ref
+    g = np.load(os.path.join(GOLDEN, "train_tail.npz"))
+    scene = make_fixture_scene(golden_index, name)
+    o = cpu_ref.forward_scene(scene, weight_sets["ins_infer"], "ins_infer", keep=True)["stages"]
+    Wc = {k[2:]: g[k] for k in g.files if k.startswith("w.classifier.")}
+    K = np.unique(o["ins5"]).shape[0]
+    t = cpu_ref.train_tail(o["feat5"], o["ins5"], o["sem5"], Wc, cpu_ref.dropout_keep(K))
+    assert np.array_equal(g[f"{name}.keep"], cpu_ref.dropout_keep(K))
+    assert np.abs(t["feat6"] - g[f"{name}.feat6"]).max() < 1e-4
+    assert np.abs(t["logits"] - g[f"{name}.logits"]).max() < 1e-4
+    want = g[f"{name}.loss"]
+    assert t["loss"][1] == want[0, 1] and abs(t["loss"][0] - want[0, 0]) < 1e-4 * abs(want[0, 0])
