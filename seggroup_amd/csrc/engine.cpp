@@ -342,20 +342,29 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
             if (h && count) std::memcpy(h, v, count * 4);
             return d;
         };
-        // tiles of 64 consecutive member positions of one cluster
+        // tiles of 64 consecutive member positions of one cluster, LARGEST clusters first: a tile's cost grows with its cluster
+        // (more segments and chunks to test, more candidates), one wave runs one tile, and the launch ends when its slowest
+        // wave does -- the long tiles must start first (the tile order is free: every tile names its cluster)
         int T = 0;
         for (int cc = 0; cc < C; ++cc) T += (Ln.cl_pt_off[cc + 1] - Ln.cl_pt_off[cc] + 63) / 64;
         {
+            tmp.resize(C);
+            for (int cc = 0; cc < C; ++cc) tmp[cc] = cc;
+            std::stable_sort(tmp.begin(), tmp.end(), [&](int a, int b) {
+                return Ln.cl_pt_off[a + 1] - Ln.cl_pt_off[a] > Ln.cl_pt_off[b + 1] - Ln.cl_pt_off[b];
+            });
             int32_t *d_cl = nullptr, *d_lo = nullptr, *d_hi = nullptr;
             int32_t* t_cl = par.take<int32_t>(std::max(T, 1), &d_cl);
             int32_t* t_lo = par.take<int32_t>(std::max(T, 1), &d_lo);
             int32_t* t_hi = par.take<int32_t>(std::max(T, 1), &d_hi);
             if (t_cl && t_lo && t_hi) {
                 int t = 0;
-                for (int cc = 0; cc < C; ++cc)
+                for (int k = 0; k < C; ++k) {
+                    const int cc = tmp[k];
                     for (int lo = Ln.cl_pt_off[cc]; lo < Ln.cl_pt_off[cc + 1]; lo += 64, ++t) {
                         t_cl[t] = cc; t_lo[t] = lo; t_hi[t] = std::min(lo + 64, Ln.cl_pt_off[cc + 1]);
                     }
+                }
             }
             c.tile_cl = d_cl; c.tile_lo = d_lo; c.tile_hi = d_hi; c.T = T;
         }

@@ -170,11 +170,15 @@ def _load_hip_runtime():
     if _runtime is not None:
         return _runtime
     cands = []
-    try:
-        import torch  # noqa: F401  (loads torch/lib/libamdhip64.so)
-        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
-    except ImportError:
-        pass
+    import sys
+    if "torch" in sys.modules or not os.environ.get("SEGGROUP_HOST_ONLY"):
+        try:
+            import torch  # noqa: F401  (loads torch/lib/libamdhip64.so)
+            cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        except ImportError:
+            pass
+    # SEGGROUP_HOST_ONLY=1 (pack-building worker processes: parsers and writers only): do not pay ~2 s for importing torch
+    # just to find its copy of the runtime; a process that will touch the GPU through torch must not set it
     cands += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
     err = None
     for c in cands:

@@ -1,0 +1,67 @@
+"""Reader for the reference's one-tensor `.pth` files (`torch.save(tensor, path)`: a STORED zip holding `data.pkl` + the
+raw storage) that does not import torch: scene packs are built by a thread / process pool, and a fresh
+interpreter spends ~2 s importing torch before it has parsed a byte.  Only what those files contain is supported -- one
+dense CPU tensor, any strides -- anything else raises and the caller falls back to `torch.load`.
+"""
+from __future__ import annotations
+
+import collections
+import pickle
+import zipfile
+
+import numpy as np
+
+_DTYPES = {"FloatStorage": np.float32, "DoubleStorage": np.float64, "HalfStorage": np.float16, "LongStorage": np.int64,
+           "IntStorage": np.int32, "ShortStorage": np.int16, "CharStorage": np.int8, "ByteStorage": np.uint8, "BoolStorage": np.bool_}
+
+
+class _Storage:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+
+def _rebuild_tensor_v2(storage, offset, size, stride, requires_grad=False, backward_hooks=None, metadata=None):
+    arr, dtype = storage
+    flat = np.frombuffer(arr, dtype=dtype)
+    item = np.dtype(dtype).itemsize
+    view = np.lib.stride_tricks.as_strided(flat[offset:], shape=tuple(size), strides=tuple(s * item for s in stride), writeable=False)
+    return np.ascontiguousarray(view)
+
+
+class _Unpickler(pickle.Unpickler):
+    def __init__(self, f, zf, prefix):
+        super().__init__(f)
+        self.zf, self.prefix = zf, prefix
+
+    def find_class(self, module, name):
+        if module == "torch._utils" and name == "_rebuild_tensor_v2":
+            return _rebuild_tensor_v2
+        if module == "torch" and name in _DTYPES:
+            return _Storage(_DTYPES[name])
+        if module == "collections" and name == "OrderedDict":
+            return collections.OrderedDict
+        raise pickle.UnpicklingError(f"{module}.{name} is not part of a plain tensor file")
+
+    def persistent_load(self, pid):
+        kind, storage, key, _location, _numel = pid
+        if kind != "storage" or not isinstance(storage, _Storage):
+            raise pickle.UnpicklingError("unexpected persistent id")
+        return self.zf.read(f"{self.prefix}/data/{key}"), storage.dtype
+
+
+def load_tensor(path: str) -> np.ndarray:
+    """`torch.load(path).numpy()` for a file written by `torch.save(tensor, path)` (zip format, little endian)."""
+    with zipfile.ZipFile(path) as zf:
+        names = zf.namelist()
+        pkl = [n for n in names if n.endswith("/data.pkl")]
+        if len(pkl) != 1:
+            raise ValueError(f"{path}: not a torch zip archive with one data.pkl")
+        prefix = pkl[0][:-len("/data.pkl")]
+        bo = f"{prefix}/byteorder"
+        if bo in names and zf.read(bo).strip() != b"little":
+            raise ValueError(f"{path}: big-endian storage")
+        with zf.open(pkl[0]) as f:
+            out = _Unpickler(f, zf, prefix).load()
+    if not isinstance(out, np.ndarray):
+        raise ValueError(f"{path}: holds a {type(out).__name__}, not a single tensor")
+    return out

@@ -97,18 +97,24 @@ class DeviceScene:
     def from_reference_tree(cls, scene_name: str, data=None, weak_label=None, root: str = ".", label_style: str = "manual",
                             device="cuda") -> "DeviceScene":
         """Read one scene from the reference's on-disk layout under `root` (CWD in the reference)."""
-        import torch
+        from .pth import load_tensor
 
         base = os.path.join(root, "dataset", "scannet")
-        ld = lambda *p: torch.load(os.path.join(base, *p), map_location="cpu")
+
+        def ld(*p):
+            try:
+                return load_tensor(os.path.join(base, *p))
+            except Exception:
+                import torch
+                return torch.load(os.path.join(base, *p), map_location="cpu").numpy()
         if data is None:
             data = ld("data", "resampled", scene_name, scene_name + ".pcl.pth")
         if weak_label is None:
             weak_label = ld("label", "seg", label_style, "resampled", scene_name, scene_name + ".label.pth")
         data = data.detach().cpu().numpy() if hasattr(data, "detach") else np.asarray(data)
         weak_label = weak_label.detach().cpu().numpy() if hasattr(weak_label, "detach") else np.asarray(weak_label)
-        adj = ld("adj", "mesh", "resampled", scene_name, scene_name + ".adj.pth").numpy()
-        unmap = ld("data", "resampled", scene_name, scene_name + ".unmap.pth").numpy()
-        gt = ld("label", "real", "raw", scene_name, scene_name + ".label.pth").numpy()
+        adj = ld("adj", "mesh", "resampled", scene_name, scene_name + ".adj.pth")
+        unmap = ld("data", "resampled", scene_name, scene_name + ".unmap.pth")
+        gt = ld("label", "real", "raw", scene_name, scene_name + ".label.pth")
         seg = seg_from_file(os.path.join(base, "label", "real", "resampled", scene_name, scene_name + ".seg.json"), data.shape[0])
         return cls(data, weak_label, seg, adj, unmap, gt, device=device, name=scene_name)

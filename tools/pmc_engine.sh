@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() {   # name, counters...
   local name=$1; shift
   local out=$R/gpurun_out/${TAG}_pmc_raw_$name
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-files --groups $G --per-group $B --parity-scenes 1 > $out.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-files --groups $G --per-group $B --parity-scenes 1 --no-extras > $out.log 2>&1
   python3 - "$out" "$R/gpurun_out/${TAG}_pmc_$name.json" "$G" "$B" <<'PY'
 import csv, glob, json, sys, collections, re
 src, dst, G, B = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])

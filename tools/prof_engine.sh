@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-solo8}; G=${2:-1}; B=${3:-8}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-files --groups $G --per-group $B > $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-files --groups $G --per-group $B --no-extras > $R/gpurun_out/prof_$TAG.log 2>&1
 f=$(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys

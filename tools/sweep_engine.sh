@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for gb in "$@"; do
   g=${gb%x*}; b=${gb#*x}
-  SG_ENGINE_PROFILE=1 timeout 300 python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-files --groups $g --per-group $b > /tmp/o.json 2> /tmp/o.err
+  SG_ENGINE_PROFILE=1 timeout 300 python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-files --no-extras --groups $g --per-group $b > /tmp/o.json 2> /tmp/o.err
   python3 - <<PY
 import json
 try:
