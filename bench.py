@@ -388,6 +388,7 @@ def main(argv=None):
             # single pipeline like the main batch
             runner.run(extra_scenes, hip.MODE_INS_INFER)
             torch.cuda.synchronize()
+            runner.reset_stage_stats()
             t1 = time.perf_counter()
             reps, pend, res_x = 4, [], None
             for _ in range(reps):                                  # queued two ahead, like the timed loop
@@ -402,8 +403,9 @@ def main(argv=None):
             same_x = all(label_digest(res_x[i]) == label_digest(solo2.forward(extra_scenes[i], hip.MODE_INS_INFER)) for i in range(min(4, len(extra_scenes))))
             solo2.close()
             seg_max = max(int(s_.h_seg_size.max()) for s_ in extra_scenes)
+            stage_x = {k_: round(v, 4) for k_, v in runner.mean_stage_ms().items() if v > 0}
             extras["scannet_profile"] = {"scenes_per_s": round(reps * len(extra_scenes) / dt, 3), "scenes": len(extra_scenes), "largest_segment_points": seg_max,
-                                         "equals_single_pipeline": bool(same_x),
+                                         "equals_single_pipeline": bool(same_x), "stage_ms": stage_x,
                                          "cluster_trace_scene0": list(res_x[0].trace)}
             if not same_x:
                 parity_all = False

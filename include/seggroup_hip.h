@@ -45,6 +45,9 @@ const char* sg_last_error(void);
 int  sg_version(void);
 /* number of visible HIP devices (0 when no GPU): lets callers fail loudly before first use */
 int  sg_device_count(void);
+/* device self-test of the DPP wave reductions the structural-layer kernels use (csrc/wave_ops.h) against the ds_bpermute
+ * butterflies they replace; *h_mismatches = 0 on a healthy build.  Synchronises the stream. */
+int  sg_selftest_wave_ops(int* h_mismatches, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a3  update_adj, first call (model.py:291-302 with model.py:724-733): contract the point-level

@@ -13,6 +13,7 @@
 
 #include "engine_ctx.h"
 #include "sg_common.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -30,13 +31,7 @@ __device__ inline Best better(Best a, Best b) {   // larger value wins, ties -> 
 
 template <int BLOCK>
 __device__ inline Best block_argmax(Best b, Best* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        Best t;
-        t.v = __shfl_xor(b.v, o);
-        t.i = __shfl_xor(b.i, o);
-        b = better(b, t);
-    }
+    sgw::wave_argmax(b.v, b.i);                                  // DPP network + readlane (same total order as better())
     if constexpr (BLOCK > 64) {
         const int wid = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) red[wid] = b;
@@ -153,8 +148,7 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
         q[0] = x; q[1] = y; q[2] = z;
         amax = fmaxf(amax, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    amax = sgw::wave_max(amax);
     if constexpr (BLOCK > 64) {
         if ((tid & 63) == 0) wmax[tid >> 6] = amax;
         __syncthreads();

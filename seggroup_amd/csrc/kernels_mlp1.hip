@@ -12,6 +12,7 @@
 //   3. k_mlp1_apply       : conv + affine + LeakyReLU + max_k, then wave-reduced max/mean over the lanes.
 #include "engine_ctx.h"
 #include "sg_common.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -41,7 +42,8 @@ __device__ __forceinline__ void mlp1_knn_moments_body(const float* __restrict__ 
     for (int t = 0; t < K1; ++t) { bv[t] = -INFINITY; bi[t] = 0; }
 #pragma unroll 8
     for (int j = 0; j < 64; ++j) {
-        const float s = knn_score(f[0], f[1], f[2], xx, __shfl(f[0], j), __shfl(f[1], j), __shfl(f[2], j), __shfl(xx, j));
+        // candidate j is the same for every lane: v_readlane broadcasts instead of four ds_bpermute round trips
+        const float s = knn_score(f[0], f[1], f[2], xx, sgw::bcast(f[0], j), sgw::bcast(f[1], j), sgw::bcast(f[2], j), sgw::bcast(xx, j));
         if (s > bv[K1 - 1]) {                       // sorted insertion, earlier candidate first on ties
             float v = s;
             int id = j;
@@ -86,9 +88,7 @@ __device__ __forceinline__ void mlp1_knn_moments_body(const float* __restrict__ 
     }
 #pragma unroll
     for (int q = 0; q < 27; ++q) {
-        double v = acc[q];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const double v = sgw::wave_sum(acc[q]);                 // DPP network, fixed order
         if (lane == 0) partial[(size_t)c * 27 + q] = v;
     }
 }
@@ -180,10 +180,10 @@ __device__ __forceinline__ void mlp1_apply_body(const float* __restrict__ sample
             y = fmaxf(y, 0.2f * y);                              // LeakyReLU(0.2), slope < 1
             h = fmaxf(h, y);                                     // max over k (model.py:76)
         }
-        float mx = h;
-        double sm = (double)h;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); sm += __shfl_xor(sm, o); }
+        // wave reductions on the DPP path (wave_ops.h): 64 channels x 12 dependent ds_bpermute round trips were most of this
+        // kernel's time
+        const float mx = sgw::wave_max(h);
+        const double sm = sgw::wave_sum((double)h);
         if (lane == 0) { out[ch] = mx; out[64 + ch] = (float)(sm / 64.0); }    // model.py:77-79
     }
 }

@@ -1,0 +1,103 @@
+// Wave64 reductions on the DPP data path (CDNA / GFX9 encodings: quad_perm, row_ror, row_bcast15 / 31) with the result
+// handed back through v_readlane -- no LDS traffic.  `__shfl_xor` compiles to ds_bpermute_b32 on gfx950: every butterfly
+// step is an LDS round trip (~100 cycles of latency in a dependent chain), which is what the one-wave-per-segment kernels
+// of the structural layer (FPS, MLP1) spent most of their time on.
+//
+//   step 1-2  quad_perm [1,0,3,2], [2,3,0,1] : every lane holds its quad's result
+//   step 3-4  row_ror 4, row_ror 8           : every lane holds its 16-lane row's result
+//   step 5    row_bcast15 (rows 1 and 3)     : lane 15 of row r-1 is combined into row r
+//   step 6    row_bcast31 (rows 2 and 3)     : lane 31 is combined into rows 2-3 -> lane 63 holds the wave's result
+//   readlane 63                              : the result, wave-uniform (an SGPR)
+// The association order of a floating-point sum is fixed by this network (deterministic, but different from a xor
+// butterfly's).  All 64 lanes must be active.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sgw {
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(old), __float_as_int(v)));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_d(double old, double v) {
+    const long long o = __double_as_longlong(old), x = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL, ROW_MASK>((int)(o & 0xffffffffll), (int)(x & 0xffffffffll));
+    const int hi = dpp_i<CTRL, ROW_MASK>((int)(o >> 32), (int)(x >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowRor4 = 0x124, kRowRor8 = 0x128, kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+
+// generic network: `op(a, b)` must be associative and commutative; `self` is what a lane outside the row mask of the two
+// broadcast steps sees as the incoming value (the identity of op, or -- for idempotent ops -- the lane's own value)
+#define SGW_REDUCE(T, DPP, v, OP, IDENT)                                           \
+    do {                                                                           \
+        v = OP(v, DPP<kQuadXor1>(v, v));                                           \
+        v = OP(v, DPP<kQuadXor2>(v, v));                                           \
+        v = OP(v, DPP<kRowRor4>(v, v));                                            \
+        v = OP(v, DPP<kRowRor8>(v, v));                                            \
+        v = OP(v, DPP<kRowBcast15, 0xA>(IDENT, v));                                \
+        v = OP(v, DPP<kRowBcast31, 0xC>(IDENT, v));                                \
+    } while (0)
+
+__device__ __forceinline__ float op_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float op_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float op_add(float a, float b) { return a + b; }
+__device__ __forceinline__ double op_addd(double a, double b) { return a + b; }
+__device__ __forceinline__ int op_maxi(int a, int b) { return max(a, b); }
+
+__device__ __forceinline__ float wave_max(float v) {
+    SGW_REDUCE(float, dpp_f, v, op_max, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_min(float v) {
+    SGW_REDUCE(float, dpp_f, v, op_min, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_max(int v) {
+    SGW_REDUCE(int, dpp_i, v, op_maxi, v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    SGW_REDUCE(float, dpp_f, v, op_add, 0.f);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    SGW_REDUCE(double, dpp_d, v, op_addd, 0.0);
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(x & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(x >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// argmax with "larger value wins, ties -> lower index" (np.argmax): a total order on (value, index), hence associative,
+// commutative and idempotent
+__device__ __forceinline__ void wave_argmax(float& val, int& idx) {
+#define SGW_ARG_STEP(CTRL, MASK)                                                                           \
+    do {                                                                                                   \
+        const float ov = dpp_f<CTRL, MASK>(val, val);                                                      \
+        const int oi = dpp_i<CTRL, MASK>(idx, idx);                                                        \
+        const bool take = ov > val || (ov == val && oi < idx);                                             \
+        val = take ? ov : val;                                                                             \
+        idx = take ? oi : idx;                                                                             \
+    } while (0)
+    SGW_ARG_STEP(kQuadXor1, 0xF);
+    SGW_ARG_STEP(kQuadXor2, 0xF);
+    SGW_ARG_STEP(kRowRor4, 0xF);
+    SGW_ARG_STEP(kRowRor8, 0xF);
+    SGW_ARG_STEP(kRowBcast15, 0xA);
+    SGW_ARG_STEP(kRowBcast31, 0xC);
+#undef SGW_ARG_STEP
+    val = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), 63));
+    idx = __builtin_amdgcn_readlane(idx, 63);
+}
+
+// lane `j` (wave-uniform) of v for every lane: v_readlane_b32 instead of a ds_bpermute round trip
+__device__ __forceinline__ float bcast(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+__device__ __forceinline__ int bcast(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+
+}  // namespace sgw

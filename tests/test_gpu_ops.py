@@ -630,3 +630,12 @@ def test_segments_beyond_the_lds_sort_cap(env, cfg):
         hip.check(lib.sg_segment_sort_boxes(d_data.data_ptr(), N, d_pts.data_ptr(), d_off.data_ptr(), d_sop.data_ptr(), S, d_co.data_ptr(),
                                             int(counts.max()), box2.data_ptr(), sperm2.data_ptr(), cbox2.data_ptr(), sums.data_ptr(),
                                             ws2.data_ptr(), 1024, None))
+
+
+def test_dpp_wave_reductions_selftest(env):
+    """csrc/wave_ops.h: sums (float, double), max / min, integer max, argmax with the lowest-index tie rule and the readlane
+    broadcasts equal the ds_bpermute butterflies on 512 waves x 64 rounds of pseudo-random values (ties included)."""
+    lib, torch, hip = env
+    bad = C.c_int(-1)
+    hip.check(lib.sg_selftest_wave_ops(C.byref(bad), None))
+    assert bad.value == 0
