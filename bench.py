@@ -82,7 +82,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline leg")
     ap.add_argument("--no-files", action="store_true", help="skip the separate with-files measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra leg (scenes/s on the ScanNet-shaped segment profile)")
-    ap.add_argument("--extra-scannet", type=int, default=16, help="scenes of the ScanNet-shaped profile in the extra leg (rank 0, N = 1)")
+    ap.add_argument("--extra-scannet", type=int, default=48, help="scenes of the ScanNet-shaped profile in the extra leg (rank 0, N = 1)")
     ap.add_argument("--writer-threads", type=int, default=16, help="native writer threads for the with-files leg")
     ap.add_argument("--gen-workers", type=int, default=0, help="scene generator processes (0 = min(16, cores))")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU rehearsals of the reduction)")

@@ -18,6 +18,7 @@
 #include "engine_ctx.h"
 #include "knn_device.h"
 #include "sg_common.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -514,7 +515,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     __shared__ unsigned long long buf[kBufS][64 * kSlices];     // append buffers; later lists[slice][K][64]
     __shared__ unsigned int thr_pub[kSlices][64];             // score part of each slice's 20th best
     __shared__ unsigned int thr5_pub[kSlices][64];            // score part of each slice's (K / kSlices)-th best
-    __shared__ float chunkbox_lds[kSlices][64];
+    __shared__ __attribute__((aligned(16))) float chunkbox_lds[kSlices][kSlices == 1 ? 256 : 64];      // one wave per tile: 32 boxes at a time
     __shared__ int st_m[kSlotBatch], st_c0[kSlotBatch], st_d[kSlotBatch], st_pc[kSlotBatch];
     __shared__ __attribute__((aligned(16))) float st_box[kSlotBatch][8];
     const int c = tile_cl[t];
@@ -624,12 +625,60 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     // takes it.  The segment's chunk boxes are staged 8 at a time through a wave-private LDS strip (one coalesced
     // load instead of one dependent global load per chunk).
     float* cbx = &chunkbox_lds[wave][0];
+    // Large segments (a floor of 40k points is 1,300 chunks): testing every chunk box lane-uniformly costs ~25 instructions
+    // per chunk and tile.  One wave per tile: 64 chunk boxes are tested AT ONCE, one per lane, against the box of the tile's
+    // 64 queries and the weakest threshold any lane still accepts (the same conservative bound as box_score_bound, taken for
+    // the whole tile); only the survivors go through the exact per-query test.
+    float qlo[3] = {0.f, 0.f, 0.f}, qhi[3] = {0.f, 0.f, 0.f}, qw = 0.f;
+    if (kSlices == 1) {
+        const float4 m0 = active ? me : make_float4(sgw::bcast(me.x, 0), sgw::bcast(me.y, 0), sgw::bcast(me.z, 0), sgw::bcast(me.w, 0));
+        qlo[0] = sgw::wave_min(m0.x); qlo[1] = sgw::wave_min(m0.y); qlo[2] = sgw::wave_min(m0.z);
+        qhi[0] = sgw::wave_max(m0.x); qhi[1] = sgw::wave_max(m0.y); qhi[2] = sgw::wave_max(m0.z);
+        qw = sgw::wave_max(m0.w);
+    }
     auto scan_segment = [&](int sg_m, int sg_c0, int d, const float* sbox, int pc, int& item) {
         const int nch = (sg_m + kChunkPts - 1) / kChunkPts;
         const unsigned long long use = best_thr();
         if (kSeeded) ok = pc < 0 || pc != myprev;
         if ((dbg & 32) && lane == 0 && wave == 0) atomicAdd(&g_knn5_stats[7], 1ull);
         if (!__any(ok && make_key(box_score_bound(me, sbox), 0) >= use)) { item += nch; return; }
+        if constexpr (kSlices == 1) {
+            // 32 chunk boxes per coalesced load (one per lane), staged in the wave's LDS strip; ONE call site of scan_chunk
+            for (int j0 = 0; j0 < nch; j0 += 32) {
+                const int nb = min(32, nch - j0);
+                bool pass = lane < nb;
+                // the weakest score any lane still accepts (thresholds only rise: refreshed per 32 chunks; all lanes take part)
+                float weakest = -INFINITY;
+                if (nch > 16) {
+                    const unsigned int o = (unsigned int)(best_thr() >> 32);
+                    float mine = INFINITY;
+                    if (active && ok) mine = o == 0u ? -INFINITY : __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+                    weakest = sgw::wave_min(mine);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < nb) {
+                    const float4* bp = reinterpret_cast<const float4*>(chunk_box + (size_t)(sg_c0 + j0 + lane) * 8);
+                    const float4 b0 = bp[0], b1 = bp[1];
+                    reinterpret_cast<float4*>(cbx)[2 * lane] = b0;
+                    reinterpret_cast<float4*>(cbx)[2 * lane + 1] = b1;
+                    if (nch > 16) {
+                        const float gx = fmaxf(fmaxf(b0.x - qhi[0], qlo[0] - b0.w), 0.f);
+                        const float gy = fmaxf(fmaxf(b0.y - qhi[1], qlo[1] - b1.x), 0.f);
+                        const float gz = fmaxf(fmaxf(b0.z - qhi[2], qlo[2] - b1.y), 0.f);
+                        pass = -((gx * gx + gy * gy) + gz * gz) * 0.999999f + 9.6e-7f * (qw + b1.z) >= weakest;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long live = __ballot(pass);
+                while (live) {
+                    const int j = __ffsll((unsigned long long)live) - 1;
+                    live &= live - 1;
+                    scan_chunk(cbx + j * 8, d + (j0 + j) * kChunkPts, min(kChunkPts, sg_m - (j0 + j) * kChunkPts));
+                }
+            }
+            item += nch;
+            return;
+        }
         for (int j0 = 0; j0 < nch; j0 += 8) {
             const int nb = min(8, nch - j0);
             __builtin_amdgcn_wave_barrier();
