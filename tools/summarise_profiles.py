@@ -28,9 +28,10 @@ def short(n):
 
 
 def stats(src_dir, dst, title):
-    fs = glob.glob(os.path.join(G, src_dir, "**", "*kernel_stats.csv"), recursive=True)
+    fs = sorted(glob.glob(os.path.join(G, src_dir, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if not fs:
         return None
+    fs = fs[-1:]                                               # the newest run merged into gpurun_out/
     rows = list(csv.DictReader(open(fs[0])))
     with open(os.path.join(P, dst), "w") as o:
         o.write(f"# {title}\n# source: rocprofv3 --kernel-trace --stats ({os.path.basename(fs[0])})\n")

@@ -20,6 +20,10 @@ for it in range(4):
 print({k: round(v, 3) for k, v in st.items()})
 import ctypes
 lib = hip.lib()
+if not hasattr(lib, "sg_debug_knn_stats"):
+    print("(release build: the kNN work counters are compiled out -- make -C seggroup_amd/csrc PROFILE=1 keeps them)")
+    sys.exit(0)
+
 buf = (ctypes.c_ulonglong * 8)()
 lib.sg_debug_knn_stats(buf, 1)
 res = pipe.forward(ds, hip.MODE_INS_INFER)
