@@ -372,25 +372,35 @@ __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m,
         const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
         xi[0] = q0.x; xi[1] = q0.y; xi[2] = q0.z; xi[3] = q0.w; xi[4] = q1.x; xi[5] = q1.y; xi[6] = q1.z; xi[7] = q1.w; xi[8] = q2.x;
         const float cx = x9m[0], cy = x9m[1], cz = x9m[2];       // moments of [d, x_i - [c, 0]]: see "Conditioning" in the header
+        // this kernel waits on memory 70 % of its life (PMC): neighbour rows are requested FOUR slots at a time (12 loads of
+        // 16 B in flight per lane instead of 3), the neighbour ids of the next group while the current one is consumed
         const int32_t* krow = knn + (size_t)pt * K;
-        int nb = krow[0];
-        const float4* xp = reinterpret_cast<const float4*>(x9m + (size_t)nb * 12);
-        float4 p0 = xp[0], p1 = xp[1], p2 = xp[2];
-        for (int j = 0; j < K; ++j) {
-            const float4 n0 = p0, n1 = p1, n2 = p2;
-            if (j + 1 < K) {
-                nb = krow[j + 1];
-                const float4* xq = reinterpret_cast<const float4*>(x9m + (size_t)nb * 12);
-                p0 = xq[0]; p1 = xq[1]; p2 = xq[2];
+        constexpr int kG = 4;
+        int ids[kG];
+#pragma unroll
+        for (int u = 0; u < kG; ++u) ids[u] = u < K ? krow[u] : 0;
+        for (int j0 = 0; j0 < K; j0 += kG) {
+            float4 r0[kG], r1[kG], r2[kG];
+#pragma unroll
+            for (int u = 0; u < kG; ++u) {
+                const float4* xq = reinterpret_cast<const float4*>(x9m + (size_t)ids[u] * 12);
+                r0[u] = xq[0]; r1[u] = xq[1]; r2[u] = xq[2];
             }
-            const float d[9] = {n0.x - xi[0], n0.y - xi[1], n0.z - xi[2], n0.w - xi[3], n1.x - xi[4],
-                                n1.y - xi[5], n1.z - xi[6], n1.w - xi[7], n2.x - xi[8]};
-            int t = 0;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                a[k] += d[k];
+            for (int u = 0; u < kG; ++u) ids[u] = j0 + kG + u < K ? krow[j0 + kG + u] : 0;
 #pragma unroll
-                for (int l = k; l < 9; ++l) { D[t] = __builtin_fmaf(d[k], d[l], D[t]); ++t; }
+            for (int u = 0; u < kG; ++u) {
+                if (j0 + u >= K) break;
+                const float4 n0 = r0[u], n1 = r1[u], n2 = r2[u];
+                const float d[9] = {n0.x - xi[0], n0.y - xi[1], n0.z - xi[2], n0.w - xi[3], n1.x - xi[4],
+                                    n1.y - xi[5], n1.z - xi[6], n1.w - xi[7], n2.x - xi[8]};
+                int t = 0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    a[k] += d[k];
+#pragma unroll
+                    for (int l = k; l < 9; ++l) { D[t] = __builtin_fmaf(d[k], d[l], D[t]); ++t; }
+                }
             }
         }
         xi[0] -= cx; xi[1] -= cy; xi[2] -= cz;                   // d is done with the raw coordinates; the x_i terms are centred

@@ -74,7 +74,66 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
     const int rep = P / n, rem = P % n;
     const int tid = threadIdx.x;
 
-    if (rem > 0) {
+    bool sampled = false;
+    if constexpr (BLOCK == 64) {
+        // Segments of <= 256 points (almost all of them): coordinates and running minima live in REGISTERS, four points per
+        // lane (point i = lane + 64 u, the same assignment as the strided loop below, so the first-index argmax is unchanged);
+        // the newest pick's coordinates come from its owner lane through v_readlane.  The 64 dependent steps of a segment
+        // were bound by LDS round trips (4 reads + 1 write per point and step, then 3 broadcast reads).
+        if (rem > 0 && n <= 256) {
+            constexpr int kU = 4;
+            float X[kU], Y[kU], Z[kU], M[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int i = tid + 64 * u;
+                X[u] = Y[u] = Z[u] = 0.f; M[u] = 0.f;
+                if (i < n) {
+                    const float* row = data + (size_t)members[lo + i] * ch_in;
+                    X[u] = row[0]; Y[u] = row[1]; Z[u] = row[2];
+                }
+            }
+            auto pass = [&](float qx, float qy, float qz, bool reset) {
+                Best b{-INFINITY, INT_MAX};
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int i = tid + 64 * u;
+                    if (i < n) {
+                        const float dx = X[u] - qx, dy = Y[u] - qy, dz = Z[u] - qz;
+                        float d = (dx * dx + dy * dy) + dz * dz;
+                        if (!reset) d = fminf(M[u], d);
+                        M[u] = d;
+                        if (d > b.v) { b.v = d; b.i = i; }
+                    }
+                }
+                sgw::wave_argmax(b.v, b.i);
+                return b;
+            };
+            auto coords = [&](int cur, float& qx, float& qy, float& qz) {     // cur is wave-uniform
+                const int u = cur >> 6, l = cur & 63;
+                const float sx = u == 0 ? X[0] : u == 1 ? X[1] : u == 2 ? X[2] : X[3];
+                const float sy = u == 0 ? Y[0] : u == 1 ? Y[1] : u == 2 ? Y[2] : Y[3];
+                const float sz = u == 0 ? Z[0] : u == 1 ? Z[1] : u == 2 ? Z[2] : Z[3];
+                qx = sgw::bcast(sx, l); qy = sgw::bcast(sy, l); qz = sgw::bcast(sz, l);
+            };
+            float qx, qy, qz;
+            coords(0, qx, qy, qz);
+            Best b = pass(qx, qy, qz, true);                          // start at member 0 (model.py:382-386)
+            int cur = b.i;
+            if (tid == 0) picks[0] = cur;
+            coords(cur, qx, qy, qz);
+            b = pass(qx, qy, qz, true);
+            for (int it = 1; it < rem; ++it) {                       // model.py:389-394
+                cur = b.i;
+                if (tid == 0) picks[it] = cur;
+                if (it + 1 < rem) {
+                    coords(cur, qx, qy, qz);
+                    b = pass(qx, qy, qz, false);
+                }
+            }
+            sampled = true;
+        }
+    }
+    if (rem > 0 && !sampled) {
         float *X, *Y, *Z, *M;
         if (n <= lds_pts) { X = lds_f; Y = X + lds_pts; Z = Y + lds_pts; M = Z + lds_pts; }
         else { X = ws + lo; Y = ws + (size_t)N + lo; Z = ws + 2 * (size_t)N + lo; M = ws + 3 * (size_t)N + lo; }
@@ -97,6 +156,8 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
                 b = fps_pass<BLOCK, false>(X, Y, Z, M, n, X[cur], Y[cur], Z[cur], red);
             }
         }
+    }
+    if (rem > 0) {
         __syncthreads();
         if (tid == 0 && picks[rem - 1] == 0) {                       // trailing-zero fix-up (model.py:407-412)
             int j = 1;
