@@ -74,7 +74,9 @@ __device__ inline int acc_channel(int tile, int reg, int half) { return 32 * til
 struct Lds {
     // A fragments, four MFMA steps per ds_read_b128 (conflict-free: consecutive lanes, 16 B each)
     // conv1, split by input half (e = [d, x_i], d = x_j - x_i): five K=2 steps each, k = 2s + (lane>>5) < 9 (k = 9: zero)
-    float4 a1d[2][2][64];    // a1d[t][s>>2][lane][s&3] = W1[32t + (lane&31)][k]        the d columns, used every neighbour slot
+    // conv1, d columns (used every neighbour slot), bf16 pieces: a1db[piece][t][lane] = 8 bf16 = piece of
+    // W1[32t + (lane&31)][8 (lane>>5) + j], j = 0..7 (k >= 9: zero)
+    u32x4 a1db[3][2][64];
     float4 a1x[2][2][64];    // a1x[t][s>>2][lane][s&3] = W1[32t + (lane&31)][9 + k]    the x_i columns, used once per point
     // conv2, bf16 pieces: a2b[piece][ot][kb][lane] = 8 bf16 = piece of W2[32ot + (lane&31)][acc_channel(kb>>1, 8(kb&1) + j, lane>>5)], j = 0..7
     u32x4 a2b[3][2][4][64];
@@ -93,12 +95,37 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
     const int r = lane & 31, half = lane >> 5;
 
     // the last layer's rows carry the sign of its BN gamma (see the header): y' = sgn(gamma) * y exactly
-    for (int i = tid; i < 2 * 2 * 8 * 64; i += 64 * kWaves) {       // [part][t][step 0..7][lane]; steps 5..7 and k = 9 stay zero
-        const int l = i & 63, s = (i >> 6) & 7, t = (i >> 9) & 1, part = i >> 10;
+    for (int i = tid; i < 2 * 8 * 64; i += 64 * kWaves) {           // x_i columns: [t][step 0..7][lane]; steps 5..7 and k = 9 stay zero
+        const int l = i & 63, s = (i >> 6) & 7, t = (i >> 9) & 1;
         const int ch = 32 * t + (l & 31), k = 2 * s + (l >> 5);
-        float v = (s < 5 && k < 9) ? w1[ch * 18 + 9 * part + k] : 0.f;
+        float v = (s < 5 && k < 9) ? w1[ch * 18 + 9 + k] : 0.f;
         if (MODE == S1X && gamma_last[ch] < 0.f) v = -v;
-        (&(part ? lds.a1x : lds.a1d)[t][s >> 2][l].x)[s & 3] = v;
+        (&lds.a1x[t][s >> 2][l].x)[s & 3] = v;
+    }
+    for (int i = tid; i < 2 * 64; i += 64 * kWaves) {               // d columns, cut into bf16 pieces (see conv2 below)
+        const int l = i & 63, t = i >> 6;
+        const int ch = 32 * t + (l & 31);
+        const bool neg = MODE == S1X && gamma_last[ch] < 0.f;
+        unsigned int p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            unsigned int h1[2], h2[2], h3[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = 8 * (l >> 5) + 2 * jj + u;
+                float v = k < 9 ? w1[ch * 18 + k] : 0.f;
+                if (neg) v = -v;
+                const float a = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+                const float r = v - a;
+                const float b = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+                const float c = r - b;
+                h1[u] = __float_as_uint(a) >> 16; h2[u] = __float_as_uint(b) >> 16; h3[u] = __float_as_uint(c) >> 16;
+            }
+            p1[jj] = h1[0] | (h1[1] << 16); p2[jj] = h2[0] | (h2[1] << 16); p3[jj] = h3[0] | (h3[1] << 16);
+        }
+        lds.a1db[0][t][l] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+        lds.a1db[1][t][l] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+        lds.a1db[2][t][l] = u32x4{p3[0], p3[1], p3[2], p3[3]};
     }
     if (kTwo) {
         // one (ot, kb, lane) fragment per iteration: 8 weights, each cut into its three bf16 pieces
@@ -149,6 +176,9 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
         // contribution W1[:, 9:18] x_i (+ the folded BN1 shift) is evaluated ONCE into `base` and every slot's accumulator
         // starts from it (first MFMA: C = base, D = acc1) -- 10 instead of 18 conv1 MFMAs per slot
         const float xsel[5] = {half ? xi[1] : xi[0], half ? xi[3] : xi[2], half ? xi[5] : xi[4], half ? xi[7] : xi[6], half ? 0.f : xi[8]};
+        // d = x_j - x_i as the B operand of ONE 16-deep bf16 k block: lanes 0-31 carry k = 0..7, lanes 32-63 k = 8 (+ zeros)
+        const float xs[8] = {half ? xi[8] : xi[0], half ? 0.f : xi[1], half ? 0.f : xi[2], half ? 0.f : xi[3],
+                             half ? 0.f : xi[4], half ? 0.f : xi[5], half ? 0.f : xi[6], half ? 0.f : xi[7]};
         // the x_i half sees coordinates relative to row 0 (see "Conditioning" in the header); d below uses the raw ones
         const float xcen[5] = {half ? xi[1] - x9m[1] : xi[0] - x9m[0], half ? xi[3] : xi[2] - x9m[2], xsel[2], xsel[3], xsel[4]};
         f32x16 base[2];
@@ -207,23 +237,42 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
                 p0 = xq[0]; p1 = xq[1]; p2 = xq[2];
                 if (j + 2 < K) nb_next = krow[j + 2];
             }
-            // d = x_j - x_i for this lane's k = 2s + half
-            const float bd[5] = {(half ? n0.y : n0.x) - xsel[0], (half ? n0.w : n0.z) - xsel[1], (half ? n1.y : n1.x) - xsel[2],
-                                 (half ? n1.w : n1.z) - xsel[3], half ? 0.f : n2.x - xsel[4]};
+            // conv1 on the bf16 pipe like conv2: d (8 values per lane) cut into three bf16 pieces, six products per output tile
+            // on top of the point's base accumulator (12 MFMAs of 32 cycles instead of 10 fp32 MFMAs of 64)
             f32x16 acc1[2];
             {
-                const float4 wa = lds.a1d[0][0][lane], wb = lds.a1d[1][0][lane];
-                const float wa4 = lds.a1d[0][1][lane].x, wb4 = lds.a1d[1][1][lane].x;
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, bd[0], base[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.x, bd[0], base[1], 0, 0, 0);
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, bd[1], acc1[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.y, bd[1], acc1[1], 0, 0, 0);
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, bd[2], acc1[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.z, bd[2], acc1[1], 0, 0, 0);
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, bd[3], acc1[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.w, bd[3], acc1[1], 0, 0, 0);
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa4, bd[4], acc1[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb4, bd[4], acc1[1], 0, 0, 0);
+                const float nv[8] = {half ? n2.x : n0.x, half ? 0.f : n0.y, half ? 0.f : n0.z, half ? 0.f : n0.w,
+                                     half ? 0.f : n1.x, half ? 0.f : n1.y, half ? 0.f : n1.z, half ? 0.f : n1.w};
+                unsigned int q1[4], q2[4], q3[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float v0 = nv[2 * jj] - xs[2 * jj], v1 = nv[2 * jj + 1] - xs[2 * jj + 1];
+                    const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u);
+                    const float r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
+                    const float c0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+                    const float c1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+                    q1[jj] = __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);
+                    q2[jj] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                    q3[jj] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
+                }
+                const bf16x8 x1 = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
+                const bf16x8 x2 = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+                const bf16x8 x3 = __builtin_bit_cast(bf16x8, u32x4{q3[0], q3[1], q3[2], q3[3]});
+                const bf16x8 wa1 = __builtin_bit_cast(bf16x8, lds.a1db[0][0][lane]), wb1 = __builtin_bit_cast(bf16x8, lds.a1db[0][1][lane]);
+                const bf16x8 wa2 = __builtin_bit_cast(bf16x8, lds.a1db[1][0][lane]), wb2 = __builtin_bit_cast(bf16x8, lds.a1db[1][1][lane]);
+                const bf16x8 wa3 = __builtin_bit_cast(bf16x8, lds.a1db[2][0][lane]), wb3 = __builtin_bit_cast(bf16x8, lds.a1db[2][1][lane]);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa3, x1, base[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb3, x1, base[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2, x2, acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb2, x2, acc1[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x3, acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x3, acc1[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2, x1, acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb2, x1, acc1[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x2, acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x2, acc1[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x1, acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x1, acc1[1], 0, 0, 0);
             }
             if (!kTwo) {
 #pragma unroll
