@@ -576,6 +576,20 @@ int sg_gcn_backward(const float* d_x, int S, int D, const int32_t* d_adj, int E,
                     const int32_t* d_eid, const float* d_w, float alpha, const float* d_gout, float* d_gx, float* d_gw,
                     void* d_ws, size_t ws_bytes, void* stream);
 
+/* backward of sg_edgeconv_forward (get_graph_feature2 + MLP2 / MLP3, model.py:83-138; autograd differentiates it in the reference's
+ * training step, train.py:167).  The inputs carry no gradient: parameter gradients only.
+ *   d_x9m [N,12], d_knn [N,k]   as for the forward call
+ *   d_gout [N,64]               gradient w.r.t. the op's OUTPUT (the post-activation max over k), e.g. from sg_segment_max_backward
+ *   d_gw1 [64,18] d_gg1 d_gb1 [64]; layers == 2: d_gw2 [64,64] d_gg2 d_gb2 [64]
+ *   d_bn_stats [256] or NULL    batch mean1 | biased var1 | mean2 | var2 (for the running-statistics update, momentum 0.1)
+ * BatchNorm2d is differentiated WITH its batch statistics over all N*k rows (training mode).  Deterministic (ordered fp64
+ * reductions).  d_ws needs sg_edgeconv_backward_ws_bytes(N). */
+size_t sg_edgeconv_backward_ws_bytes(int N);
+int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
+                         const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, const float* d_gout, float* d_gw1,
+                         float* d_gg1, float* d_gb1, float* d_gw2, float* d_gg2, float* d_gb2, float* d_bn_stats, void* d_ws,
+                         size_t ws_bytes, void* stream);
+
 /* =============================================================================================
  * Readers for the reference's on-disk inputs.  Host only.
  * ============================================================================================= */

@@ -469,7 +469,8 @@ def group_nearby(part: Partition, dist, adj, layer: Layer, th):
 # ------------------------------------------------------------------------------------------------
 # A.12  group_unlabeled_clusters  (model.py:439-509)
 # ------------------------------------------------------------------------------------------------
-def group_unlabeled(part: Partition, feat, adj, layer: Layer, data, faithful=False):
+def group_unlabeled(part: Partition, feat, adj, layer: Layer, data, faithful=False, record=None):
+    """`record` (a list): receives the row groups of every max-aggregation made here, in order (the training tape)."""
     old = layer
     adj = np.asarray(adj, dtype=np.int64).reshape(-1, 2)
     count_old = feat.shape[0]
@@ -490,6 +491,8 @@ def group_unlabeled(part: Partition, feat, adj, layer: Layer, data, faithful=Fal
         groups, _ = new.parents_of(old, part)
         adj = contract_edges(adj, part, old.unmap, new, faithful)
         feat = group_max(feat, groups)
+        if record is not None:
+            record.append(groups)
         old = new
         if feat.shape[0] == count_old:
             break
@@ -517,6 +520,8 @@ def group_unlabeled(part: Partition, feat, adj, layer: Layer, data, faithful=Fal
         groups, _ = new.parents_of(old, part)
         adj = contract_edges(adj, part, old.unmap, new, faithful)
         feat = group_max(feat, groups)
+        if record is not None:
+            record.append(groups)
     return feat, adj
 
 
@@ -644,7 +649,7 @@ def forward_scene(scene, W, mode="ins_infer", faithful=False, keep=False):
     feat2 = group_max(feat1, g21)
     ins_pred, sem_pred = export("layer_2", L2)
     if keep:
-        st.update(samples=samples, feat1=feat1, d1=d1, adj1=adj1, adj2=adj2, root2=part.root.copy())
+        st.update(samples=samples, feat1=feat1, d1=d1, adj1=adj1, adj2=adj2, root2=part.root.copy(), g21=g21)
     trace = [L1.count, L2.count]
     if mode == "sem_infer":
         return dict(labels=labels, metrics=evaluate(scene.gt, sem_pred, ins_pred), trace=trace, stages=st,
@@ -662,19 +667,21 @@ def forward_scene(scene, W, mode="ins_infer", faithful=False, keep=False):
         groups, _ = Ln.parents_of(Lc, part)
         adj_n = contract_edges(adj_c[~conn], part, Lc.unmap, Ln, faithful)
         if keep:
-            st[which] = dict(point_feat=pf, cat=fc, gcn=fg, d=d, adj=adj_n, root=part.root.copy(), knn=knn)
+            st[which] = dict(point_feat=pf, cat=fc, gcn=fg, d=d, adj=adj_n, root=part.root.copy(), knn=knn,
+                             members=Lc.members, x9=x9, adj_in=np.asarray(adj_c, dtype=np.int64).reshape(-1, 2), groups=groups)
         return Ln, group_max(fg, groups), adj_n, stl
 
     L3, feat3, adj3, s2 = semantic_layer(L2, feat2, adj2, "mlp_2", "gcn_2.fc.weight")
     export("layer_3", L3)
     L4, feat4, adj4, s3 = semantic_layer(L3, feat3, adj3, "mlp_3", "gcn_3.fc.weight")
     export("layer_4", L4)
-    feat5, adj5 = group_unlabeled(part, feat4, adj4, L4, data, faithful)
+    groups45 = []
+    feat5, adj5 = group_unlabeled(part, feat4, adj4, L4, data, faithful, record=groups45)
     L5 = Layer(part)
     ins_pred, sem_pred = export("final", L5)
     trace += [L3.count, L4.count, L5.count]
     if keep:
-        st.update(feat4=feat4, adj4=adj4, feat5=feat5, adj5=adj5, root5=part.root.copy(),
+        st.update(feat4=feat4, adj4=adj4, feat5=feat5, adj5=adj5, root5=part.root.copy(), groups45=groups45,
                   ins5=np.array([part.ins[part.root[r]] for r in L5.unmap], dtype=np.int64),
                   sem5=np.array([part.sem[part.root[r]] for r in L5.unmap], dtype=np.int64))
     return dict(labels=labels, metrics=evaluate(scene.gt, sem_pred, ins_pred), trace=trace, stages=st,

@@ -587,16 +587,16 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     };
     bool ok = true;                                           // seeded: false while the segment at hand belongs to my former cluster
     // one 32-point chunk: sorted positions [p0, p0 + m)
-    auto scan_chunk = [&](const float* bx, int p0, int m) {
+    // one 32-point chunk whose operands are in registers (lanes < kChunkPts + kQuadS hold point `lane`, padded with +inf)
+    auto scan_loaded = [&](const float* bx, const float4 cv, const int cidx, int m) {
         const unsigned long long use = best_thr();
         if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[6], 1ull);
         if (!__any(ok && make_key(box_score_bound(me, bx), 0) >= use)) return;
         if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[5], 1ull);
         __builtin_amdgcn_wave_barrier();
         if (lane < kChunkPts + kQuadS) {
-            const bool in = lane < m;
-            cw[lane] = in ? sxyzw[p0 + lane] : make_float4(0.f, 0.f, 0.f, INFINITY);
-            ci[lane] = in ? smpos[p0 + lane] - clo : 0x7fffffff;
+            cw[lane] = cv;
+            ci[lane] = cidx;
         }
         __builtin_amdgcn_wave_barrier();
         for (int i = 0; i < m; i += kQuadS) {
@@ -610,6 +610,24 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             }
             if (__any(cnt > kBufS - kQuadS)) drain();
         }
+    };
+    // the operands of sorted positions [p0, p0 + m): requested one survivor AHEAD of the scan by the one-wave-per-tile path
+    // (the round trip of a chunk's 32 points hides behind the previous chunk's 32 x 64 distance evaluations)
+    auto fetch_chunk = [&](int p0, int m, float4& cv, int& cidx) {
+        const bool in = lane < m;
+        cv = in ? sxyzw[p0 + lane] : make_float4(0.f, 0.f, 0.f, INFINITY);
+        cidx = in ? smpos[p0 + lane] - clo : 0x7fffffff;
+    };
+    auto scan_chunk = [&](const float* bx, int p0, int m) {
+        const unsigned long long use = best_thr();
+        if (!__any(ok && make_key(box_score_bound(me, bx), 0) >= use)) {
+            if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[6], 1ull);
+            return;
+        }
+        float4 cv;
+        int cidx;
+        fetch_chunk(p0, m, cv, cidx);
+        scan_loaded(bx, cv, cidx, m);
     };
     const int so0 = cl_seg_off[c], nslots = cl_seg_off[c + 1] - so0;
     const int own = slot_of_pos[active ? myrow : smpos[tile_lo[t]]] - so0;   // lanes of a tile may span segments: lane 0 decides
@@ -674,12 +692,27 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
                 }
                 __builtin_amdgcn_wave_barrier();
                 unsigned long long live = __ballot(pass);
-                while (live) {
-                    const int j = __ffsll((unsigned long long)live) - 1;
-                    live &= live - 1;
+                auto chunk_of = [&](int j) {
                     int ch = start + j0 + j;
-                    if (ch >= nch) ch -= nch;
-                    scan_chunk(cbx + j * 8, d + ch * kChunkPts, min(kChunkPts, sg_m - ch * kChunkPts));
+                    return ch >= nch ? ch - nch : ch;
+                };
+                float4 nv = make_float4(0.f, 0.f, 0.f, INFINITY);
+                int ni = 0x7fffffff;
+                if (live) {
+                    const int ch = chunk_of(__ffsll(live) - 1);
+                    fetch_chunk(d + ch * kChunkPts, min(kChunkPts, sg_m - ch * kChunkPts), nv, ni);
+                }
+                while (live) {
+                    const int j = __ffsll(live) - 1;
+                    live &= live - 1;
+                    const int ch = chunk_of(j);
+                    const float4 cv = nv;
+                    const int cidx = ni;
+                    if (live) {
+                        const int chn = chunk_of(__ffsll(live) - 1);
+                        fetch_chunk(d + chn * kChunkPts, min(kChunkPts, sg_m - chn * kChunkPts), nv, ni);
+                    }
+                    scan_loaded(cbx + j * 8, cv, cidx, min(kChunkPts, sg_m - ch * kChunkPts));
                 }
             }
             item += nch;

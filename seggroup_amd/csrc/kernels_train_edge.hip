@@ -1,0 +1,643 @@
+// Training step: backward of get_graph_feature2 + MLP2 / MLP3 (model.py:83-138) -- conv1x1 18->64
+// (+ conv1x1 64->64), BatchNorm2d with BATCH statistics over all N*k rows, LeakyReLU(0.2), max over the k neighbours.
+// The inputs (point coordinates / colours) carry no gradient, so the op returns parameter gradients only.
+//
+// What makes it a dense problem: with batch statistics,  dy = gamma/sigma (da - mean(da) - xhat mean(da xhat)).  `da` is
+// nonzero on ONE of the k rows of a (point, channel) that carries output gradient, but the two mean terms reach every one
+// of the N*k rows.  For the LAST BatchNorm of the stack that dense part is an affine function of the layer's own input
+// and folds into input moments:
+//     sum_r dy[r] e[r]^T = gamma/sigma ( sum_r da[r] e[r]^T - mean(da) sum_r e[r]^T - mean(da xhat) sum_r xhat[r] e[r]^T ),
+//     sum_r xhat[r] e[r]^T = (W See - mu Se^T) / sigma                with Se = sum e, See = sum e e^T   (fp64).
+// MLP2 (one conv) therefore needs no dense backward pass at all.  MLP3's second BatchNorm sits behind a LeakyReLU, so its
+// dense part has to be carried through explicitly: one dense pass that recomputes conv1 -> h1 -> conv2 per 64-row tile
+// and forms dy2, dW2 += dy2^T h1, dh1 = dy2 W2, da1 = dh1 lrelu'(a1), sum da1 e^T -- then the moment identity above for BN1.
+//
+// Passes (layers == 2):  moments of e -> BN1 statistics | dense forward: BN2 statistics, per (point, channel) the extreme
+// pre-activation over k and its k | elementwise: d beta2, d gamma2 | dense backward | fold.   (layers == 1: the dense
+// forward over conv1 only, then one sparse pass.)
+// Arithmetic: fp32 FMAs on LDS tiles (256 threads, 4x4 register blocks), every reduction across tiles in fp64, block
+// partials reduced in a fixed order (deterministic).  Conditioning: the XYZ of the x_i half is taken relative to row 0
+// (BatchNorm is invariant to that shift, and sum_r dy[r] = 0 makes dW invariant too), like the forward kernels.
+#include "sg_common.h"
+
+namespace {
+
+constexpr int kR = 64;        // rows per tile
+constexpr int kES = 20;       // row stride of the edge-feature tile (18 used)
+constexpr int kHS = 68;       // row stride of the 64-wide tiles
+constexpr int kThreads = 256;
+constexpr float kSlope = 0.2f;
+constexpr double kBnEps = 1e-5;
+constexpr int kMom = 420;     // 20 x 20 second moments + 20 sums
+constexpr int kPart3 = 4096 + 64 * kES + 128;     // dense backward: dW2 | sum da1 e^T | sum da1, sum da1 xhat1
+// per-channel constants (floats) the passes share
+enum { MU1 = 0, INV1 = 64, MU2 = 128, INV2 = 192, DB2 = 256, DG2 = 320, X0 = 384, kCst = 388 };
+
+struct Tile {
+    float E[kR * kES];
+    float H1[kR * kHS];
+    float D2[kR * kHS];
+    float W1t[kES * 64];      // [j][c]
+    float W2[64 * kHS];       // [o][i]
+    float G[4 * 64];          // output gradient of the tile's points (P <= 3 for k = 20; up to 4)
+    int argk[4 * 64];
+    int rown[kR];
+};                                                                    // 64.8 KB: just inside the static LDS limit
+__device__ __forceinline__ double* red_of(Tile& s) { return reinterpret_cast<double*>(s.H1); }   // [16][64] doubles, after the tile loop
+
+__device__ __forceinline__ float lrelu(float a) { return a > 0.f ? a : kSlope * a; }
+__device__ __forceinline__ float dlrelu(float a) { return a > 0.f ? 1.f : kSlope; }     // torch: x > 0 ? g : g * slope
+
+// rows r < P*K of tile `tile`: point n = tile*P + r/K, neighbour k = r%K.  Rows past N (and r >= P*K) are zero, rown = -1.
+__device__ __forceinline__ void build_edge_rows(Tile& s, const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P,
+                                                int tile, const float* __restrict__ cst) {
+    const int t = threadIdx.x;
+    if (t < kR) {
+        const int p = t / K, k = t - p * K, n = tile * P + p;
+        const bool valid = p < P && n < N;
+        float v[kES];
+#pragma unroll
+        for (int j = 0; j < kES; ++j) v[j] = 0.f;
+        if (valid) {
+            const int j = knn[(size_t)n * K + k];
+            const float* xi = x9 + (size_t)n * 12;
+            const float* xj = x9 + (size_t)j * 12;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const float a = xi[c];
+                v[c] = xj[c] - a;
+                v[9 + c] = a;
+            }
+            v[9] -= cst[X0]; v[10] -= cst[X0 + 1]; v[11] -= cst[X0 + 2];
+        }
+        float4* dst = reinterpret_cast<float4*>(&s.E[t * kES]);
+#pragma unroll
+        for (int q = 0; q < kES / 4; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        s.rown[t] = valid ? n : -1;
+    }
+}
+
+__device__ __forceinline__ void stage_weights(Tile& s, const float* __restrict__ w1, const float* __restrict__ w2) {
+    for (int i = threadIdx.x; i < kES * 64; i += kThreads) {
+        const int j = i >> 6, c = i & 63;
+        s.W1t[i] = j < 18 ? w1[c * 18 + j] : 0.f;
+    }
+    if (w2)
+        for (int i = threadIdx.x; i < 64 * 64; i += kThreads) s.W2[(i >> 6) * kHS + (i & 63)] = w2[i];
+}
+
+// y1 block of thread (tr, tc): rows 4 tr + i, columns 4 tc + j
+__device__ __forceinline__ void conv1_block(const Tile& s, int tr, int tc, float (&acc)[4][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < kES / 4; ++q) {
+        float4 e[4], w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = *reinterpret_cast<const float4*>(&s.E[(4 * tr + i) * kES + 4 * q]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(&s.W1t[(4 * q + u) * 64 + 4 * tc]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ev[4] = {e[i].x, e[i].y, e[i].z, e[i].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[i][0] = fmaf(ev[u], w[u].x, acc[i][0]);
+                acc[i][1] = fmaf(ev[u], w[u].y, acc[i][1]);
+                acc[i][2] = fmaf(ev[u], w[u].z, acc[i][2]);
+                acc[i][3] = fmaf(ev[u], w[u].w, acc[i][3]);
+            }
+        }
+    }
+}
+
+// y2 block of thread (tr, tc): rows 4 tr + i, columns tc + 16 j   (W2 rows are read along their contiguous input index)
+__device__ __forceinline__ void conv2_block(const Tile& s, int tr, int tc, float (&acc)[4][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k = 0; k < 64; k += 4) {
+        float4 h[4], w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = *reinterpret_cast<const float4*>(&s.H1[(4 * tr + i) * kHS + k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const float4*>(&s.W2[(tc + 16 * j) * kHS + k]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = fmaf(h[i].w, w[j].w, fmaf(h[i].z, w[j].z, fmaf(h[i].y, w[j].y, fmaf(h[i].x, w[j].x, acc[i][j]))));
+    }
+}
+
+// ordered block reduction of one double per thread over the 16 threads that share (t & 15) [column owner = tc] or (t & 63)
+// -> `out[c]` for c < ncol; `part` = how many threads share a column (16: columns by tc..., 4: columns by t & 63)
+__device__ __forceinline__ void store_partial(double* __restrict__ dst, const double* red, int ncol, int nshare, int t) {
+    if (t < ncol) {
+        double a = 0.0;
+        for (int r = 0; r < nshare; ++r) a += red[r * 64 + t];
+        dst[t] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 0: moments of the edge features  (block partials: [20*20 | 20] doubles)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_eb_moments(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P, int ntiles,
+                                                         const float* __restrict__ cst, double* __restrict__ partial) {
+    __shared__ float E[kR * kES];
+    // build_edge_rows works on a Tile; this pass only needs E: a private copy of the row builder keeps its LDS small
+    const int t = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    const int id0 = t, id1 = t + kThreads;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        if (t < kR) {
+            const int p = t / K, k = t - p * K, n = tile * P + p;
+            const bool valid = p < P && n < N;
+            float v[kES];
+#pragma unroll
+            for (int j = 0; j < kES; ++j) v[j] = 0.f;
+            if (valid) {
+                const int j = knn[(size_t)n * K + k];
+                const float* xi = x9 + (size_t)n * 12;
+                const float* xj = x9 + (size_t)j * 12;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    const float a = xi[c];
+                    v[c] = xj[c] - a;
+                    v[9 + c] = a;
+                }
+                v[9] -= cst[X0]; v[10] -= cst[X0 + 1]; v[11] -= cst[X0 + 2];
+            }
+#pragma unroll
+            for (int j = 0; j < kES; ++j) E[t * kES + j] = v[j];
+        }
+        __syncthreads();
+        {
+            const int i = id0 / kES, j = id0 - i * kES;                // id0 < 256 < 400: a second moment
+            double a = 0.0;
+            for (int r = 0; r < kR; ++r) a += (double)E[r * kES + i] * (double)E[r * kES + j];
+            a0 += a;
+        }
+        if (id1 < kMom) {
+            double a = 0.0;
+            if (id1 < 400) {
+                const int i = id1 / kES, j = id1 - i * kES;
+                for (int r = 0; r < kR; ++r) a += (double)E[r * kES + i] * (double)E[r * kES + j];
+            } else {
+                for (int r = 0; r < kR; ++r) a += (double)E[r * kES + (id1 - 400)];
+            }
+            a1 += a;
+        }
+    }
+    partial[(size_t)blockIdx.x * kMom + id0] = a0;
+    if (id1 < kMom) partial[(size_t)blockIdx.x * kMom + id1] = a1;
+}
+
+// BN1 statistics from the moments: mu1 = W1 m, var1 = w^T Cov w  (fp64).  mom_out keeps the reduced moments for the fold.
+__global__ void k_eb_fold1(const double* __restrict__ partial, int nblocks, double rows, const float* __restrict__ w1, float* __restrict__ cst,
+                           double* __restrict__ mom_out, float* __restrict__ stats_out) {
+    __shared__ double mom[kMom];
+    for (int i = threadIdx.x; i < kMom; i += blockDim.x) {
+        double a = 0.0;
+        for (int b = 0; b < nblocks; ++b) a += partial[(size_t)b * kMom + i];
+        mom[i] = a;
+        mom_out[i] = a;
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < 64) {
+        double mu = 0.0, ex2 = 0.0, shift = 0.0;
+        for (int i = 0; i < 18; ++i) {
+            const double wi = w1[c * 18 + i];
+            mu += wi * mom[400 + i] / rows;
+            double row = 0.0;
+            for (int j = 0; j < 18; ++j) row += (double)w1[c * 18 + j] * mom[i * kES + j];
+            ex2 += wi * row / rows;
+        }
+        for (int a = 0; a < 3; ++a) shift += (double)w1[c * 18 + 9 + a] * (double)cst[X0 + a];
+        const double var = fmax(ex2 - mu * mu, 0.0);
+        cst[MU1 + c] = (float)mu;
+        cst[INV1 + c] = (float)(1.0 / sqrt(var + kBnEps));
+        if (stats_out) { stats_out[c] = (float)(mu + shift); stats_out[64 + c] = (float)var; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 1: dense forward.  LAYERS == 2: sum y2, sum y2^2 (block partials [64 | 64]) and, per (point, channel), the extreme
+// of y2 over k in the direction of sign(gamma2) + the FIRST k that attains it.  LAYERS == 1: the same for y1 (no sums).
+// ---------------------------------------------------------------------------------------------------------------
+template <int LAYERS>
+__global__ void __launch_bounds__(kThreads) k_eb_forward(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P, int ntiles,
+                                                         const float* __restrict__ w1, const float* __restrict__ g1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ g2, const float* __restrict__ cst,
+                                                         float* __restrict__ ext, uint8_t* __restrict__ argk, double* __restrict__ partial) {
+    __shared__ Tile s;
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    stage_weights(s, w1, LAYERS == 2 ? w2 : nullptr);
+    float mu1[4], sc1[4], sh1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * tc + j;
+        mu1[j] = cst[MU1 + c];
+        sc1[j] = cst[INV1 + c] * g1[c];
+        sh1[j] = b1[c];
+    }
+    double sy[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* gl = LAYERS == 2 ? g2 : g1;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        build_edge_rows(s, x9, knn, N, K, P, tile, cst);
+        __syncthreads();
+        float acc[4][4];
+        conv1_block(s, tr, tc, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 h;
+            if (LAYERS == 2) {
+                const bool valid = s.rown[4 * tr + i] >= 0;
+                h.x = valid ? lrelu((acc[i][0] - mu1[0]) * sc1[0] + sh1[0]) : 0.f;
+                h.y = valid ? lrelu((acc[i][1] - mu1[1]) * sc1[1] + sh1[1]) : 0.f;
+                h.z = valid ? lrelu((acc[i][2] - mu1[2]) * sc1[2] + sh1[2]) : 0.f;
+                h.w = valid ? lrelu((acc[i][3] - mu1[3]) * sc1[3] + sh1[3]) : 0.f;
+            } else {
+                h = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);      // the pre-activation itself
+            }
+            *reinterpret_cast<float4*>(&s.H1[(4 * tr + i) * kHS + 4 * tc]) = h;
+        }
+        __syncthreads();
+        const float* src = s.H1;
+        if (LAYERS == 2) {
+            conv2_block(s, tr, tc, acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool valid = s.rown[4 * tr + i] >= 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s.D2[(4 * tr + i) * kHS + tc + 16 * j] = acc[i][j];
+                    if (valid) { sy[j] += (double)acc[i][j]; sq[j] += (double)acc[i][j] * (double)acc[i][j]; }
+                }
+            }
+            __syncthreads();
+            src = s.D2;
+        }
+        if (t < P * 64) {
+            const int p = t >> 6, o = t & 63, n = tile * P + p;
+            if (n < N) {
+                const float go = gl[o];
+                const bool up = go >= 0.f;
+                float best = src[(p * K) * kHS + o];
+                int bk = 0;
+                for (int k = 1; k < (go == 0.f ? 1 : K); ++k) {          // gamma == 0: every row ties, torch.max keeps the first
+                    const float v = src[(p * K + k) * kHS + o];
+                    if (up ? v > best : v < best) { best = v; bk = k; }
+                }
+                ext[(size_t)n * 64 + o] = best;
+                argk[(size_t)n * 64 + o] = (uint8_t)bk;
+            }
+        }
+    }
+    if (LAYERS == 2) {
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red_of(s)[tr * 64 + tc + 16 * j] = which ? sq[j] : sy[j];
+            __syncthreads();
+            store_partial(partial + (size_t)blockIdx.x * 128 + which * 64, red_of(s), 64, 16, t);
+        }
+    }
+}
+
+__global__ void k_eb_fold2(const double* __restrict__ partial, int nblocks, double rows, float* __restrict__ cst, float* __restrict__ stats_out) {
+    const int c = threadIdx.x;
+    if (c >= 64) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblocks; ++b) { s += partial[(size_t)b * 128 + c]; q += partial[(size_t)b * 128 + 64 + c]; }
+    const double mu = s / rows, var = fmax(q / rows - mu * mu, 0.0);
+    cst[MU2 + c] = (float)mu;
+    cst[INV2 + c] = (float)(1.0 / sqrt(var + kBnEps));
+    if (stats_out) { stats_out[128 + c] = (float)mu; stats_out[192 + c] = (float)var; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 2 (elementwise over [N,64]): da of the LAST BatchNorm at the extreme row -> d beta, d gamma (block partials
+// [64 | 64]); LAYERS == 1 additionally sum da e^T over the hit rows ([64 x 20] more), e rebuilt from the table.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LAYERS>
+__global__ void __launch_bounds__(kThreads) k_eb_last_bn(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ cst,
+                                                         const float* __restrict__ ext, const uint8_t* __restrict__ argk, const float* __restrict__ gout,
+                                                         double* __restrict__ partial) {
+    __shared__ double red[4 * 64];
+    const int t = threadIdx.x, p = t >> 6, o = t & 63;
+    const float mu = cst[(LAYERS == 2 ? MU2 : MU1) + o], inv = cst[(LAYERS == 2 ? INV2 : INV1) + o], g = gamma[o], b = beta[o];
+    const float x0[3] = {cst[X0], cst[X0 + 1], cst[X0 + 2]};
+    double sdb = 0.0, sdg = 0.0;
+    double ge[LAYERS == 1 ? 18 : 1];
+#pragma unroll
+    for (int j = 0; j < (LAYERS == 1 ? 18 : 1); ++j) ge[j] = 0.0;
+    for (int n = blockIdx.x * 4 + p; n < N; n += gridDim.x * 4) {
+        const float go = gout[(size_t)n * 64 + o];
+        if (go == 0.f) continue;
+        const float xh = (ext[(size_t)n * 64 + o] - mu) * inv;
+        const float d = go * dlrelu(xh * g + b);
+        sdb += (double)d;
+        sdg += (double)d * (double)xh;
+        if (LAYERS == 1) {
+            const int j = knn[(size_t)n * K + argk[(size_t)n * 64 + o]];
+            const float* xi = x9 + (size_t)n * 12;
+            const float* xj = x9 + (size_t)j * 12;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const float a = xi[c];
+                ge[c] += (double)d * (double)(xj[c] - a);
+                ge[9 + c] += (double)d * (double)(c < 3 ? a - x0[c] : a);
+            }
+        }
+    }
+    const int nq = LAYERS == 1 ? 20 : 2;
+    double* dst = partial + (size_t)blockIdx.x * (LAYERS == 1 ? 128 + 64 * kES : 128);
+#pragma unroll 1
+    for (int q = 0; q < nq; ++q) {
+        __syncthreads();
+        double v = q == 0 ? sdb : q == 1 ? sdg : 0.0;
+        if (LAYERS == 1 && q >= 2) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) v = (q - 2 == j) ? ge[j] : v;
+        }
+        red[p * 64 + o] = v;
+        __syncthreads();
+        if (t < 64) {
+            const double a = ((red[t] + red[64 + t]) + red[128 + t]) + red[192 + t];
+            if (q < 2) dst[q * 64 + t] = a;
+            else dst[128 + t * kES + (q - 2)] = a;
+        }
+    }
+}
+
+// d beta2, d gamma2 -> outputs + the per-row constants of the dense backward (mean terms of BN2's backward)
+__global__ void k_eb_fold3(const double* __restrict__ partial, int nblocks, double rows, float* __restrict__ cst, float* __restrict__ gg2,
+                           float* __restrict__ gb2) {
+    const int c = threadIdx.x;
+    if (c >= 64) return;
+    double db = 0.0, dg = 0.0;
+    for (int b = 0; b < nblocks; ++b) { db += partial[(size_t)b * 128 + c]; dg += partial[(size_t)b * 128 + 64 + c]; }
+    gb2[c] = (float)db;
+    gg2[c] = (float)dg;
+    cst[DB2 + c] = (float)(db / rows);
+    cst[DG2 + c] = (float)(dg / rows);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 3 (layers == 2): dense backward.  Block partials: dW2 [64 x 64] | sum da1 e^T [64 x 20] | sum da1 [64] | sum da1 xhat1 [64]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_eb_backward(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P, int ntiles,
+                                                          const float* __restrict__ w1, const float* __restrict__ g1, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ g2, const float* __restrict__ b2,
+                                                          const float* __restrict__ cst, const uint8_t* __restrict__ argk, const float* __restrict__ gout,
+                                                          double* __restrict__ partial) {
+    __shared__ Tile s;
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    stage_weights(s, w1, w2);
+    float mu1[4], inv1[4], sc1[4], sh1[4];                   // columns 4 tc + j
+    float mu2[4], inv2[4], ga2[4], be2[4], db2[4], dg2[4];   // columns tc + 16 j
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * tc + j, o = tc + 16 * j;
+        mu1[j] = cst[MU1 + c]; inv1[j] = cst[INV1 + c]; sc1[j] = inv1[j] * g1[c]; sh1[j] = b1[c];
+        mu2[j] = cst[MU2 + o]; inv2[j] = cst[INV2 + o]; ga2[j] = g2[o]; be2[j] = b2[o]; db2[j] = cst[DB2 + o]; dg2[j] = cst[DG2 + o];
+    }
+    double dW2[4][4], gE[5], sda[4], sdx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sda[i] = 0.0; sdx[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dW2[i][j] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) gE[j] = 0.0;
+    const int ec = t & 63, eg = t >> 6;                       // sum da1 e^T: channel ec, e-columns 5 eg .. 5 eg + 4
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        build_edge_rows(s, x9, knn, N, K, P, tile, cst);
+        if (t < P * 64) {
+            const int n = tile * P + (t >> 6);
+            s.G[t] = n < N ? gout[(size_t)n * 64 + (t & 63)] : 0.f;
+            s.argk[t] = n < N ? argk[(size_t)n * 64 + (t & 63)] : -1;
+        }
+        __syncthreads();
+        float acc[4][4], xh1[4][4];
+        unsigned pos1 = 0u;                                   // bit 4 i + j: a1 > 0
+        conv1_block(s, tr, tc, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool valid = s.rown[4 * tr + i] >= 0;
+            float h[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xh1[i][j] = (acc[i][j] - mu1[j]) * inv1[j];
+                const float a = (acc[i][j] - mu1[j]) * sc1[j] + sh1[j];     // same expression as the forward pass (bit-equal h1)
+                pos1 |= (a > 0.f ? 1u : 0u) << (4 * i + j);
+                h[j] = valid ? lrelu(a) : 0.f;
+            }
+            *reinterpret_cast<float4*>(&s.H1[(4 * tr + i) * kHS + 4 * tc]) = make_float4(h[0], h[1], h[2], h[3]);
+        }
+        __syncthreads();
+        conv2_block(s, tr, tc, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * tr + i;
+            const bool valid = s.rown[r] >= 0;
+            const int p = r / K, k = r - p * K;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = tc + 16 * j;
+                const float xh = (acc[i][j] - mu2[j]) * inv2[j];
+                float da = 0.f;
+                if (valid && s.argk[p * 64 + o] == k) da = s.G[p * 64 + o] * dlrelu(xh * ga2[j] + be2[j]);
+                s.D2[r * kHS + o] = valid ? ga2[j] * inv2[j] * ((da - db2[j]) - xh * dg2[j]) : 0.f;
+            }
+        }
+        __syncthreads();
+        // dW2[o][i] += sum_r dy2[r][o] h1[r][i]      block: o = 4 tr + a, i = 4 tc + b
+        {
+            float w[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) w[a][b] = 0.f;
+            for (int r = 0; r < kR; ++r) {
+                const float4 d = *reinterpret_cast<const float4*>(&s.D2[r * kHS + 4 * tr]);
+                const float4 h = *reinterpret_cast<const float4*>(&s.H1[r * kHS + 4 * tc]);
+                const float dv[4] = {d.x, d.y, d.z, d.w}, hv[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) w[a][b] = fmaf(dv[a], hv[b], w[a][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) dW2[a][b] += (double)w[a][b];
+        }
+        // dh1[r][i] = sum_o dy2[r][o] W2[o][i]       block: rows 4 tr + i, columns 4 tc + j  (the conv1 block: xh1, pos1 are at hand)
+        float da1[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) da1[i][j] = 0.f;
+        for (int o = 0; o < 64; o += 4) {
+            float4 d[4], w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const float4*>(&s.D2[(4 * tr + i) * kHS + o]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(&s.W2[(o + u) * kHS + 4 * tc]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dv[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    da1[i][0] = fmaf(dv[u], w[u].x, da1[i][0]);
+                    da1[i][1] = fmaf(dv[u], w[u].y, da1[i][1]);
+                    da1[i][2] = fmaf(dv[u], w[u].z, da1[i][2]);
+                    da1[i][3] = fmaf(dv[u], w[u].w, da1[i][3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool valid = s.rown[4 * tr + i] >= 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                da1[i][j] = valid ? da1[i][j] * (((pos1 >> (4 * i + j)) & 1u) ? 1.f : kSlope) : 0.f;
+                sda[j] += (double)da1[i][j];
+                sdx[j] += (double)da1[i][j] * (double)xh1[i][j];
+            }
+        }
+        __syncthreads();                                      // every reader of D2 (dy2) is done
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&s.D2[(4 * tr + i) * kHS + 4 * tc]) = make_float4(da1[i][0], da1[i][1], da1[i][2], da1[i][3]);
+        __syncthreads();
+        {
+            float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < kR; ++r) {
+                const float d = s.D2[r * kHS + ec];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) a[j] = fmaf(d, s.E[r * kES + 5 * eg + j], a[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) gE[j] += (double)a[j];
+        }
+    }
+    double* dst = partial + (size_t)blockIdx.x * kPart3;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dst[(4 * tr + a) * 64 + 4 * tc + b] = dW2[a][b];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dst[4096 + ec * kES + 5 * eg + j] = gE[j];
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red_of(s)[tr * 64 + 4 * tc + j] = which ? sdx[j] : sda[j];
+        __syncthreads();
+        store_partial(dst + 4096 + 64 * kES + which * 64, red_of(s), 64, 16, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fold: block partials -> gradients.  `off_e` / `off_s`: where sum da1 e^T [64 x 20] and sum da1 | sum da1 xhat1 sit in a
+// block's partial; dW2 (layers == 2) is the first 4096 entries.  BN1's dense part comes from the moments (file header).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_eb_final(const double* __restrict__ partial, int nblocks, int stride, int off_e, int off_s, int layers, double rows,
+                           const double* __restrict__ mom, const float* __restrict__ w1, const float* __restrict__ g1, const float* __restrict__ cst,
+                           float* __restrict__ gw1, float* __restrict__ gg1, float* __restrict__ gb1, float* __restrict__ gw2) {
+    __shared__ double sda[64], sdx[64];
+    const int t = threadIdx.x;
+    if (layers == 2)
+        for (int i = t; i < 4096; i += blockDim.x) {
+            double a = 0.0;
+            for (int b = 0; b < nblocks; ++b) a += partial[(size_t)b * stride + i];
+            gw2[i] = (float)a;
+        }
+    if (t < 128) {
+        double a = 0.0;
+        for (int b = 0; b < nblocks; ++b) a += partial[(size_t)b * stride + off_s + t];
+        if (t < 64) { sda[t] = a; gb1[t] = (float)a; }
+        else { sdx[t - 64] = a; gg1[t - 64] = (float)a; }
+    }
+    __syncthreads();
+    for (int i = t; i < 64 * 18; i += blockDim.x) {
+        const int c = i / 18, j = i - c * 18;
+        double ge = 0.0;
+        for (int b = 0; b < nblocks; ++b) ge += partial[(size_t)b * stride + off_e + c * kES + j];
+        const double inv = (double)cst[INV1 + c], mu = (double)cst[MU1 + c];
+        double wsee = 0.0;
+        for (int q = 0; q < 18; ++q) wsee += (double)w1[c * 18 + q] * mom[q * kES + j];
+        const double xe = (wsee - mu * mom[400 + j]) * inv;                       // sum_r xhat1[r][c] e[r][j]
+        gw1[i] = (float)((double)g1[c] * inv * (ge - sda[c] / rows * mom[400 + j] - sdx[c] / rows * xe));
+    }
+}
+
+__global__ void k_eb_init(const float* __restrict__ x9, float* __restrict__ cst) {
+    if (threadIdx.x < 3) cst[X0 + threadIdx.x] = x9[threadIdx.x];
+}
+
+}  // namespace
+
+extern "C" {
+
+static int eb_blocks(int ntiles) { return std::max(1, std::min(ntiles, 512)); }
+
+size_t sg_edgeconv_backward_ws_bytes(int N) {
+    const size_t n = (size_t)std::max(N, 1);
+    return sg::align_up(512 * (size_t)kPart3 * 8) + sg::align_up(n * 64 * 4) + sg::align_up(n * 64) + sg::align_up(kCst * 4) + sg::align_up(kMom * 8) + 4096;
+}
+
+int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1, const float* d_b1,
+                         const float* d_w2, const float* d_g2, const float* d_b2, const float* d_gout, float* d_gw1, float* d_gg1, float* d_gb1,
+                         float* d_gw2, float* d_gg2, float* d_gb2, float* d_bn_stats, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(N > 0 && k > 0 && k <= 32 && (layers == 1 || layers == 2) && d_x9m && d_knn && d_w1 && d_g1 && d_b1 && d_gout && d_gw1 && d_gg1 && d_gb1 && d_ws,
+               "sg_edgeconv_backward: bad arguments (k = %d must be <= 32)", k);
+    SG_REQUIRE(layers == 1 || (d_w2 && d_g2 && d_b2 && d_gw2 && d_gg2 && d_gb2), "sg_edgeconv_backward: layers == 2 needs the second conv's tensors");
+    sg::Carver cv(d_ws, ws_bytes);
+    double* partial = cv.take<double>(512 * (size_t)kPart3);
+    float* ext = cv.take<float>((size_t)N * 64);
+    uint8_t* argk = cv.take<uint8_t>((size_t)N * 64);
+    float* cst = cv.take<float>(kCst);
+    double* mom = cv.take<double>(kMom);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_edgeconv_backward: workspace too small (%zu < %zu)", ws_bytes, sg_edgeconv_backward_ws_bytes(N));
+    hipStream_t st = sg::as_stream(stream);
+    const int P = std::min(kR / k, 4), ntiles = sg::cdiv(N, P), nb = eb_blocks(ntiles);
+    const double rows = (double)N * (double)k;
+    k_eb_init<<<1, 64, 0, st>>>(d_x9m, cst);
+    k_eb_moments<<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, cst, partial);
+    k_eb_fold1<<<1, 256, 0, st>>>(partial, nb, rows, d_w1, cst, mom, d_bn_stats);
+    const int nb2 = std::max(1, std::min(sg::cdiv(N, 4), 1024));
+    if (layers == 1) {
+        k_eb_forward<1><<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, nullptr, nullptr, cst, ext, argk, partial);
+        const int stride = 128 + 64 * kES;
+        SG_REQUIRE((size_t)nb2 * stride <= 512 * (size_t)kPart3, "sg_edgeconv_backward: partial buffer");
+        k_eb_last_bn<1><<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_g1, d_b1, cst, ext, argk, d_gout, partial);
+        k_eb_final<<<1, 1024, 0, st>>>(partial, nb2, stride, 128, 0, 1, rows, mom, d_w1, d_g1, cst, d_gw1, d_gg1, d_gb1, nullptr);
+    } else {
+        k_eb_forward<2><<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, cst, ext, argk, partial);
+        k_eb_fold2<<<1, 64, 0, st>>>(partial, nb, rows, cst, d_bn_stats);
+        k_eb_last_bn<2><<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_g2, d_b2, cst, ext, argk, d_gout, partial);
+        k_eb_fold3<<<1, 64, 0, st>>>(partial, nb2, rows, cst, d_gg2, d_gb2);
+        k_eb_backward<<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, cst, argk, d_gout, partial);
+        k_eb_final<<<1, 1024, 0, st>>>(partial, nb, kPart3, 4096, 4096 + 64 * kES, 2, rows, mom, d_w1, d_g1, cst, d_gw1, d_gg1, d_gb1, d_gw2);
+    }
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+}  // extern "C"

@@ -515,6 +515,31 @@ def segment_max_backward(rows, cl_off, grad_out):
     return out
 
 
+def edgeconv_backward(x, idx, grad_out, w1, g1, b1, w2=None, g2=None, b2=None):
+    """Parameter gradients of `edgeconv_forward` (MLP2 / MLP3 with batch-statistics BatchNorm2d, model.py:83-138):
+    x [1,9,N], idx [1,N,k], grad_out [1,64,N] -> dict(w1 [64,18], g1, b1[, w2 [64,64], g2, b2], bn_stats [256])."""
+    _need_cuda(x, "x")
+    lib = hip.lib()
+    dev = x.device
+    N, k = int(x.shape[2]), int(idx.shape[-1])
+    x12 = torch.zeros((N, 12), dtype=torch.float32, device=dev)
+    x12[:, :9] = x[0].transpose(1, 0)
+    knn_ = idx.reshape(N, k).to(_i32).contiguous()
+    go = grad_out[0].transpose(1, 0).contiguous().float()
+    two = w2 is not None
+    keep = [t.reshape(t.shape[0], -1).contiguous().float() if t is not None else None for t in (w1, g1, b1, w2, g2, b2)]
+    out = {"w1": torch.empty((64, 18), device=dev), "g1": torch.empty(64, device=dev), "b1": torch.empty(64, device=dev),
+           "bn_stats": torch.zeros(256, device=dev)}
+    if two:
+        out.update(w2=torch.empty((64, 64), device=dev), g2=torch.empty(64, device=dev), b2=torch.empty(64, device=dev))
+    ws = _ws(lib.sg_edgeconv_backward_ws_bytes(N), dev)
+    hip.check(lib.sg_edgeconv_backward(x12.data_ptr(), knn_.data_ptr(), N, k, 2 if two else 1, *[None if t is None else t.data_ptr() for t in keep],
+                                       go.data_ptr(), out["w1"].data_ptr(), out["g1"].data_ptr(), out["b1"].data_ptr(),
+                                       out["w2"].data_ptr() if two else None, out["g2"].data_ptr() if two else None,
+                                       out["b2"].data_ptr() if two else None, out["bn_stats"].data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
 class TrainTail:
     """model.py:900-932: per-instance max feature -> Classifier (154-166) -> label-smoothed cross entropy (util.py:12-29),
     forward and backward on HIP.  `keep` is the pinned dropout mask [K,128] already scaled by 1 / (1 - p) (None = no dropout)."""

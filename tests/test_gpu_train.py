@@ -149,3 +149,49 @@ def test_gcn_backward_matches_autograd(S, D, E):
     ref.backward(torch.from_numpy(gout).double())
     assert np.abs(gx - x.grad.numpy()).max() < TOL * max(1.0, np.abs(x.grad.numpy()).max())
     assert np.abs(gw - w.grad.numpy()).max() < TOL * max(1.0, np.abs(w.grad.numpy()).max())
+
+
+def _rand_edge_problem(N, K, seed, offset=0.0):
+    rng = np.random.default_rng(seed)
+    x9 = rng.normal(size=(N, 9)).astype(np.float32)
+    x9[:, :3] += np.float32(offset)
+    x9[:, 6:] = x9[:, :3] - x9[:, :3].mean(0)
+    knn = rng.integers(0, N, size=(N, K)).astype(np.int64)
+    knn[:, 0] = np.arange(N)
+    knn[::7, 3] = knn[::7, 2]                                    # duplicated neighbours: tied rows inside a point's k rows
+    W = {"w1": rng.normal(size=(64, 18)) * 0.4, "g1": rng.normal(size=64) * 0.5 + 1.0, "b1": rng.normal(size=64) * 0.1,
+         "w2": rng.normal(size=(64, 64)) * 0.2, "g2": rng.normal(size=64) * 0.5 + 1.0, "b2": rng.normal(size=64) * 0.1}
+    W["g1"][5] = -0.7                                            # a negative scale: the max over k picks the smallest pre-activation
+    W["g2"][9] = -0.4
+    gout = rng.normal(size=(N, 64)) * (rng.random(size=(N, 64)) < 0.05)     # sparse, like the point -> cluster max leaves it
+    return x9, knn, {k: v.astype(np.float32) for k, v in W.items()}, gout.astype(np.float32)
+
+
+@pytest.mark.parametrize("layers,N,K,offset", [(1, 3001, 20, 0.0), (2, 3001, 20, 0.0), (2, 20000, 20, 0.0), (2, 997, 20, 500.0), (1, 400, 7, 0.0), (2, 400, 16, 0.0)])
+def test_edgeconv_backward_matches_autograd(layers, N, K, offset):
+    """sg_edgeconv_backward (MLP2 / MLP3 with batch-statistics BatchNorm2d, model.py:83-138) against torch.autograd over the float64
+    restatement oracle.train_ref.edgeconv; gradients compared relative to each tensor's largest entry."""
+    import torch
+    from oracle import train_ref
+    from seggroup_amd import functional as F
+    x9, knn, W, gout = _rand_edge_problem(N, K, 11 + layers)
+    x9[:, :3] += np.float32(offset)
+    P = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in W.items()}
+    args = [P["w1"], P["g1"], P["b1"]] + ([P["w2"], P["g2"], P["b2"]] if layers == 2 else [])
+    pf, stats = train_ref.edgeconv(torch.tensor(x9.astype(np.float64)), torch.from_numpy(knn), *args)
+    (pf * torch.tensor(gout.astype(np.float64))).sum().backward()
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    got = F.edgeconv_backward(t(x9.T[None]), t(knn[None]), t(gout.T[None]), *[t(W[k]) for k in (("w1", "g1", "b1", "w2", "g2", "b2") if layers == 2 else ("w1", "g1", "b1"))])
+    torch.cuda.synchronize()
+    for k in args and (("w1", "g1", "b1", "w2", "g2", "b2") if layers == 2 else ("w1", "g1", "b1")):
+        want = P[k].grad.numpy()
+        have = got[k].cpu().numpy().astype(np.float64)
+        scale = np.abs(want).max()
+        assert np.abs(have - want).max() <= 2e-4 * scale, (k, np.abs(have - want).max() / scale)
+    bs = got["bn_stats"].cpu().numpy()
+    assert np.abs(bs[:64] - stats[0][0].detach().numpy()).max() < 1e-4 * max(1.0, abs(offset))
+    assert np.abs(bs[64:128] - stats[0][1].detach().numpy()).max() < 1e-4 * np.abs(stats[0][1].detach().numpy()).max()
+    if layers == 2:
+        assert np.abs(bs[128:192] - stats[1][0].detach().numpy()).max() < 1e-4
+        assert np.abs(bs[192:] - stats[1][1].detach().numpy()).max() < 1e-4 * np.abs(stats[1][1].detach().numpy()).max()

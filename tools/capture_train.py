@@ -8,7 +8,10 @@ stated with the same mask on both sides), and stores what the tail consumes and 
 
     classifier weights (torch default init under manual_seed(1)), Feat_6, logits, loss [1,2], the pinned mask
 
-into tests/golden/train_tail.npz.  usage: python tools/capture_train.py
+into tests/golden/train_tail.npz, and -- the rest of the training step (model.py:900-932 + train.py:164-168) -- the
+gradients `loss.backward()` leaves on EVERY parameter of the reference model for loss = loss_sum / loss_num, together with the
+running BatchNorm statistics after that one forward, into tests/golden/train_grads.npz (`<fixture>.grad.<parameter>`,
+`<fixture>.buf.<buffer>`).  usage: python tools/capture_train.py
 """
 import os
 import sys
@@ -35,6 +38,7 @@ def main():
     wts = W.load_npz(os.path.join(REPO, "tests", "golden", "weights_g2.npz"))
     index = json.load(open(os.path.join(REPO, "tests", "golden", "index.json")))
     blobs = {}
+    grads = {}
     for name in ("tiny_4k", "tiny_dup_4k", "small_20k", "island_20k"):
         e = index[name]
         scene = synthetic.make_scene(e["n"], e["s"], e["seed"], name=f"scene{e['seed']:05d}_00", **e["kw"])
@@ -58,6 +62,14 @@ def main():
                 net.classifier.register_forward_hook(lambda m, i, o: seen.update(feat6=i[0].detach().numpy().copy(), logits=o.detach().numpy().copy()))
                 out = net(torch.from_numpy(scene.data)[None], torch.from_numpy(scene.weak_label)[None], torch.tensor([[0]]))
                 assert net.training
+                # train.py:164-168 on one rank
+                step_loss = torch.sum(out[0][:, 0]) / torch.sum(out[0][:, 1])
+                step_loss.backward()
+                for k, p in net.named_parameters():
+                    grads[f"{name}.grad.{k}"] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().copy()
+                for k, b in net.named_buffers():
+                    grads[f"{name}.buf.{k}"] = b.detach().numpy().copy()
+                grads[f"{name}.step_loss"] = np.array([float(step_loss)], dtype=np.float64)
             finally:
                 os.chdir(cwd)
         loss = out[0].detach().numpy()
@@ -71,6 +83,7 @@ def main():
                 if k.startswith("classifier.") and "running" not in k and "num_batches" not in k:
                     blobs["w." + k] = v.detach().numpy().copy()
     np.savez_compressed(os.path.join(REPO, "tests", "golden", "train_tail.npz"), **blobs)
+    np.savez_compressed(os.path.join(REPO, "tests", "golden", "train_grads.npz"), **grads)
 
 
 if __name__ == "__main__":
