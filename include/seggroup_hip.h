@@ -576,6 +576,14 @@ int sg_gcn_backward(const float* d_x, int S, int D, const int32_t* d_adj, int E,
                     const int32_t* d_eid, const float* d_w, float alpha, const float* d_gout, float* d_gx, float* d_gw,
                     void* d_ws, size_t ws_bytes, void* stream);
 
+/* backward of sg_mlp1_forward w.r.t. its parameters (MLP1, model.py:39-80; batch-statistics BatchNorm2d over all C*64*10 rows):
+ *   d_gfeat rows of g_stride floats: gradient w.r.t. Feat_1 [C,128] ([max | mean] over the 64 samples)
+ *   d_gw [64,6], d_gg [64], d_gb [64];  d_bn_stats [128] or NULL = batch mean | biased variance of the conv output
+ * d_ws needs sg_mlp1_backward_ws_bytes(C). */
+size_t sg_mlp1_backward_ws_bytes(int C);
+int sg_mlp1_backward(const float* d_samples, int C, const float* d_w, const float* d_gamma, const float* d_beta, const float* d_gfeat,
+                     int g_stride, float* d_gw, float* d_gg, float* d_gb, float* d_bn_stats, void* d_ws, size_t ws_bytes, void* stream);
+
 /* backward of sg_edgeconv_forward (get_graph_feature2 + MLP2 / MLP3, model.py:83-138; autograd differentiates it in the reference's
  * training step, train.py:167).  The inputs carry no gradient: parameter gradients only.
  *   d_x9m [N,12], d_knn [N,k]   as for the forward call

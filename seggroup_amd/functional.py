@@ -515,6 +515,24 @@ def segment_max_backward(rows, cl_off, grad_out):
     return out
 
 
+def mlp1_backward(x, grad_feat, conv_w, bn_w, bn_b):
+    """Parameter gradients of `mlp1_forward` (model.py:39-80): x [S,6,64] samples, grad_feat [S,128] ->
+    dict(w [64,6], g [64], b [64], bn_stats [128])."""
+    _need_cuda(x, "x")
+    lib = hip.lib()
+    dev = x.device
+    S = int(x.shape[0])
+    samples = x.transpose(2, 1).contiguous().float()                   # [S,64,6]
+    g = grad_feat.contiguous().float()
+    w, ga, be = conv_w.reshape(64, 6).contiguous().float(), bn_w.contiguous().float(), bn_b.contiguous().float()
+    out = {"w": torch.empty((64, 6), device=dev), "g": torch.empty(64, device=dev), "b": torch.empty(64, device=dev),
+           "bn_stats": torch.zeros(128, device=dev)}
+    ws = _ws(lib.sg_mlp1_backward_ws_bytes(S), dev)
+    hip.check(lib.sg_mlp1_backward(samples.data_ptr(), S, w.data_ptr(), ga.data_ptr(), be.data_ptr(), g.data_ptr(), 128, out["w"].data_ptr(),
+                                   out["g"].data_ptr(), out["b"].data_ptr(), out["bn_stats"].data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
 def edgeconv_backward(x, idx, grad_out, w1, g1, b1, w2=None, g2=None, b2=None):
     """Parameter gradients of `edgeconv_forward` (MLP2 / MLP3 with batch-statistics BatchNorm2d, model.py:83-138):
     x [1,9,N], idx [1,N,k], grad_out [1,64,N] -> dict(w1 [64,18], g1, b1[, w2 [64,64], g2, b2], bn_stats [256])."""

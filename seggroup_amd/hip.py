@@ -109,6 +109,8 @@ SIGNATURES = {
     "sg_segment_max_backward": (_I, [vp, _I, _I, vp, _I, vp, _I, vp, vp]),
     "sg_gcn_backward_ws_bytes": (_Z, [_I, _I, _I]),
     "sg_gcn_backward": (_I, [vp, _I, _I, vp, _I, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, _Z, vp]),
+    "sg_mlp1_backward_ws_bytes": (_Z, [_I]),
+    "sg_mlp1_backward": (_I, [vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_edgeconv_backward_ws_bytes": (_Z, [_I]),
     "sg_edgeconv_backward": (_I, [vp, vp, _I, _I, _I] + [vp] * 14 + [vp, _Z, vp]),
     "sg_parse_seg_json": (_I, [C.c_char_p, _I, vp]),

@@ -195,3 +195,34 @@ def test_edgeconv_backward_matches_autograd(layers, N, K, offset):
     if layers == 2:
         assert np.abs(bs[128:192] - stats[1][0].detach().numpy()).max() < 1e-4
         assert np.abs(bs[192:] - stats[1][1].detach().numpy()).max() < 1e-4 * np.abs(stats[1][1].detach().numpy()).max()
+
+
+@pytest.mark.parametrize("S,dup", [(37, False), (600, True)])
+def test_mlp1_backward_matches_autograd(S, dup):
+    """sg_mlp1_backward against torch.autograd over oracle.train_ref.mlp1 (float64), the kNN-10 table taken from the oracle.
+    `dup`: clusters smaller than 64 points repeat their members (model.py:405-419), so tied samples are the normal case."""
+    import torch
+    from oracle import cpu_ref, train_ref
+    from seggroup_amd import functional as F
+    rng = np.random.default_rng(5 + S)
+    samples = rng.normal(size=(S, 64, 6)).astype(np.float32)
+    if dup:
+        samples[::3, 32:] = samples[::3, :32]
+        samples[1::5, 1:] = samples[1::5, :1]                     # a one-point segment: all 64 samples coincide
+    W = {"mlp_1.conv1.0.weight": (rng.normal(size=(64, 6)) * 0.5).astype(np.float32), "mlp_1.bn1.weight": (rng.normal(size=64) * 0.5 + 1).astype(np.float32),
+         "mlp_1.bn1.bias": (rng.normal(size=64) * 0.1).astype(np.float32)}
+    W["mlp_1.bn1.weight"][3] = -0.6
+    _, idx = cpu_ref.mlp1_forward(samples, W, return_knn=True)
+    P = [torch.tensor(W[k].astype(np.float64), requires_grad=True) for k in ("mlp_1.conv1.0.weight", "mlp_1.bn1.weight", "mlp_1.bn1.bias")]
+    feat, mean, var = train_ref.mlp1(torch.tensor(samples.astype(np.float64)), torch.from_numpy(idx), *P)
+    gfeat = rng.normal(size=(S, 128)).astype(np.float32)
+    (feat * torch.tensor(gfeat.astype(np.float64))).sum().backward()
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    got = F.mlp1_backward(t(samples.transpose(0, 2, 1)), t(gfeat), *[t(W[k]) for k in ("mlp_1.conv1.0.weight", "mlp_1.bn1.weight", "mlp_1.bn1.bias")])
+    torch.cuda.synchronize()
+    for k, p in zip(("w", "g", "b"), P):
+        want, have = p.grad.numpy(), got[k].cpu().numpy().astype(np.float64)
+        assert np.abs(have - want).max() <= 2e-4 * np.abs(want).max(), (k, np.abs(have - want).max() / np.abs(want).max())
+    bs = got["bn_stats"].cpu().numpy()
+    assert np.abs(bs[:64] - mean.detach().numpy()).max() < 1e-4 and np.abs(bs[64:] - var.detach().numpy()).max() < 1e-4 * var.detach().numpy().max()
