@@ -396,6 +396,7 @@ typedef struct sg_debug {         /* optional taps for stage-level parity tests 
     int32_t* h_ins5;                /* HOST [S] weak instance label of every final cluster (-1 = none)    */
     int32_t* h_sem5;                /* HOST [S] weak semantic label of every final cluster                */
     int32_t  n5;                    /* final clusters written                                             */
+    void*    tape;                  /* library-internal (sg_trainer): the training step's record of this forward; NULL otherwise */
 } sg_debug;
 
 sg_pipeline* sg_pipeline_create(int max_points, int max_segments, int max_edges, int max_vertices,
@@ -597,6 +598,43 @@ int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k,
                          const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, const float* d_gout, float* d_gw1,
                          float* d_gg1, float* d_gb1, float* d_gw2, float* d_gg2, float* d_gb2, float* d_bn_stats, void* d_ws,
                          size_t ws_bytes, void* stream);
+
+/* batch mean | biased variance [128 | 128] of classifier.bn1 as left in d_ws by sg_train_tail_forward (running-statistics update) */
+int sg_train_tail_bn_stats(void* d_ws, size_t ws_bytes, int K, float* d_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One training step (train.py:160-168 around SegModel.forward in train mode).  Parameters and gradients are flat DEVICE
+ * vectors of SG_NUM_PARAMS floats in the reference's `named_parameters()` order (sg_param_slot), owned by the caller: the
+ * host side all-reduces the gradient vector over RCCL (train.py:88 DistributedDataParallel averages it over the ranks) and
+ * applies the optimizer to the same vectors.
+ * ------------------------------------------------------------------------------------------- */
+#define SG_NUM_PARAM_TENSORS 19
+#define SG_NUM_PARAMS 147880
+#define SG_NUM_BN_STATS 768
+typedef struct sg_trainer sg_trainer;
+int sg_param_slot(int index, const char** name, int* offset, int* count);
+sg_trainer* sg_trainer_create(int max_points, int max_segments, int max_edges, int max_vertices, float* d_params, float* d_grads, void* stream);
+void sg_trainer_destroy(sg_trainer* tr);
+size_t sg_trainer_device_bytes(const sg_trainer* tr);
+/* SegModel.forward in train mode up to the classifier (model.py:684-914) with the CURRENT parameter vector: pseudo labels and
+ * metrics as in ins_infer (`out`), the record the backward needs, *final_clusters = rows of Feat_5, *instances = K rows of Feat_6 */
+int sg_trainer_forward(sg_trainer* tr, const sg_scene* scene, sg_result* out, int* final_clusters, int* instances);
+/* Classifier + label-smoothed cross entropy (model.py:916-930) of the last sg_trainer_forward: h_loss[2] = {loss_sum, K} (the
+ * reference's `loss [1,2]`); d_keep: DEVICE dropout keep mask [K,128] already scaled by 1 / (1 - p), or NULL (no dropout);
+ * d_logits_out [K,40] may be NULL.  K < 2: SG_EUNSUP (BatchNorm1d in training mode raises in the reference). */
+int sg_trainer_loss(sg_trainer* tr, const float* d_keep, float* h_loss, float* d_logits_out);
+/* loss.backward() for loss = scale * loss_sum (scale <= 0: 1 / K, train.py:164-166), after sg_trainer_loss with the same mask:
+ * fills the whole gradient vector. */
+int sg_trainer_backward(sg_trainer* tr, const float* d_keep, float scale);
+/* HOST h_out[SG_NUM_BN_STATS]: batch mean | biased variance of mlp_1.bn1 [64|64], mlp_2.bn1, mlp_3.bn1, mlp_3.bn2, classifier.bn1
+ * [128|128] of the last step (after sg_trainer_backward); h_rows[5] = rows each statistic ran over (running_var is unbiased) */
+int sg_trainer_bn_stats(const sg_trainer* tr, float* h_out, double* h_rows);
+
+/* torch.optim.SGD (train.py:96: lr * 100, momentum, weight_decay 1e-4; dampening 0, no Nesterov) on flat vectors */
+int sg_optimizer_sgd(float* d_params, const float* d_grads, float* d_momentum_buf, int n, float lr, float momentum, float weight_decay,
+                     int first_step, void* stream);
+/* torch.optim.Adam (train.py:98: betas 0.9 / 0.999, eps 1e-8, weight_decay added to the gradient); step counts from 1 */
+int sg_optimizer_adam(float* d_params, const float* d_grads, float* d_m, float* d_v, int n, float lr, float weight_decay, int step, void* stream);
 
 /* =============================================================================================
  * Readers for the reference's on-disk inputs.  Host only.

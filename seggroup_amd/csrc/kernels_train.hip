@@ -12,6 +12,8 @@
 //
 // Everything here is tiny (K <= a few hundred instances, C <= S clusters, D <= 256): one or a few blocks, fp64
 // accumulation, no tuning -- the EdgeConv / BatchNorm2d backward (the part with real work) is the next slice.
+#include <cmath>
+
 #include "sg_common.h"
 
 namespace {
@@ -285,6 +287,52 @@ __global__ void k_gcn_bwd_x(const float* __restrict__ x, int D, const int32_t* _
 
 }  // namespace
 
+namespace {
+
+// torch.optim.SGD (train.py:96): g' = g + wd * p;  buf = first ? g' : momentum * buf + g';  p -= lr * buf
+__global__ void k_sgd_step(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int n, float lr, float momentum, float wd,
+                           int first) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float gg = g[i] + wd * p[i];
+        const float b = first ? gg : momentum * buf[i] + gg;
+        buf[i] = b;
+        p[i] = p[i] - lr * b;
+    }
+}
+
+// torch.optim.Adam (train.py:98; betas 0.9 / 0.999, eps 1e-8, L2 weight decay added to the gradient), step = 1, 2, ...
+__global__ void k_adam_step(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n, float lr, float wd,
+                            float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float gg = g[i] + wd * p[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gg;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gg * gg;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+__global__ void k_transpose_square(const float* __restrict__ src, float* __restrict__ dst, int D) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y)
+        if (by + r < D && bx + (int)threadIdx.x < D) tile[r][threadIdx.x] = src[(size_t)(by + r) * D + bx + threadIdx.x];
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y)
+        if (bx + r < D && by + (int)threadIdx.x < D) dst[(size_t)(bx + r) * D + by + threadIdx.x] = tile[threadIdx.x][r];
+}
+
+}  // namespace
+
+namespace sg {
+int transpose_square(const float* d_src, float* d_dst, int D, hipStream_t st) {
+    k_transpose_square<<<dim3(cdiv(D, 32), cdiv(D, 32)), dim3(32, 8), 0, st>>>(d_src, d_dst, D);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+}  // namespace sg
+
 extern "C" {
 
 size_t sg_train_tail_ws_bytes(int C, int K) {
@@ -381,4 +429,44 @@ int sg_gcn_backward(const float* d_x, int S, int D, const int32_t* d_adj, int E,
     return SG_OK;
 }
 
+namespace {
+__global__ void k_tail_bn_stats(const float* __restrict__ stat, float* __restrict__ out) {
+    const int j = threadIdx.x;
+    if (j < kH) {
+        const double inv = (double)stat[kH + j];
+        out[j] = stat[j];
+        out[kH + j] = (float)fmax(1.0 / (inv * inv) - 1e-5, 0.0);
+    }
+}
+}  // namespace
+
+int sg_train_tail_bn_stats(void* d_ws, size_t ws_bytes, int K, float* d_out, void* stream) {
+    SG_REQUIRE(d_ws && d_out && K >= 2, "sg_train_tail_bn_stats: bad arguments");
+    TailWs t = carve_tail(d_ws, ws_bytes, K);
+    if (!t.ok) return sg::fail(SG_ENOMEM, "sg_train_tail_bn_stats: workspace too small");
+    k_tail_bn_stats<<<1, kH, 0, sg::as_stream(stream)>>>(t.stat, d_out);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_optimizer_sgd(float* d_params, const float* d_grads, float* d_momentum_buf, int n, float lr, float momentum, float weight_decay,
+                     int first_step, void* stream) {
+    SG_REQUIRE(d_params && d_grads && d_momentum_buf && n >= 0, "sg_optimizer_sgd: bad arguments");
+    if (n == 0) return SG_OK;
+    k_sgd_step<<<std::min(sg::cdiv(n, 256), 1024), 256, 0, sg::as_stream(stream)>>>(d_params, d_grads, d_momentum_buf, n, lr, momentum, weight_decay, first_step);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_optimizer_adam(float* d_params, const float* d_grads, float* d_m, float* d_v, int n, float lr, float weight_decay, int step, void* stream) {
+    SG_REQUIRE(d_params && d_grads && d_m && d_v && n >= 0 && step >= 1, "sg_optimizer_adam: bad arguments (step counts from 1)");
+    if (n == 0) return SG_OK;
+    const double b1 = 0.9, b2 = 0.999;
+    const float bc1 = (float)(1.0 - std::pow(b1, step)), bc2s = (float)std::sqrt(1.0 - std::pow(b2, step));
+    k_adam_step<<<std::min(sg::cdiv(n, 256), 1024), 256, 0, sg::as_stream(stream)>>>(d_params, d_grads, d_m, d_v, n, lr, weight_decay, 0.9f, 0.999f, 1e-8f, bc1, bc2s);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
 }  // extern "C"
+

@@ -178,6 +178,9 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     };
     hipStream_t st = pl->stream;
     void* stv = (void*)st;
+    sg_tape* tape = dbg ? reinterpret_cast<sg_tape*>(dbg->tape) : nullptr;
+    if (tape) tape->filled = false;
+    SG_REQUIRE(!tape || mode == SG_MODE_INS_INFER, "the training tape needs the full (ins_infer) forward");
     const float* W = pl->w.p;
     pl->n_ev = 0;
     out->stalled = 0; out->used_fallback = 0;
@@ -444,6 +447,21 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                 if (dbg->d_knn[layer]) PL_HIP(hipMemcpyAsync(dbg->d_knn[layer], pl->knn.p, (size_t)N * 20 * 4, hipMemcpyDeviceToDevice, st));
                 if (dbg->d_members[layer]) PL_HIP(hipMemcpyAsync(dbg->d_members[layer], pl->members.p, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
             }
+            if (tape) {
+                sg_tape::Layer& TL = tape->layer[layer];
+                TL.o = o; TL.C = C; TL.Cprev = Lcur.C; TL.Dcat = Dcat; TL.Dprev = feat_prev_dim; TL.E = E;
+                if ((size_t)N * 12 > TL.x9m.n || (size_t)N * 20 > TL.knn.n || (size_t)N * 64 > TL.pf.n || o.total > TL.desc.n || (size_t)C * Dcat > TL.cat.n ||
+                    (size_t)C * Dcat > TL.gcn.n) {
+                    sg_partition_destroy(part);
+                    return sg::fail(SG_ENOMEM, "training tape smaller than the scene");
+                }
+                PL_HIP(hipMemcpyAsync(TL.x9m.p, pl->x9m.p, (size_t)N * 12 * 4, hipMemcpyDeviceToDevice, st));
+                PL_HIP(hipMemcpyAsync(TL.knn.p, pl->knn.p, (size_t)N * 20 * 4, hipMemcpyDeviceToDevice, st));
+                PL_HIP(hipMemcpyAsync(TL.pf.p, pl->pf.p, (size_t)N * 64 * 4, hipMemcpyDeviceToDevice, st));
+                PL_HIP(hipMemcpyAsync(TL.desc.p, pl->desc.p, o.total * 4, hipMemcpyDeviceToDevice, st));
+                PL_HIP(hipMemcpyAsync(TL.cat.p, cat, (size_t)C * Dcat * 4, hipMemcpyDeviceToDevice, st));
+                PL_HIP(hipMemcpyAsync(TL.gcn.p, gcn_out, (size_t)C * Dcat * 4, hipMemcpyDeviceToDevice, st));
+            }
             pl->mark(sb + 5);
             lap(4);
             PL_HIP(timed_sync(st));
@@ -510,7 +528,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             out->used_fallback = 1;
         }
         out->trace[4] = sg_partition_num_clusters(part);
-        if (dbg && dbg->h_feat5 && dbg->h_ins5 && dbg->h_sem5) {
+        if (tape || (dbg && dbg->h_feat5 && dbg->h_ins5 && dbg->h_sem5)) {
             // Feat_5 + the weak labels of the final clusters: what the train-mode tail consumes (model.py:900-914).  After the
             // FPS-1024 fallback the reference max-aggregates once more into the final numbering (model.py:495-507).
             LayerDesc L6;
@@ -521,12 +539,30 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                 const float* src = &feat4[(size_t)j * D4];
                 for (int k = 0; k < D4; ++k) dstp[k] = std::max(dstp[k], src[k]);
             }
-            std::copy(f6.begin(), f6.end(), dbg->h_feat5);
+            std::vector<int32_t> ins6(C6), sem6(C6);
             for (int c = 0; c < C6; ++c) {
                 double np_ = 0.0;
-                PL_CHECK(sg_partition_label(part, L6.root[c], &dbg->h_ins5[c], &dbg->h_sem5[c], &np_));
+                PL_CHECK(sg_partition_label(part, L6.root[c], &ins6[c], &sem6[c], &np_));
             }
-            dbg->n5 = C6;
+            if (dbg->h_feat5 && dbg->h_ins5 && dbg->h_sem5) {
+                std::copy(f6.begin(), f6.end(), dbg->h_feat5);
+                std::copy(ins6.begin(), ins6.end(), dbg->h_ins5);
+                std::copy(sem6.begin(), sem6.end(), dbg->h_sem5);
+                dbg->n5 = C6;
+            }
+            if (tape) {
+                // rows of the last GCN output (Lcur numbering) -> final cluster: the composition of the max-aggregations above
+                tape->C6 = C6; tape->N = N; tape->S = S;
+                tape->fin_goff.assign(C6 + 1, 0);
+                tape->fin_gidx.resize(Lcur.C);
+                for (int j = 0; j < Lcur.C; ++j) ++tape->fin_goff[L6.cl_of_seg[Lcur.root[j]] + 1];
+                for (int c = 0; c < C6; ++c) tape->fin_goff[c + 1] += tape->fin_goff[c];
+                std::vector<int32_t> fill(tape->fin_goff.begin(), tape->fin_goff.end() - 1);
+                for (int j = 0; j < Lcur.C; ++j) tape->fin_gidx[fill[L6.cl_of_seg[Lcur.root[j]]]++] = j;
+                tape->feat5.swap(f6);
+                tape->ins5.swap(ins6); tape->sem5.swap(sem6);
+                tape->filled = true;
+            }
         }
         PL_CHECK(tables_for(12, false));                  // final.{ins,sem}
         n_tables = 14; ins_row = 12; sem_row = 13;

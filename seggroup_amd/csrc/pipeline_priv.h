@@ -105,3 +105,22 @@ struct DescOffsets {
 };
 
 }  // namespace sgp
+
+// What the training step's backward needs from one forward (trainer.cpp): the pipeline's work buffers are
+// reused from layer to layer, so the per-layer operands are copied out (device to device, on the pipeline's stream) while
+// the forward runs.  Owned and sized by the trainer; `sg_debug::tape` hands it to sg_pipeline_forward.
+struct sg_tape {
+    struct Layer {
+        sgp::DevBuf<float> x9m, pf, cat, gcn;      // [N,12] centred rows | [N,64] pre-activation extremes | [C,Dcat] GCN input | [C,Dcat] GCN output
+        sgp::DevBuf<int32_t> knn, desc;            // [N,20] | the layer's descriptor block (offsets in `o`)
+        sgp::DescOffsets o;
+        int C = 0, Cprev = 0, Dcat = 0, Dprev = 0, E = 0;
+    } layer[2];
+    int N = 0, S = 0;
+    // final clusters (after group_unlabeled): row j of layer[1].gcn belongs to final cluster fin_gidx^-1; CSR over final clusters
+    std::vector<int32_t> fin_goff, fin_gidx, ins5, sem5;
+    std::vector<float> feat5;                       // [C6,256]
+    int C6 = 0;
+    bool filled = false;
+};
+

@@ -57,7 +57,7 @@ class Classifier(C.Structure):
 class Debug(C.Structure):
     _fields_ = [("d_samples1", vp), ("d_feat1", vp), ("d_pointfeat", vp * 2), ("d_knn", vp * 2), ("d_members", vp * 2),
                 ("h_gcn", vp * 2), ("h_dist", vp * 3), ("h_adj", vp * 4), ("n_adj", C.c_int32 * 4),
-                ("h_feat5", vp), ("h_ins5", vp), ("h_sem5", vp), ("n5", C.c_int32)]
+                ("h_feat5", vp), ("h_ins5", vp), ("h_sem5", vp), ("n5", C.c_int32), ("tape", vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/seggroup_hip.h
@@ -109,6 +109,17 @@ SIGNATURES = {
     "sg_segment_max_backward": (_I, [vp, _I, _I, vp, _I, vp, _I, vp, vp]),
     "sg_gcn_backward_ws_bytes": (_Z, [_I, _I, _I]),
     "sg_gcn_backward": (_I, [vp, _I, _I, vp, _I, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, _Z, vp]),
+    "sg_train_tail_bn_stats": (_I, [vp, _Z, _I, vp, vp]),
+    "sg_param_slot": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sg_trainer_create": (vp, [_I, _I, _I, _I, vp, vp, vp]),
+    "sg_trainer_destroy": (None, [vp]),
+    "sg_trainer_device_bytes": (_Z, [vp]),
+    "sg_trainer_forward": (_I, [vp, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sg_trainer_loss": (_I, [vp, vp, C.POINTER(C.c_float), vp]),
+    "sg_trainer_backward": (_I, [vp, vp, C.c_float]),
+    "sg_trainer_bn_stats": (_I, [vp, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    "sg_optimizer_sgd": (_I, [vp, vp, vp, _I, C.c_float, C.c_float, C.c_float, _I, vp]),
+    "sg_optimizer_adam": (_I, [vp, vp, vp, vp, _I, C.c_float, C.c_float, _I, vp]),
     "sg_mlp1_backward_ws_bytes": (_Z, [_I]),
     "sg_mlp1_backward": (_I, [vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_edgeconv_backward_ws_bytes": (_Z, [_I]),

@@ -226,3 +226,83 @@ def test_mlp1_backward_matches_autograd(S, dup):
         assert np.abs(have - want).max() <= 2e-4 * np.abs(want).max(), (k, np.abs(have - want).max() / np.abs(want).max())
     bs = got["bn_stats"].cpu().numpy()
     assert np.abs(bs[:64] - mean.detach().numpy()).max() < 1e-4 and np.abs(bs[64:] - var.detach().numpy()).max() < 1e-4 * var.detach().numpy().max()
+
+
+def _full_state(weight_sets, g):
+    """reference-keyed state: the inference fixture weights + the classifier of the golden capture"""
+    from seggroup_amd import weights as Wm
+    st = {k: v for k, v in Wm.to_state_dict(weight_sets["ins_infer"], prefix="").items()}
+    st = {k: (v.numpy() if hasattr(v, "numpy") else np.asarray(v)) for k, v in st.items()}
+    for k in g.files:
+        if k.startswith("w.classifier."):
+            st[k[2:]] = g[k]
+    return st
+
+
+@pytest.mark.parametrize("name", ["tiny_4k", "tiny_dup_4k", "small_20k", "island_20k"])
+def test_training_step_gradients_match_reference_capture(golden_index, weight_sets, name):
+    """The whole backward chain on HIP (tail -> Feat_5 -> GCN_3 / MLP3 -> GCN_2 / MLP2 -> MLP1) against the gradients the REAL
+    reference leaves on every parameter after loss.backward() (tests/golden/train_grads.npz, tools/capture_train.py; pinned dropout
+    mask).  Tolerance: relative to each tensor's largest entry; the 4k fixtures end with K = 2 instances, where BatchNorm1d over two
+    rows amplifies fp32 rounding (the reference's own fp32 gradients sit 3.5e-4 from the float64 chain there)."""
+    import torch
+    from seggroup_amd import trainer as T
+    from seggroup_amd.scene import DeviceScene
+    gt = np.load(os.path.join(GOLDEN, "train_tail.npz"))
+    gg = np.load(os.path.join(GOLDEN, "train_grads.npz"))
+    scene = make_fixture_scene(golden_index, name)
+    sc = DeviceScene.from_synthetic(scene, device="cuda:0")
+    tr = T.Trainer(_full_state(weight_sets, gt), (sc.N, sc.S, sc.E0, sc.V), device="cuda:0")
+    res = tr.forward(sc)
+    gl = np.load(os.path.join(GOLDEN, name + ".npz"))
+    from seggroup_amd import hip
+    for i in range(14):
+        assert np.array_equal(res.labels[i], gl[f"ins.label.{hip.LABEL_NAMES[i]}"])
+    mask = tr.dropout_mask("pinned")
+    loss = tr.loss(mask)
+    want_loss = gt[f"{name}.loss"]
+    assert loss[0, 1] == want_loss[0, 1] and abs(loss[0, 0] - want_loss[0, 0]) <= TOL * abs(want_loss[0, 0])
+    flat = tr.backward(mask).cpu().numpy().astype(np.float64)
+    tol = 2e-3 if name.startswith("tiny") else 2e-4
+    worst = 0.0
+    for pname, off, cnt in T.param_slots():
+        want = gg[f"{name}.grad.{pname}"].reshape(-1).astype(np.float64)
+        err = np.abs(flat[off:off + cnt] - want).max() / np.abs(want).max()
+        worst = max(worst, err)
+        assert err <= tol, (pname, err)
+    # running BatchNorm statistics after this one forward == the reference's buffers
+    tr.update_running_stats()
+    sd = tr.state_dict()
+    for bname, _, _ in T.BN_LAYERS:
+        for kind in ("running_mean", "running_var"):
+            want = gg[f"{name}.buf.{bname}.{kind}"]
+            assert np.abs(sd[f"{bname}.{kind}"].numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), (bname, kind)
+        assert int(sd[f"{bname}.num_batches_tracked"]) == int(gg[f"{name}.buf.{bname}.num_batches_tracked"]) == 1
+    tr.close()
+
+
+@pytest.mark.parametrize("use_sgd", [True, False])
+def test_optimizer_kernels_match_torch_optim(use_sgd):
+    """sg_optimizer_sgd / sg_optimizer_adam on the flat vectors against torch.optim with train.py:95-99's settings, five steps"""
+    import ctypes as C
+    import torch
+    from seggroup_amd import hip
+    lib = hip.lib()
+    n = 147880
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=0.1, momentum=0.9, weight_decay=1e-4) if use_sgd else torch.optim.Adam([ref], lr=0.001, weight_decay=1e-4)
+    p = p0.clone().cuda()
+    a, b = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * 0.1
+        ref.grad = grad.clone()
+        opt.step()
+        gd = grad.cuda()
+        if use_sgd:
+            hip.check(lib.sg_optimizer_sgd(p.data_ptr(), gd.data_ptr(), a.data_ptr(), n, C.c_float(0.1), C.c_float(0.9), C.c_float(1e-4), int(step == 1), None))
+        else:
+            hip.check(lib.sg_optimizer_adam(p.data_ptr(), gd.data_ptr(), a.data_ptr(), b.data_ptr(), n, C.c_float(0.001), C.c_float(1e-4), step, None))
+        torch.cuda.synchronize()
+        assert (p.cpu() - ref.detach()).abs().max().item() < 2e-6
