@@ -144,5 +144,5 @@ def training_step(scene, W, keep="pinned", dtype=torch.float64, stages=None):
     step_loss = loss_sum / K
     step_loss.backward()
     grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().reshape(np.asarray(W[k]).shape) for k, p in P.items()}
-    return dict(loss=np.array([float(loss_sum), K]), step_loss=float(step_loss), grads=grads,
+    return dict(loss=np.array([float(loss_sum.detach()), K]), step_loss=float(step_loss.detach()), grads=grads,
                 bn={k: (m.detach().numpy(), v.detach().numpy(), r) for k, (m, v, r) in bn.items()}, forward=fw, feat5=feat.detach().numpy())

@@ -21,6 +21,7 @@ from .model import SceneResult
 from .scene import DeviceScene
 
 NUM_PARAMS = 147880
+NUM_EXTRAS = 168          # floats riding behind the gradient in the same all-reduce: loss, 2 x 2 x 40 IoU sums, 4 accuracies, a count
 BN_LAYERS = (("mlp_1.bn1", 0, 64), ("mlp_2.bn1", 128, 64), ("mlp_3.bn1", 256, 64), ("mlp_3.bn2", 384, 64), ("classifier.bn1", 512, 128))
 
 
@@ -54,6 +55,25 @@ def flatten_state(state: Dict[str, "np.ndarray | torch.Tensor"]) -> np.ndarray:
     return flat
 
 
+def allreduce_step(grads_full: torch.Tensor, extras: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+    """grads_full = [gradient (NUM_PARAMS) | extras (NUM_EXTRAS)]: all-reduce (sum) once, then the gradient part is divided by the
+    world size (DDP averages, train.py:88) and the summed extras are returned.  A no-op on one rank."""
+    import torch.distributed as dist
+    n = 0 if extras is None else int(np.asarray(extras).size)
+    if n > NUM_EXTRAS:
+        raise ValueError(f"{n} extras, room for {NUM_EXTRAS}")
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        return None if extras is None else np.asarray(extras, np.float32).copy()
+    tail = grads_full[NUM_PARAMS:]
+    tail.zero_()
+    if n:
+        tail[:n] = torch.as_tensor(np.asarray(extras, np.float32).reshape(-1)).to(tail.device)
+    dist.all_reduce(grads_full)
+    grads_full[:NUM_PARAMS].div_(world)
+    return tail[:n].cpu().numpy() if n else None
+
+
 class Trainer:
     """`step(scene)` = forward + loss + backward + gradient averaging over the ranks + optimizer step, all on the device.
 
@@ -66,7 +86,9 @@ class Trainer:
         self.device = torch.device(device if device is not None else "cuda")
         self.caps = tuple(int(c) for c in caps)
         self.params = torch.from_numpy(flatten_state(state)).to(self.device)
-        self.grads = torch.zeros(NUM_PARAMS, dtype=torch.float32, device=self.device)
+        # gradient vector + the per-step log quantities of train.py:170-173 behind it: ONE collective per step
+        self.grads_full = torch.zeros(NUM_PARAMS + NUM_EXTRAS, dtype=torch.float32, device=self.device)
+        self.grads = self.grads_full[:NUM_PARAMS]
         self.use_sgd, self.lr, self.momentum, self.weight_decay = bool(use_sgd), float(lr), float(momentum), float(weight_decay)
         self.opt_a = torch.zeros_like(self.params)          # SGD momentum buffer / Adam exp_avg
         self.opt_b = torch.zeros_like(self.params)          # Adam exp_avg_sq
@@ -128,12 +150,11 @@ class Trainer:
             hip.check(self.lib.sg_trainer_backward(self.handle, hip.ptr(mask), C.c_float(scale)))
         return self.grads
 
-    def average_gradients(self) -> None:
-        """DistributedDataParallel's gradient averaging (train.py:88): one all-reduce of the flat vector over RCCL"""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grads)
-            self.grads.div_(dist.get_world_size())
+    def average_gradients(self, extras: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+        """DistributedDataParallel's gradient averaging (train.py:88) as one all-reduce of the flat vector over RCCL; `extras`
+        (<= NUM_EXTRAS floats: this rank's loss / IoU / accuracy terms, train.py:170-173) ride in the same collective and come
+        back SUMMED over the ranks."""
+        return allreduce_step(self.grads_full, extras)
 
     def optimizer_step(self) -> None:
         self.steps += 1
@@ -163,15 +184,17 @@ class Trainer:
             self.buffers[name + ".num_batches_tracked"] += 1
 
     def step(self, sc: DeviceScene, keep="random"):
-        """One iteration of train.py:160-170 on this rank's scene -> (loss [1,2], SceneResult)"""
+        """One iteration of train.py:160-173 on this rank's scene -> (loss [1,2], SceneResult, summed log terms).
+        Log terms (summed over the ranks): [loss_sum / K, IoU_sem (2 x 40), IoU_ins (2 x 40), acc (4), 1]."""
         res = self.forward(sc)
         mask = self.dropout_mask(keep)
         loss = self.loss(mask)
         self.backward(mask)
-        self.average_gradients()
+        extras = np.concatenate([[loss[0, 0] / loss[0, 1]], res.iou_sem.reshape(-1), res.iou_ins.reshape(-1), res.acc.reshape(-1), [1.0]]).astype(np.float32)
+        summed = self.average_gradients(extras)
         self.optimizer_step()
         self.update_running_stats()
-        return loss, res
+        return loss, res, summed
 
     # ---- checkpoint contract -----------------------------------------------------------------------------------------
     def state_dict(self) -> Dict[str, torch.Tensor]:
@@ -180,6 +203,11 @@ class Trainer:
         for name, off, cnt in param_slots():
             out[name] = flat[off:off + cnt].clone().reshape(PARAM_SHAPES.get(name, (cnt,)))
         out.update({k: v.clone() for k, v in self.buffers.items()})
+        # the reference registers every BatchNorm2d twice -- as `bnN` and as element 1 of the `convN` Sequential (model.py:42-44,
+        # 88-90,121-126) -- so its state_dict carries both names and load_state_dict(strict=True) wants both
+        for blk, n in (("mlp_1", 1), ("mlp_2", 1), ("mlp_3", 1), ("mlp_3", 2)):
+            for leaf in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+                out[f"{blk}.conv{n}.1.{leaf}"] = out[f"{blk}.bn{n}.{leaf}"].clone()
         return out
 
     def load_state_dict(self, state) -> None:

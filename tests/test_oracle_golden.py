@@ -157,3 +157,28 @@ def test_oracle_train_tail_matches_reference_capture(golden_index, weight_sets, 
     assert np.abs(t["logits"] - g[f"{name}.logits"]).max() < 1e-4
     want = g[f"{name}.loss"]
     assert t["loss"][1] == want[0, 1] and abs(t["loss"][0] - want[0, 0]) < 1e-4 * abs(want[0, 0])
+
+
+@pytest.mark.parametrize("name,tol", [("tiny_4k", 1e-3), ("small_20k", 5e-5)])
+def test_oracle_training_step_gradients_match_reference_capture(golden_index, weight_sets, name, tol):
+    """the torch-autograd restatement of the differentiable chain (oracle/train_ref.py, float64, on the discrete
+    structure the oracle's own forward records) against the gradients the REAL reference leaves on every parameter after
+    loss.backward() (tests/golden/train_grads.npz, tools/capture_train.py).  tiny_4k ends with K = 2 instances: BatchNorm1d over
+    two rows amplifies the reference's own fp32 rounding (3.5e-4)."""
+    import os
+    from conftest import GOLDEN, make_fixture_scene
+    from oracle import train_ref
+    gt = np.load(os.path.join(GOLDEN, "train_tail.npz"))
+    gg = np.load(os.path.join(GOLDEN, "train_grads.npz"))
+    W = dict(weight_sets["ins_infer"])
+    W.update({k[2:]: gt[k] for k in gt.files if k.startswith("w.")})
+    r = train_ref.training_step(make_fixture_scene(golden_index, name), W)
+    assert abs(r["step_loss"] - float(gg[f"{name}.step_loss"][0])) < 1e-5 * abs(r["step_loss"])
+    for k in train_ref.PARAM_KEYS:
+        want = gg[f"{name}.grad.{k}"].reshape(-1).astype(np.float64)
+        assert np.abs(r["grads"][k].reshape(-1) - want).max() <= tol * np.abs(want).max(), k
+    # the batch statistics this chain normalises with reproduce the reference's running buffers after one step
+    for k, (m, v, rows) in r["bn"].items():
+        want_m, want_v = gg[f"{name}.buf.{k}.running_mean"], gg[f"{name}.buf.{k}.running_var"]
+        assert np.abs(0.1 * m - want_m).max() < 1e-5 * max(1.0, np.abs(want_m).max())
+        assert np.abs(0.9 + 0.1 * v * rows / (rows - 1) - want_v).max() < 1e-4 * max(1.0, np.abs(want_v).max())
