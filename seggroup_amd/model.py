@@ -370,13 +370,41 @@ def write_label_files(output_root: str, result: SceneResult, formats=("txt", "np
     return written
 
 
+class _SceneLoss(torch.autograd.Function):
+    """loss [1,2] of one scene as a function of the module's parameters: backward = csrc/trainer.cpp's chain.  The upstream
+    gradient of loss[0,0] (= 1 / loss_num in train.py:166) is the scale of the whole backward; loss[0,1] (the instance count)
+    carries none."""
+
+    @staticmethod
+    def forward(ctx, tr, mask, loss, module, *params):
+        ctx.tr, ctx.mask, ctx.module = tr, mask, module
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.token = tr.steps_forward = getattr(tr, "steps_forward", 0) + 1
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        tr = ctx.tr
+        if ctx.token != tr.steps_forward:
+            raise RuntimeError("backward through a scene whose record was overwritten by a later forward of the same SegModel")
+        flat = tr.backward(ctx.mask, float(gout[0, 0]))
+        if ctx.module is not None:
+            ctx.module._update_running_stats(tr)
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = int(np.prod(shp))
+            grads.append(flat[off:off + n].reshape(shp).clone())
+            off += n
+        return (None, None, None, None) + tuple(grads)
+
+
 class SegModel(nn.Module):
-    """Drop-in for the reference `SegModel` (model.py:658-897), inference modes only.
+    """Drop-in for the reference `SegModel` (model.py:658-932).
 
     With neither infer flag set, `forward` runs the whole ins_infer forward (pseudo labels are exported under
     `epoch_<n>/` like the reference does) and then the train-mode tail of model.py:900-932 on HIP, returning
-    `(loss[1,2], IoU_sem, IoU_ins, acc)`; `self.last_tail.backward()` gives the classifier / Feat_5 gradients.  The
-    backward through EdgeConv / BatchNorm2d and the optimizer step are the next slice of SURVEY.md 8f-4.
+    `(loss[1,2], IoU_sem, IoU_ins, acc)`; `loss` carries an autograd node whose backward is the hand-written HIP chain
+    (csrc/trainer.cpp), so `loss.backward()` leaves `.grad` on every parameter like the reference's autograd does.
     """
 
     def __init__(self, exp_name='exp', cuda=True, visualize=False, sem_infer=False, ins_infer=False,
@@ -411,8 +439,11 @@ class SegModel(nn.Module):
         self.async_write = True          # label files are written by native threads; flush() waits for them
         self.last_result: Optional[SceneResult] = None
         self.last_tail = None
-        from .synthetic import uniform01
-        self.dropout_keep = lambda K: np.where(uniform01(97, int(K), int(K) * 128).reshape(int(K), 128) < 0.5, 2.0, 0.0).astype(np.float32)
+        self._trainer = None
+        self.last_logits = None
+        # classifier Dropout(p=0.5) in train mode: "random" (this build's generator), "pinned" (the counter-based mask of the golden
+        # capture: parity with the reference is stated with the same mask on both sides), None, or a callable K -> [K,128] mask
+        self.dropout_keep = "random"
 
     # -- parameters -> C ABI ----------------------------------------------------------------------
     def export_weights(self) -> Dict[str, np.ndarray]:
@@ -448,8 +479,10 @@ class SegModel(nn.Module):
     def forward_scene(self, sc: DeviceScene, write: bool = True) -> SceneResult:
         """Hot path on a staged scene.  Returns the SceneResult; writes the label files if `write`."""
         with self._lock:
-            train = not (self.sem_infer or self.ins_infer)
-            res = self.pipeline_for(sc).forward(sc, self.mode(), want_feat5=train)
+            if self.sem_infer or self.ins_infer:
+                res = self.pipeline_for(sc).forward(sc, self.mode())
+            else:                                            # train mode: the same forward, recorded for the backward (csrc/trainer.cpp)
+                res = self.trainer_for(sc).forward(sc)
             if write:
                 if self.async_write:
                     if self._writer is None:
@@ -461,15 +494,24 @@ class SegModel(nn.Module):
         return res
 
     def train_tail(self, sc: DeviceScene, res: SceneResult):
-        """The train-mode tail of this scene (functional.TrainTail) from the Feat_5 tap of the forward just made.  Dropout is
-        PINNED: `self.dropout_keep(K)` -> [K,128] mask of {0, 2}; default = the counter-based mask of
-        `oracle`-independent `synthetic.uniform01(97, K, K * 128) < 0.5`, the one the golden capture used."""
+        """The train-mode tail as a standalone operator (functional.TrainTail) from a Feat_5 tap (`Pipeline.forward(want_feat5=True)`);
+        the training step proper goes through `trainer_for` / `forward`."""
         if res.feat5 is None:
-            raise RuntimeError("train_tail needs a forward made in train mode (Feat_5 tap)")
+            raise RuntimeError("train_tail needs a forward made with want_feat5=True (Feat_5 tap)")
         K = int(np.unique(res.ins5).shape[0])
-        keep = self.dropout_keep(K) if self.dropout_keep is not None else None
+        keep = self.dropout_keep(K) if callable(self.dropout_keep) else self._trainer_mask(K)
         cls = {k[len("classifier."):]: v for k, v in self.state_dict().items() if k.startswith("classifier.")}
         return _F.TrainTail(torch.from_numpy(res.feat5).to(sc.device), res.ins5, res.sem5, cls, keep)
+
+    def _trainer_mask(self, K: int):
+        if self.dropout_keep is None:
+            return None
+        if isinstance(self.dropout_keep, str) and self.dropout_keep == "pinned":
+            from .synthetic import uniform01
+            return np.where(uniform01(97, int(K), int(K) * 128).reshape(int(K), 128) < 0.5, 2.0, 0.0).astype(np.float32)
+        if isinstance(self.dropout_keep, str):
+            return (np.random.default_rng().random((K, 128)) >= 0.5).astype(np.float32) * 2.0
+        return np.asarray(self.dropout_keep, np.float32)
 
     def flush(self) -> None:
         """Wait until every label file submitted so far is on disk (raises on the first I/O error)."""
@@ -495,9 +537,45 @@ class SegModel(nn.Module):
         out = (torch.from_numpy(res.iou_sem).to(dev), torch.from_numpy(res.iou_ins).to(dev), torch.from_numpy(res.acc).to(dev))
         if self.sem_infer or self.ins_infer:
             return out
-        # train mode (model.py:900-932), first slice of SURVEY.md 8f-4: the classifier tail + label-smoothed cross entropy
-        # run on HIP and `self.last_tail.backward()` yields the gradients of the classifier and of Feat_5; the backward
-        # through EdgeConv / BatchNorm2d (hence an optimizer step over all 147,880 parameters) is the next slice, so the
-        # returned loss carries no autograd graph.
-        self.last_tail = self.train_tail(sc, res)
-        return (self.last_tail.forward(),) + out
+        # train mode (model.py:900-932): the loss carries an autograd node whose backward runs the whole HIP
+        # backward chain and hands every parameter its gradient, so the reference's loop body (train.py:160-168) --
+        #     loss = loss_raw[:, 0].sum() / loss_raw[:, 1].sum();  optimizer.zero_grad();  loss.backward();  optimizer.step()
+        # -- works unchanged with torch.optim and DistributedDataParallel around this module.  (seggroup_amd/train.py drives the
+        # same kernels through flat vectors and one all-reduce instead.)
+        return (self._train_loss(sc),) + out
+
+    def trainer_for(self, sc: DeviceScene):
+        """The `Trainer` behind train mode, holding THIS module's current parameter values (flat copy, 0.59 MB per forward)."""
+        from . import trainer as _T
+        tr = self._trainer
+        if tr is None or not tr.fits(sc) or tr.device != sc.device:
+            if tr is not None:
+                tr.close()
+            caps = (sc.N, sc.S, sc.E0, sc.V) if tr is None else tuple(max(a, b) for a, b in zip(tr.caps, (sc.N, sc.S, sc.E0, sc.V)))
+            tr = self._trainer = _T.Trainer({k: v for k, v in self.state_dict().items()}, caps, device=sc.device)
+        with torch.no_grad():
+            tr.params.copy_(torch.cat([p.detach().reshape(-1).float() for _, p in self.named_parameters()]))
+        return tr
+
+    def _train_loss(self, sc: DeviceScene):
+        params = [p for _, p in self.named_parameters()]
+        with self._lock:
+            tr = self._trainer                               # forward_scene just ran this scene through it
+            keep = self.dropout_keep(tr.K) if callable(self.dropout_keep) else self.dropout_keep
+            mask = tr.dropout_mask(keep)
+            loss = torch.from_numpy(tr.loss(mask, want_logits=True)).to(sc.device)
+            self.last_logits = tr.logits
+        return _SceneLoss.apply(tr, mask, loss, self if self.training else None, *params)
+
+    def _update_running_stats(self, tr) -> None:
+        """BatchNorm's running statistics (momentum 0.1).  The batch statistics of the three EdgeConv / MLP1 BatchNorms fall out of
+        the backward kernels, so the buffers move when `loss.backward()` has run -- not, as in the reference, during forward."""
+        with torch.no_grad():
+            bufs = dict(self.named_buffers())
+            for k in tr.buffers:
+                tr.buffers[k] = bufs[k].detach().cpu().clone()
+            tr.update_running_stats()
+            for k, b in bufs.items():
+                src = tr.buffers.get(k.replace(".conv1.1.", ".bn1.").replace(".conv2.1.", ".bn2."))
+                if src is not None:
+                    b.copy_(src.to(b.device))

@@ -94,6 +94,8 @@ class Trainer:
         self.opt_b = torch.zeros_like(self.params)          # Adam exp_avg_sq
         self.steps = 0
         self.buffers: Dict[str, torch.Tensor] = {}
+        host = lambda v: None if v is None else (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+        state = {k: host(v) for k, v in state.items()}
         for name, _, n in BN_LAYERS:
             rm, rv = state.get(name + ".running_mean"), state.get(name + ".running_var")
             self.buffers[name + ".running_mean"] = torch.as_tensor(np.asarray(rm, np.float32) if rm is not None else np.zeros(n, np.float32)).clone()

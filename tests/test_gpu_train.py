@@ -35,8 +35,9 @@ def test_train_mode_forward_matches_reference_capture(golden_index, weight_sets,
     net.load_weights(weight_sets["ins_infer"])
     _classifier_from_golden(net, g)
     net.epoch = "0"
+    net.dropout_keep = "pinned"
     sc = DeviceScene.from_synthetic(scene, device="cuda:0")
-    res = net.forward_scene(sc, write=False)
+    res = net.pipeline_for(sc).forward(sc, hip.MODE_INS_INFER, want_feat5=True)
     assert res.feat5 is not None and res.feat5.shape[1] == 256 and res.feat5.shape[0] == res.trace[4]
     tail = net.train_tail(sc, res)
     loss = tail.forward().cpu().numpy()
@@ -306,3 +307,46 @@ def test_optimizer_kernels_match_torch_optim(use_sgd):
             hip.check(lib.sg_optimizer_adam(p.data_ptr(), gd.data_ptr(), a.data_ptr(), b.data_ptr(), n, C.c_float(0.001), C.c_float(1e-4), step, None))
         torch.cuda.synchronize()
         assert (p.cpu() - ref.detach()).abs().max().item() < 2e-6
+
+
+def test_reference_training_loop_body_runs_unchanged(golden_index, weight_sets, tmp_path):
+    """train.py:160-168 verbatim around seggroup_amd's SegModel: `loss.backward()` runs the HIP backward chain through the autograd
+    node of the returned loss and leaves the reference's gradients on the module's parameters; torch.optim.SGD then moves them."""
+    import torch
+    from seggroup_amd import synthetic
+    from seggroup_amd.model import SegModel
+    name = "small_20k"
+    e = golden_index[name]
+    scene = synthetic.make_scene(e["n"], e["s"], e["seed"], name="scene00000_00", **e["kw"])
+    root = str(tmp_path)
+    synthetic.write_reference_tree(root, [scene])
+    gt = np.load(os.path.join(GOLDEN, "train_tail.npz"))
+    gg = np.load(os.path.join(GOLDEN, "train_grads.npz"))
+    model = SegModel(exp_name="loop", data_root=root, out_formats=("npy",)).to("cuda:0")
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in _full_state(weight_sets, gt).items()}, strict=False)
+    model.dropout_keep = "pinned"
+    model.train()
+    model.epoch = "1"
+    optimizer = torch.optim.SGD(model.parameters(), lr=0.001 * 100, momentum=0.9, weight_decay=1e-4)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    data, weak_label, info = torch.from_numpy(scene.data)[None].cuda(), torch.from_numpy(scene.weak_label)[None].cuda(), torch.tensor([[0]])
+    # ---- train.py:163-168 ----
+    loss_raw, IoU_sem, IoU_ins, acc = model(data, weak_label, info)
+    loss_sum = torch.sum(loss_raw[:, 0])
+    loss_num = torch.sum(loss_raw[:, 1])
+    loss = loss_sum / loss_num
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    # --------------------------
+    assert abs(float(loss.detach()) - float(gg[f"{name}.step_loss"][0])) < 1e-4 * float(loss.detach())
+    for k, p in model.named_parameters():
+        want = torch.from_numpy(gg[f"{name}.grad.{k}"]).reshape(p.shape)
+        assert (p.grad.cpu() - want).abs().max() <= 2e-4 * want.abs().max(), k
+        moved = before[k] - 0.1 * (p.grad + 1e-4 * before[k])                 # first SGD step: buf = g + wd * p
+        assert (p.detach() - moved).abs().max() < 1e-6
+    for bname in ("mlp_3.bn2", "mlp_3.conv2.1", "classifier.bn1"):          # conv2.1 is the Sequential's alias of bn2 (one module)
+        want = gg[f"{name}.buf.{bname.replace('conv2.1', 'bn2')}.running_var"]
+        assert np.abs(model.state_dict()[f"{bname}.running_var"].cpu().numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    model.flush()
+    assert os.path.exists(os.path.join(root, "results", "loop", "scene00000_00", "epoch_1", "final.ins.npy"))
