@@ -567,9 +567,11 @@ int sg_train_tail_backward(int C, int K, const int32_t* d_gold, const float* d_k
  * first maximal row (torch.max), every other row of the group gets 0; d_grows rows of `grow_stride` floats */
 int sg_group_max_rows_backward(const float* d_rows, int row_stride, int D, const int32_t* d_goff, const int32_t* d_gidx, int G,
                                const float* d_gout, int out_stride, float* d_grows, int grow_stride, void* stream);
-/* backward of sg_segment_max (model.py:793,834): rows [N,D] in member order, cluster c = rows [d_cl_off[c], d_cl_off[c+1]) */
+/* backward of sg_segment_max (model.py:793,834): rows [N,D] in member order, cluster c = rows [d_cl_off[c], d_cl_off[c+1]); the
+ * gradient of a cluster's maximum goes to its first maximal row.  d_ws needs sg_segment_max_backward_ws_bytes(C, D). */
+size_t sg_segment_max_backward_ws_bytes(int C, int D);
 int sg_segment_max_backward(const float* d_rows, int N, int D, const int32_t* d_cl_off, int C, const float* d_gout, int out_stride,
-                            float* d_grows, void* stream);
+                            float* d_grows, void* d_ws, size_t ws_bytes, void* stream);
 /* backward of sg_gcn_forward, INCLUDING the path through the similarity weights exp(-alpha ||x_a - x_b + 1e-6||) and their
  * row normalisation (autograd differentiates them in the reference: model.py:262-265,305-309): d_gx [S,D], d_gw [D,D] */
 size_t sg_gcn_backward_ws_bytes(int S, int D, int E);

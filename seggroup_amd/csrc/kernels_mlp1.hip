@@ -297,13 +297,13 @@ __global__ __launch_bounds__(64) void k_mlp1_bwd_rows(const float* __restrict__ 
 }
 
 // 512 threads: thread (ch, q) sums the clusters' partials in order; then dW, d gamma, d beta
-__global__ __launch_bounds__(512) void k_mlp1_bwd_fold(const double* __restrict__ rows_partial, int C, const double* __restrict__ mom,
+__global__ __launch_bounds__(512) void k_mlp1_bwd_fold(const double* __restrict__ rows_partial, int nparts, int C, const double* __restrict__ mom,
                                                        const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ cst,
                                                        float* __restrict__ gw, float* __restrict__ gg, float* __restrict__ gb) {
     __shared__ double acc[512];
     const int t = threadIdx.x;
     double a = 0.0;
-    for (int c = 0; c < C; ++c) a += rows_partial[(size_t)c * 512 + t];
+    for (int c = 0; c < nparts; ++c) a += rows_partial[(size_t)c * 512 + t];
     acc[t] = a;
     __syncthreads();
     const double rows = (double)C * 64.0 * K1;                    // mom holds MEANS (sum / rows)
@@ -363,7 +363,7 @@ int sg_mlp1_forward(const float* d_samples, int C, const float* d_w, const float
 
 size_t sg_mlp1_backward_ws_bytes(int C) {
     const size_t c = (size_t)std::max(C, 1);
-    return sg::align_up(c * 64 * K1) + sg::align_up(c * 27 * 8) + sg::align_up(c * 512 * 8) + sg::align_up(27 * 8) + sg::align_up(128 * 4);
+    return sg::align_up(c * 64 * K1) + sg::align_up(c * 27 * 8) + sg::align_up(c * 512 * 8) + sg::align_up(27 * 8) + sg::align_up(128 * 4) + sg::align_up(512 * 8);
 }
 
 int sg_mlp1_backward(const float* d_samples, int C, const float* d_w, const float* d_gamma, const float* d_beta, const float* d_gfeat,
@@ -375,12 +375,14 @@ int sg_mlp1_backward(const float* d_samples, int C, const float* d_w, const floa
     double* rows_partial = cv.take<double>((size_t)C * 512);
     double* mom = cv.take<double>(27);
     float* cst = cv.take<float>(128);
+    double* red = cv.take<double>(512);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_mlp1_backward: workspace too small (%zu < %zu)", ws_bytes, sg_mlp1_backward_ws_bytes(C));
     hipStream_t st = sg::as_stream(stream);
     k_mlp1_knn_moments<<<C, 64, 0, st>>>(d_samples, knn, partial);
     k_mlp1_bwd_stats<<<1, 27 * 32, 0, st>>>(partial, C, d_w, mom, cst, d_bn_stats);
     k_mlp1_bwd_rows<<<C, 64, 0, st>>>(d_samples, knn, d_w, d_gamma, d_beta, cst, d_gfeat, g_stride, rows_partial);
-    k_mlp1_bwd_fold<<<1, 512, 0, st>>>(rows_partial, C, mom, d_w, d_gamma, cst, d_gw, d_gg, d_gb);
+    if (int rc = sg::reduce_partials(rows_partial, C, 512, 512, red, st)) return rc;
+    k_mlp1_bwd_fold<<<1, 512, 0, st>>>(red, 1, C, mom, d_w, d_gamma, cst, d_gw, d_gg, d_gb);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

@@ -179,20 +179,44 @@ __global__ void k_group_max_backward(const float* __restrict__ rows, int row_str
     }
 }
 
-// ---- backward of the point -> cluster max (model.py:793,834): rows in member order, cluster c = rows [cl_off[c], cl_off[c+1])
-__global__ void k_segment_max_backward(const float* __restrict__ rows, int D, const int32_t* __restrict__ cl_off, const float* __restrict__ gout,
-                                       int out_stride, float* __restrict__ grows) {
-    const int c = blockIdx.x;
-    const int lo = cl_off[c], hi = cl_off[c + 1];
-    for (int k = threadIdx.x; k < D; k += blockDim.x) {
-        float m = -INFINITY;
-        int a = -1;
-        for (int r = lo; r < hi; ++r) {
-            const float v = rows[(size_t)r * D + k];
-            if (a < 0 || v > m) { m = v; a = r; }
-        }
-        for (int r = lo; r < hi; ++r) grows[(size_t)r * D + k] = r == a ? gout[(size_t)c * out_stride + k] : 0.f;
+// ---- backward of the point -> cluster max (model.py:793,834): rows in member order, cluster c = rows [cl_off[c], cl_off[c+1]).
+// A floor or wall is one cluster of tens of thousands of rows, so the arg-max runs over ROWS in parallel: 64 rows per block and
+// one thread per column reduce to one key, then one atomicMax per (block, cluster, column) on
+//     key = order-preserving bits of the value << 32 | ~row          (largest value, FIRST row on ties, whatever the arrival order)
+// and a second kernel sends the cluster's gradient to the winning row (everything else was zeroed by a memset).
+__device__ __forceinline__ unsigned long long segmax_key(float v, int row) {
+    const unsigned int u = __float_as_uint(v);
+    const unsigned int o = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+    return ((unsigned long long)o << 32) | (unsigned int)(0xffffffffu - (unsigned int)row);
+}
+__global__ void k_segment_max_keys(const float* __restrict__ rows, int N, int D, const int32_t* __restrict__ cl_off, int C,
+                                   unsigned long long* __restrict__ keys) {
+    const int r0 = blockIdx.x * 64, r1 = min(N, r0 + 64), k = threadIdx.x;
+    int lo = 0, hi = C;                                       // the cluster of row r0: largest c with cl_off[c] <= r0
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cl_off[mid] <= r0) lo = mid; else hi = mid;
     }
+    int c = lo, end = cl_off[c + 1];
+    unsigned long long best = 0ull;
+    for (int r = r0; r < r1; ++r) {
+        if (r >= end) {
+            if (best) atomicMax(&keys[(size_t)c * D + k], best);
+            best = 0ull;
+            while (r >= end) { ++c; end = cl_off[c + 1]; }
+        }
+        const unsigned long long key = segmax_key(rows[(size_t)r * D + k], r);
+        best = key > best ? key : best;
+    }
+    if (best) atomicMax(&keys[(size_t)c * D + k], best);
+}
+__global__ void k_segment_max_scatter(const unsigned long long* __restrict__ keys, int D, const float* __restrict__ gout, int out_stride,
+                                      float* __restrict__ grows) {
+    const int c = blockIdx.x, k = threadIdx.x;
+    const unsigned long long key = keys[(size_t)c * D + k];
+    if (key == 0ull) return;                                  // an empty cluster
+    const int row = (int)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
+    grows[(size_t)row * D + k] = gout[(size_t)c * out_stride + k];
 }
 
 // ---- GCN backward.  forward: s_e = exp(-alpha d_e), d_e = ||x_a - x_b + 1e-6||, r_i = 1 + sum_j s_ij,
@@ -392,11 +416,19 @@ int sg_group_max_rows_backward(const float* d_rows, int row_stride, int D, const
     return SG_OK;
 }
 
+size_t sg_segment_max_backward_ws_bytes(int C, int D) { return sg::align_up((size_t)std::max(C, 1) * std::max(D, 1) * 8); }
+
 int sg_segment_max_backward(const float* d_rows, int N, int D, const int32_t* d_cl_off, int C, const float* d_gout, int out_stride,
-                            float* d_grows, void* stream) {
-    SG_REQUIRE(N >= 0 && C >= 0 && D > 0 && d_rows && d_cl_off && d_gout && d_grows, "sg_segment_max_backward: bad arguments");
-    if (C == 0) return SG_OK;
-    k_segment_max_backward<<<C, 64, 0, sg::as_stream(stream)>>>(d_rows, D, d_cl_off, d_gout, out_stride, d_grows);
+                            float* d_grows, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(N >= 0 && C >= 0 && D > 0 && D <= 1024 && d_rows && d_cl_off && d_gout && d_grows && d_ws, "sg_segment_max_backward: bad arguments");
+    if (C == 0 || N == 0) return SG_OK;
+    if (ws_bytes < sg_segment_max_backward_ws_bytes(C, D)) return sg::fail(SG_ENOMEM, "sg_segment_max_backward: workspace too small");
+    hipStream_t st = sg::as_stream(stream);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(d_ws);
+    SG_HIP(hipMemsetAsync(keys, 0, (size_t)C * D * 8, st));
+    SG_HIP(hipMemsetAsync(d_grows, 0, (size_t)N * D * 4, st));
+    k_segment_max_keys<<<sg::cdiv(N, 64), D, 0, st>>>(d_rows, N, D, d_cl_off, C, keys);
+    k_segment_max_scatter<<<C, D, 0, st>>>(keys, D, d_gout, out_stride, d_grows);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

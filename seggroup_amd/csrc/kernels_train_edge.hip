@@ -587,6 +587,33 @@ __global__ void k_eb_final(const double* __restrict__ partial, int nblocks, int 
     }
 }
 
+}  // namespace
+
+namespace sg {
+// out[i] = sum over b < nblocks of partial[b * stride + i], i < count: one thread per output (coalesced across the block), eight
+// independent running sums combined in a fixed order -- the fold kernels used to walk the blocks' partials one dependent load at
+// a time from a single workgroup (0.25-0.8 ms each)
+__global__ void k_reduce_partials(const double* __restrict__ partial, int nblocks, int stride, int count, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int b = 0;
+    for (; b + 8 <= nblocks; b += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += partial[(size_t)(b + u) * stride + i];
+    }
+    for (int u = 0; b < nblocks; ++b, ++u) a[u] += partial[(size_t)b * stride + i];
+    out[i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+int reduce_partials(const double* d_partial, int nblocks, int stride, int count, double* d_out, hipStream_t st) {
+    k_reduce_partials<<<cdiv(count, 256), 256, 0, st>>>(d_partial, nblocks, stride, count, d_out);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+}  // namespace sg
+
+namespace {
+
 __global__ void k_eb_init(const float* __restrict__ x9, float* __restrict__ cst) {
     if (threadIdx.x < 3) cst[X0 + threadIdx.x] = x9[threadIdx.x];
 }
@@ -599,7 +626,7 @@ static int eb_blocks(int ntiles) { return std::max(1, std::min(ntiles, 512)); }
 
 size_t sg_edgeconv_backward_ws_bytes(int N) {
     const size_t n = (size_t)std::max(N, 1);
-    return sg::align_up(512 * (size_t)kPart3 * 8) + sg::align_up(n * 64 * 4) + sg::align_up(n * 64) + sg::align_up(kCst * 4) + sg::align_up(kMom * 8) + 4096;
+    return sg::align_up(512 * (size_t)kPart3 * 8) + sg::align_up(n * 64 * 4) + sg::align_up(n * 64) + sg::align_up(kCst * 4) + sg::align_up(kMom * 8) + sg::align_up(kPart3 * 8) + 4096;
 }
 
 int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1, const float* d_b1,
@@ -614,27 +641,33 @@ int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k,
     uint8_t* argk = cv.take<uint8_t>((size_t)N * 64);
     float* cst = cv.take<float>(kCst);
     double* mom = cv.take<double>(kMom);
+    double* red = cv.take<double>(kPart3);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_edgeconv_backward: workspace too small (%zu < %zu)", ws_bytes, sg_edgeconv_backward_ws_bytes(N));
     hipStream_t st = sg::as_stream(stream);
     const int P = std::min(kR / k, 4), ntiles = sg::cdiv(N, P), nb = eb_blocks(ntiles);
     const double rows = (double)N * (double)k;
     k_eb_init<<<1, 64, 0, st>>>(d_x9m, cst);
     k_eb_moments<<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, cst, partial);
-    k_eb_fold1<<<1, 256, 0, st>>>(partial, nb, rows, d_w1, cst, mom, d_bn_stats);
+    if (int rc = sg::reduce_partials(partial, nb, kMom, kMom, red, st)) return rc;
+    k_eb_fold1<<<1, 256, 0, st>>>(red, 1, rows, d_w1, cst, mom, d_bn_stats);
     const int nb2 = std::max(1, std::min(sg::cdiv(N, 4), 1024));
     if (layers == 1) {
         k_eb_forward<1><<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, nullptr, nullptr, cst, ext, argk, partial);
         const int stride = 128 + 64 * kES;
         SG_REQUIRE((size_t)nb2 * stride <= 512 * (size_t)kPart3, "sg_edgeconv_backward: partial buffer");
         k_eb_last_bn<1><<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_g1, d_b1, cst, ext, argk, d_gout, partial);
-        k_eb_final<<<1, 1024, 0, st>>>(partial, nb2, stride, 128, 0, 1, rows, mom, d_w1, d_g1, cst, d_gw1, d_gg1, d_gb1, nullptr);
+        if (int rc = sg::reduce_partials(partial, nb2, stride, stride, red, st)) return rc;
+        k_eb_final<<<1, 1024, 0, st>>>(red, 1, stride, 128, 0, 1, rows, mom, d_w1, d_g1, cst, d_gw1, d_gg1, d_gb1, nullptr);
     } else {
         k_eb_forward<2><<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, cst, ext, argk, partial);
-        k_eb_fold2<<<1, 64, 0, st>>>(partial, nb, rows, cst, d_bn_stats);
+        if (int rc = sg::reduce_partials(partial, nb, 128, 128, red, st)) return rc;
+        k_eb_fold2<<<1, 64, 0, st>>>(red, 1, rows, cst, d_bn_stats);
         k_eb_last_bn<2><<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_g2, d_b2, cst, ext, argk, d_gout, partial);
-        k_eb_fold3<<<1, 64, 0, st>>>(partial, nb2, rows, cst, d_gg2, d_gb2);
+        if (int rc = sg::reduce_partials(partial, nb2, 128, 128, red, st)) return rc;
+        k_eb_fold3<<<1, 64, 0, st>>>(red, 1, rows, cst, d_gg2, d_gb2);
         k_eb_backward<<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, cst, argk, d_gout, partial);
-        k_eb_final<<<1, 1024, 0, st>>>(partial, nb, kPart3, 4096, 4096 + 64 * kES, 2, rows, mom, d_w1, d_g1, cst, d_gw1, d_gg1, d_gb1, d_gw2);
+        if (int rc = sg::reduce_partials(partial, nb, kPart3, kPart3, red, st)) return rc;
+        k_eb_final<<<1, 1024, 0, st>>>(red, 1, kPart3, 4096, 4096 + 64 * kES, 2, rows, mom, d_w1, d_g1, cst, d_gw1, d_gg1, d_gb1, d_gw2);
     }
     SG_LAUNCH_CHECK();
     return SG_OK;

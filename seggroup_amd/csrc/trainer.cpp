@@ -39,7 +39,7 @@ struct sg_trainer {
     int maxN = 0, maxS = 0;
     sgp::DevBuf<float> feat5, g_feat5, gA, gB, gC, g_pf, bn, loss, logits;
     sgp::DevBuf<int32_t> group, gold, fin;
-    sgp::DevBuf<char> ws_tail, ws_gcn, ws_edge, ws_mlp1;
+    sgp::DevBuf<char> ws_tail, ws_gcn, ws_edge, ws_mlp1, ws_seg;
     int C6 = 0, K = 0;
     bool have_forward = false, have_loss = false;
     const float* P(int slot) const { return params + kSlots[slot].off; }
@@ -90,6 +90,7 @@ sg_trainer* sg_trainer_create(int maxN, int maxS, int maxE, int maxV, float* d_p
     bad |= tr->feat5.alloc(S * 256) | tr->g_feat5.alloc(S * 256) | tr->gA.alloc(S * 256) | tr->gB.alloc(S * 256) | tr->gC.alloc(S * 256) | tr->g_pf.alloc(N * 64);
     bad |= tr->bn.alloc(SG_NUM_BN_STATS) | tr->loss.alloc(2) | tr->logits.alloc(S * 40) | tr->group.alloc(S) | tr->gold.alloc(S) | tr->fin.alloc(2 * S + 2);
     bad |= tr->ws_tail.alloc(sg_train_tail_ws_bytes(maxS, maxS)) | tr->ws_gcn.alloc(sg_gcn_backward_ws_bytes(maxS, 256, (int)maxE1));
+    bad |= tr->ws_seg.alloc(sg_segment_max_backward_ws_bytes(maxS, 64));
     bad |= tr->ws_edge.alloc(sg_edgeconv_backward_ws_bytes(maxN)) | tr->ws_mlp1.alloc(sg_mlp1_backward_ws_bytes(maxS));
     if (bad) { sg::fail(SG_ENOMEM, "sg_trainer_create: device allocation failed (N=%d S=%d)", maxN, maxS); return nullptr; }
     return tr.release();
@@ -193,7 +194,7 @@ int sg_trainer_backward(sg_trainer* tr, const float* d_keep, float scale) {
         TR_CHECK(sg_gcn_backward(L1.cat.p, L1.C, 256, dd + o.adj, L1.E, dd + o.rowptr, dd + o.col, dd + o.eid, tr->P(G3), 0.125f, tr->gA.p, tr->gB.p, tr->G(G3),
                                  tr->ws_gcn.p, tr->ws_gcn.n, sv));
         TR_CHECK(sg_group_max_rows_backward(L0.gcn.p, 192, 192, dd + o.goff, dd + o.gidx, L1.C, tr->gB.p, 256, tr->gC.p, 192, sv));
-        TR_CHECK(sg_segment_max_backward(L1.pf.p, N, 64, dd + o.cl_pt_off, L1.C, tr->gB.p + 192, 256, tr->g_pf.p, sv));
+        TR_CHECK(sg_segment_max_backward(L1.pf.p, N, 64, dd + o.cl_pt_off, L1.C, tr->gB.p + 192, 256, tr->g_pf.p, tr->ws_seg.p, tr->ws_seg.n, sv));
         TR_CHECK(sg_edgeconv_backward(L1.x9m.p, L1.knn.p, N, 20, 2, tr->P(M3W1), tr->P(M3G1), tr->P(M3B1), tr->P(M3W2), tr->P(M3G2), tr->P(M3B2), tr->g_pf.p,
                                       tr->G(M3W1), tr->G(M3G1), tr->G(M3B1), tr->G(M3W2), tr->G(M3G2), tr->G(M3B2), tr->bn.p + 256, tr->ws_edge.p, tr->ws_edge.n, sv));
     }
@@ -204,7 +205,7 @@ int sg_trainer_backward(sg_trainer* tr, const float* d_keep, float scale) {
         TR_CHECK(sg_gcn_backward(L0.cat.p, L0.C, 192, dd + o.adj, L0.E, dd + o.rowptr, dd + o.col, dd + o.eid, tr->P(G2), 0.125f, tr->gC.p, tr->gB.p, tr->G(G2),
                                  tr->ws_gcn.p, tr->ws_gcn.n, sv));
         TR_CHECK(sg_group_max_rows_backward(pl->feat1.p, 128, 128, dd + o.goff, dd + o.gidx, L0.C, tr->gB.p, 192, tr->gA.p, 128, sv));
-        TR_CHECK(sg_segment_max_backward(L0.pf.p, N, 64, dd + o.cl_pt_off, L0.C, tr->gB.p + 128, 192, tr->g_pf.p, sv));
+        TR_CHECK(sg_segment_max_backward(L0.pf.p, N, 64, dd + o.cl_pt_off, L0.C, tr->gB.p + 128, 192, tr->g_pf.p, tr->ws_seg.p, tr->ws_seg.n, sv));
         TR_CHECK(sg_edgeconv_backward(L0.x9m.p, L0.knn.p, N, 20, 1, tr->P(M2W), tr->P(M2G), tr->P(M2B), nullptr, nullptr, nullptr, tr->g_pf.p, tr->G(M2W),
                                       tr->G(M2G), tr->G(M2B), nullptr, nullptr, nullptr, tr->bn.p + 128, tr->ws_edge.p, tr->ws_edge.n, sv));
     }

@@ -511,7 +511,8 @@ def segment_max_backward(rows, cl_off, grad_out):
     off = torch.as_tensor(np.asarray(cl_off, dtype=np.int32)).to(dev)
     N, D, Cn = int(r.shape[0]), int(r.shape[1]), int(off.shape[0]) - 1
     out = torch.zeros_like(r)
-    hip.check(lib.sg_segment_max_backward(r.data_ptr(), N, D, off.data_ptr(), Cn, g.data_ptr(), D, out.data_ptr(), _stream()))
+    ws = _ws(lib.sg_segment_max_backward_ws_bytes(Cn, D), dev)
+    hip.check(lib.sg_segment_max_backward(r.data_ptr(), N, D, off.data_ptr(), Cn, g.data_ptr(), D, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
     return out
 
 

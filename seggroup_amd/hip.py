@@ -106,7 +106,8 @@ SIGNATURES = {
     "sg_train_tail_forward": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_train_tail_backward": (_I, [_I, _I, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_group_max_rows_backward": (_I, [vp, _I, _I, vp, vp, _I, vp, _I, vp, _I, vp]),
-    "sg_segment_max_backward": (_I, [vp, _I, _I, vp, _I, vp, _I, vp, vp]),
+    "sg_segment_max_backward_ws_bytes": (_Z, [_I, _I]),
+    "sg_segment_max_backward": (_I, [vp, _I, _I, vp, _I, vp, _I, vp, vp, _Z, vp]),
     "sg_gcn_backward_ws_bytes": (_Z, [_I, _I, _I]),
     "sg_gcn_backward": (_I, [vp, _I, _I, vp, _I, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, _Z, vp]),
     "sg_train_tail_bn_stats": (_I, [vp, _Z, _I, vp, vp]),
