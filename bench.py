@@ -82,6 +82,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline leg")
     ap.add_argument("--no-files", action="store_true", help="skip the separate with-files measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra leg (scenes/s on the ScanNet-shaped segment profile)")
+    ap.add_argument("--extra-train", type=int, default=8, help="training steps timed in the extra leg (rank 0, N = 1; 0 = skip)")
     ap.add_argument("--extra-scannet", type=int, default=48, help="scenes of the ScanNet-shaped profile in the extra leg (rank 0, N = 1)")
     ap.add_argument("--writer-threads", type=int, default=16, help="native writer threads for the with-files leg")
     ap.add_argument("--gen-workers", type=int, default=0, help="scene generator processes (0 = min(16, cores))")
@@ -409,6 +410,32 @@ def main(argv=None):
                                          "cluster_trace_scene0": list(res_x[0].trace)}
             if not same_x:
                 parity_all = False
+
+        if world == 1 and not args.no_extras and args.extra_train > 0:
+            # one training step (forward with tape + loss + backward + optimizer) per scene, batch 1 like train.py
+            from seggroup_amd import train as _train, trainer as _trainer
+            st = _train.initial_state(1)
+            st.update({k_: (v.numpy() if hasattr(v, "numpy") else np.asarray(v)) for k_, v in weights.to_state_dict(W, prefix="").items()})
+            trn = _trainer.Trainer(st, caps, device=dev)
+            tt = {"forward": 0.0, "loss": 0.0, "backward": 0.0, "optimizer": 0.0}
+            for it in range(-2, args.extra_train):
+                sc_ = scenes[it % len(scenes)]
+                torch.cuda.synchronize(); a0 = time.perf_counter()
+                trn.forward(sc_)
+                torch.cuda.synchronize(); a1 = time.perf_counter()
+                mk = trn.dropout_mask("random")
+                trn.loss(mk)
+                torch.cuda.synchronize(); a2 = time.perf_counter()
+                trn.backward(mk)
+                torch.cuda.synchronize(); a3 = time.perf_counter()
+                trn.average_gradients(); trn.optimizer_step()
+                torch.cuda.synchronize(); a4 = time.perf_counter()
+                if it >= 0:
+                    tt["forward"] += a1 - a0; tt["loss"] += a2 - a1; tt["backward"] += a3 - a2; tt["optimizer"] += a4 - a3
+            extras["train_step"] = {"ms_per_step": round(sum(tt.values()) / args.extra_train * 1e3, 3), "steps": args.extra_train,
+                                    "ms": {k_: round(v / args.extra_train * 1e3, 3) for k_, v in tt.items()},
+                                    "note": "one scene per step on one stream (train.py's batch size 1), SGD; off the headline metric"}
+            trn.close()
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -532,9 +532,10 @@ int sg_segment_lists(const int32_t* d_seg_indices, int V, const int64_t* d_mappe
 int sg_write_seg_json(const char* path, const int32_t* h_seg_points, const int32_t* h_seg_off, int G, int Np);
 
 /* =============================================================================================
- * Training step, first slice: the train-mode tail of SegModel.forward + its backward, and the backward
- * of the three cluster-level operators in front of it.  EdgeConv / BatchNorm2d backward, SGD and the DDP gradient
- * all-reduce (train.py:96-99,160-170) are the next slice.
+ * Training step, operator level: the train-mode tail of SegModel.forward + its backward, and the backward
+ * of every operator in front of it (group max, point->cluster max, GCN, EdgeConv MLP2 / MLP3, MLP1); further down the whole step
+ * as one object (sg_trainer_*) and the optimizers.  The DDP gradient all-reduce (train.py:88) is the host side's: one
+ * torch.distributed all-reduce of the flat gradient vector over RCCL (seggroup_amd/trainer.py).
  * ============================================================================================= */
 typedef struct sg_classifier {    /* DEVICE pointers, float32, row-major (model.py:154-166)                         */
     const float* w1;                /* linear1.weight [128,256] (no bias)                                          */

@@ -526,7 +526,7 @@ def group_unlabeled(part: Partition, feat, adj, layer: Layer, data, faithful=Fal
 
 
 # ------------------------------------------------------------------------------------------------
-# 8f-4 (first slice)  train-mode tail: per-instance features -> Classifier -> label-smoothed CE  (model.py:900-932,
+# 8f-4  train-mode tail (forward; the gradients are oracle/train_ref.py): per-instance features -> Classifier -> label-smoothed CE  (model.py:900-932,
 # 154-166; util.py:12-29).  Dropout is PINNED: `keep` [K,128] is the mask already scaled by 1 / (1 - p).
 # ------------------------------------------------------------------------------------------------
 def dropout_keep(K, seed=97):

@@ -1,4 +1,4 @@
-// SURVEY.md 8f-4, first slice: the TRAIN-mode tail of SegModel.forward and the backward of the three cluster-level
+// the TRAIN-mode tail of SegModel.forward and the backward of the three cluster-level
 // operators in front of it (reference seggroup/model.py:900-932, Classifier 154-166, util.py:12-29, train.py:160-170).
 //
 //   forward   Feat_5 [C,256] --max over the clusters of one weak instance--> Feat_6 [K,256]
@@ -11,7 +11,8 @@
 //             in the reference: model.py:262-265,305-309).
 //
 // Everything here is tiny (K <= a few hundred instances, C <= S clusters, D <= 256): one or a few blocks, fp64
-// accumulation, no tuning -- the EdgeConv / BatchNorm2d backward (the part with real work) is the next slice.
+// accumulation, no tuning -- the EdgeConv / BatchNorm2d backward (the part with real work) is kernels_train_edge.hip, the
+// optimizers are at the end of this file, the chain is trainer.cpp.
 #include <cmath>
 
 #include "sg_common.h"

@@ -463,7 +463,7 @@ def _sym_csr(a: np.ndarray, S: int):
 
 
 # ------------------------------------------------------------------------------------------------
-# training step, first slice: backward of the cluster-level operators + the classifier tail
+# training step, operator level: backward of every operator of the chain + the classifier tail
 # ------------------------------------------------------------------------------------------------
 def gcn_backward(X, Edge_adj, fc_weight, grad_out, alpha=1 / 8):
     """Gradients of `gcn_forward` w.r.t. X and fc_weight, including the path through the similarity weights

@@ -1,4 +1,4 @@
-"""SURVEY.md 8f-4, first slice, on the GPU: the train-mode tail of SegModel.forward against the capture of the real reference
+"""SURVEY.md 8f-4 on the GPU: the train-mode tail of SegModel.forward against the capture of the real reference
 (tests/golden/train_tail.npz: tools/capture_train.py, dropout pinned), and every backward entry point against torch autograd
 of a float64 restatement of the same operator."""
 import os

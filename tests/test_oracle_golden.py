@@ -141,7 +141,7 @@ def test_group_nearby_stall_is_detected():
 
 @pytest.mark.parametrize("name", ["tiny_4k", "tiny_dup_4k", "small_20k", "island_20k"])
 def test_oracle_train_tail_matches_reference_capture(golden_index, weight_sets, name):
-    """SURVEY 8f-4, first slice: the oracle's restatement of the train-mode tail (model.py:900-932, Classifier, label-smoothed
+    """the oracle's restatement of the train-mode tail (model.py:900-932, Classifier, label-smoothed
     CE) against the capture of the real reference with the same pinned dropout mask (tools/capture_train.py)."""
     import os
     from conftest import GOLDEN, make_fixture_scene
