@@ -45,6 +45,8 @@ def stats(src_dir, dst, title):
 bench = stats("prof_bench", f"{tag}_bench_kernel_stats.csv", "python bench.py --no-cpu-baseline --no-files (default engine shape), 150k/1.5k scenes")
 solo = stats("prof_solo8", f"{tag}_solo_batched_kernel_stats.csv", "python bench.py --groups 1 --per-group 8 --no-cpu-baseline --no-files: one group, 8 scenes per batched launch, nothing else on the GPU")
 
+train = stats("prof_train", f"{tag}_train_kernel_stats.csv", "python tools/time_train.py --steps 6: the training step (forward with tape + loss + backward + SGD), 150k/1.5k scenes, one scene per step")
+
 passes = {}
 for name in ("sq", "mfma", "fetch", "write"):
     p = os.path.join(G, f"{tag}_pmc_{name}.json")
@@ -98,7 +100,7 @@ if passes:
         o.write(f"# {out['configuration']}\n# SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY, averages per batched launch\n")
         o.write("\n".join(lines) + "\n")
     print("pmc: %d kernels" % len(out["per_kernel_raw"]))
-for name, d in (("bench", bench), ("solo batched", solo)):
+for name, d in (("bench", bench), ("solo batched", solo), ("training step", train)):
     if d:
         print(name, "top kernels (avg us per launch):")
         for k in list(d)[:8]:
