@@ -587,22 +587,31 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     };
     bool ok = true;                                           // seeded: false while the segment at hand belongs to my former cluster
     // one 32-point chunk: sorted positions [p0, p0 + m)
-    // one 32-point chunk whose operands are in registers (lanes < kChunkPts + kQuadS hold point `lane`, padded with +inf)
-    auto scan_loaded = [&](const float* bx, const float4 cv, const int cidx, int m) {
+    // one 32-point chunk: sorted positions [p0, p0 + m)
+    auto scan_chunk = [&](const float* bx, int p0, int m) {
         const unsigned long long use = best_thr();
         if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[6], 1ull);
         if (!__any(ok && make_key(box_score_bound(me, bx), 0) >= use)) return;
         if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[5], 1ull);
         __builtin_amdgcn_wave_barrier();
         if (lane < kChunkPts + kQuadS) {
-            cw[lane] = cv;
-            ci[lane] = cidx;
+            const bool in = lane < m;
+            cw[lane] = in ? sxyzw[p0 + lane] : make_float4(0.f, 0.f, 0.f, INFINITY);
+            ci[lane] = in ? smpos[p0 + lane] - clo : 0x7fffffff;
         }
         __builtin_amdgcn_wave_barrier();
         for (int i = 0; i < m; i += kQuadS) {
+            // all kQuadS operand reads first: behind the first conditional store the scheduler would issue them one candidate
+            // at a time and every candidate would wait out its own LDS round trip (with the reads together the compiler also
+            // pairs the candidates' arithmetic into v_pk_mul / v_pk_fma_f32: same IEEE operations, fewer issue slots; a slab laid
+            // out in candidate pairs to drop the packing moves measured no faster)
+            float4 c4[kQuadS];
+            int id4[kQuadS];
+#pragma unroll
+            for (int u = 0; u < kQuadS; ++u) { c4[u] = cw[i + u]; id4[u] = ci[i + u]; }
 #pragma unroll
             for (int u = 0; u < kQuadS; ++u) {
-                const unsigned long long key = make_key(score4(me, cw[i + u]), ci[i + u]);
+                const unsigned long long key = make_key(score4(me, c4[u]), id4[u]);
                 if (ok && key > use && key > thr) {
                     buf[cnt][tid] = key;
                     ++cnt;
@@ -610,24 +619,6 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             }
             if (__any(cnt > kBufS - kQuadS)) drain();
         }
-    };
-    // the operands of sorted positions [p0, p0 + m): requested one survivor AHEAD of the scan by the one-wave-per-tile path
-    // (the round trip of a chunk's 32 points hides behind the previous chunk's 32 x 64 distance evaluations)
-    auto fetch_chunk = [&](int p0, int m, float4& cv, int& cidx) {
-        const bool in = lane < m;
-        cv = in ? sxyzw[p0 + lane] : make_float4(0.f, 0.f, 0.f, INFINITY);
-        cidx = in ? smpos[p0 + lane] - clo : 0x7fffffff;
-    };
-    auto scan_chunk = [&](const float* bx, int p0, int m) {
-        const unsigned long long use = best_thr();
-        if (!__any(ok && make_key(box_score_bound(me, bx), 0) >= use)) {
-            if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[6], 1ull);
-            return;
-        }
-        float4 cv;
-        int cidx;
-        fetch_chunk(p0, m, cv, cidx);
-        scan_loaded(bx, cv, cidx, m);
     };
     const int so0 = cl_seg_off[c], nslots = cl_seg_off[c + 1] - so0;
     const int own = slot_of_pos[active ? myrow : smpos[tile_lo[t]]] - so0;   // lanes of a tile may span segments: lane 0 decides
@@ -692,27 +683,12 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
                 }
                 __builtin_amdgcn_wave_barrier();
                 unsigned long long live = __ballot(pass);
-                auto chunk_of = [&](int j) {
-                    int ch = start + j0 + j;
-                    return ch >= nch ? ch - nch : ch;
-                };
-                float4 nv = make_float4(0.f, 0.f, 0.f, INFINITY);
-                int ni = 0x7fffffff;
-                if (live) {
-                    const int ch = chunk_of(__ffsll(live) - 1);
-                    fetch_chunk(d + ch * kChunkPts, min(kChunkPts, sg_m - ch * kChunkPts), nv, ni);
-                }
                 while (live) {
-                    const int j = __ffsll(live) - 1;
+                    const int j = __ffsll((unsigned long long)live) - 1;
                     live &= live - 1;
-                    const int ch = chunk_of(j);
-                    const float4 cv = nv;
-                    const int cidx = ni;
-                    if (live) {
-                        const int chn = chunk_of(__ffsll(live) - 1);
-                        fetch_chunk(d + chn * kChunkPts, min(kChunkPts, sg_m - chn * kChunkPts), nv, ni);
-                    }
-                    scan_loaded(cbx + j * 8, cv, cidx, min(kChunkPts, sg_m - ch * kChunkPts));
+                    int ch = start + j0 + j;
+                    if (ch >= nch) ch -= nch;
+                    scan_chunk(cbx + j * 8, d + ch * kChunkPts, min(kChunkPts, sg_m - ch * kChunkPts));
                 }
             }
             item += nch;
