@@ -279,10 +279,11 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const float y = acc1[t][q] * vmask;
+                        // rows past N (the last tile) are masked when the lanes are summed, not here
+                        const float y = acc1[t][q];
                         stat_s[16 * t + q] += y;
                         stat_q[16 * t + q] = __builtin_fmaf(y, y, stat_q[16 * t + q]);
-                        best[t][q] = fmaxf(best[t][q], acc1[t][q]);
+                        best[t][q] = fmaxf(best[t][q], y);
                     }
             } else {
                 // LeakyReLU(BN1(.)) in place -> B operand of conv2
@@ -298,9 +299,15 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
                 for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc2[ot][q] = 0.f;
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    unsigned int q1[4], q2[4], q3[4];
+                // The wave issues in order, and an MFMA that finds the matrix pipe busy blocks everything behind it: with the split
+                // of a k block written in front of its twelve MFMAs, split and MFMAs alternate and the pipe idles during every split
+                // (56 % busy, PMC).  The split of block kb + 1 only needs conv1's accumulator, so it is computed WHILE block kb's
+                // MFMAs run: one MFMA, then four of the next block's VALU instructions in its 32-cycle shadow, pinned with
+                // sched_group_barrier (0x8 = MFMA, 0x2 = VALU).  (Pipelining further -- the next slot's conv1 under this slot's
+                // statistics, the d split under the last k block -- needs both accumulators live across the loop edge: 100-300 B of
+                // scratch per lane at 2 waves/SIMD, and 1 wave/SIMD is 1.5x slower; measured, not kept.)
+                unsigned int q1[4], q2[4], q3[4];
+                auto split_block = [&](int kb, unsigned int (&o1)[4], unsigned int (&o2)[4], unsigned int (&o3)[4]) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const float v0 = acc1[kb >> 1][8 * (kb & 1) + 2 * jj], v1 = acc1[kb >> 1][8 * (kb & 1) + 2 * jj + 1];
@@ -309,16 +316,22 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
                         const float c0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
                         const float c1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
                         // {low half: high 16 bits of the even value, high half: high 16 bits of the odd value}
-                        q1[jj] = __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);
-                        q2[jj] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-                        q3[jj] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
+                        o1[jj] = __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);
+                        o2[jj] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                        o3[jj] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
                     }
+                };
+                split_block(0, q1, q2, q3);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
                     const bf16x8 x1 = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
                     const bf16x8 x2 = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
                     const bf16x8 x3 = __builtin_bit_cast(bf16x8, u32x4{q3[0], q3[1], q3[2], q3[3]});
                     const bf16x8 wa1 = __builtin_bit_cast(bf16x8, lds.a2b[0][0][kb][lane]), wb1 = __builtin_bit_cast(bf16x8, lds.a2b[0][1][kb][lane]);
                     const bf16x8 wa2 = __builtin_bit_cast(bf16x8, lds.a2b[1][0][kb][lane]), wb2 = __builtin_bit_cast(bf16x8, lds.a2b[1][1][kb][lane]);
                     const bf16x8 wa3 = __builtin_bit_cast(bf16x8, lds.a2b[2][0][kb][lane]), wb3 = __builtin_bit_cast(bf16x8, lds.a2b[2][1][kb][lane]);
+                    unsigned int n1[4], n2[4], n3[4];
+                    if (kb < 3) split_block(kb + 1, n1, n2, n3);
                     // smallest terms first
                     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa3, x1, acc2[0], 0, 0, 0);
                     acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb3, x1, acc2[1], 0, 0, 0);
@@ -332,15 +345,24 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
                     acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x2, acc2[1], 0, 0, 0);
                     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x1, acc2[0], 0, 0, 0);
                     acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x1, acc2[1], 0, 0, 0);
+                    if (kb < 3) {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) { q1[jj] = n1[jj]; q2[jj] = n2[jj]; q3[jj] = n3[jj]; }
+                    }
                 }
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const float z = acc2[ot][q] * vmask;
+                        const float z = acc2[ot][q];
                         stat_s[16 * ot + q] += z;
                         stat_q[16 * ot + q] = __builtin_fmaf(z, z, stat_q[16 * ot + q]);
-                        best[ot][q] = fmaxf(best[ot][q], acc2[ot][q]);
+                        best[ot][q] = fmaxf(best[ot][q], z);
                     }
             }
         }
@@ -349,7 +371,7 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
         // adds into the wave's fp64 LDS accumulators
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
-            float s = stat_s[q], v = stat_q[q];
+            float s = stat_s[q] * vmask, v = stat_q[q] * vmask;
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o); v += __shfl_xor(v, o); }
             if (r == 0) {
