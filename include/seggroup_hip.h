@@ -184,11 +184,13 @@ int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_point
                           int32_t* d_sperm, float* d_chunk_box, double* d_seg_sums, void* d_ws, size_t ws_bytes, void* stream);
 /* One launch for what sg_gather_members + sg_center_clusters + sg_knn_operands produce for a layer (same arrays, same
  * bits): d_cl[i] = cluster of the i-th segment in member order, d_cl_mean [C,3] = the clusters' centroids as fp32
- * (= (float)(sum of the members' xyz in double / count), e.g. from sg_segment_sort_boxes' d_seg_sums). */
+ * (= (float)(sum of the members' xyz in double / count), e.g. from sg_segment_sort_boxes' d_seg_sums).
+ * d_point_rec (may be NULL): [N,4] indexed by POINT id = {x, y, z, bits of the point's member position in this layer}: the
+ * 16-byte record sg_cluster_knn_seeded gathers per seed (instead of a row of d_data and an entry of d_pos_of_point). */
 int sg_layer_layout(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl, const float* d_cl_mean, int32_t* d_members,
                     int32_t* d_pos_of_point, int32_t* d_cluster_of_pos, int32_t* d_slot_of_pos, float* d_x9m, float* d_sxyzw,
-                    int32_t* d_smpos, void* stream);
+                    int32_t* d_smpos, float* d_point_rec, void* stream);
 int sg_knn_operands(const float* d_data, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, float* d_sxyzw, int32_t* d_smpos, void* stream);
 int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off,
@@ -201,7 +203,7 @@ int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, c
  * previous list is the exact top k inside its former cluster).  sg_knn_seed_points turns the previous table (rows and
  * entries = member positions of that layer, d_members = its position -> point map) into d_seed [N,k] indexed by and
  * holding POINT ids.  sg_cluster_knn_seeded = sg_cluster_knn_sorted with one wave per tile that starts every query
- * from its seeds (d_members / d_pos_of_point: THIS layer's maps, d_data the raw [N,6] cloud) and skips the chunks of
+ * from its seeds (d_members: THIS layer's position -> point map, d_point_rec: sg_layer_layout's records of THIS layer) and skips the chunks of
  * segments whose former cluster (d_seg_prevcl[S]) is the query's own; d_seg_prevcl = -1 marks segments of former
  * clusters with <= k points, which have no kNN list (model.py:516-518).  Same table as every other variant. */
 int sg_knn_seed_points(const int32_t* d_knn, const int32_t* d_members, int N, int k, int32_t* d_seed, void* stream);
@@ -210,8 +212,8 @@ int sg_cluster_knn_seeded(const float* d_sxyzw, const int32_t* d_smpos, int N, c
                           const int32_t* d_cl_seg_off, const int32_t* d_order, const int32_t* d_dst,
                           const int32_t* d_seg_off, const int32_t* d_seg_chunk_off, const float* d_segbox,
                           const float* d_chunk_box, const int32_t* d_slot_of_pos, const int32_t* d_seed,
-                          const int32_t* d_seg_prevcl, const int32_t* d_members, const int32_t* d_pos_of_point,
-                          const float* d_data, int k, int pos0, int32_t* d_knn, void* stream);
+                          const int32_t* d_seg_prevcl, const int32_t* d_members, const float* d_point_rec,
+                          int k, int pos0, int32_t* d_knn, void* stream);
 
 /* Two-pass kernel over a cluster-ordered chunk table (same tables once more; variant 0 of sg_pipeline_set_knn_variant:
  * faster on 500k-point scenes and on large segments, on par with the one-pass kernel at 150k / 1.5k).  Per layer the host provides d_slot_chunk0[S+1] (exclusive prefix, in cluster slot order, of the

@@ -71,6 +71,7 @@ struct SlotCtx {
     const float* cl_mean;
     int32_t* members;
     int32_t* pos_of_point;
+    float4* point_rec;                 // [N] by point id: xyz + this layer's member position (seeded kNN)
     int32_t* cluster_of_pos;
     int32_t* slot_of_pos;
     float* x9m;                        // [N,12]

@@ -421,7 +421,8 @@ __device__ __forceinline__ void layer_layout_body(const float* __restrict__ data
                                                   const int32_t* __restrict__ sperm, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
                                                   const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
                                                   int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
-                                                  float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos, int i) {
+                                                  float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos,
+                                                  float4* __restrict__ point_rec, int i) {
     const int s = order[i];
     const int lo = seg_off[s], n = seg_off[s + 1] - lo, d = dst[i], c = cl[i];
     const float mx = cl_mean[3 * c], my = cl_mean[3 * c + 1], mz = cl_mean[3 * c + 2];
@@ -433,6 +434,8 @@ __device__ __forceinline__ void layer_layout_body(const float* __restrict__ data
         slot_of_pos[d + r] = i;
         const float* row = data + (size_t)p * 6;
         const float x = row[0], y = row[1], z = row[2];
+        // XYZ + this layer's member position of the point in ONE 16-byte record: what the seeded kNN of the layer gathers per seed
+        if (point_rec) point_rec[p] = make_float4(x, y, z, __int_as_float(d + r));
         float4* o = reinterpret_cast<float4*>(x9m + (size_t)(d + r) * 12);
         o[0] = make_float4(x, y, z, row[3]);
         o[1] = make_float4(row[4], row[5], x - mx, y - my);
@@ -447,15 +450,15 @@ __global__ void k_layer_layout(const float* __restrict__ data, const int32_t* __
                                const int32_t* __restrict__ sperm, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
                                const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
                                int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
-                               float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos) {
+                               float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos, float4* __restrict__ point_rec) {
     layer_layout_body(data, seg_points, seg_off, sperm, order, dst, cl, cl_mean, members, pos_of_point, cluster_of_pos, slot_of_pos, x9m, sxyzw,
-                      smpos, blockIdx.x);
+                      smpos, point_rec, blockIdx.x);
 }
 __global__ void k_layer_layout_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.S) return;
     layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, c.pos_of_point, c.cluster_of_pos,
-                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, blockIdx.x);
+                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, blockIdx.x);
 }
 
 // per layer: block i = i-th segment in member order; writes the operand and the member position in SORTED order
@@ -500,7 +503,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off, const float* __restrict__ segbox,
     const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg_arg,
     const int32_t* __restrict__ seed, const int32_t* __restrict__ seg_prevcl, const int32_t* __restrict__ members,
-    const int32_t* __restrict__ pos_of_point, const float* __restrict__ data, int t) {
+    const float4* __restrict__ point_rec, int t) {
     static_assert(!kSeeded || kSlices == 1, "seeding is built for one wave per tile");
     const int dbg = kKnnProfile ? dbg_arg : 0;
     // LDS per wave decides how many tiles a CU keeps in flight, and this kernel waits on memory ~45 % of the time:
@@ -542,10 +545,9 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             const int32_t* sp = seed + (size_t)members[myrow] * K;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const int p = sp[j];
-                const float* row = data + (size_t)p * 6;
-                const float x = row[0], y = row[1], z = row[2];
-                kv[j] = make_key(score4(me, make_float4(x, y, z, (x * x + y * y) + z * z)), pos_of_point[p] - clo);
+                const float4 rec = point_rec[sp[j]];              // XYZ + this layer's member position: one gather per seed
+                kv[j] = make_key(score4(me, make_float4(rec.x, rec.y, rec.z, (rec.x * rec.x + rec.y * rec.y) + rec.z * rec.z)),
+                                 __float_as_int(rec.w) - clo);
             }
             thr = kv[K - 1];
         }
@@ -789,9 +791,9 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off, const float* __restrict__ segbox,
     const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg_arg,
     const int32_t* __restrict__ seed = nullptr, const int32_t* __restrict__ seg_prevcl = nullptr, const int32_t* __restrict__ members = nullptr,
-    const int32_t* __restrict__ pos_of_point = nullptr, const float* __restrict__ data = nullptr) {
+    const float4* __restrict__ point_rec = nullptr) {
     cluster_knn_sorted_body<K, kSlices, kSeeded>(sxyzw, smpos, cl_off, tile_cl, tile_lo, tile_hi, cl_seg_off, order, dst, seg_off, seg_chunk_off,
-                                                 segbox, chunk_box, slot_of_pos, pos0, knn, dbg_arg, seed, seg_prevcl, members, pos_of_point, data,
+                                                 segbox, chunk_box, slot_of_pos, pos0, knn, dbg_arg, seed, seg_prevcl, members, point_rec,
                                                  blockIdx.x);
 }
 // one wave per tile: these waves wait on memory two thirds of their life (PMC: 35 % issuing).  The seeded kernel gets a
@@ -803,7 +805,7 @@ __global__ __launch_bounds__(64 * kSlices, kSlices == 1 && kSeeded ? 4 : 1) void
     if ((int)blockIdx.x >= c.T) return;
     cluster_knn_sorted_body<K, kSlices, kSeeded>(c.sxyzw, c.smpos, c.cl_pt_off, c.tile_cl, c.tile_lo, c.tile_hi, c.cl_seg_off, c.order, c.dst,
                                                  c.seg_off, c.seg_chunk_off, c.segbox, c.chunk_box, c.slot_of_pos, c.pos0, c.knn, 0, c.knn_seed,
-                                                 c.seg_prevcl, c.members, c.pos_of_point, c.data, blockIdx.x);
+                                                 c.seg_prevcl, c.members, c.point_rec, blockIdx.x);
 }
 
 
@@ -1156,13 +1158,13 @@ int sg_segment_spatial_sort(const float* d_data, int N, const int32_t* d_seg_poi
 int sg_layer_layout(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl, const float* d_cl_mean, int32_t* d_members,
                     int32_t* d_pos_of_point, int32_t* d_cluster_of_pos, int32_t* d_slot_of_pos, float* d_x9m, float* d_sxyzw,
-                    int32_t* d_smpos, void* stream) {
+                    int32_t* d_smpos, float* d_point_rec, void* stream) {
     SG_REQUIRE(N >= 0 && S >= 0 && d_sperm && d_cl_mean && d_members && d_pos_of_point && d_cluster_of_pos && d_slot_of_pos && d_x9m &&
                    d_sxyzw && d_smpos, "sg_layer_layout: bad arguments");
     if (S == 0) return SG_OK;
     k_layer_layout<<<S, 128, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_sperm, d_order, d_dst, d_cl, d_cl_mean, d_members,
                                                         d_pos_of_point, d_cluster_of_pos, d_slot_of_pos, d_x9m,
-                                                        reinterpret_cast<float4*>(d_sxyzw), d_smpos);
+                                                        reinterpret_cast<float4*>(d_sxyzw), d_smpos, reinterpret_cast<float4*>(d_point_rec));
     SG_LAUNCH_CHECK();
     return SG_OK;
 }
@@ -1206,16 +1208,16 @@ int sg_cluster_knn_seeded(const float* d_sxyzw, const int32_t* d_smpos, int N, c
                           const int32_t* d_tile_lo, const int32_t* d_tile_hi, int T, const int32_t* d_cl_seg_off,
                           const int32_t* d_order, const int32_t* d_dst, const int32_t* d_seg_off, const int32_t* d_seg_chunk_off,
                           const float* d_segbox, const float* d_chunk_box, const int32_t* d_slot_of_pos, const int32_t* d_seed,
-                          const int32_t* d_seg_prevcl, const int32_t* d_members, const int32_t* d_pos_of_point, const float* d_data,
+                          const int32_t* d_seg_prevcl, const int32_t* d_members, const float* d_point_rec,
                           int k, int pos0, int32_t* d_knn, void* stream) {
-    SG_REQUIRE(N >= 0 && T >= 0 && d_knn && d_sxyzw && d_smpos && d_seed && d_seg_prevcl && d_members && d_pos_of_point && d_data,
+    SG_REQUIRE(N >= 0 && T >= 0 && d_knn && d_sxyzw && d_smpos && d_seed && d_seg_prevcl && d_members && d_point_rec,
                "sg_cluster_knn_seeded: bad arguments");
     if (k != 20) return sg::fail(SG_EUNSUP, "sg_cluster_knn_seeded: only k == 20 is built (model.py:788,829), got %d", k);
     if (T == 0) return SG_OK;
     k_cluster_knn_sorted<20, 1, true><<<T, 64, 0, sg::as_stream(stream)>>>(
         reinterpret_cast<const float4*>(d_sxyzw), d_smpos, d_cl_off, d_tile_cl, d_tile_lo, d_tile_hi, d_cl_seg_off, d_order, d_dst,
         d_seg_off, d_seg_chunk_off, d_segbox, d_chunk_box, d_slot_of_pos, pos0, d_knn, g_knn5_dbg, d_seed, d_seg_prevcl, d_members,
-        d_pos_of_point, d_data);
+        reinterpret_cast<const float4*>(d_point_rec));
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

@@ -129,7 +129,7 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
     D(pl->feat1, S * 128); D(pl->featA, S * 256); D(pl->featB, S * 256);
     D(pl->seg_sums, S * 3); P(pl->h_seg_sums, S * 3); D(pl->segbox, S * 8); D(pl->chunk_box, (N / 32 + S + 1) * 8); D(pl->chunk_table, (N / 32 + S + 1) * 8); D(pl->sperm, N); D(pl->smpos, N); D(pl->seg_chunk_off, S + 1);
-    D(pl->ws_sort, sg_spatial_sort_ws_bytes(maxN)); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64);
+    D(pl->ws_sort, sg_spatial_sort_ws_bytes(maxN)); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64); D(pl->point_rec, N * 4);
     P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4); P(pl->h_chunk_off, S + 1);
     P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
     if (bad) { sg::fail(SG_ENOMEM, "sg_pipeline_create: device/pinned allocation failed (N=%d S=%d E=%d V=%d)", maxN, maxS, maxE, maxV); return nullptr; }
@@ -392,7 +392,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             // member arrays + centred rows + sorted kNN operands of the layer: one launch
             PL_CHECK(sg_layer_layout(sc->d_data, N, sc->d_seg_points, sc->d_seg_off, pl->sperm.p, S, dd + o.order, dd + o.dst, dd + o.cl,
                                      reinterpret_cast<const float*>(dd + o.cl_mean), pl->members.p, pl->pos_of_point.p, pl->cluster_of_pos.p,
-                                     pl->slot_of_pos.p, pl->x9m.p, pl->xyzw.p, pl->smpos.p, stv));
+                                     pl->slot_of_pos.p, pl->x9m.p, pl->xyzw.p, pl->smpos.p, pl->point_rec.p, stv));
             // + -inf into the 64 columns the point->cluster max fills below
             PL_CHECK(sg::group_max_rows_fill(feat_prev, feat_prev_stride, feat_prev_dim, dd + o.goff, dd + o.gidx, C, cat, Dcat, 64, stv));
             pl->mark(sb + 0);
@@ -410,7 +410,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                 PL_CHECK(sg_cluster_knn_seeded(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
                                                dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->segbox.p,
                                                pl->chunk_box.p, pl->slot_of_pos.p, pl->knn_seed.p, dd + o.seg_prevcl, pl->members.p,
-                                               pl->pos_of_point.p, sc->d_data, 20, pos0, pl->knn.p, stv));
+                                               pl->point_rec.p, 20, pos0, pl->knn.p, stv));
             } else {
                 PL_CHECK(sg_cluster_knn_sorted_w(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
                                                  dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->segbox.p,

@@ -452,13 +452,15 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         lay = dict(members=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"), pop=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"),
                    cop=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"), sop=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"),
                    x9m=torch.full((N, 12), 7.0, device="cuda:0"), sx=torch.zeros(N, 4, device="cuda:0"),
-                   sm=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"))
+                   sm=torch.full((N,), -1, dtype=torch.int32, device="cuda:0"), rec=torch.zeros(N, 4, device="cuda:0"))
         d_cls, d_mean = _up(torch, cl_of_slot), _up(torch, mean)
         hip.check(lib.sg_layer_layout(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S,
                                       d["order"].data_ptr(), d["dst"].data_ptr(), d_cls.data_ptr(), d_mean.data_ptr(), lay["members"].data_ptr(),
                                       lay["pop"].data_ptr(), lay["cop"].data_ptr(), lay["sop"].data_ptr(), lay["x9m"].data_ptr(),
-                                      lay["sx"].data_ptr(), lay["sm"].data_ptr(), None))
+                                      lay["sx"].data_ptr(), lay["sm"].data_ptr(), lay["rec"].data_ptr(), None))
         assert np.array_equal(lay["members"].cpu().numpy(), members) and np.array_equal(lay["pop"].cpu().numpy(), pos_of_point)
+        rec = lay["rec"].cpu().numpy()                          # by point id: xyz + the bits of the point's member position
+        assert np.array_equal(rec[:, :3], d_data.cpu().numpy()[:, :3]) and np.array_equal(rec[:, 3].copy().view(np.int32), pos_of_point.astype(np.int32))
         assert np.array_equal(lay["cop"].cpu().numpy(), np.repeat(np.arange(L.count), np.diff(off)))
         assert np.array_equal(lay["sop"].cpu().numpy(), slot_of_pos)
         assert torch.equal(lay["x9m"], x9m) and torch.equal(lay["sx"], sxyzw) and torch.equal(lay["sm"], smpos)
@@ -574,12 +576,17 @@ def test_seeded_knn_equals_bruteforce(env, golden_index, name, fine, coarse):
     Lc = O.Layer(part)
     c = _knn_layer_setup(lib, torch, hip, sc, Lc)
     d_prev = _up(torch, seg_prevcl)
+    # sg_layer_layout's per-point records of THIS layer: xyz + the bits of the member position
+    rec_np = np.zeros((N, 4), np.float32)
+    rec_np[:, :3] = c["data"].cpu().numpy()[:, :3]
+    rec_np[:, 3] = c["pos_of_point"].cpu().numpy().astype(np.int32).view(np.float32)
+    rec = _up(torch, rec_np)
     out = torch.full((N, 20), -7, dtype=torch.int32, device="cuda:0")
     hip.check(lib.sg_cluster_knn_seeded(c["sxyzw"].data_ptr(), c["smpos"].data_ptr(), N, c["off"].data_ptr(), c["tc4"].data_ptr(),
                                         c["lo4"].data_ptr(), c["hi4"].data_ptr(), c["nt4"], c["cso"].data_ptr(), c["order"].data_ptr(),
                                         c["dst"].data_ptr(), c["segoff"].data_ptr(), c["co"].data_ptr(), c["box"].data_ptr(), c["cbox"].data_ptr(),
                                         c["slot"].data_ptr(), seed.data_ptr(), d_prev.data_ptr(), c["members"].data_ptr(),
-                                        c["pos_of_point"].data_ptr(), c["data"].data_ptr(), 20, c["pos0"], out.data_ptr(), None))
+                                        rec.data_ptr(), 20, c["pos0"], out.data_ptr(), None))
     a_, b_ = c["brute"].cpu().numpy(), out.cpu().numpy()
     assert np.array_equal(a_, b_), f"{int(np.any(a_ != b_, axis=1).sum())} rows differ between brute force and seeded"
 
