@@ -234,6 +234,13 @@ def run_worker(rank: int, world: int, args, make_trainer: Optional[Callable] = N
         for i, si in enumerate(mine):
             sc = nxt.result()
             nxt = pool.submit(stage, names[mine[i + 1]]) if i + 1 < len(mine) else None      # the next scene is staged while this one trains
+            if hasattr(tr, "fits") and not tr.fits(sc):
+                # a scene beyond the trainer's capacities: same parameters / optimizer state / BatchNorm buffers, larger buffers
+                bigger = tuple(max(a, b) for a, b in zip(tr.caps, (sc.N, sc.S, sc.E0, sc.V)))
+                grown = Trainer(tr.state_dict(), bigger, device=dev, use_sgd=args.use_sgd, lr=args.lr, momentum=args.momentum, seed=args.seed + rank)
+                grown.load_optimizer_state(tr.optimizer_state())
+                tr.close()
+                tr = grown
             try:
                 loss, res, summed = tr.step(sc)
             except Exception as e:                                                   # e.g. a scene with one weak instance: BatchNorm1d raises

@@ -224,7 +224,7 @@ class Trainer:
 
     def load_optimizer_state(self, st) -> None:
         self.steps = int(st["steps"])
-        self.opt_a.copy_(st["a"]); self.opt_b.copy_(st["b"])
+        self.opt_a.copy_(st["a"].to(self.opt_a.device)); self.opt_b.copy_(st["b"].to(self.opt_b.device))
 
     def device_bytes(self) -> int:
         return int(self.lib.sg_trainer_device_bytes(self.handle))

@@ -386,3 +386,46 @@ def test_training_step_full_size_matches_oracle_chain(workload, seed):
     print(json.dumps({k: float("%.2e" % v) for k, v in worst.items()}))
     assert max(worst.values()) <= 2e-5, worst      # measured: <= 2.3e-6 on both workloads
     tr.close()
+
+
+def test_train_driver_end_to_end(golden_index, tmp_path):
+    """`python -m seggroup_amd.train` on a three-scene tree in the reference's on-disk layout: two epochs on one GPU, pseudo-label files
+    under epoch_1 / epoch_last, the reference's log lines, checkpoints the inference driver (and SegModel, strictly) reads back, and a
+    --resume that picks the optimizer state up."""
+    import torch
+    from seggroup_amd import infer, synthetic, train
+    from seggroup_amd.model import SegModel
+    root = str(tmp_path)
+    scenes = []
+    for i, name in enumerate(("tiny_4k", "tiny_dup_4k", "small_20k")):
+        e = golden_index[name]
+        scenes.append(synthetic.make_scene(e["n"], e["s"], e["seed"], name=f"scene{i:04d}_00", **e["kw"]))
+    synthetic.write_reference_tree(root, scenes)
+    args = train.build_parser().parse_args(["-n", "e2e", "--root", root, "--epochs", "2", "--out-format", "npy", "--lr", "0.0002"])
+    for d in ("checkpoints/e2e/models", "results/e2e"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    r = train.run_worker(0, 1, args)
+    assert r["epoch"] == 2 and r["scenes"] == 3 and np.isfinite(r["loss"])
+    log = open(os.path.join(root, "checkpoints", "e2e", "run.log")).read()
+    assert "Epoch[1/2](0003/0003)    Loss:" in log and "==> Epoch[2/2]" in log and "Instance mIoU (18 classes)" in log
+    for tag in ("epoch_1", "epoch_last"):
+        for sc in scenes:
+            assert os.path.exists(os.path.join(root, "results", "e2e", sc.name, tag, "final.ins.npy")), (tag, sc.name)
+    ck = torch.load(os.path.join(root, "checkpoints", "e2e", "models", "last.t7"), map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 2 and len(ck["optimizer"]["state"]) == 19
+    net = SegModel(exp_name="x", data_root=root)
+    net.load_state_dict({k[len("module."):]: v for k, v in ck["state_dict"].items()}, strict=True)
+    first = torch.load(os.path.join(root, "checkpoints", "e2e", "models", "epoch_1.t7"), map_location="cpu", weights_only=False)
+    moved = max(float((ck["state_dict"][k].float() - first["state_dict"][k].float()).abs().max()) for k in ck["state_dict"] if k.endswith("weight"))
+    assert moved > 0.0 and all(torch.isfinite(v.float()).all() for v in ck["state_dict"].values())
+    assert int(ck["state_dict"]["module.mlp_3.bn2.num_batches_tracked"]) == 6
+    # resume: one more epoch from the stored state
+    args3 = train.build_parser().parse_args(["-n", "e2e", "--root", root, "--epochs", "3", "--out-format", "", "-r", "--lr", "0.0002"])
+    r3 = train.run_worker(0, 1, args3)
+    assert r3["epoch"] == 3
+    ck3 = torch.load(os.path.join(root, "checkpoints", "e2e", "models", "last.t7"), map_location="cpu", weights_only=False)
+    assert ck3["epoch"] == 3 and int(ck3["state_dict"]["module.mlp_3.bn2.num_batches_tracked"]) == 9
+    # the inference driver reads what the training driver wrote
+    iargs = infer.build_parser().parse_args(["-n", "e2e", "--ins_infer", "--root", root, "--batch", "0", "--out-format", "npy"])
+    res = infer.run_worker(0, 1, iargs)
+    assert res["n"] == 3
