@@ -37,7 +37,18 @@ __global__ void k_tail_group_max(const float* __restrict__ feat5, int C, const i
     arg[(size_t)k * kD5 + d] = a;
 }
 
-// one block: classifier + loss.  Saved for the backward: h (pre-BN), xhat, pre-activation y, z (after dropout), softmax p.
+// linear1 (no bias): one block per instance, one thread per output
+__global__ __launch_bounds__(kH) void k_tail_linear1(const float* __restrict__ feat6, const float* __restrict__ w1, float* __restrict__ h) {
+    __shared__ float f[kD5];
+    const int k = blockIdx.x, j = threadIdx.x;
+    for (int d = j; d < kD5; d += kH) f[d] = feat6[(size_t)k * kD5 + d];
+    __syncthreads();
+    double acc = 0.0;
+    for (int d = 0; d < kD5; ++d) acc = fma((double)f[d], (double)w1[j * kD5 + d], acc);
+    h[k * kH + j] = (float)acc;
+}
+
+// one block: classifier behind linear1 + loss.  Saved for the backward: h (pre-BN), xhat, pre-activation y, z (after dropout), softmax p.
 __global__ __launch_bounds__(256) void k_tail_classifier(const float* __restrict__ feat6, int K, const int32_t* __restrict__ gold,
                                                          const float* __restrict__ keep, const float* __restrict__ w1, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ w2, const float* __restrict__ b2,
@@ -45,14 +56,7 @@ __global__ __launch_bounds__(256) void k_tail_classifier(const float* __restrict
                                                          float* __restrict__ prob, float* __restrict__ stat, float* __restrict__ logits_out,
                                                          float* __restrict__ loss_out) {
     __shared__ double red[256];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < K * kH; i += 256) {                 // linear1, no bias
-        const int k = i / kH, j = i % kH;
-        double acc = 0.0;
-        for (int d = 0; d < kD5; ++d) acc = fma((double)feat6[(size_t)k * kD5 + d], (double)w1[j * kD5 + d], acc);
-        h[i] = (float)acc;
-    }
-    __syncthreads();
+    const int tid = threadIdx.x;                              // h = linear1(feat6) comes from k_tail_linear1 (one block per instance)
     if (tid < kH) {                                           // BatchNorm1d, batch statistics (biased variance, eps 1e-5)
         double s = 0.0, q = 0.0;
         for (int k = 0; k < K; ++k) { const double v = h[k * kH + tid]; s += v; }
@@ -146,21 +150,27 @@ __global__ __launch_bounds__(256) void k_tail_backward(const float* __restrict__
             dh[k * kH + tid] = (float)(gi * ((double)dy[k * kH + tid] - sdy / K - (double)xhat[k * kH + tid] * sdyx / K));
     }
     __syncthreads();
-    for (int i = tid; i < kH * kD5; i += 256) {               // gw1[j][d] = sum_k dh[k][j] feat6[k][d]
-        const int j = i / kD5, d = i % kD5;
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) s = fma((double)dh[k * kH + j], (double)feat6[(size_t)k * kD5 + d], s);
-        gw1[i] = (float)s;
-    }
-    for (int i = tid; i < C * kD5; i += 256) gfeat5[i] = 0.f;
+}
+
+// gw1[j][d] = sum_k dh[k][j] feat6[k][d]: block j, thread d
+__global__ __launch_bounds__(kD5) void k_tail_backward_w1(const float* __restrict__ feat6, const float* __restrict__ dh, int K, float* __restrict__ gw1) {
+    const int j = blockIdx.x, d = threadIdx.x;
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s = fma((double)dh[k * kH + j], (double)feat6[(size_t)k * kD5 + d], s);
+    gw1[j * kD5 + d] = (float)s;
+}
+
+// d Feat_6 = dh W1 -> the row of Feat_5 that won the max (gfeat5 zeroed before): block k, thread d
+__global__ __launch_bounds__(kD5) void k_tail_backward_feat(const float* __restrict__ dh, const float* __restrict__ w1, const int32_t* __restrict__ arg,
+                                                            float* __restrict__ gfeat5) {
+    __shared__ float dhk[kH];
+    const int k = blockIdx.x, d = threadIdx.x;
+    if (d < kH) dhk[d] = dh[k * kH + d];
     __syncthreads();
-    for (int i = tid; i < K * kD5; i += 256) {                // d Feat_6 -> the row that won the max
-        const int k = i / kD5, d = i % kD5;
-        double s = 0.0;
-        for (int j = 0; j < kH; ++j) s = fma((double)dh[k * kH + j], (double)w1[j * kD5 + d], s);
-        const int a = arg[i];
-        if (a >= 0) gfeat5[(size_t)a * kD5 + d] = (float)s;   // every (instance, channel) has its own winner row: no conflicts
-    }
+    double s = 0.0;
+    for (int j = 0; j < kH; ++j) s = fma((double)dhk[j], (double)w1[j * kD5 + d], s);
+    const int a = arg[(size_t)k * kD5 + d];
+    if (a >= 0) gfeat5[(size_t)a * kD5 + d] = (float)s;       // every (instance, channel) has its own winner row: no conflicts
 }
 
 // ---- backward of aggregate_cluster_feature (model.py:278-288): the gradient of a group's maximum goes to the first maximal row
@@ -391,6 +401,7 @@ int sg_train_tail_forward(const float* d_feat5, int C, const int32_t* d_group, i
     if (!t.ok) return sg::fail(SG_ENOMEM, "sg_train_tail_forward: workspace too small (%zu < %zu)", ws_bytes, sg_train_tail_ws_bytes(C, K));
     hipStream_t st = sg::as_stream(stream);
     k_tail_group_max<<<K, kD5, 0, st>>>(d_feat5, C, d_group, K, t.feat6, t.arg);
+    k_tail_linear1<<<K, kH, 0, st>>>(t.feat6, cls->w1, t.h);
     k_tail_classifier<<<1, 256, 0, st>>>(t.feat6, K, d_gold, d_keep, cls->w1, cls->gamma, cls->beta, cls->w2, cls->b2, t.h, t.xhat, t.ypre, t.z, t.prob,
                                          t.stat, d_logits, d_loss);
     SG_LAUNCH_CHECK();
@@ -402,8 +413,12 @@ int sg_train_tail_backward(int C, int K, const int32_t* d_gold, const float* d_k
     SG_REQUIRE(d_gold && cls && d_gw1 && d_ggamma && d_gbeta && d_gw2 && d_gb2 && d_gfeat5 && d_ws && C > 0 && K >= 2, "sg_train_tail_backward: bad arguments");
     TailWs t = carve_tail(d_ws, ws_bytes, K);
     if (!t.ok) return sg::fail(SG_ENOMEM, "sg_train_tail_backward: workspace too small");
-    k_tail_backward<<<1, 256, 0, sg::as_stream(stream)>>>(t.feat6, t.arg, K, C, d_gold, d_keep, cls->w1, cls->gamma, cls->w2, t.xhat, t.ypre, t.z, t.prob,
-                                                          t.stat, scale, t.dlog, t.dy, t.dh, d_gw1, d_ggamma, d_gbeta, d_gw2, d_gb2, d_gfeat5);
+    hipStream_t st = sg::as_stream(stream);
+    SG_HIP(hipMemsetAsync(d_gfeat5, 0, (size_t)C * kD5 * 4, st));
+    k_tail_backward<<<1, 256, 0, st>>>(t.feat6, t.arg, K, C, d_gold, d_keep, cls->w1, cls->gamma, cls->w2, t.xhat, t.ypre, t.z, t.prob,
+                                       t.stat, scale, t.dlog, t.dy, t.dh, d_gw1, d_ggamma, d_gbeta, d_gw2, d_gb2, d_gfeat5);
+    k_tail_backward_w1<<<kH, kD5, 0, st>>>(t.feat6, t.dh, K, d_gw1);
+    k_tail_backward_feat<<<K, kD5, 0, st>>>(t.dh, cls->w1, t.arg, d_gfeat5);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }
