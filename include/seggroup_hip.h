@@ -604,6 +604,12 @@ int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k,
                          float* d_gg1, float* d_gb1, float* d_gw2, float* d_gg2, float* d_gb2, float* d_bn_stats, void* d_ws,
                          size_t ws_bytes, void* stream);
 
+/* cross_entropy_loss (util.py:12-29) on its own: sum over the K rows of -sum_c t_c log softmax(logits)_c with the smoothed target
+ * (0.8 on the gold class, 0.2 / (C - 1) elsewhere) or, smoothing == 0, the one-hot target.  d_prob [K,C] receives the softmax
+ * (what the backward needs); backward: d_glogits = scale * (softmax - target). */
+int sg_cross_entropy_forward(const float* d_logits, int K, int C, const int32_t* d_gold, int smoothing, float* d_prob, float* d_loss, void* stream);
+int sg_cross_entropy_backward(const float* d_prob, int K, int C, const int32_t* d_gold, int smoothing, float scale, float* d_glogits, void* stream);
+
 /* batch mean | biased variance [128 | 128] of classifier.bn1 as left in d_ws by sg_train_tail_forward (running-statistics update) */
 int sg_train_tail_bn_stats(void* d_ws, size_t ws_bytes, int K, float* d_out, void* stream);
 

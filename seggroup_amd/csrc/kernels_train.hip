@@ -497,6 +497,58 @@ int sg_train_tail_bn_stats(void* d_ws, size_t ws_bytes, int K, float* d_out, voi
     return SG_OK;
 }
 
+namespace {
+// cross_entropy_loss (util.py:12-29): label smoothing eps = 0.2 over the C - 1 other classes, or the plain sum; one block
+__global__ __launch_bounds__(256) void k_cross_entropy(const float* __restrict__ logits, int K, int C, const int32_t* __restrict__ gold, int smoothing,
+                                                       float* __restrict__ prob, float* __restrict__ loss_out) {
+    __shared__ double red[256];
+    double local = 0.0;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        double mx = -1e300;
+        for (int c = 0; c < C; ++c) mx = fmax(mx, (double)logits[(size_t)k * C + c]);
+        double se = 0.0;
+        for (int c = 0; c < C; ++c) se += exp((double)logits[(size_t)k * C + c] - mx);
+        const double lse = mx + log(se);
+        const int g = gold[k];
+        for (int c = 0; c < C; ++c) {
+            const double lp = (double)logits[(size_t)k * C + c] - lse;
+            prob[(size_t)k * C + c] = (float)exp(lp);
+            const double t = smoothing ? (c == g ? 1.0 - (double)kEps : (double)kEps / (C - 1)) : (c == g ? 1.0 : 0.0);
+            local -= t * lp;
+        }
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < 256; ++i) s += red[i];
+        loss_out[0] = (float)s;
+    }
+}
+__global__ void k_cross_entropy_backward(const float* __restrict__ prob, int K, int C, const int32_t* __restrict__ gold, int smoothing, float scale,
+                                         float* __restrict__ glogits) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K * C; i += gridDim.x * blockDim.x) {
+        const int k = i / C, c = i - k * C;
+        const float t = smoothing ? (c == gold[k] ? 1.f - kEps : kEps / (C - 1)) : (c == gold[k] ? 1.f : 0.f);
+        glogits[i] = scale * (prob[i] - t);
+    }
+}
+}  // namespace
+
+int sg_cross_entropy_forward(const float* d_logits, int K, int C, const int32_t* d_gold, int smoothing, float* d_prob, float* d_loss, void* stream) {
+    SG_REQUIRE(d_logits && d_gold && d_prob && d_loss && K > 0 && C > 1, "sg_cross_entropy_forward: bad arguments");
+    k_cross_entropy<<<1, 256, 0, sg::as_stream(stream)>>>(d_logits, K, C, d_gold, smoothing, d_prob, d_loss);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int sg_cross_entropy_backward(const float* d_prob, int K, int C, const int32_t* d_gold, int smoothing, float scale, float* d_glogits, void* stream) {
+    SG_REQUIRE(d_prob && d_gold && d_glogits && K > 0 && C > 1, "sg_cross_entropy_backward: bad arguments");
+    k_cross_entropy_backward<<<std::min(sg::cdiv((long long)K * C, 256), 1024), 256, 0, sg::as_stream(stream)>>>(d_prob, K, C, d_gold, smoothing, scale, d_glogits);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
 int sg_optimizer_sgd(float* d_params, const float* d_grads, float* d_momentum_buf, int n, float lr, float momentum, float weight_decay,
                      int first_step, void* stream) {
     SG_REQUIRE(d_params && d_grads && d_momentum_buf && n >= 0, "sg_optimizer_sgd: bad arguments");

@@ -110,6 +110,8 @@ SIGNATURES = {
     "sg_segment_max_backward": (_I, [vp, _I, _I, vp, _I, vp, _I, vp, vp, _Z, vp]),
     "sg_gcn_backward_ws_bytes": (_Z, [_I, _I, _I]),
     "sg_gcn_backward": (_I, [vp, _I, _I, vp, _I, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, _Z, vp]),
+    "sg_cross_entropy_forward": (_I, [vp, _I, _I, vp, _I, vp, vp, vp]),
+    "sg_cross_entropy_backward": (_I, [vp, _I, _I, vp, _I, C.c_float, vp, vp]),
     "sg_train_tail_bn_stats": (_I, [vp, _Z, _I, vp, vp]),
     "sg_param_slot": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sg_trainer_create": (vp, [_I, _I, _I, _I, vp, vp, vp]),

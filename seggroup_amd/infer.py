@@ -61,20 +61,7 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
-class IOStream:
-    """print + append + flush (reference seggroup/util.py:41-51)."""
-
-    def __init__(self, path):
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        self.f = open(path, 'a')
-
-    def cprint(self, text):
-        print(text)
-        self.f.write(text + '\n')
-        self.f.flush()
-
-    def close(self):
-        self.f.close()
+from .util import IOStream  # noqa: E402,F401  (the reference keeps it in util.py)
 
 
 def scene_indices(num_scenes: int, rank: int, world: int, sampler: str) -> List[int]:

@@ -429,3 +429,27 @@ def test_train_driver_end_to_end(golden_index, tmp_path):
     iargs = infer.build_parser().parse_args(["-n", "e2e", "--ins_infer", "--root", root, "--batch", "0", "--out-format", "npy"])
     res = infer.run_worker(0, 1, iargs)
     assert res["n"] == 3
+
+
+@pytest.mark.parametrize("smoothing", [True, False])
+def test_util_cross_entropy_loss_matches_reference_formula(smoothing):
+    """seggroup_amd.util.cross_entropy_loss (HIP, with autograd) against the reference's formula (util.py:12-29) in torch float64"""
+    import torch
+    import torch.nn.functional as F
+    from seggroup_amd.util import cross_entropy_loss
+    g = torch.Generator().manual_seed(4)
+    pred = torch.randn(37, 40, generator=g) * 3
+    gold = torch.randint(0, 40, (37,), generator=g)
+    ref = pred.double().clone().requires_grad_(True)
+    if smoothing:
+        one_hot = torch.zeros_like(ref).scatter(1, gold.view(-1, 1), 1)
+        one_hot = one_hot * (1 - 0.2) + (1 - one_hot) * 0.2 / (40 - 1)
+        want = -(one_hot * F.log_softmax(ref, dim=1)).sum()
+    else:
+        want = F.cross_entropy(ref, gold, reduction='sum')
+    (want * 0.125).backward()
+    mine = pred.cuda().requires_grad_(True)
+    got = cross_entropy_loss(mine, gold.cuda(), smoothing=smoothing)
+    (got * 0.125).backward()
+    assert abs(float(got.detach()) - float(want.detach())) < 1e-5 * float(want.detach())
+    assert (mine.grad.cpu().double() - ref.grad).abs().max() < 1e-6
