@@ -512,6 +512,14 @@ size_t sg_prep_sample_ws_bytes(int V, int Np);
 int sg_prep_sample_points(const float* d_xyz, const uint8_t* d_rgb, int V, const int64_t* d_mapper, int Np,
                           float* d_pcl, int64_t* d_unmap, int* h_unsampled, void* d_ws, size_t ws_bytes, void* stream);
 
+/* get_adj_from_pointcloud (dataset/scannet/util.py:814-834; optional in the reference -- nothing calls it): the k nearest
+ * neighbours of every point against the whole cloud in cal_pairwise_distance's exact fp32 formula (the best-scoring entry of
+ * topk(k + 1), normally the point itself, is dropped), as per-row sorted, lexicographically sorted, unique [*, 2] int64 rows.
+ * d_points rows of `stride` floats, xyz first; k in {5, 10, 20}; d_adj needs room for [N*k,2]; *h_n = rows written.
+ * Equal scores: the lower index ranks first (torch.topk leaves that order unspecified). */
+size_t sg_pointcloud_adjacency_ws_bytes(int N, int k);
+int sg_pointcloud_adjacency(const float* d_points, int stride, int N, int k, int64_t* d_adj, int* h_n, void* d_ws, size_t ws_bytes, void* stream);
+
 /* get_adj_from_mesh (util.py:771-792).  d_faces [F,3]: edges (0,1), (0,2), (1,2) of every face, zero-length ones
  * dropped (783); d_adj_raw = ascending ids per row, unique rows in lexicographic order; d_adj_res (may be NULL)
  * = the same rows mapped through d_unmap first (rows that collapse to (a, a) only then are kept, as in the

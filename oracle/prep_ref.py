@@ -6,6 +6,7 @@ the hot path's inputs.  Pinned against outputs of the REAL reference functions r
 
     sample_points      generate_pointcloud_pth   util.py:633-693   (colour centring, mapper, unmapper)
     get_unmapper       get_unmapper              util.py:538-550   (+ cal_pairwise_distance 530-535)
+    get_adj_from_pointcloud  get_adj_from_pointcloud  util.py:814-834
     get_adj_from_mesh  get_adj_from_mesh         util.py:771-792
     segment_lists      generate_seg_labels_and_ds_set  util.py:174-220
 """
@@ -69,6 +70,25 @@ def tie_rows(x, y, chunk: int = 4096):
         s = pairwise_scores(x[i:i + chunk], y)
         bad[i:i + chunk] = (s == s.max(axis=1, keepdims=True)).sum(axis=1) > 1
     return bad
+
+
+def get_adj_from_pointcloud(points, k: int = 10, chunk: int = 2048):
+    """util.py:814-834: every point's k best-scoring other rows of the cloud (topk(k + 1) with the top entry dropped) as
+    per-row sorted, unique [*, 2] int64 rows.  `topk` leaves the order of equal scores unspecified; the build DEFINES: lower index
+    first.  -> (adj, tie_rows) where tie_rows marks the points whose top k + 2 scores contain an equal pair (there the reference's
+    own choice may differ)."""
+    x = np.ascontiguousarray(np.asarray(points, dtype=F32)[:, :3])
+    n = x.shape[0]
+    pairs = np.empty((n, k, 2), dtype=np.int64)
+    ties = np.zeros(n, dtype=bool)
+    for i in range(0, n, chunk):
+        s = pairwise_scores(x[i:i + chunk], x)
+        order = np.argsort(-s, axis=1, kind="stable")[:, :k + 2]          # descending score, ascending index inside a tie
+        top = np.take_along_axis(s, order, axis=1)
+        ties[i:i + chunk] = (top[:, 1:] == top[:, :-1]).any(axis=1)
+        pairs[i:i + chunk, :, 0] = np.arange(i, min(n, i + chunk))[:, None]
+        pairs[i:i + chunk, :, 1] = order[:, 1:k + 1]
+    return np.unique(np.sort(pairs.reshape(-1, 2), axis=1), axis=0), ties
 
 
 def sample_points(xyz, rgb_u8, num_points: int, perm):

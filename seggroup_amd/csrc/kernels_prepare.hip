@@ -4,6 +4,7 @@
 //                           unmapper (last occurrence of a vertex in the mapper wins, 687-689), and for vertices that
 //                           were not sampled the nearest sampled point (get_unmapper 538-550)
 //   sg_nearest_point        get_unmapper / cal_pairwise_distance 530-550
+//   sg_pointcloud_adjacency get_adj_from_pointcloud 814-834 (optional in the reference: nothing calls it): kNN graph of the cloud
 //   sg_mesh_adjacency       get_adj_from_mesh 771-792: per-row sorted, lexicographically unique edge lists, raw and resampled
 //   sg_segment_lists        generate_seg_labels_and_ds_set 174-220: compacted segment ids + member lists
 //
@@ -66,6 +67,50 @@ __global__ __launch_bounds__(kTile) void k_nearest(const float* __restrict__ qxy
         }
     }
     if (live) out[scatter ? row : u] = arg;
+}
+
+// get_adj_from_pointcloud (util.py:814-834): the KK = k + 1 best-scoring candidates of every point against the WHOLE cloud in the same
+// exact formula (topk keeps descending score; equal scores: lower index first), then the k pairs (i, j_t), t = 1..k -- the top entry,
+// normally the point itself, is dropped like the reference's `[:, 1:]` -- as sorted pair keys lo << 32 | hi.
+template <int KK>
+__global__ __launch_bounds__(kTile) void k_nearest_k(const float4* __restrict__ cand, int N, unsigned long long* __restrict__ keys) {
+    __shared__ float4 tile[kTile];
+    const int u = blockIdx.x * kTile + threadIdx.x;
+    const bool live = u < N;
+    const float4 me = cand[live ? u : 0];
+    float bs[KK];
+    int bi[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) { bs[t] = -INFINITY; bi[t] = 0x7fffffff; }
+    for (int c0 = 0; c0 < N; c0 += kTile) {
+        __syncthreads();
+        tile[threadIdx.x] = c0 + threadIdx.x < N ? cand[c0 + threadIdx.x] : make_float4(0.f, 0.f, 0.f, INFINITY);
+        __syncthreads();
+        const int m = min(kTile, N - c0);
+        for (int j = 0; j < m; ++j) {
+            const float sc = pair_score(me.x, me.y, me.z, me.w, tile[j]);
+            if (sc > bs[KK - 1]) {                             // candidates arrive in ascending index: `>` keeps the earlier one of a tie
+                float v = sc;
+                int id = c0 + j;
+                bool placed = false;
+#pragma unroll
+                for (int t = 0; t < KK; ++t) {
+                    if (placed || v > bs[t]) {
+                        placed = true;
+                        const float tv = bs[t]; const int ti = bi[t];
+                        bs[t] = v; bi[t] = id; v = tv; id = ti;
+                    }
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int t = 1; t < KK; ++t) {
+            const int j = bi[t];
+            keys[(size_t)u * (KK - 1) + (t - 1)] = ((unsigned long long)(unsigned)min(u, j) << 32) | (unsigned)max(u, j);
+        }
+    }
 }
 
 // pcl[i] = [xyz[m], rgb[m] / 127.5 - 1 evaluated in double, rounded to fp32]; unmap[m] = max i (last occurrence)
@@ -274,6 +319,48 @@ int sg_mesh_adjacency(const int32_t* d_faces, int F, const int64_t* d_unmap, int
     if (res && cnt[1] > 0) k_unpack_edges<<<sg::cdiv(cnt[1], 256), 256, 0, st>>>(r1, cnt[1], d_adj_res);
     *h_n_raw = cnt[0];
     if (res) *h_n_res = cnt[1];
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+size_t sg_pointcloud_adjacency_ws_bytes(int N, int k) {
+    const size_t n = (size_t)std::max(N, 1) * std::max(k, 1);
+    return sg::align_up(std::max(sort_keys_temp((int)n), unique_temp((int)n))) + 2 * sg::align_up(n * 8) + sg::align_up((size_t)std::max(N, 1) * 16) + 256;
+}
+
+// get_adj_from_pointcloud (util.py:814-834): d_points rows of `stride` floats (xyz first), k in {5, 10, 20}; d_adj: room for [N*k,2]
+// int64; *h_n = rows written (per-row sorted, lexicographically sorted, unique)
+int sg_pointcloud_adjacency(const float* d_points, int stride, int N, int k, int64_t* d_adj, int* h_n, void* d_ws, size_t ws_bytes, void* stream) {
+    SG_REQUIRE(d_points && stride >= 3 && N > 0 && d_adj && h_n && d_ws, "sg_pointcloud_adjacency: bad arguments");
+    if (k != 5 && k != 10 && k != 20) return sg::fail(SG_EUNSUP, "sg_pointcloud_adjacency: k = %d is not built (5, 10 = the reference's default, 20)", k);
+    if (N <= k) return sg::fail(SG_EINVAL, "sg_pointcloud_adjacency: %d points for k = %d (topk(k + 1) raises in the reference)", N, k);
+    *h_n = 0;
+    const int n = N * k;
+    const size_t temp = std::max(sort_keys_temp(n), unique_temp(n));
+    sg::Carver cv(d_ws, ws_bytes);
+    char* tmp = cv.take<char>(temp);
+    unsigned long long* k0 = cv.take<unsigned long long>(n);
+    unsigned long long* k1 = cv.take<unsigned long long>(n);
+    float4* cand = cv.take<float4>(N);
+    int* d_count = cv.take<int>(1);
+    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_pointcloud_adjacency: workspace too small (%zu < %zu)", ws_bytes, sg_pointcloud_adjacency_ws_bytes(N, k));
+    hipStream_t st = sg::as_stream(stream);
+    k_pack_xyzw<<<sg::cdiv(N, 256), 256, 0, st>>>(d_points, stride, N, cand);
+    if (k == 5) k_nearest_k<6><<<sg::cdiv(N, kTile), kTile, 0, st>>>(cand, N, k0);
+    else if (k == 10) k_nearest_k<11><<<sg::cdiv(N, kTile), kTile, 0, st>>>(cand, N, k0);
+    else k_nearest_k<21><<<sg::cdiv(N, kTile), kTile, 0, st>>>(cand, N, k0);
+    size_t t = temp;
+    hipcub::DoubleBuffer<unsigned long long> d(k0, k1);
+    SG_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, t, d, n, 0, 64, st));
+    unsigned long long* sorted = d.Current();
+    unsigned long long* other = sorted == k0 ? k1 : k0;
+    t = temp;
+    SG_HIP(hipcub::DeviceSelect::Unique(tmp, t, sorted, other, d_count, n, st));
+    int cnt = 0;
+    SG_HIP(hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, st));
+    SG_HIP(hipStreamSynchronize(st));
+    if (cnt > 0) k_unpack_edges<<<sg::cdiv(cnt, 256), 256, 0, st>>>(other, cnt, d_adj);
+    *h_n = cnt;
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

@@ -97,6 +97,8 @@ SIGNATURES = {
     "sg_nearest_point": (_I, [vp, _I, vp, _I, _I, vp, vp, _Z, vp]),
     "sg_prep_sample_ws_bytes": (_Z, [_I, _I]),
     "sg_prep_sample_points": (_I, [vp, vp, _I, vp, _I, vp, vp, C.POINTER(C.c_int), vp, _Z, vp]),
+    "sg_pointcloud_adjacency_ws_bytes": (_Z, [_I, _I]),
+    "sg_pointcloud_adjacency": (_I, [vp, _I, _I, _I, vp, C.POINTER(C.c_int), vp, _Z, vp]),
     "sg_mesh_adjacency_ws_bytes": (_Z, [_I]),
     "sg_mesh_adjacency": (_I, [vp, _I, vp, _I, vp, C.POINTER(C.c_int), vp, C.POINTER(C.c_int), vp, _Z, vp]),
     "sg_segment_lists_ws_bytes": (_Z, [_I, _I]),

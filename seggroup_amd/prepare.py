@@ -224,6 +224,23 @@ def get_adj_from_mesh(plydata, unmapper=None, device=None):
     return raw.cpu(), (res.cpu() if res is not None else None)
 
 
+def get_adj_from_pointcloud(pointcloud, k=10, device=None):
+    """util.py:814-834 (optional in the reference: nothing calls it): the kNN graph of the cloud as a per-row sorted, unique
+    [*, 2] LongTensor (CPU, like the reference's).  Equal scores rank by ascending index (torch.topk leaves that open)."""
+    import torch
+    dev = _dev(device)
+    lib = hip.lib()
+    pts = _t(pointcloud, torch.float32, dev)
+    n, stride = int(pts.shape[0]), int(pts.shape[1])
+    out = torch.empty((n * int(k), 2), dtype=torch.int64, device=dev)
+    ws = _ws(lib.sg_pointcloud_adjacency_ws_bytes(n, int(k)), dev)
+    cnt = C.c_int(0)
+    with torch.cuda.device(dev):
+        hip.check(lib.sg_pointcloud_adjacency(pts.data_ptr(), stride, n, int(k), out.data_ptr(), C.byref(cnt), ws.data_ptr(), ws.numel(), None))
+        torch.cuda.synchronize()
+    return out[:cnt.value].cpu()
+
+
 # ---- the reference's file-producing functions -------------------------------------------------------------------------
 def _scene_name(scene_path: str) -> str:
     return os.path.split(scene_path[:-1] if scene_path.endswith("/") else scene_path)[-1]

@@ -191,3 +191,28 @@ def test_full_size_scan_properties():
         m = pts[off[g_]:off[g_ + 1]]
         assert (np.diff(m) > 0).all() and len(set(lab_s[m].tolist())) == 1 and int((lab_s == lab_s[m[0]]).sum()) == m.size
     assert np.array_equal(lab, np.searchsorted(np.unique(scan.seg_indices), scan.seg_indices))
+
+
+def test_pointcloud_adjacency_matches_reference_and_oracle():
+    """prepare.get_adj_from_pointcloud (sg_pointcloud_adjacency) against the capture of the real reference outside the tie points, and
+    against the oracle everywhere (both rank equal scores by ascending index), also on an 8k-point cloud and for k = 5 / 20."""
+    import torch
+    from oracle import prep_ref
+    from seggroup_amd import prepare
+    g = np.load(os.path.join(GOLD, "prep_sub_3k.npz"))
+    ref = np.load(os.path.join(GOLD, "prep_pointcloud_adj.npz"))
+    got = prepare.get_adj_from_pointcloud(torch.from_numpy(g["pcl"]), k=10)
+    assert got.dtype == torch.int64 and not got.is_cuda
+    got = got.numpy()
+    adj, tie = prep_ref.get_adj_from_pointcloud(g["pcl"], k=10)
+    assert np.array_equal(got, adj)
+    keep = lambda e: e[~(tie[e[:, 0]] | tie[e[:, 1]])]
+    assert np.array_equal(keep(got), keep(ref["adj"].astype(np.int64)))
+    rng = np.random.default_rng(12)
+    cloud = (rng.random((8000, 6)) * np.array([8, 6, 3, 1, 1, 1])).astype(np.float32)
+    for k in (5, 10, 20):
+        want, _ = prep_ref.get_adj_from_pointcloud(cloud, k=k)
+        have = prepare.get_adj_from_pointcloud(cloud, k=k).numpy()
+        assert np.array_equal(have, want), k
+    with pytest.raises(Exception):
+        prepare.get_adj_from_pointcloud(cloud, k=7)

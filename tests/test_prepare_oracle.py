@@ -98,3 +98,18 @@ def test_seg_json_writer_is_byte_identical_to_json_dump(tmp_path, sg_lib, name):
     assert json.load(open(p)) == lists
     bad_off = off.copy(); bad_off[1] = 0
     assert sg_lib.sg_write_seg_json(p.encode(), pts.ctypes.data, bad_off.ctypes.data, len(groups), len(lists)) < 0
+
+
+def test_oracle_pointcloud_adjacency_matches_reference_capture():
+    """get_adj_from_pointcloud (util.py:814-834; optional in the reference) on the sampled cloud of prep_sub_3k, k = 10: the oracle's
+    rows equal the real reference's wherever no two of a point's leading scores are equal (torch.topk leaves that order open; the
+    capture lists those points)."""
+    from oracle import prep_ref
+    g = np.load(os.path.join(GOLD, "prep_sub_3k.npz"))
+    ref = np.load(os.path.join(GOLD, "prep_pointcloud_adj.npz"))
+    adj, tie = prep_ref.get_adj_from_pointcloud(g["pcl"], k=10)
+    assert np.array_equal(np.nonzero(tie)[0], ref["tie_points"])
+    keep = lambda e: e[~(tie[e[:, 0]] | tie[e[:, 1]])]
+    want = ref["adj"].astype(np.int64)
+    assert np.array_equal(keep(adj), keep(want)) and keep(adj).shape[0] > 8000
+    assert np.all(adj[:, 0] <= adj[:, 1]) and np.array_equal(adj, np.unique(adj, axis=0))   # (i, i) rows: a duplicate outranked the point itself

@@ -141,6 +141,18 @@ def main():
                  "oracle_equals_reference": checks,
                  "sha": {k: (hashlib.sha256(v).hexdigest() if isinstance(v, bytes) else sha(v)) for k, v in got.items()},
                  "shapes": {k: (len(v) if isinstance(v, bytes) else list(v.shape)) for k, v in got.items()}}
+        if name == "prep_sub_3k":
+            # get_adj_from_pointcloud (util.py:814-834; nothing in the reference calls it): run on the sampled cloud, k = 10
+            import torch
+            pc = util.get_adj_from_pointcloud(torch.from_numpy(got["pcl"][:, :3].copy()), k=10).numpy()
+            mine, tie = prep_ref.get_adj_from_pointcloud(got["pcl"], k=10)
+            keep = lambda e: e[~(tie[e[:, 0]] | tie[e[:, 1]])]
+            checks["pointcloud_adj_outside_ties"] = bool(np.array_equal(keep(mine), keep(pc)))
+            checks["pointcloud_adj_everywhere"] = bool(np.array_equal(mine, pc))
+            print(f"[{name}] get_adj_from_pointcloud: {pc.shape[0]} rows, {int(tie.sum())} points with tied scores, oracle == reference: "
+                  f"{checks['pointcloud_adj_outside_ties']} (everywhere: {checks['pointcloud_adj_everywhere']})")
+            np.savez_compressed(os.path.join(a.out, "prep_pointcloud_adj.npz"), adj=pc.astype(np.int32), tie_points=np.nonzero(tie)[0].astype(np.int32))
+            entry["oracle_equals_reference"] = checks
         if fx["full"]:
             np.savez_compressed(os.path.join(a.out, name + ".npz"), pcl=got["pcl"], map=got["map"], unmap=got["unmap"], info=got["info"],
                                 adj_raw=got["adj_raw"], adj_resampled=got["adj_resampled"],
