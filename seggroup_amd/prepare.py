@@ -316,11 +316,23 @@ def generate_mesh_adjcency_pth(scene_name, plydata=None, root: str = ".", scene_
         torch.save(t, p)
 
 
-def prepare_scene(scene_path, item, num_points: int = 150000, root: str = ".", perm=None, device=None):
-    """What prepare_data.py:36-71 + prepare_weak_label.py's adjacency step do for one scan, minus the annotation-derived
-    label files: point cloud, mapper / unmapper, segment lists, mesh adjacency."""
+# the annotation-derived label producers of the same reference file (util.py:76-170, 224-427, 697-768) live in labels.py
+from .labels import (generate_real_label_pth, generate_real_labels, generate_seg_adjacency_matrix, generate_weak_label_pth,  # noqa: E402,F401
+                     generate_weak_labels, group_adjacency_segs, load_aggregation, load_labels, read_label_mapper)
+
+
+def prepare_scene(scene_path, item, num_points: int = 150000, root: str = ".", perm=None, device=None, label_style: Optional[str] = None,
+                  manual_label_path: Optional[str] = None):
+    """What prepare_data.py:36-71 + prepare_weak_label.py:60-90 do for one scan: point cloud, mapper / unmapper, segment lists,
+    mesh adjacency and -- with `label_style` and ScanNet's annotation files next to the mesh -- the ground-truth and weak-label
+    files, i.e. every input of SegModel.forward."""
     scene_name = _scene_name(scene_path)
     ply = read_ply(os.path.join(scene_path, scene_name + "_vh_clean_2.ply"))
     generate_pointcloud_pth(scene_path, item, num_points, ply, root=root, perm=perm, device=device)
     generate_seg_labels_and_ds_set(scene_path, root=root, device=device)
     generate_mesh_adjcency_pth(scene_name, ply, root=root, device=device)
+    if label_style is not None:
+        generate_real_labels(scene_path, root=root)
+        generate_real_label_pth(scene_path, root=root)
+        generate_weak_labels(scene_path, ply, label_style=label_style, manual_label_path=manual_label_path, root=root)
+        generate_weak_label_pth(scene_name, label_style, root=root)

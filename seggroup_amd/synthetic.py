@@ -441,3 +441,41 @@ def make_raw_scan(grid_w: int, grid_h: int, seed: int, *, name: Optional[str] = 
     forder = np.argsort(splitmix64(seed, 44, faces.shape[0]), kind="stable")          # faces in no particular order
     perm = np.argsort(splitmix64(seed, 45, v), kind="stable").astype(np.int64)
     return RawScan(name or f"scan{seed:04d}_00", xyz, rgb, faces[forder].astype(np.int32), seg.astype(np.int32), perm)
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic ANNOTATIONS of a raw scan (what ScanNet ships next to the mesh), for the label producers of seggroup_amd/labels.py
+# ------------------------------------------------------------------------------------------------
+_CATEGORIES = (("wall", 1), ("floor", 2), ("cabinet", 3), ("bed", 4), ("chair", 5), ("sofa", 6), ("table", 7), ("office chair", 5),
+               ("desk", 14), ("trash can", 39), ("object", 40))
+
+
+def make_annotations(scan: "RawScan", seed: int, blocks_per_row: int):
+    """-> dict(aggregation=<.aggregation.json content>, tsv=<scannetv2-labels.combined.tsv text>, manual=<click file content>).
+    `blocks_per_row` = ceil(grid_w / cell) of make_raw_scan.  Objects are 3 x 2 blocks of the scan's segment grid; every fifth object
+    loses its middle column (two disconnected parts of two segments), every fifth + 2 keeps one corner segment apart from the
+    rest (a small second part), ~12 % of the segments stay unlabeled, one segment is listed by two objects (the later one wins,
+    util.py:123-125).  The manual file clicks one or two segments per object (raw segment ids; strings are allowed too)."""
+    seg = np.asarray(scan.seg_indices, dtype=np.int64)
+    uniq = np.unique(seg)
+    blocks = (uniq - 3) // 7                                  # make_raw_scan: id = 7 * block + 3
+    by, bx = blocks // blocks_per_row, blocks % blocks_per_row
+    obj_of = (by // 2) * ((blocks_per_row + 2) // 3) + bx // 3
+    drop = uniform01(seed, 60, uniq.shape[0]) < 0.12
+    groups, manual = [], {}
+    for k, o in enumerate(np.unique(obj_of)):
+        mine = (obj_of == o) & ~drop
+        if k % 5 == 4:
+            mine &= bx % 3 != 1                               # two parts that do not touch
+        if k % 5 == 2:
+            mine &= ~((bx % 3 == 1) | ((bx % 3 == 2) & (by % 2 == 1)))      # a big part and a single far corner
+        members = uniq[mine]
+        if members.size == 0:
+            continue
+        label = _CATEGORIES[k % len(_CATEGORIES)][0]
+        groups.append({"id": k, "objectId": k, "segments": [int(s) for s in members], "label": label})
+        manual[str(k + 1)] = [int(members[0])] if k % 3 else [int(members[0]), str(int(members[-1]))]
+    if len(groups) > 2:
+        groups[2]["segments"].append(groups[1]["segments"][0])              # claimed twice: the later group overwrites
+    tsv = "id\traw_category\tcategory\tcount\tnyu40id\n" + "".join(f"{i}\t{n}\t{n}\t1\t{c}\n" for i, (n, c) in enumerate(_CATEGORIES))
+    return dict(aggregation={"sceneId": scan.name, "segGroups": groups}, tsv=tsv, manual=manual)
