@@ -152,6 +152,53 @@ def test_prepared_tree_feeds_the_hot_path(tmp_path, weight_sets):
         assert np.array_equal(res.labels[i], ref["labels"][hip.LABEL_NAMES[i]].astype(np.int32)), hip.LABEL_NAMES[i]
 
 
+def test_raw_scan_directory_to_training_step(tmp_path, weight_sets):
+    """A raw scan directory as ScanNet ships it (mesh, segs.json, aggregation.json, label map, click file) -> prepare_scene with a
+    label style -> every input file of the reference's tree -> the inference forward equals the oracle on those files, and one
+    training step runs on them."""
+    import torch
+    from oracle import cpu_ref
+    from seggroup_amd import hip, prepare, synthetic, train, trainer as T
+    from seggroup_amd.model import SegModel
+    from seggroup_amd.scene import DeviceScene, seg_from_lists
+    scan = synthetic.make_raw_scan(64, 48, 21, name="scene0021_00", cell=8)
+    ann = synthetic.make_annotations(scan, 11, blocks_per_row=8)
+    root, n = str(tmp_path), 2500
+    base = os.path.join(root, "dataset", "scannet")
+    sp = os.path.join(base, "scans", scan.name)
+    os.makedirs(sp)
+    prepare.write_ply(os.path.join(sp, scan.name + "_vh_clean_2.ply"), scan.xyz, scan.rgb, scan.faces)
+    json.dump({"segIndices": scan.seg_indices.tolist()}, open(os.path.join(sp, scan.name + "_vh_clean_2.0.010000.segs.json"), "w"))
+    json.dump(ann["aggregation"], open(os.path.join(sp, scan.name + ".aggregation.json"), "w"))
+    open(os.path.join(base, "scannetv2-labels.combined.tsv"), "w").write(ann["tsv"])
+    os.makedirs(os.path.join(root, "clicks"))
+    json.dump(ann["manual"], open(os.path.join(root, "clicks", scan.name + ".json"), "w"))
+    open(os.path.join(base, "scannetv2_train.txt"), "w").write(scan.name + "\n")
+    prepare.prepare_scene(sp, 0, n, root=base, perm=scan.perm, device="cuda:0", label_style="manual", manual_label_path=os.path.join(root, "clicks"))
+    ds = DeviceScene.from_reference_tree(scan.name, root=root, device="cuda:0")
+    ld = lambda *q: torch.load(os.path.join(base, *q)).numpy()
+    weak = ld("label", "seg", "manual", "resampled", scan.name, scan.name + ".label.pth")
+    gt = ld("label", "real", "raw", scan.name, scan.name + ".label.pth")
+    assert weak.shape == (n, 2) and (weak[:, 1] >= 0).sum() > 200 and weak.min() == -1 and gt.shape == (scan.xyz.shape[0], 2)
+    lists = json.load(open(os.path.join(base, "label", "real", "resampled", scan.name, scan.name + ".seg.json")))
+    seg = seg_from_lists(lists, n)
+    sc = synthetic.Scene(scan.name, ld("data", "resampled", scan.name, scan.name + ".pcl.pth"), weak, seg,
+                         ld("adj", "mesh", "resampled", scan.name, scan.name + ".adj.pth"), ld("data", "resampled", scan.name, scan.name + ".unmap.pth"), gt)
+    net = SegModel(exp_name="t", ins_infer=True, data_root=root)
+    net.load_weights(weight_sets["ins_infer"])
+    net.epoch = "ins_infer"
+    res = net.forward_scene(ds, write=False)
+    ref = cpu_ref.forward_scene(sc, weight_sets["ins_infer"], "ins_infer")
+    assert res.trace == ref["trace"]
+    for i in range(14):
+        assert np.array_equal(res.labels[i], ref["labels"][hip.LABEL_NAMES[i]].astype(np.int32)), hip.LABEL_NAMES[i]
+    st = train.initial_state(1)
+    tr = T.Trainer(st, (ds.N, ds.S, ds.E0, ds.V), device="cuda:0")
+    loss, _, _ = tr.step(ds)
+    assert loss[0, 1] >= 2 and np.isfinite(loss[0, 0]) and torch.isfinite(tr.params).all()
+    tr.close()
+
+
 def test_full_size_scan_properties():
     """ScanNet-sized scan (V = 245k > num_points = 150k: 95k nearest-point searches against 150k samples) through
     size-independent properties: every sampled vertex unmaps to a copy of itself, every unsampled one to a sample no
