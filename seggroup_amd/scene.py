@@ -70,7 +70,8 @@ class DeviceScene:
         dev = torch.device(device)
         self.device = dev
         # device tensors pass through (views into a scene pack's blob); host arrays are uploaded
-        up = lambda x: x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x)).to(dev, non_blocking=False)
+        host = lambda x: (lambda a: a if a.flags.writeable else a.copy())(np.ascontiguousarray(x))     # read-only views (np.load, mmap) are copied
+        up = lambda x: x if isinstance(x, torch.Tensor) else torch.from_numpy(host(x)).to(dev, non_blocking=False)
         self.d_data = up(a["data"])
         self.d_adj = up(a["adj"])
         self.d_seg_of_point = up(a["seg_of_point"])
