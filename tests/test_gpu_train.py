@@ -453,3 +453,32 @@ def test_util_cross_entropy_loss_matches_reference_formula(smoothing):
     (got * 0.125).backward()
     assert abs(float(got.detach()) - float(want.detach())) < 1e-5 * float(want.detach())
     assert (mine.grad.cpu().double() - ref.grad).abs().max() < 1e-6
+
+
+def test_single_instance_scene_is_refused_like_the_reference(golden_index, weight_sets):
+    """One weak instance in a scene -> Feat_6 has one row and BatchNorm1d in training mode raises in the reference ('Expected more
+    than 1 value per channel'); the trainer reports SG_EUNSUP at the loss instead of producing NaNs, and stays usable."""
+    import copy
+    from seggroup_amd import hip, trainer as T
+    from seggroup_amd.scene import DeviceScene
+    gt = np.load(os.path.join(GOLDEN, "train_tail.npz"))
+    scene = make_fixture_scene(golden_index, "tiny_4k")
+    one = copy.deepcopy(scene)
+    wl = one.weak_label.copy()
+    first = wl[wl[:, 1] >= 0, 1].min()
+    keep = wl[:, 1] == first
+    wl[~keep] = -1                                               # every click but the first instance's removed
+    wl[keep, 1] = 0
+    one.weak_label = wl
+    tr = T.Trainer(_full_state(weight_sets, gt), (scene.data.shape[0], 4096, 1 << 20, scene.unmap.shape[0] if hasattr(scene, "unmap") else scene.data.shape[0]),
+                   device="cuda:0")
+    tr.forward(DeviceScene.from_synthetic(one, device="cuda:0"))
+    if tr.K >= 2:
+        pytest.skip("the unlabeled remainder formed its own final cluster (K = %d)" % tr.K)
+    with pytest.raises(hip.SgError) as e:
+        tr.loss(None)
+    assert "BatchNorm1d" in str(e.value)
+    # the trainer is still usable
+    tr.forward(DeviceScene.from_synthetic(scene, device="cuda:0"))
+    assert np.isfinite(tr.loss(tr.dropout_mask("pinned"))[0, 0])
+    tr.close()
