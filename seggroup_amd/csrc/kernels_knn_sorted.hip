@@ -588,6 +588,13 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
         }
     };
     bool ok = true;                                           // seeded: false while the segment at hand belongs to my former cluster
+    // the fp32 score a candidate must reach to be worth a key: the score part of the larger threshold (key 0 = nothing yet = -inf;
+    // an idle lane's all-ones key decodes to NaN, which no score reaches; +inf while the segment at hand is already covered)
+    auto score_bound = [](unsigned long long key, bool open) {
+        const unsigned int o = (unsigned int)(key >> 32);
+        const float f = o == 0u ? -INFINITY : __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+        return open ? f : INFINITY;
+    };
     // one 32-point chunk: sorted positions [p0, p0 + m)
     // one 32-point chunk: sorted positions [p0, p0 + m)
     auto scan_chunk = [&](const float* bx, int p0, int m) {
@@ -602,6 +609,11 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             ci[lane] = in ? smpos[p0 + lane] - clo : 0x7fffffff;
         }
         __builtin_amdgcn_wave_barrier();
+        // Most candidates lose against the running 20th best: they are turned away on the fp32 SCORE alone (one compare instead of
+        // building the 64-bit key and comparing it twice: 7 instead of 13 VALU per candidate and lane); a score equal to the bound
+        // goes on to the exact key comparison, which also settles the index order of ties.  `fbound` is refreshed wherever the
+        // thresholds move (chunk start, drain).
+        float fbound = score_bound(use > thr ? use : thr, ok);
         for (int i = 0; i < m; i += kQuadS) {
             // all kQuadS operand reads first: behind the first conditional store the scheduler would issue them one candidate
             // at a time and every candidate would wait out its own LDS round trip (with the reads together the compiler also
@@ -613,13 +625,19 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             for (int u = 0; u < kQuadS; ++u) { c4[u] = cw[i + u]; id4[u] = ci[i + u]; }
 #pragma unroll
             for (int u = 0; u < kQuadS; ++u) {
-                const unsigned long long key = make_key(score4(me, c4[u]), id4[u]);
-                if (ok && key > use && key > thr) {
-                    buf[cnt][tid] = key;
-                    ++cnt;
+                const float sc = score4(me, c4[u]);
+                if (sc >= fbound) {
+                    const unsigned long long key = make_key(sc, id4[u]);
+                    if (key > use && key > thr) {
+                        buf[cnt][tid] = key;
+                        ++cnt;
+                    }
                 }
             }
-            if (__any(cnt > kBufS - kQuadS)) drain();
+            if (__any(cnt > kBufS - kQuadS)) {
+                drain();
+                fbound = score_bound(use > thr ? use : thr, ok);
+            }
         }
     };
     const int so0 = cl_seg_off[c], nslots = cl_seg_off[c + 1] - so0;
