@@ -49,31 +49,47 @@ __device__ __forceinline__ float lrelu(float a) { return a > 0.f ? a : kSlope * 
 __device__ __forceinline__ float dlrelu(float a) { return a > 0.f ? 1.f : kSlope; }     // torch: x > 0 ? g : g * slope
 
 // rows r < P*K of tile `tile`: point n = tile*P + r/K, neighbour k = r%K.  Rows past N (and r >= P*K) are zero, rown = -1.
-__device__ __forceinline__ void build_edge_rows(Tile& s, const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P,
-                                                int tile, const float* __restrict__ cst) {
+// The two dependent gathers of a row (kNN entry, then that neighbour's 9 values) are requested ONE TILE AHEAD into registers
+// (`fetch_edge_rows`) and turned into the LDS tile at the top of the next iteration (`store_edge_rows`): a block runs ~100 tiles
+// back to back and used to wait out both round trips in front of every one of them (~17 us per tile for ~1 us of arithmetic).
+struct RowFetch {
+    float xi[9], xj[9];
+    int n;
+};
+__device__ __forceinline__ void fetch_edge_rows(RowFetch& f, const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P,
+                                                int tile, int ntiles) {
     const int t = threadIdx.x;
-    if (t < kR) {
+    f.n = -1;
+    if (t < kR && tile < ntiles) {
         const int p = t / K, k = t - p * K, n = tile * P + p;
-        const bool valid = p < P && n < N;
-        float v[kES];
-#pragma unroll
-        for (int j = 0; j < kES; ++j) v[j] = 0.f;
-        if (valid) {
+        if (p < P && n < N) {
             const int j = knn[(size_t)n * K + k];
             const float* xi = x9 + (size_t)n * 12;
             const float* xj = x9 + (size_t)j * 12;
 #pragma unroll
+            for (int c = 0; c < 9; ++c) { f.xi[c] = xi[c]; f.xj[c] = xj[c]; }
+            f.n = n;
+        }
+    }
+}
+__device__ __forceinline__ void store_edge_rows(Tile& s, const RowFetch& f, const float* __restrict__ cst) {
+    const int t = threadIdx.x;
+    if (t < kR) {
+        float v[kES];
+#pragma unroll
+        for (int j = 0; j < kES; ++j) v[j] = 0.f;
+        if (f.n >= 0) {
+#pragma unroll
             for (int c = 0; c < 9; ++c) {
-                const float a = xi[c];
-                v[c] = xj[c] - a;
-                v[9 + c] = a;
+                v[c] = f.xj[c] - f.xi[c];
+                v[9 + c] = f.xi[c];
             }
             v[9] -= cst[X0]; v[10] -= cst[X0 + 1]; v[11] -= cst[X0 + 2];
         }
         float4* dst = reinterpret_cast<float4*>(&s.E[t * kES]);
 #pragma unroll
         for (int q = 0; q < kES / 4; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-        s.rown[t] = valid ? n : -1;
+        s.rown[t] = f.n;
     }
 }
 
@@ -119,6 +135,7 @@ __device__ __forceinline__ void conv2_block(const Tile& s, int tr, int tc, float
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+#pragma unroll 2
     for (int k = 0; k < 64; k += 4) {
         float4 h[4], w[4];
 #pragma unroll
@@ -232,7 +249,7 @@ __global__ void k_eb_fold1(const double* __restrict__ partial, int nblocks, doub
 // of y2 over k in the direction of sign(gamma2) + the FIRST k that attains it.  LAYERS == 1: the same for y1 (no sums).
 // ---------------------------------------------------------------------------------------------------------------
 template <int LAYERS>
-__global__ void __launch_bounds__(kThreads) k_eb_forward(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P, int ntiles,
+__global__ void __launch_bounds__(kThreads, 2) k_eb_forward(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P, int ntiles,
                                                          const float* __restrict__ w1, const float* __restrict__ g1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ g2, const float* __restrict__ cst,
                                                          float* __restrict__ ext, uint8_t* __restrict__ argk, double* __restrict__ partial) {
@@ -249,9 +266,12 @@ __global__ void __launch_bounds__(kThreads) k_eb_forward(const float* __restrict
     }
     double sy[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
     const float* gl = LAYERS == 2 ? g2 : g1;
+    RowFetch rf;
+    fetch_edge_rows(rf, x9, knn, N, K, P, blockIdx.x, ntiles);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
-        build_edge_rows(s, x9, knn, N, K, P, tile, cst);
+        store_edge_rows(s, rf, cst);
+        fetch_edge_rows(rf, x9, knn, N, K, P, tile + gridDim.x, ntiles);
         __syncthreads();
         float acc[4][4];
         conv1_block(s, tr, tc, acc);
@@ -396,7 +416,7 @@ __global__ void k_eb_fold3(const double* __restrict__ partial, int nblocks, doub
 // ---------------------------------------------------------------------------------------------------------------
 // pass 3 (layers == 2): dense backward.  Block partials: dW2 [64 x 64] | sum da1 e^T [64 x 20] | sum da1 [64] | sum da1 xhat1 [64]
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kThreads) k_eb_backward(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P, int ntiles,
+__global__ void __launch_bounds__(kThreads, 2) k_eb_backward(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P, int ntiles,
                                                           const float* __restrict__ w1, const float* __restrict__ g1, const float* __restrict__ b1,
                                                           const float* __restrict__ w2, const float* __restrict__ g2, const float* __restrict__ b2,
                                                           const float* __restrict__ cst, const uint8_t* __restrict__ argk, const float* __restrict__ gout,
@@ -404,14 +424,8 @@ __global__ void __launch_bounds__(kThreads) k_eb_backward(const float* __restric
     __shared__ Tile s;
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     stage_weights(s, w1, w2);
-    float mu1[4], inv1[4], sc1[4], sh1[4];                   // columns 4 tc + j
-    float mu2[4], inv2[4], ga2[4], be2[4], db2[4], dg2[4];   // columns tc + 16 j
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = 4 * tc + j, o = tc + 16 * j;
-        mu1[j] = cst[MU1 + c]; inv1[j] = cst[INV1 + c]; sc1[j] = inv1[j] * g1[c]; sh1[j] = b1[c];
-        mu2[j] = cst[MU2 + o]; inv2[j] = cst[INV2 + o]; ga2[j] = g2[o]; be2[j] = b2[o]; db2[j] = cst[DB2 + o]; dg2[j] = cst[DG2 + o];
-    }
+    // the per-channel constants are re-read where they are used (L1-resident, 40 registers otherwise: the kernel has to fit 256 VGPRs
+    // for two workgroups per CU -- with one, every tile waits out its own gathers and barriers)
     double dW2[4][4], gE[5], sda[4], sdx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -423,9 +437,12 @@ __global__ void __launch_bounds__(kThreads) k_eb_backward(const float* __restric
     for (int j = 0; j < 5; ++j) gE[j] = 0.0;
     const int ec = t & 63, eg = t >> 6;                       // sum da1 e^T: channel ec, e-columns 5 eg .. 5 eg + 4
 
+    RowFetch rf;
+    fetch_edge_rows(rf, x9, knn, N, K, P, blockIdx.x, ntiles);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
-        build_edge_rows(s, x9, knn, N, K, P, tile, cst);
+        store_edge_rows(s, rf, cst);
+        fetch_edge_rows(rf, x9, knn, N, K, P, tile + gridDim.x, ntiles);
         if (t < P * 64) {
             const int n = tile * P + (t >> 6);
             s.G[t] = n < N ? gout[(size_t)n * 64 + (t & 63)] : 0.f;
@@ -441,8 +458,10 @@ __global__ void __launch_bounds__(kThreads) k_eb_backward(const float* __restric
             float h[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                xh1[i][j] = (acc[i][j] - mu1[j]) * inv1[j];
-                const float a = (acc[i][j] - mu1[j]) * sc1[j] + sh1[j];     // same expression as the forward pass (bit-equal h1)
+                const int c = 4 * tc + j;
+                const float mu1 = cst[MU1 + c], inv1 = cst[INV1 + c];
+                xh1[i][j] = (acc[i][j] - mu1) * inv1;
+                const float a = (acc[i][j] - mu1) * (inv1 * g1[c]) + b1[c];     // same expression as the forward pass (bit-equal h1)
                 pos1 |= (a > 0.f ? 1u : 0u) << (4 * i + j);
                 h[j] = valid ? lrelu(a) : 0.f;
             }
@@ -458,10 +477,11 @@ __global__ void __launch_bounds__(kThreads) k_eb_backward(const float* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int o = tc + 16 * j;
-                const float xh = (acc[i][j] - mu2[j]) * inv2[j];
+                const float inv2 = cst[INV2 + o], ga2 = g2[o];
+                const float xh = (acc[i][j] - cst[MU2 + o]) * inv2;
                 float da = 0.f;
-                if (valid && s.argk[p * 64 + o] == k) da = s.G[p * 64 + o] * dlrelu(xh * ga2[j] + be2[j]);
-                s.D2[r * kHS + o] = valid ? ga2[j] * inv2[j] * ((da - db2[j]) - xh * dg2[j]) : 0.f;
+                if (valid && s.argk[p * 64 + o] == k) da = s.G[p * 64 + o] * dlrelu(xh * ga2 + b2[o]);
+                s.D2[r * kHS + o] = valid ? ga2 * inv2 * ((da - cst[DB2 + o]) - xh * cst[DG2 + o]) : 0.f;
             }
         }
         __syncthreads();
@@ -472,6 +492,7 @@ __global__ void __launch_bounds__(kThreads) k_eb_backward(const float* __restric
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) w[a][b] = 0.f;
+#pragma unroll 2
             for (int r = 0; r < kR; ++r) {
                 const float4 d = *reinterpret_cast<const float4*>(&s.D2[r * kHS + 4 * tr]);
                 const float4 h = *reinterpret_cast<const float4*>(&s.H1[r * kHS + 4 * tc]);
@@ -492,6 +513,7 @@ __global__ void __launch_bounds__(kThreads) k_eb_backward(const float* __restric
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) da1[i][j] = 0.f;
+#pragma unroll 2
         for (int o = 0; o < 64; o += 4) {
             float4 d[4], w[4];
 #pragma unroll
@@ -527,6 +549,7 @@ __global__ void __launch_bounds__(kThreads) k_eb_backward(const float* __restric
         __syncthreads();
         {
             float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
             for (int r = 0; r < kR; ++r) {
                 const float d = s.D2[r * kHS + ec];
 #pragma unroll
