@@ -699,6 +699,15 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     return SG_OK;
 }
 
+// the edge-feature moments on their own, for the training step's BatchNorm backward (kernels_train_edge.hip): per-block partials
+// [cdiv(N, 256)][189] in edge_moments_body's layout (a | K x_i | D upper | a x_i^T | K x_i x_i^T upper; x_i XYZ relative to row 0)
+int edge_moments_partials(const float* d_x9m, const int32_t* d_knn, int N, int K, double* d_partial, hipStream_t st) {
+    if (N <= 0) return SG_OK;
+    k_edge_moments<<<sg::cdiv(N, 256), 256, 0, st>>>(d_x9m, d_knn, N, K, d_partial);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
 int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mark)(void*, int), void* mark_arg, hipStream_t st) {
     if (bd.nslots == 0 || bd.max_N == 0) return SG_OK;
     const int nblocks = sg::cdiv(sg::cdiv(bd.max_N, 32), kWaves);

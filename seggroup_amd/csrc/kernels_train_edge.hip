@@ -12,7 +12,7 @@
 // dense part has to be carried through explicitly: one dense pass that recomputes conv1 -> h1 -> conv2 per 64-row tile
 // and forms dy2, dW2 += dy2^T h1, dh1 = dy2 W2, da1 = dh1 lrelu'(a1), sum da1 e^T -- then the moment identity above for BN1.
 //
-// Passes (layers == 2):  moments of e -> BN1 statistics | dense forward: BN2 statistics, per (point, channel) the extreme
+// Passes (layers == 2):  moments of e (the forward's own kernel, kernels_edgeconv.hip) -> BN1 statistics | dense forward: BN2 statistics, per (point, channel) the extreme
 // pre-activation over k and its k | elementwise: d beta2, d gamma2 | dense backward | fold.   (layers == 1: the dense
 // forward over conv1 only, then one sparse pass.)
 // Arithmetic: fp32 FMAs on LDS tiles (256 threads, 4x4 register blocks), every reduction across tiles in fp64, block
@@ -161,58 +161,30 @@ __device__ __forceinline__ void store_partial(double* __restrict__ dst, const do
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass 0: moments of the edge features  (block partials: [20*20 | 20] doubles)
+// pass 0: moments of the edge features
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kThreads) k_eb_moments(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P, int ntiles,
-                                                         const float* __restrict__ cst, double* __restrict__ partial) {
-    __shared__ float E[kR * kES];
-    // build_edge_rows works on a Tile; this pass only needs E: a private copy of the row builder keeps its LDS small
+// the forward's structured moments (kernels_edgeconv.hip: per point a = sum_j d_j and D = sum_j d_j d_j^T over its 20 slots, one
+// gather pass, ~6x cheaper than accumulating all 18 x 18 products per row) -> this file's [20 x 20 | 20] layout
+__global__ void k_eb_unpack_moments(const double* __restrict__ m189, double* __restrict__ out) {
     const int t = threadIdx.x;
-    double a0 = 0.0, a1 = 0.0;
-    const int id0 = t, id1 = t + kThreads;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();
-        if (t < kR) {
-            const int p = t / K, k = t - p * K, n = tile * P + p;
-            const bool valid = p < P && n < N;
-            float v[kES];
-#pragma unroll
-            for (int j = 0; j < kES; ++j) v[j] = 0.f;
-            if (valid) {
-                const int j = knn[(size_t)n * K + k];
-                const float* xi = x9 + (size_t)n * 12;
-                const float* xj = x9 + (size_t)j * 12;
-#pragma unroll
-                for (int c = 0; c < 9; ++c) {
-                    const float a = xi[c];
-                    v[c] = xj[c] - a;
-                    v[9 + c] = a;
-                }
-                v[9] -= cst[X0]; v[10] -= cst[X0 + 1]; v[11] -= cst[X0 + 2];
-            }
-#pragma unroll
-            for (int j = 0; j < kES; ++j) E[t * kES + j] = v[j];
-        }
-        __syncthreads();
-        {
-            const int i = id0 / kES, j = id0 - i * kES;                // id0 < 256 < 400: a second moment
-            double a = 0.0;
-            for (int r = 0; r < kR; ++r) a += (double)E[r * kES + i] * (double)E[r * kES + j];
-            a0 += a;
-        }
-        if (id1 < kMom) {
-            double a = 0.0;
-            if (id1 < 400) {
-                const int i = id1 / kES, j = id1 - i * kES;
-                for (int r = 0; r < kR; ++r) a += (double)E[r * kES + i] * (double)E[r * kES + j];
-            } else {
-                for (int r = 0; r < kR; ++r) a += (double)E[r * kES + (id1 - 400)];
-            }
-            a1 += a;
+    if (t >= kMom) return;
+    auto tri = [](int k, int l) {                               // index of (k <= l) in a 9 x 9 upper triangle stored row by row
+        return k * 9 - k * (k - 1) / 2 + (l - k);
+    };
+    double v = 0.0;
+    if (t >= 400) {
+        const int i = t - 400;
+        v = i < 18 ? m189[i] : 0.0;                              // [a | K x_i]
+    } else {
+        const int i = t / kES, j = t - i * kES;
+        if (i < 18 && j < 18) {
+            if (i < 9 && j < 9) v = m189[18 + tri(min(i, j), max(i, j))];            // d d^T
+            else if (i < 9) v = m189[63 + 9 * i + (j - 9)];                           // d x^T
+            else if (j < 9) v = m189[63 + 9 * j + (i - 9)];                           // x d^T
+            else v = m189[144 + tri(min(i, j) - 9, max(i, j) - 9)];                    // x x^T
         }
     }
-    partial[(size_t)blockIdx.x * kMom + id0] = a0;
-    if (id1 < kMom) partial[(size_t)blockIdx.x * kMom + id1] = a1;
+    out[t] = v;
 }
 
 // BN1 statistics from the moments: mu1 = W1 m, var1 = w^T Cov w  (fp64).  mom_out keeps the reduced moments for the fold.
@@ -670,8 +642,14 @@ int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k,
     const int P = std::min(kR / k, 4), ntiles = sg::cdiv(N, P), nb = eb_blocks(ntiles);
     const double rows = (double)N * (double)k;
     k_eb_init<<<1, 64, 0, st>>>(d_x9m, cst);
-    k_eb_moments<<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, cst, partial);
-    if (int rc = sg::reduce_partials(partial, nb, kMom, kMom, red, st)) return rc;
+    {
+        const int mb = sg::cdiv(N, 256);
+        double* m189 = red + kMom;                               // red has kPart3 doubles
+        SG_REQUIRE((size_t)mb * 189 <= 512 * (size_t)kPart3, "sg_edgeconv_backward: partial buffer");
+        if (int rc = sg::edge_moments_partials(d_x9m, d_knn, N, k, partial, st)) return rc;
+        if (int rc = sg::reduce_partials(partial, mb, 189, 189, m189, st)) return rc;
+        k_eb_unpack_moments<<<1, 512, 0, st>>>(m189, red);
+    }
     k_eb_fold1<<<1, 256, 0, st>>>(red, 1, rows, d_w1, cst, mom, d_bn_stats);
     const int nb2 = std::max(1, std::min(sg::cdiv(N, 4), 1024));
     if (layers == 1) {

@@ -63,6 +63,7 @@ int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_o
 int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, const int32_t* d_rowptr, const int32_t* d_col,
                    const int32_t* d_eid, const float* d_wt, float alpha, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
 
+int edge_moments_partials(const float* d_x9m, const int32_t* d_knn, int N, int K, double* d_partial, hipStream_t st);   // kernels_edgeconv.hip, [cdiv(N,256)][189]
 int reduce_partials(const double* d_partial, int nblocks, int stride, int count, double* d_out, hipStream_t st);   // kernels_train_edge.hip
 int transpose_square(const float* d_src, float* d_dst, int D, hipStream_t st);      // kernels_train.hip
 
