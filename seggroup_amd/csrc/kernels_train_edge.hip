@@ -14,7 +14,7 @@
 //
 // Passes (layers == 2):  moments of e (the forward's own kernel, kernels_edgeconv.hip) -> BN1 statistics | dense forward: BN2 statistics, per (point, channel) the extreme
 // pre-activation over k and its k | elementwise: d beta2, d gamma2 | dense backward | fold.   (layers == 1: the dense
-// forward over conv1 only, then one sparse pass.)
+// sparse pass only -- k_eb_sparse1.)
 // Arithmetic: fp32 FMAs on LDS tiles (256 threads, 4x4 register blocks), every reduction across tiles in fp64, block
 // partials reduced in a fixed order (deterministic).  Conditioning: the XYZ of the x_i half is taken relative to row 0
 // (BatchNorm is invariant to that shift, and sum_r dy[r] = 0 makes dW invariant too), like the forward kernels.
@@ -372,6 +372,78 @@ __global__ void __launch_bounds__(kThreads) k_eb_last_bn(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// layers == 1 (MLP2) needs no dense pass at all: the output gradient is nonzero on at most C x 64 (point, channel) pairs (the
+// arg-maxima of the point -> cluster max), and for such a pair the 20 pre-activations of the point are recomputed on the spot:
+// one wave per point, lane = channel (its weight row in registers), the point's 20 edge rows in LDS.  Points without gradient
+// (three quarters of them) cost one load.  Block partials as k_eb_last_bn<1>: [d beta 64 | d gamma 64 | sum da e^T 64 x 20].
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_eb_sparse1(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K,
+                                                         const float* __restrict__ w1, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ cst, const float* __restrict__ gout, double* __restrict__ partial) {
+    __shared__ float E[4][32][kES];
+    __shared__ double red[4 * 64];
+    const int t = threadIdx.x, p = t >> 6, o = t & 63;
+    const float mu = cst[MU1 + o], inv = cst[INV1 + o], g = gamma[o], b = beta[o];
+    const float x0[3] = {cst[X0], cst[X0 + 1], cst[X0 + 2]};
+    float w[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) w[j] = w1[o * 18 + j];
+    double sdb = 0.0, sdg = 0.0, ge[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) ge[j] = 0.0;
+    for (int n = blockIdx.x * 4 + p; n < N; n += gridDim.x * 4) {            // wave-uniform: one point per wave and iteration
+        const float go = gout[(size_t)n * 64 + o];
+        if (!__any(go != 0.f)) continue;
+        __builtin_amdgcn_wave_barrier();
+        if (o < K) {
+            const int j = knn[(size_t)n * K + o];
+            const float* xi = x9 + (size_t)n * 12;
+            const float* xj = x9 + (size_t)j * 12;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const float a = xi[c];
+                E[p][o][c] = xj[c] - a;
+                E[p][o][9 + c] = c < 3 ? a - x0[c] : a;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (go != 0.f) {
+            float best = 0.f;
+            int bk = 0;
+            for (int k = 0; k < (g == 0.f ? 1 : K); ++k) {                   // gamma == 0: every row ties, torch.max keeps the first
+                float y = 0.f;
+#pragma unroll
+                for (int j = 0; j < 18; ++j) y = fmaf(E[p][k][j], w[j], y);
+                if (k == 0 || (g >= 0.f ? y > best : y < best)) { best = y; bk = k; }
+            }
+            const float xh = (best - mu) * inv;
+            const float d = go * dlrelu(xh * g + b);
+            sdb += (double)d;
+            sdg += (double)d * (double)xh;
+#pragma unroll
+            for (int j = 0; j < 18; ++j) ge[j] += (double)d * (double)E[p][bk][j];
+        }
+    }
+    double* dst = partial + (size_t)blockIdx.x * (128 + 64 * kES);
+#pragma unroll 1
+    for (int q = 0; q < 20; ++q) {
+        __syncthreads();
+        double v = q == 0 ? sdb : q == 1 ? sdg : 0.0;
+        if (q >= 2) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) v = (q - 2 == j) ? ge[j] : v;
+        }
+        red[p * 64 + o] = v;
+        __syncthreads();
+        if (t < 64) {
+            const double a = ((red[t] + red[64 + t]) + red[128 + t]) + red[192 + t];
+            if (q < 2) dst[q * 64 + t] = a;
+            else dst[128 + t * kES + (q - 2)] = a;
+        }
+    }
+}
+
 // d beta2, d gamma2 -> outputs + the per-row constants of the dense backward (mean terms of BN2's backward)
 __global__ void k_eb_fold3(const double* __restrict__ partial, int nblocks, double rows, float* __restrict__ cst, float* __restrict__ gg2,
                            float* __restrict__ gb2) {
@@ -653,10 +725,9 @@ int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k,
     k_eb_fold1<<<1, 256, 0, st>>>(red, 1, rows, d_w1, cst, mom, d_bn_stats);
     const int nb2 = std::max(1, std::min(sg::cdiv(N, 4), 1024));
     if (layers == 1) {
-        k_eb_forward<1><<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, nullptr, nullptr, cst, ext, argk, partial);
         const int stride = 128 + 64 * kES;
         SG_REQUIRE((size_t)nb2 * stride <= 512 * (size_t)kPart3, "sg_edgeconv_backward: partial buffer");
-        k_eb_last_bn<1><<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_g1, d_b1, cst, ext, argk, d_gout, partial);
+        k_eb_sparse1<<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_w1, d_g1, d_b1, cst, d_gout, partial);
         if (int rc = sg::reduce_partials(partial, nb2, stride, stride, red, st)) return rc;
         k_eb_final<<<1, 1024, 0, st>>>(red, 1, stride, 128, 0, 1, rows, mom, d_w1, d_g1, cst, d_gw1, d_gg1, d_gb1, nullptr);
     } else {
