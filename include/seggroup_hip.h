@@ -603,14 +603,16 @@ int sg_mlp1_backward(const float* d_samples, int C, const float* d_w, const floa
  *   d_x9m [N,12], d_knn [N,k]   as for the forward call
  *   d_gout [N,64]               gradient w.r.t. the op's OUTPUT (the post-activation max over k), e.g. from sg_segment_max_backward
  *   d_gw1 [64,18] d_gg1 d_gb1 [64]; layers == 2: d_gw2 [64,64] d_gg2 d_gb2 [64]
+ *   d_bn2_in [128] or NULL      layers == 2: batch mean | biased variance of the SECOND BatchNorm's input as the forward computed
+ *                               them (sg_trainer's tape); given, the dense forward pass that would recompute them is skipped
  *   d_bn_stats [256] or NULL    batch mean1 | biased var1 | mean2 | var2 (for the running-statistics update, momentum 0.1)
  * BatchNorm2d is differentiated WITH its batch statistics over all N*k rows (training mode).  Deterministic (ordered fp64
  * reductions).  d_ws needs sg_edgeconv_backward_ws_bytes(N). */
 size_t sg_edgeconv_backward_ws_bytes(int N);
 int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
                          const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, const float* d_gout, float* d_gw1,
-                         float* d_gg1, float* d_gb1, float* d_gw2, float* d_gg2, float* d_gb2, float* d_bn_stats, void* d_ws,
-                         size_t ws_bytes, void* stream);
+                         float* d_gg1, float* d_gb1, float* d_gw2, float* d_gg2, float* d_gb2, const float* d_bn2_in, float* d_bn_stats,
+                         void* d_ws, size_t ws_bytes, void* stream);
 
 /* cross_entropy_loss (util.py:12-29) on its own: sum over the K rows of -sum_c t_c log softmax(logits)_c with the smoothed target
  * (0.8 on the gold class, 0.2 / (C - 1) elsewhere) or, smoothing == 0, the one-hot target.  d_prob [K,C] receives the softmax

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(1024) void k_bn_fold_moments_b(const sg::SlotCtx* _
 // eight group sums are added in a fixed order, so the result does not depend on scheduling.
 __device__ __forceinline__ void bn_fold_body(const double* __restrict__ partial, int nblocks, double rows,
                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                             float* __restrict__ a_out, float* __restrict__ shift) {
+                                             float* __restrict__ a_out, float* __restrict__ shift, float* __restrict__ stats = nullptr) {
     __shared__ double part[8][128];
     __shared__ double tot[128];
     const int v = threadIdx.x & 127, g = threadIdx.x >> 7;
@@ -608,12 +608,16 @@ __device__ __forceinline__ void bn_fold_body(const double* __restrict__ partial,
         const double a = fabs((double)gamma[ch]) / sqrt(var + 1e-5);
         a_out[ch] = (float)a;
         shift[ch] = (float)((double)beta[ch] - a * mean);
+        if (stats) {                                              // batch mean of y itself | biased variance (the training step's tape)
+            stats[ch] = (float)(gamma[ch] < 0.f ? -mean : mean);
+            stats[64 + ch] = (float)var;
+        }
     }
 }
 __global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ partial, int nblocks, double rows,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  float* __restrict__ a_out, float* __restrict__ shift) {
-    bn_fold_body(partial, nblocks, rows, gamma, beta, a_out, shift);
+                                                  float* __restrict__ a_out, float* __restrict__ shift, float* __restrict__ stats) {
+    bn_fold_body(partial, nblocks, rows, gamma, beta, a_out, shift, stats);
 }
 // layers == 1: MLP2's only BN (-> ec_w1f = |a|, ec_sh1); layers == 2: MLP3's last BN (-> ec_w2f, ec_sh2)
 __global__ __launch_bounds__(1024) void k_bn_fold_b(const sg::SlotCtx* __restrict__ cx, int layers) {
@@ -660,17 +664,18 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
                             const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
                             size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine) {
     SG_REQUIRE(N >= 0 && k > 0 && (layers == 1 || layers == 2) && d_ws, "sg_edgeconv_forward: bad arguments");
-    if (d_affine) { d_affine[0] = nullptr; d_affine[1] = nullptr; }
+    if (d_affine) { d_affine[0] = nullptr; d_affine[1] = nullptr; d_affine[2] = nullptr; }
     if (N == 0) return SG_OK;
     const int nblocks = sg::cdiv(sg::cdiv(N, 32), kWaves);
     sg::Carver cv(d_ws, ws_bytes);
     double* partial = cv.take<double>(std::max((size_t)nblocks * 128, (size_t)sg::cdiv(N, 256) * kMom));
-    float* fold = cv.take<float>(64 * 18 + 64 + 64 * 64 + 64);
+    float* fold = cv.take<float>(64 * 18 + 64 + 64 * 64 + 64 + 128);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_edgeconv_forward: workspace too small (%zu < %zu)", ws_bytes, sg_edgeconv_ws_bytes(N));
     float* w1f = fold;
     float* sh1 = w1f + 64 * 18;
     float* w2f = sh1 + 64;
     float* sh2 = w2f + 64 * 64;
+    float* stats_last = sh2 + 64;                                // batch mean | variance of the LAST BatchNorm's input
     hipStream_t st = sg::as_stream(stream);
     const double rows = (double)N * (double)k;
     const dim3 grid(nblocks), block(64 * kWaves);
@@ -678,9 +683,9 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     const int egrid = (int)std::min<size_t>((n4 + 255) / 256, 2048);
     if (layers == 1) {
         k_edgeconv<S1X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, d_g1, d_out, partial);
-        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, w1f, sh1);
+        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, w1f, sh1, stats_last);
         if (mark) mark(0);
-        if (d_affine) { d_affine[0] = w1f; d_affine[1] = sh1; }        // the caller applies LReLU(|a| E + b') where it consumes E
+        if (d_affine) { d_affine[0] = w1f; d_affine[1] = sh1; d_affine[2] = stats_last; }        // the caller applies LReLU(|a| E + b') where it consumes E
         else k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w1f, sh1);
         if (mark) mark(1);
     } else {
@@ -689,9 +694,9 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
         k_bn_fold_moments<<<1, 1024, 0, st>>>(partial, mblocks, rows, d_g1, d_b1, d_w1, w1f, sh1);
         if (mark) mark(0);
         k_edgeconv<S2X, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, d_w2, d_g2, d_out, partial);
-        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, w2f, sh2);
+        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, w2f, sh2, stats_last);
         if (mark) mark(1);
-        if (d_affine) { d_affine[0] = w2f; d_affine[1] = sh2; }
+        if (d_affine) { d_affine[0] = w2f; d_affine[1] = sh2; d_affine[2] = stats_last; }
         else k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w2f, sh2);
         if (mark) mark(2);
     }
@@ -735,7 +740,7 @@ extern "C" {
 size_t sg_edgeconv_ws_bytes(int N) {
     const size_t nblocks = (size_t)sg::cdiv(sg::cdiv(std::max(N, 1), 32), kWaves);
     const size_t mblocks = (size_t)sg::cdiv(std::max(N, 1), 256);
-    return sg::align_up(std::max(nblocks * 128, mblocks * 189) * 8) + sg::align_up((64 * 18 + 64 + 64 * 64 + 64) * 4);
+    return sg::align_up(std::max(nblocks * 128, mblocks * 189) * 8) + sg::align_up((64 * 18 + 64 + 64 * 64 + 64 + 128) * 4);
 }
 
 int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,

@@ -444,6 +444,92 @@ __global__ void __launch_bounds__(kThreads) k_eb_sparse1(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// layers == 2 with the forward's BN2 statistics at hand (the training step's tape): the dense FORWARD pass is not needed -- what
+// it produced is only read at (point, channel) pairs that carry gradient.  One wave per such point: its 20 edge rows and
+// h1 = LReLU(BN1(conv1)) [20 x 64] in LDS, then every lane whose channel carries gradient evaluates its 20 conv2 outputs (same
+// FMA order as the dense kernels: bit-equal y2), takes the extreme in the direction of sign(gamma2) and its first k.
+// Writes argk for those pairs (the dense backward reads nothing else) and block partials [d beta2 64 | d gamma2 64].
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_eb_sparse2(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K,
+                                                         const float* __restrict__ w1, const float* __restrict__ g1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ g2, const float* __restrict__ b2,
+                                                         const float* __restrict__ cst, const float* __restrict__ gout, uint8_t* __restrict__ argk,
+                                                         double* __restrict__ partial) {
+    __shared__ float E[4][32][kES];
+    __shared__ float H[4][32][64];
+    __shared__ double red[4 * 64];
+    const int t = threadIdx.x, p = t >> 6, o = t & 63;
+    const float mu1 = cst[MU1 + o], sc1 = cst[INV1 + o] * g1[o], sh1 = b1[o];
+    const float mu2 = cst[MU2 + o], inv2 = cst[INV2 + o], ga2 = g2[o], be2 = b2[o];
+    const float x0[3] = {cst[X0], cst[X0 + 1], cst[X0 + 2]};
+    float w[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) w[j] = w1[o * 18 + j];
+    double sdb = 0.0, sdg = 0.0;
+    for (int n = blockIdx.x * 4 + p; n < N; n += gridDim.x * 4) {            // wave-uniform: one point per wave and iteration
+        const float go = gout[(size_t)n * 64 + o];
+        if (!__any(go != 0.f)) continue;
+        __builtin_amdgcn_wave_barrier();
+        if (o < K) {
+            const int j = knn[(size_t)n * K + o];
+            const float* xi = x9 + (size_t)n * 12;
+            const float* xj = x9 + (size_t)j * 12;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const float a = xi[c];
+                E[p][o][c] = xj[c] - a;
+                E[p][o][9 + c] = c < 3 ? a - x0[c] : a;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < K; ++k) {                                        // h1[k][o], the dense kernels' expression and FMA order
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < 18; ++j) y = fmaf(E[p][k][j], w[j], y);
+            H[p][k][o] = lrelu((y - mu1) * sc1 + sh1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (go != 0.f) {
+            float best = 0.f;
+            int bk = 0;
+            const float4* wr = reinterpret_cast<const float4*>(w2 + (size_t)o * 64);
+            for (int k = 0; k < (ga2 == 0.f ? 1 : K); ++k) {
+                float y = 0.f;
+#pragma unroll 4
+                for (int c = 0; c < 16; ++c) {
+                    const float4 wv = wr[c];
+                    const float4 hv = *reinterpret_cast<const float4*>(&H[p][k][4 * c]);
+                    y = fmaf(hv.w, wv.w, fmaf(hv.z, wv.z, fmaf(hv.y, wv.y, fmaf(hv.x, wv.x, y))));
+                }
+                if (k == 0 || (ga2 >= 0.f ? y > best : y < best)) { best = y; bk = k; }
+            }
+            argk[(size_t)n * 64 + o] = (uint8_t)bk;
+            const float xh = (best - mu2) * inv2;
+            const float d = go * dlrelu(xh * ga2 + be2);
+            sdb += (double)d;
+            sdg += (double)d * (double)xh;
+        }
+    }
+    double* dst = partial + (size_t)blockIdx.x * 128;
+#pragma unroll 1
+    for (int q = 0; q < 2; ++q) {
+        __syncthreads();
+        red[p * 64 + o] = q ? sdg : sdb;
+        __syncthreads();
+        if (t < 64) dst[q * 64 + t] = ((red[t] + red[64 + t]) + red[128 + t]) + red[192 + t];
+    }
+}
+
+// BN2 statistics handed in (batch mean | biased variance) -> the constants the passes share
+__global__ void k_eb_set_bn2(const float* __restrict__ stats_in, float* __restrict__ cst, float* __restrict__ stats_out) {
+    const int c = threadIdx.x;
+    if (c >= 64) return;
+    cst[MU2 + c] = stats_in[c];
+    cst[INV2 + c] = (float)(1.0 / sqrt((double)stats_in[64 + c] + kBnEps));
+    if (stats_out) { stats_out[128 + c] = stats_in[c]; stats_out[192 + c] = stats_in[64 + c]; }
+}
+
 // d beta2, d gamma2 -> outputs + the per-row constants of the dense backward (mean terms of BN2's backward)
 __global__ void k_eb_fold3(const double* __restrict__ partial, int nblocks, double rows, float* __restrict__ cst, float* __restrict__ gg2,
                            float* __restrict__ gb2) {
@@ -698,7 +784,7 @@ size_t sg_edgeconv_backward_ws_bytes(int N) {
 
 int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1, const float* d_b1,
                          const float* d_w2, const float* d_g2, const float* d_b2, const float* d_gout, float* d_gw1, float* d_gg1, float* d_gb1,
-                         float* d_gw2, float* d_gg2, float* d_gb2, float* d_bn_stats, void* d_ws, size_t ws_bytes, void* stream) {
+                         float* d_gw2, float* d_gg2, float* d_gb2, const float* d_bn2_in, float* d_bn_stats, void* d_ws, size_t ws_bytes, void* stream) {
     SG_REQUIRE(N > 0 && k > 0 && k <= 32 && (layers == 1 || layers == 2) && d_x9m && d_knn && d_w1 && d_g1 && d_b1 && d_gout && d_gw1 && d_gg1 && d_gb1 && d_ws,
                "sg_edgeconv_backward: bad arguments (k = %d must be <= 32)", k);
     SG_REQUIRE(layers == 1 || (d_w2 && d_g2 && d_b2 && d_gw2 && d_gg2 && d_gb2), "sg_edgeconv_backward: layers == 2 needs the second conv's tensors");
@@ -731,10 +817,16 @@ int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k,
         if (int rc = sg::reduce_partials(partial, nb2, stride, stride, red, st)) return rc;
         k_eb_final<<<1, 1024, 0, st>>>(red, 1, stride, 128, 0, 1, rows, mom, d_w1, d_g1, cst, d_gw1, d_gg1, d_gb1, nullptr);
     } else {
-        k_eb_forward<2><<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, cst, ext, argk, partial);
-        if (int rc = sg::reduce_partials(partial, nb, 128, 128, red, st)) return rc;
-        k_eb_fold2<<<1, 64, 0, st>>>(red, 1, rows, cst, d_bn_stats);
-        k_eb_last_bn<2><<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_g2, d_b2, cst, ext, argk, d_gout, partial);
+        if (d_bn2_in) {
+            // the forward's BN2 statistics are at hand (the training step's tape): no dense forward pass
+            k_eb_set_bn2<<<1, 64, 0, st>>>(d_bn2_in, cst, d_bn_stats);
+            k_eb_sparse2<<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, cst, d_gout, argk, partial);
+        } else {
+            k_eb_forward<2><<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, cst, ext, argk, partial);
+            if (int rc = sg::reduce_partials(partial, nb, 128, 128, red, st)) return rc;
+            k_eb_fold2<<<1, 64, 0, st>>>(red, 1, rows, cst, d_bn_stats);
+            k_eb_last_bn<2><<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_g2, d_b2, cst, ext, argk, d_gout, partial);
+        }
         if (int rc = sg::reduce_partials(partial, nb2, 128, 128, red, st)) return rc;
         k_eb_fold3<<<1, 64, 0, st>>>(red, 1, rows, cst, d_gg2, d_gb2);
         k_eb_backward<<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, cst, argk, d_gout, partial);

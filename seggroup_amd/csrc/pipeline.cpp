@@ -426,7 +426,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             const int sub0 = layer == 0 ? 19 : 21;
             auto mark_pass = [&](int i) { pl->mark(sub0 + i); };
             // pf = pre-activation maxima; the last BN + LeakyReLU is applied inside the segment max (affine[0..1] = |a|, b')
-            const float* affine[2];
+            const float* affine[3];
             if (layer == 0)
                 PL_CHECK(sg::edgeconv_forward_marked(pl->x9m.p, pl->knn.p, N, 20, 1, W + pl->o_m2w, W + pl->o_m2g, W + pl->o_m2b, nullptr,
                                                      nullptr, nullptr, pl->pf.p, pl->ws_edge.p, pl->ws_edge.n, stv, mark_pass, affine));
@@ -461,6 +461,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                 PL_HIP(hipMemcpyAsync(TL.desc.p, pl->desc.p, o.total * 4, hipMemcpyDeviceToDevice, st));
                 PL_HIP(hipMemcpyAsync(TL.cat.p, cat, (size_t)C * Dcat * 4, hipMemcpyDeviceToDevice, st));
                 PL_HIP(hipMemcpyAsync(TL.gcn.p, gcn_out, (size_t)C * Dcat * 4, hipMemcpyDeviceToDevice, st));
+                PL_HIP(hipMemcpyAsync(TL.bn_last.p, affine[2], 128 * 4, hipMemcpyDeviceToDevice, st));
             }
             pl->mark(sb + 5);
             lap(4);

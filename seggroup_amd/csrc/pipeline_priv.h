@@ -112,6 +112,7 @@ struct DescOffsets {
 struct sg_tape {
     struct Layer {
         sgp::DevBuf<float> x9m, pf, cat, gcn;      // [N,12] centred rows | [N,64] pre-activation extremes | [C,Dcat] GCN input | [C,Dcat] GCN output
+        sgp::DevBuf<float> bn_last;                // [128] batch mean | variance of the EdgeConv stack's last BatchNorm (from the forward's fold)
         sgp::DevBuf<int32_t> knn, desc;            // [N,20] | the layer's descriptor block (offsets in `o`)
         sgp::DescOffsets o;
         int C = 0, Cprev = 0, Dcat = 0, Dprev = 0, E = 0;

@@ -50,7 +50,7 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
                             const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
                             size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine);
 // d_affine != nullptr: the last BatchNorm + LeakyReLU is NOT applied; d_out holds E = max_k sgn(gamma) y_k and
-// d_affine[0..1] receive the device pointers of |a| [64] and b' [64] (inside d_ws) for a consumer that applies
+// d_affine[0..2] receive the device pointers of |a| [64], b' [64] and the last BatchNorm's batch mean | variance [128] (inside d_ws) for a consumer that applies
 // LReLU(|a| E + b') itself (segment_max_prefilled does); edgeconv_apply is the epilogue on its own.
 int edgeconv_apply(const float* d_e, int N, const float* d_a, const float* d_shift, float* d_dst, void* stream);
 

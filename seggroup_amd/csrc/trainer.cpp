@@ -84,7 +84,7 @@ sg_trainer* sg_trainer_create(int maxN, int maxS, int maxE, int maxV, float* d_p
     int bad = 0;
     const size_t N = maxN, S = maxS;
     for (sg_tape::Layer& L : tr->tape.layer) {
-        bad |= L.x9m.alloc(N * 12) | L.pf.alloc(N * 64) | L.knn.alloc(N * 20) | L.desc.alloc(tr->pl->desc.n) | L.cat.alloc(S * 256) | L.gcn.alloc(S * 256);
+        bad |= L.x9m.alloc(N * 12) | L.pf.alloc(N * 64) | L.knn.alloc(N * 20) | L.desc.alloc(tr->pl->desc.n) | L.cat.alloc(S * 256) | L.gcn.alloc(S * 256) | L.bn_last.alloc(128);
     }
     const size_t maxE1 = tr->pl->adj1.n / 2;
     bad |= tr->feat5.alloc(S * 256) | tr->g_feat5.alloc(S * 256) | tr->gA.alloc(S * 256) | tr->gB.alloc(S * 256) | tr->gC.alloc(S * 256) | tr->g_pf.alloc(N * 64);
@@ -196,7 +196,7 @@ int sg_trainer_backward(sg_trainer* tr, const float* d_keep, float scale) {
         TR_CHECK(sg_group_max_rows_backward(L0.gcn.p, 192, 192, dd + o.goff, dd + o.gidx, L1.C, tr->gB.p, 256, tr->gC.p, 192, sv));
         TR_CHECK(sg_segment_max_backward(L1.pf.p, N, 64, dd + o.cl_pt_off, L1.C, tr->gB.p + 192, 256, tr->g_pf.p, tr->ws_seg.p, tr->ws_seg.n, sv));
         TR_CHECK(sg_edgeconv_backward(L1.x9m.p, L1.knn.p, N, 20, 2, tr->P(M3W1), tr->P(M3G1), tr->P(M3B1), tr->P(M3W2), tr->P(M3G2), tr->P(M3B2), tr->g_pf.p,
-                                      tr->G(M3W1), tr->G(M3G1), tr->G(M3B1), tr->G(M3W2), tr->G(M3G2), tr->G(M3B2), tr->bn.p + 256, tr->ws_edge.p, tr->ws_edge.n, sv));
+                                      tr->G(M3W1), tr->G(M3G1), tr->G(M3B1), tr->G(M3W2), tr->G(M3G2), tr->G(M3B2), L1.bn_last.p, tr->bn.p + 256, tr->ws_edge.p, tr->ws_edge.n, sv));
     }
     // ---- semantic layer 1 (GCN_2, MLP2) ----
     {
@@ -207,7 +207,7 @@ int sg_trainer_backward(sg_trainer* tr, const float* d_keep, float scale) {
         TR_CHECK(sg_group_max_rows_backward(pl->feat1.p, 128, 128, dd + o.goff, dd + o.gidx, L0.C, tr->gB.p, 192, tr->gA.p, 128, sv));
         TR_CHECK(sg_segment_max_backward(L0.pf.p, N, 64, dd + o.cl_pt_off, L0.C, tr->gB.p + 128, 192, tr->g_pf.p, tr->ws_seg.p, tr->ws_seg.n, sv));
         TR_CHECK(sg_edgeconv_backward(L0.x9m.p, L0.knn.p, N, 20, 1, tr->P(M2W), tr->P(M2G), tr->P(M2B), nullptr, nullptr, nullptr, tr->g_pf.p, tr->G(M2W),
-                                      tr->G(M2G), tr->G(M2B), nullptr, nullptr, nullptr, tr->bn.p + 128, tr->ws_edge.p, tr->ws_edge.n, sv));
+                                      tr->G(M2G), tr->G(M2B), nullptr, nullptr, nullptr, nullptr, tr->bn.p + 128, tr->ws_edge.p, tr->ws_edge.n, sv));
     }
     // ---- structural layer (MLP1) ----
     TR_CHECK(sg_mlp1_backward(pl->samples.p, S, tr->P(M1W), tr->P(M1G), tr->P(M1B), tr->gA.p, 128, tr->G(M1W), tr->G(M1G), tr->G(M1B), tr->bn.p, tr->ws_mlp1.p,

@@ -534,9 +534,10 @@ def mlp1_backward(x, grad_feat, conv_w, bn_w, bn_b):
     return out
 
 
-def edgeconv_backward(x, idx, grad_out, w1, g1, b1, w2=None, g2=None, b2=None):
+def edgeconv_backward(x, idx, grad_out, w1, g1, b1, w2=None, g2=None, b2=None, bn2_stats=None):
     """Parameter gradients of `edgeconv_forward` (MLP2 / MLP3 with batch-statistics BatchNorm2d, model.py:83-138):
-    x [1,9,N], idx [1,N,k], grad_out [1,64,N] -> dict(w1 [64,18], g1, b1[, w2 [64,64], g2, b2], bn_stats [256])."""
+    x [1,9,N], idx [1,N,k], grad_out [1,64,N] -> dict(w1 [64,18], g1, b1[, w2 [64,64], g2, b2], bn_stats [256]).
+    bn2_stats [128] (MLP3 only): the second BatchNorm's batch mean | variance from the forward; given, no dense forward pass is made."""
     _need_cuda(x, "x")
     lib = hip.lib()
     dev = x.device
@@ -551,11 +552,14 @@ def edgeconv_backward(x, idx, grad_out, w1, g1, b1, w2=None, g2=None, b2=None):
            "bn_stats": torch.zeros(256, device=dev)}
     if two:
         out.update(w2=torch.empty((64, 64), device=dev), g2=torch.empty(64, device=dev), b2=torch.empty(64, device=dev))
+    if bn2_stats is not None:
+        bn2_stats = bn2_stats.contiguous().float()
     ws = _ws(lib.sg_edgeconv_backward_ws_bytes(N), dev)
     hip.check(lib.sg_edgeconv_backward(x12.data_ptr(), knn_.data_ptr(), N, k, 2 if two else 1, *[None if t is None else t.data_ptr() for t in keep],
                                        go.data_ptr(), out["w1"].data_ptr(), out["g1"].data_ptr(), out["b1"].data_ptr(),
                                        out["w2"].data_ptr() if two else None, out["g2"].data_ptr() if two else None,
-                                       out["b2"].data_ptr() if two else None, out["bn_stats"].data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+                                       out["b2"].data_ptr() if two else None, hip.ptr(bn2_stats), out["bn_stats"].data_ptr(), ws.data_ptr(), ws.numel(),
+                                       _stream()))
     return out
 
 

@@ -128,7 +128,7 @@ SIGNATURES = {
     "sg_mlp1_backward_ws_bytes": (_Z, [_I]),
     "sg_mlp1_backward": (_I, [vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_edgeconv_backward_ws_bytes": (_Z, [_I]),
-    "sg_edgeconv_backward": (_I, [vp, vp, _I, _I, _I] + [vp] * 14 + [vp, _Z, vp]),
+    "sg_edgeconv_backward": (_I, [vp, vp, _I, _I, _I] + [vp] * 15 + [vp, _Z, vp]),
     "sg_parse_seg_json": (_I, [C.c_char_p, _I, vp]),
     "sg_stage_segments": (_I, [vp, _I, _I, vp, vp, vp, vp]),
     "sg_edgeconv_ws_bytes": (_Z, [_I]),

@@ -190,6 +190,13 @@ def test_edgeconv_backward_matches_autograd(layers, N, K, offset):
         have = got[k].cpu().numpy().astype(np.float64)
         scale = np.abs(want).max()
         assert np.abs(have - want).max() <= 2e-4 * scale, (k, np.abs(have - want).max() / scale)
+    if layers == 2:
+        # the same with the second BatchNorm's statistics handed in (the training step's tape): no dense forward pass, same gradients
+        bn2 = torch.cat([stats[1][0].detach(), stats[1][1].detach()]).float().to(dev)
+        again = F.edgeconv_backward(t(x9.T[None]), t(knn[None]), t(gout.T[None]), *[t(W[k]) for k in ("w1", "g1", "b1", "w2", "g2", "b2")], bn2_stats=bn2)
+        for k in ("w1", "g1", "b1", "w2", "g2", "b2"):
+            want = P[k].grad.numpy()
+            assert np.abs(again[k].cpu().numpy().astype(np.float64) - want).max() <= 2e-4 * np.abs(want).max(), ("bn2 handed in", k)
     bs = got["bn_stats"].cpu().numpy()
     assert np.abs(bs[:64] - stats[0][0].detach().numpy()).max() < 1e-4 * max(1.0, abs(offset))
     assert np.abs(bs[64:128] - stats[0][1].detach().numpy()).max() < 1e-4 * np.abs(stats[0][1].detach().numpy()).max()
