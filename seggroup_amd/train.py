@@ -49,6 +49,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--port', type=int, default=23456, help='rendezvous port on 127.0.0.1 (reference: 23456)')
     p.add_argument('--max-steps', type=int, default=0, help='stop every epoch after this many steps per rank (0 = the whole scene list)')
     p.add_argument('--no-cache', action='store_true', help='do not build / use packed scene files (dataset/scannet/cache/...)')
+    p.add_argument('--param-digests', action='store_true', help='every rank writes sha256 of its final parameter vector to '
+                   'checkpoints/<exp>/models/rank<r>.sha256 (the ranks must agree: same averaged gradient, same optimizer)')
     return p
 
 
@@ -261,6 +263,12 @@ def run_worker(rank: int, world: int, args, make_trainer: Optional[Callable] = N
     pool.shutdown()
     if writer is not None:
         writer.close()
+    if args.param_digests and hasattr(tr, "params"):
+        import hashlib
+        d = os.path.join(args.root, 'checkpoints', args.exp_name, 'models')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'rank%d.sha256' % rank), 'w') as f:
+            f.write(hashlib.sha256(tr.params.detach().cpu().numpy().tobytes()).hexdigest() + '\n')
     if rank == 0:
         io.close()
     if world > 1 and init_dist:

@@ -489,3 +489,43 @@ def test_single_instance_scene_is_refused_like_the_reference(golden_index, weigh
     tr.forward(DeviceScene.from_synthetic(scene, device="cuda:0"))
     assert np.isfinite(tr.loss(tr.dropout_mask("pinned"))[0, 0])
     tr.close()
+
+
+def _two_rank_worker(rank, world, root, port):
+    import sys
+    sys.path.insert(0, ROOT_DIR)
+    from seggroup_amd import train
+    args = train.build_parser().parse_args(["-n", "ddp", "--root", root, "--epochs", "1", "--out-format", "", "--backend", "gloo", "--port", str(port),
+                                            "--param-digests", "--lr", "0.0002"])
+    train.run_worker(rank, world, args)
+
+
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_share_one_gpu_and_stay_in_step(golden_index, tmp_path):
+    """The multi-GPU training path rehearsed on one GPU: two processes (gloo rendezvous on 127.0.0.1, both on cuda:0), each with its
+    own Trainer and its DistributedSampler share of four scenes; after every step's single all-reduce both hold the same averaged
+    gradient, so their parameter vectors must stay bit-identical to the end."""
+    import socket
+    import torch.multiprocessing as mp
+    from seggroup_amd import synthetic
+    root = str(tmp_path)
+    scenes = []
+    for i, name in enumerate(("tiny_4k", "tiny_dup_4k", "small_20k", "island_20k")):
+        e = golden_index[name]
+        scenes.append(synthetic.make_scene(e["n"], e["s"], e["seed"], name=f"scene{i:04d}_00", **e["kw"]))
+    synthetic.write_reference_tree(root, scenes)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, root, port)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    d = os.path.join(root, "checkpoints", "ddp", "models")
+    a, b = open(os.path.join(d, "rank0.sha256")).read(), open(os.path.join(d, "rank1.sha256")).read()
+    assert a == b and len(a.strip()) == 64
+    log = open(os.path.join(root, "checkpoints", "ddp", "run.log")).read()
+    assert "Epoch[1/1](0004/0004)" in log
