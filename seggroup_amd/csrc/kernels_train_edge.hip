@@ -12,9 +12,11 @@
 // dense part has to be carried through explicitly: one dense pass that recomputes conv1 -> h1 -> conv2 per 64-row tile
 // and forms dy2, dW2 += dy2^T h1, dh1 = dy2 W2, da1 = dh1 lrelu'(a1), sum da1 e^T -- then the moment identity above for BN1.
 //
-// Passes (layers == 2):  moments of e (the forward's own kernel, kernels_edgeconv.hip) -> BN1 statistics | dense forward: BN2 statistics, per (point, channel) the extreme
-// pre-activation over k and its k | elementwise: d beta2, d gamma2 | dense backward | fold.   (layers == 1: the dense
-// sparse pass only -- k_eb_sparse1.)
+// Passes.  Both: moments of e (the forward's own structured-moments kernel, kernels_edgeconv.hip) -> BN1 statistics.
+//   layers == 1: one sparse pass (k_eb_sparse1), fold.
+//   layers == 2: BN2 statistics + d beta2, d gamma2 + the arg-max k of every (point, channel) that carries gradient -- from the
+//                forward's statistics and a sparse pass (k_eb_sparse2; what the training step does), or, without statistics,
+//                from a dense forward pass (k_eb_forward, k_eb_last_bn) -- then the dense backward (k_eb_backward), fold.
 // Arithmetic: fp32 FMAs on LDS tiles (256 threads, 4x4 register blocks), every reduction across tiles in fp64, block
 // partials reduced in a fixed order (deterministic).  Conditioning: the XYZ of the x_i half is taken relative to row 0
 // (BatchNorm is invariant to that shift, and sum_r dy[r] = 0 makes dW invariant too), like the forward kernels.
@@ -217,17 +219,16 @@ __global__ void k_eb_fold1(const double* __restrict__ partial, int nblocks, doub
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass 1: dense forward.  LAYERS == 2: sum y2, sum y2^2 (block partials [64 | 64]) and, per (point, channel), the extreme
-// of y2 over k in the direction of sign(gamma2) + the FIRST k that attains it.  LAYERS == 1: the same for y1 (no sums).
+// pass 1 (layers == 2, standalone operator without the forward's statistics): dense forward.  sum y2, sum y2^2 (block partials
+// [64 | 64]) and, per (point, channel), the extreme of y2 over k in the direction of sign(gamma2) + the FIRST k that attains it.
 // ---------------------------------------------------------------------------------------------------------------
-template <int LAYERS>
 __global__ void __launch_bounds__(kThreads, 2) k_eb_forward(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P, int ntiles,
                                                          const float* __restrict__ w1, const float* __restrict__ g1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ g2, const float* __restrict__ cst,
                                                          float* __restrict__ ext, uint8_t* __restrict__ argk, double* __restrict__ partial) {
     __shared__ Tile s;
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
-    stage_weights(s, w1, LAYERS == 2 ? w2 : nullptr);
+    stage_weights(s, w1, w2);
     float mu1[4], sc1[4], sh1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_eb_forward(const float* __restr
         sh1[j] = b1[c];
     }
     double sy[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
-    const float* gl = LAYERS == 2 ? g2 : g1;
+    const float* gl = g2;
     RowFetch rf;
     fetch_edge_rows(rf, x9, knn, N, K, P, blockIdx.x, ntiles);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -250,20 +251,16 @@ __global__ void __launch_bounds__(kThreads, 2) k_eb_forward(const float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 h;
-            if (LAYERS == 2) {
-                const bool valid = s.rown[4 * tr + i] >= 0;
-                h.x = valid ? lrelu((acc[i][0] - mu1[0]) * sc1[0] + sh1[0]) : 0.f;
-                h.y = valid ? lrelu((acc[i][1] - mu1[1]) * sc1[1] + sh1[1]) : 0.f;
-                h.z = valid ? lrelu((acc[i][2] - mu1[2]) * sc1[2] + sh1[2]) : 0.f;
-                h.w = valid ? lrelu((acc[i][3] - mu1[3]) * sc1[3] + sh1[3]) : 0.f;
-            } else {
-                h = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);      // the pre-activation itself
-            }
+            const bool valid = s.rown[4 * tr + i] >= 0;
+            h.x = valid ? lrelu((acc[i][0] - mu1[0]) * sc1[0] + sh1[0]) : 0.f;
+            h.y = valid ? lrelu((acc[i][1] - mu1[1]) * sc1[1] + sh1[1]) : 0.f;
+            h.z = valid ? lrelu((acc[i][2] - mu1[2]) * sc1[2] + sh1[2]) : 0.f;
+            h.w = valid ? lrelu((acc[i][3] - mu1[3]) * sc1[3] + sh1[3]) : 0.f;
             *reinterpret_cast<float4*>(&s.H1[(4 * tr + i) * kHS + 4 * tc]) = h;
         }
         __syncthreads();
-        const float* src = s.H1;
-        if (LAYERS == 2) {
+        const float* src = s.D2;
+        {
             conv2_block(s, tr, tc, acc);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -275,7 +272,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_eb_forward(const float* __restr
                 }
             }
             __syncthreads();
-            src = s.D2;
         }
         if (t < P * 64) {
             const int p = t >> 6, o = t & 63, n = tile * P + p;
@@ -293,7 +289,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_eb_forward(const float* __restr
             }
         }
     }
-    if (LAYERS == 2) {
+    {
 #pragma unroll 1
         for (int which = 0; which < 2; ++which) {
             __syncthreads();
@@ -317,22 +313,15 @@ __global__ void k_eb_fold2(const double* __restrict__ partial, int nblocks, doub
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass 2 (elementwise over [N,64]): da of the LAST BatchNorm at the extreme row -> d beta, d gamma (block partials
-// [64 | 64]); LAYERS == 1 additionally sum da e^T over the hit rows ([64 x 20] more), e rebuilt from the table.
+// pass 2 (layers == 2, standalone operator; elementwise over [N,64]): da of the LAST BatchNorm at the extreme row -> d beta2,
+// d gamma2 (block partials [64 | 64])
 // ---------------------------------------------------------------------------------------------------------------
-template <int LAYERS>
-__global__ void __launch_bounds__(kThreads) k_eb_last_bn(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ cst,
-                                                         const float* __restrict__ ext, const uint8_t* __restrict__ argk, const float* __restrict__ gout,
-                                                         double* __restrict__ partial) {
+__global__ void __launch_bounds__(kThreads) k_eb_last_bn(int N, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ cst,
+                                                         const float* __restrict__ ext, const float* __restrict__ gout, double* __restrict__ partial) {
     __shared__ double red[4 * 64];
     const int t = threadIdx.x, p = t >> 6, o = t & 63;
-    const float mu = cst[(LAYERS == 2 ? MU2 : MU1) + o], inv = cst[(LAYERS == 2 ? INV2 : INV1) + o], g = gamma[o], b = beta[o];
-    const float x0[3] = {cst[X0], cst[X0 + 1], cst[X0 + 2]};
+    const float mu = cst[MU2 + o], inv = cst[INV2 + o], g = gamma[o], b = beta[o];
     double sdb = 0.0, sdg = 0.0;
-    double ge[LAYERS == 1 ? 18 : 1];
-#pragma unroll
-    for (int j = 0; j < (LAYERS == 1 ? 18 : 1); ++j) ge[j] = 0.0;
     for (int n = blockIdx.x * 4 + p; n < N; n += gridDim.x * 4) {
         const float go = gout[(size_t)n * 64 + o];
         if (go == 0.f) continue;
@@ -340,35 +329,14 @@ __global__ void __launch_bounds__(kThreads) k_eb_last_bn(const float* __restrict
         const float d = go * dlrelu(xh * g + b);
         sdb += (double)d;
         sdg += (double)d * (double)xh;
-        if (LAYERS == 1) {
-            const int j = knn[(size_t)n * K + argk[(size_t)n * 64 + o]];
-            const float* xi = x9 + (size_t)n * 12;
-            const float* xj = x9 + (size_t)j * 12;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) {
-                const float a = xi[c];
-                ge[c] += (double)d * (double)(xj[c] - a);
-                ge[9 + c] += (double)d * (double)(c < 3 ? a - x0[c] : a);
-            }
-        }
     }
-    const int nq = LAYERS == 1 ? 20 : 2;
-    double* dst = partial + (size_t)blockIdx.x * (LAYERS == 1 ? 128 + 64 * kES : 128);
+    double* dst = partial + (size_t)blockIdx.x * 128;
 #pragma unroll 1
-    for (int q = 0; q < nq; ++q) {
+    for (int q = 0; q < 2; ++q) {
         __syncthreads();
-        double v = q == 0 ? sdb : q == 1 ? sdg : 0.0;
-        if (LAYERS == 1 && q >= 2) {
-#pragma unroll
-            for (int j = 0; j < 18; ++j) v = (q - 2 == j) ? ge[j] : v;
-        }
-        red[p * 64 + o] = v;
+        red[p * 64 + o] = q ? sdg : sdb;
         __syncthreads();
-        if (t < 64) {
-            const double a = ((red[t] + red[64 + t]) + red[128 + t]) + red[192 + t];
-            if (q < 2) dst[q * 64 + t] = a;
-            else dst[128 + t * kES + (q - 2)] = a;
-        }
+        if (t < 64) dst[q * 64 + t] = ((red[t] + red[64 + t]) + red[128 + t]) + red[192 + t];
     }
 }
 
@@ -822,10 +790,10 @@ int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k,
             k_eb_set_bn2<<<1, 64, 0, st>>>(d_bn2_in, cst, d_bn_stats);
             k_eb_sparse2<<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, cst, d_gout, argk, partial);
         } else {
-            k_eb_forward<2><<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, cst, ext, argk, partial);
+            k_eb_forward<<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, cst, ext, argk, partial);
             if (int rc = sg::reduce_partials(partial, nb, 128, 128, red, st)) return rc;
             k_eb_fold2<<<1, 64, 0, st>>>(red, 1, rows, cst, d_bn_stats);
-            k_eb_last_bn<2><<<nb2, kThreads, 0, st>>>(d_x9m, d_knn, N, k, d_g2, d_b2, cst, ext, argk, d_gout, partial);
+            k_eb_last_bn<<<nb2, kThreads, 0, st>>>(N, d_g2, d_b2, cst, ext, d_gout, partial);
         }
         if (int rc = sg::reduce_partials(partial, nb2, 128, 128, red, st)) return rc;
         k_eb_fold3<<<1, 64, 0, st>>>(red, 1, rows, cst, d_gg2, d_gb2);
