@@ -16,8 +16,8 @@
 //   layers == 1: one sparse pass (k_eb_sparse1), fold.
 //   layers == 2: BN2 statistics + d beta2, d gamma2 + the arg-max k of every (point, channel) that carries gradient -- from the
 //                forward's statistics and a sparse pass (k_eb_sparse2; what the training step does), or, without statistics,
-//                from a dense forward pass (k_eb_forward, k_eb_last_bn) -- then the dense backward (k_eb_backward), fold.
-// Arithmetic: fp32 FMAs on LDS tiles (256 threads, 4x4 register blocks), every reduction across tiles in fp64, block
+//                from a dense forward pass (k_eb_forward, k_eb_last_bn) -- then the dense backward (k_eb_backward_mfma), fold.
+// Arithmetic: fp32 (MFMA in the dense backward, FMAs on LDS tiles elsewhere), running sums flushed to fp64 every 16 tiles, block
 // partials reduced in a fixed order (deterministic).  Conditioning: the XYZ of the x_i half is taken relative to row 0
 // (BatchNorm is invariant to that shift, and sum_r dy[r] = 0 makes dW invariant too), like the forward kernels.
 #include "sg_common.h"
@@ -512,165 +512,201 @@ __global__ void k_eb_fold3(const double* __restrict__ partial, int nblocks, doub
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass 3 (layers == 2): dense backward.  Block partials: dW2 [64 x 64] | sum da1 e^T [64 x 20] | sum da1 [64] | sum da1 xhat1 [64]
+// pass 3 (layers == 2): dense backward on the matrix pipe.  Block partials: dW2 [64 x 64] | sum da1 e^T [64 x 20] | sum da1 [64] |
+// sum da1 xhat1 [64].  Five contractions per 64-row tile as v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation): a VALU
+// form with 4x4 register blocks (the first version: 2.75 ms) reads 16 bytes of LDS per 8 FMAs and is bound by LDS bandwidth at a
+// quarter of the vector peak; an MFMA step takes two 4-byte LDS reads per lane for 2 x 32 x 32 FMAs.  Four waves, one 32 x 32 output block each:
+//     y1^T [c][r] = W1 E^T          A = W1t[j][c]   B = E[r][j]        (10 steps)
+//     y2^T [o][r] = W2 H1^T         A = W2[o][c]    B = H1[r][c]       (32 steps)
+//     dW2  [o][c] += DY2^T H1       A = DY2[r][o]   B = H1[r][c]       (32 steps, over the tile's rows)
+//     dh1^T[c][r] = W2^T DY2^T      A = W2[o][c]    B = DY2[r][o]      (32 steps)
+//     gE   [c][j] += DA1^T E        A = DA1[r][c]   B = E[r][j]        (16 steps per wave: the row halves go to wave pairs)
+// With M = channel and N = row an accumulator gives every lane 16 channels OF ITS OWN ROW, so BatchNorm, LeakyReLU' and the
+// arg-max hit test are register work and conv1's xhat / sign bits are still at hand when dh1 arrives in the same layout.
+// Tiles have an odd row stride (65 / 33 floats): both a tile's rows and its columns are then conflict-free for the scalar operand
+// reads.  E carries a column of ones (j = 20), so sum da1 falls out of the last contraction.  The accumulators of the three
+// running sums are added into fp64 registers after every tile.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kThreads, 2) k_eb_backward(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P, int ntiles,
-                                                          const float* __restrict__ w1, const float* __restrict__ g1, const float* __restrict__ b1,
-                                                          const float* __restrict__ w2, const float* __restrict__ g2, const float* __restrict__ b2,
-                                                          const float* __restrict__ cst, const uint8_t* __restrict__ argk, const float* __restrict__ gout,
-                                                          double* __restrict__ partial) {
-    __shared__ Tile s;
-    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
-    stage_weights(s, w1, w2);
-    // the per-channel constants are re-read where they are used (L1-resident, 40 registers otherwise: the kernel has to fit 256 VGPRs
-    // for two workgroups per CU -- with one, every tile waits out its own gathers and barriers)
-    double dW2[4][4], gE[5], sda[4], sdx[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        sda[i] = 0.0; sdx[i] = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dW2[i][j] = 0.0;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kS = 65;        // row stride of the 64-wide tiles
+constexpr int kFlush = 16;     // tiles between two fp64 flushes of the running sums
+constexpr int kPartM = kPart3 + 8192;   // block partial of the MFMA kernel: the compact kPart3 part + its two fp64 scratch arrays
+constexpr int kSE = 33;       // row stride of the edge-feature tile (32 columns: 18 features, 2 zeros, a one, zeros)
+
+struct TileM {
+    float E[kR * kSE];
+    float H1[kR * kS];
+    float D2[kR * kS];
+    float W1t[kES * 64];      // [j][c]
+    float W2[64 * kS];        // [o][c]
+    float G[4 * 64];
+    uint8_t argk[4 * 64];
+    int rown[kR];
+};                            // 63.5 KB
+
+__global__ void __launch_bounds__(kThreads, 2) k_eb_backward_mfma(const float* __restrict__ x9, const int32_t* __restrict__ knn, int N, int K, int P,
+                                                                  int ntiles, const float* __restrict__ w1, const float* __restrict__ g1,
+                                                                  const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ g2,
+                                                                  const float* __restrict__ b2, const float* __restrict__ cst,
+                                                                  const uint8_t* __restrict__ argk, const float* __restrict__ gout,
+                                                                  double* __restrict__ partial) {
+    __shared__ TileM s;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, l32 = lane & 31, half = lane >> 5;
+    const int mb = wave >> 1, nb = wave & 1;                  // this wave's output block: channels 32 mb.., rows / columns 32 nb..
+    for (int i = t; i < kES * 64; i += kThreads) {
+        const int j = i >> 6, c = i & 63;
+        s.W1t[i] = j < 18 ? w1[c * 18 + j] : 0.f;
     }
+    for (int i = t; i < 64 * 64; i += kThreads) s.W2[(i >> 6) * kS + (i & 63)] = w2[i];
+    // channel of accumulator register v of this lane, and the per-channel constants of the two BatchNorms for it
+    auto chan = [&](int v) { return 32 * mb + (v & 3) + 8 * (v >> 2) + 4 * half; };
+    // The running sums of a block (~100 tiles x 64 rows) live in the fp32 accumulators of the matrix pipe; every kFlush tiles they are
+    // added into the block's fp64 partials in global memory (every lane owns its slots: plain read-modify-write) and cleared, so fp32
+    // only ever sums 512 rows.  fp64 copies in registers (96 more) would spill at two workgroups per CU.
+    f32x16 a3, a5;
+    float dx[16];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) gE[j] = 0.0;
-    const int ec = t & 63, eg = t >> 6;                       // sum da1 e^T: channel ec, e-columns 5 eg .. 5 eg + 4
+    for (int v = 0; v < 16; ++v) { a3[v] = 0.f; a5[v] = 0.f; dx[v] = 0.f; }
+    const int cb5 = wave & 1, rh5 = wave >> 1;                // last contraction: channel block, row half
+    double* dst = partial + (size_t)blockIdx.x * kPartM;
+    double* acc5 = dst + kPart3;                              // [row half][channel][32]
+    double* accx = acc5 + 4096;                               // [wave][register][lane]
+    // this lane's slots: register v -> channel (v & 3) + 8 (v >> 2) of its block (+ 4 half), i.e. a constant offset from three bases
+    double* const q3 = dst + (size_t)(32 * mb + 4 * half) * 64 + 32 * nb + l32;              // dW2[o][c = 32 nb + l32]
+    double* const q5 = acc5 + ((size_t)rh5 * 64 + 32 * cb5 + 4 * half) * 32 + l32;
+    double* const qx = accx + (size_t)wave * 16 * 64 + lane;
+    auto flush = [&](bool init) {
+        // four slots at a time (a compiler barrier between the groups): all 48 read-modify-writes in flight at once need 96 registers
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int cv = (v & 3) + 8 * (v >> 2);
+            q3[cv * 64] = init ? 0.0 : q3[cv * 64] + (double)a3[v];
+            a3[v] = 0.f;
+            if ((v & 3) == 3) asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int cv = (v & 3) + 8 * (v >> 2);
+            q5[cv * 32] = init ? 0.0 : q5[cv * 32] + (double)a5[v];
+            a5[v] = 0.f;
+            if ((v & 3) == 3) asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            qx[v * 64] = init ? 0.0 : qx[v * 64] + (double)dx[v];
+            dx[v] = 0.f;
+            if ((v & 3) == 3) asm volatile("" ::: "memory");
+        }
+    };
+    flush(true);
+    int since = 0;
 
     RowFetch rf;
     fetch_edge_rows(rf, x9, knn, N, K, P, blockIdx.x, ntiles);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
-        store_edge_rows(s, rf, cst);
+        if (t < kR) {
+            float* e = &s.E[t * kSE];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) e[j] = 0.f;
+            if (rf.n >= 0) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) { e[c] = rf.xj[c] - rf.xi[c]; e[9 + c] = rf.xi[c]; }
+                e[9] -= cst[X0]; e[10] -= cst[X0 + 1]; e[11] -= cst[X0 + 2];
+                e[20] = 1.f;
+            }
+            s.rown[t] = rf.n;
+        }
         fetch_edge_rows(rf, x9, knn, N, K, P, tile + gridDim.x, ntiles);
         if (t < P * 64) {
             const int n = tile * P + (t >> 6);
             s.G[t] = n < N ? gout[(size_t)n * 64 + (t & 63)] : 0.f;
-            s.argk[t] = n < N ? argk[(size_t)n * 64 + (t & 63)] : -1;
+            s.argk[t] = n < N ? argk[(size_t)n * 64 + (t & 63)] : (uint8_t)255;
         }
         __syncthreads();
-        float acc[4][4], xh1[4][4];
-        unsigned pos1 = 0u;                                   // bit 4 i + j: a1 > 0
-        conv1_block(s, tr, tc, acc);
+        const int r = 32 * nb + l32;                          // this lane's row in the [channel][row] products
+        const bool valid = s.rown[r] >= 0;
+        const int pr = r / K, kr = r - pr * K;
+        // ---- conv1: y1^T[c][r] ----
+        f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool valid = s.rown[4 * tr + i] >= 0;
-            float h[4];
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = 4 * tc + j;
-                const float mu1 = cst[MU1 + c], inv1 = cst[INV1 + c];
-                xh1[i][j] = (acc[i][j] - mu1) * inv1;
-                const float a = (acc[i][j] - mu1) * (inv1 * g1[c]) + b1[c];     // same expression as the forward pass (bit-equal h1)
-                pos1 |= (a > 0.f ? 1u : 0u) << (4 * i + j);
-                h[j] = valid ? lrelu(a) : 0.f;
-            }
-            *reinterpret_cast<float4*>(&s.H1[(4 * tr + i) * kHS + 4 * tc]) = make_float4(h[0], h[1], h[2], h[3]);
+        for (int st = 0; st < 10; ++st)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s.W1t[(2 * st + half) * 64 + 32 * mb + l32], s.E[r * kSE + 2 * st + half], acc, 0, 0, 0);
+        float xh1[16];
+        unsigned pos1 = 0u;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int c = chan(v);
+            const float mu1 = cst[MU1 + c], inv1 = cst[INV1 + c];
+            xh1[v] = (acc[v] - mu1) * inv1;
+            const float a = (acc[v] - mu1) * (inv1 * g1[c]) + b1[c];
+            pos1 |= (a > 0.f ? 1u : 0u) << v;
+            s.H1[r * kS + c] = valid ? lrelu(a) : 0.f;
         }
         __syncthreads();
-        conv2_block(s, tr, tc, acc);
+        // ---- conv2: y2^T[o][r], then dy2 for ALL rows ----
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 4 * tr + i;
-            const bool valid = s.rown[r] >= 0;
-            const int p = r / K, k = r - p * K;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int o = tc + 16 * j;
-                const float inv2 = cst[INV2 + o], ga2 = g2[o];
-                const float xh = (acc[i][j] - cst[MU2 + o]) * inv2;
-                float da = 0.f;
-                if (valid && s.argk[p * 64 + o] == k) da = s.G[p * 64 + o] * dlrelu(xh * ga2 + b2[o]);
-                s.D2[r * kHS + o] = valid ? ga2 * inv2 * ((da - cst[DB2 + o]) - xh * cst[DG2 + o]) : 0.f;
-            }
-        }
-        __syncthreads();
-        // dW2[o][i] += sum_r dy2[r][o] h1[r][i]      block: o = 4 tr + a, i = 4 tc + b
-        {
-            float w[4][4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) w[a][b] = 0.f;
-#pragma unroll 2
-            for (int r = 0; r < kR; ++r) {
-                const float4 d = *reinterpret_cast<const float4*>(&s.D2[r * kHS + 4 * tr]);
-                const float4 h = *reinterpret_cast<const float4*>(&s.H1[r * kHS + 4 * tc]);
-                const float dv[4] = {d.x, d.y, d.z, d.w}, hv[4] = {h.x, h.y, h.z, h.w};
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) w[a][b] = fmaf(dv[a], hv[b], w[a][b]);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) dW2[a][b] += (double)w[a][b];
-        }
-        // dh1[r][i] = sum_o dy2[r][o] W2[o][i]       block: rows 4 tr + i, columns 4 tc + j  (the conv1 block: xh1, pos1 are at hand)
-        float da1[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) da1[i][j] = 0.f;
-#pragma unroll 2
-        for (int o = 0; o < 64; o += 4) {
-            float4 d[4], w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const float4*>(&s.D2[(4 * tr + i) * kHS + o]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(&s.W2[(o + u) * kHS + 4 * tc]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float dv[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    da1[i][0] = fmaf(dv[u], w[u].x, da1[i][0]);
-                    da1[i][1] = fmaf(dv[u], w[u].y, da1[i][1]);
-                    da1[i][2] = fmaf(dv[u], w[u].z, da1[i][2]);
-                    da1[i][3] = fmaf(dv[u], w[u].w, da1[i][3]);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool valid = s.rown[4 * tr + i] >= 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                da1[i][j] = valid ? da1[i][j] * (((pos1 >> (4 * i + j)) & 1u) ? 1.f : kSlope) : 0.f;
-                sda[j] += (double)da1[i][j];
-                sdx[j] += (double)da1[i][j] * (double)xh1[i][j];
-            }
-        }
-        __syncthreads();                                      // every reader of D2 (dy2) is done
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&s.D2[(4 * tr + i) * kHS + 4 * tc]) = make_float4(da1[i][0], da1[i][1], da1[i][2], da1[i][3]);
-        __syncthreads();
-        {
-            float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
 #pragma unroll 4
-            for (int r = 0; r < kR; ++r) {
-                const float d = s.D2[r * kHS + ec];
+        for (int st = 0; st < 32; ++st)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s.W2[(32 * mb + l32) * kS + 2 * st + half], s.H1[r * kS + 2 * st + half], acc, 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 5; ++j) a[j] = fmaf(d, s.E[r * kES + 5 * eg + j], a[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 5; ++j) gE[j] += (double)a[j];
+        for (int v = 0; v < 16; ++v) {
+            const int o = chan(v);
+            const float inv2 = cst[INV2 + o], ga2 = g2[o];
+            const float xh = (acc[v] - cst[MU2 + o]) * inv2;
+            float da = 0.f;
+            if (valid && (int)s.argk[pr * 64 + o] == kr) da = s.G[pr * 64 + o] * dlrelu(xh * ga2 + b2[o]);
+            s.D2[r * kS + o] = valid ? ga2 * inv2 * ((da - cst[DB2 + o]) - xh * cst[DG2 + o]) : 0.f;
         }
+        __syncthreads();
+        // ---- dW2[o][c] += sum_r dy2[r][o] h1[r][c] ----
+#pragma unroll 4
+        for (int st = 0; st < 32; ++st)
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(s.D2[(2 * st + half) * kS + 32 * mb + l32], s.H1[(2 * st + half) * kS + 32 * nb + l32], a3, 0, 0, 0);
+        // ---- dh1^T[c][r] = sum_o W2[o][c] dy2[r][o]; da1 ----
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll 4
+        for (int st = 0; st < 32; ++st)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s.W2[(2 * st + half) * kS + 32 * mb + l32], s.D2[r * kS + 2 * st + half], acc, 0, 0, 0);
+        float da1[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            da1[v] = valid ? acc[v] * (((pos1 >> v) & 1u) ? 1.f : kSlope) : 0.f;
+            dx[v] = fmaf(da1[v], xh1[v], dx[v]);
+        }
+        __syncthreads();                                      // every reader of dy2 is done
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s.D2[r * kS + chan(v)] = da1[v];
+        __syncthreads();
+        // ---- gE[c][j] += sum_r da1[r][c] e[r][j]  (j = 20: the ones column -> sum da1) ----
+#pragma unroll 4
+        for (int st = 0; st < 16; ++st) {
+            const int row = 32 * rh5 + 2 * st + half;
+            a5 = __builtin_amdgcn_mfma_f32_32x32x2f32(s.D2[row * kS + 32 * cb5 + l32], s.E[row * kSE + l32], a5, 0, 0, 0);
+        }
+        if (++since == kFlush) { flush(false); since = 0; }
     }
-    double* dst = partial + (size_t)blockIdx.x * kPart3;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) dst[(4 * tr + a) * 64 + 4 * tc + b] = dW2[a][b];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) dst[4096 + ec * kES + 5 * eg + j] = gE[j];
-#pragma unroll 1
-    for (int which = 0; which < 2; ++which) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) red_of(s)[tr * 64 + 4 * tc + j] = which ? sdx[j] : sda[j];
-        __syncthreads();
-        store_partial(dst + 4096 + 64 * kES + which * 64, red_of(s), 64, 16, t);
+    flush(false);
+    __threadfence_block();
+    __syncthreads();
+    // ---- the compact block partials k_eb_final reads: dW2 [64 x 64] (in place) | sum da1 e^T [64 x 20] | sum da1 [64] | sum da1 xhat1 [64] ----
+    for (int i = t; i < 64 * 32; i += kThreads) {
+        const int c = i >> 5, j = i & 31;
+        const double sum = acc5[(size_t)c * 32 + j] + acc5[(size_t)(64 + c) * 32 + j];
+        if (j < 18) dst[4096 + c * kES + j] = sum;
+        else if (j == 20) dst[4096 + 64 * kES + c] = sum;
+    }
+    if (t < 64) {
+        // sum da1 xhat1 of channel c: register v of the lanes of its half, over the 32 rows of a wave and the two row blocks, fixed order
+        const int c = t, m = c >> 5, v = ((c & 31) & 3) + 4 * ((c & 31) >> 3), hf = ((c & 31) >> 2) & 1;
+        double sum = 0.0;
+        for (int n2 = 0; n2 < 2; ++n2)
+            for (int l = 0; l < 32; ++l) sum += accx[((size_t)(2 * m + n2) * 16 + v) * 64 + 32 * hf + l];
+        dst[4096 + 64 * kES + 64 + c] = sum;
     }
 }
 
@@ -747,7 +783,7 @@ static int eb_blocks(int ntiles) { return std::max(1, std::min(ntiles, 512)); }
 
 size_t sg_edgeconv_backward_ws_bytes(int N) {
     const size_t n = (size_t)std::max(N, 1);
-    return sg::align_up(512 * (size_t)kPart3 * 8) + sg::align_up(n * 64 * 4) + sg::align_up(n * 64) + sg::align_up(kCst * 4) + sg::align_up(kMom * 8) + sg::align_up(kPart3 * 8) + 4096;
+    return sg::align_up(512 * (size_t)kPartM * 8) + sg::align_up(n * 64 * 4) + sg::align_up(n * 64) + sg::align_up(kCst * 4) + sg::align_up(kMom * 8) + sg::align_up(kPart3 * 8) + 4096;
 }
 
 int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1, const float* d_b1,
@@ -757,7 +793,7 @@ int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k,
                "sg_edgeconv_backward: bad arguments (k = %d must be <= 32)", k);
     SG_REQUIRE(layers == 1 || (d_w2 && d_g2 && d_b2 && d_gw2 && d_gg2 && d_gb2), "sg_edgeconv_backward: layers == 2 needs the second conv's tensors");
     sg::Carver cv(d_ws, ws_bytes);
-    double* partial = cv.take<double>(512 * (size_t)kPart3);
+    double* partial = cv.take<double>(512 * (size_t)kPartM);
     float* ext = cv.take<float>((size_t)N * 64);
     uint8_t* argk = cv.take<uint8_t>((size_t)N * 64);
     float* cst = cv.take<float>(kCst);
@@ -797,8 +833,8 @@ int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k,
         }
         if (int rc = sg::reduce_partials(partial, nb2, 128, 128, red, st)) return rc;
         k_eb_fold3<<<1, 64, 0, st>>>(red, 1, rows, cst, d_gg2, d_gb2);
-        k_eb_backward<<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, cst, argk, d_gout, partial);
-        if (int rc = sg::reduce_partials(partial, nb, kPart3, kPart3, red, st)) return rc;
+        k_eb_backward_mfma<<<nb, kThreads, 0, st>>>(d_x9m, d_knn, N, k, P, ntiles, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, cst, argk, d_gout, partial);
+        if (int rc = sg::reduce_partials(partial, nb, kPartM, kPart3, red, st)) return rc;
         k_eb_final<<<1, 1024, 0, st>>>(red, 1, kPart3, 4096, 4096 + 64 * kES, 2, rows, mom, d_w1, d_g1, cst, d_gw1, d_gg1, d_gb1, d_gw2);
     }
     SG_LAUNCH_CHECK();
