@@ -79,6 +79,7 @@ sg_trainer* sg_trainer_create(int maxN, int maxS, int maxE, int maxV, float* d_p
     w.mlp3_w2 = z; w.mlp3_g2 = z; w.mlp3_b2 = z; w.gcn3_w = z;
     tr->pl = sg_pipeline_create(maxN, maxS, maxE, maxV, &w, stream);
     if (!tr->pl) return nullptr;
+    sg_pipeline_set_timing(tr->pl, 0);                        // no per-stage events in the training loop
     tr->st = sg::as_stream(stream);
     tr->params = d_params; tr->grads = d_grads; tr->maxN = maxN; tr->maxS = maxS;
     int bad = 0;
