@@ -77,7 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--scenes-total", type=int, default=0,
                     help="strong scaling: ONE set of this many scenes sharded i mod W over the ranks (configs[3]: 1201); "
                          "a step = one pass over the rank's shard in batches of --batch")
-    ap.add_argument("--groups", type=int, default=6, help="engine groups per GPU (host thread + HIP stream each)")
+    ap.add_argument("--groups", type=int, default=8, help="engine groups per GPU (host thread + HIP stream each)")
     ap.add_argument("--per-group", type=int, default=8, help="scenes a group advances in lock-step through batched launches")
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--segments", type=int, default=1500)
@@ -349,7 +349,9 @@ def main(argv=None):
                     "frac": d["frac"], "traffic": (pmc.get("hbm_bytes_per_scene_launch", {}) or {}).get(dom),
                     "traffic_source": pmc.get("configuration"),
                     "ms_per_scene_launch": d["ms_per_scene_launch"], "launches_per_scene": 1,
-                    "measured_with": "HIP events on the engine's streams, inside the timed region (duration of the batched launch / scenes in it)",
+                    "measured_with": "HIP events on the engine's streams, inside the timed region (duration of the batched launch / scenes in it); "
+                                     "the groups' launches overlap on the GPU, so a launch's duration includes the time it shares the device -- "
+                                     "single_stream (one launch alone) and whole_gpu (all MFMA work of the step / its wall time) are the undiluted views",
                     "whole_gpu": {"mfma_tflops": round(f_scene * value / world / 1e12, 2), "frac_of_fp32_mfma_peak": round(f_scene * value / world / 1e12 / MFMA_F32_PEAK_TF, 4),
                                   "flop_per_scene": f_scene},
                     "all_kernels": all_k, "single_stream": solo_k,
