@@ -168,6 +168,10 @@ __device__ __forceinline__ void mlp1_apply_body(const float* __restrict__ sample
         e[t][0] = (float)((ed[t][0] - m0) * 10.0); e[t][1] = (float)((ed[t][1] - m1) * 10.0); e[t][2] = (float)((ed[t][2] - m2) * 10.0);
     }
     float* out = feat + (size_t)c * feat_stride;
+    // h[sample][channel] goes through LDS once and lane `ch` then reduces its channel over the 64 samples serially: two LDS
+    // operations per value instead of a cross-lane network per channel (64 x ~50 DPP / readlane instructions were a third of this
+    // kernel).  Row stride 65: the column write and the row read are both conflict-free.
+    __shared__ float hs[64 * 65];
     for (int ch = 0; ch < 64; ++ch) {
         const float w0 = folded[ch * 6 + 0], w1 = folded[ch * 6 + 1], w2 = folded[ch * 6 + 2], w3 = folded[ch * 6 + 3],
                     w4 = folded[ch * 6 + 4], w5 = folded[ch * 6 + 5], b = folded[384 + ch];
@@ -180,11 +184,21 @@ __device__ __forceinline__ void mlp1_apply_body(const float* __restrict__ sample
             y = fmaxf(y, 0.2f * y);                              // LeakyReLU(0.2), slope < 1
             h = fmaxf(h, y);                                     // max over k (model.py:76)
         }
-        // wave reductions on the DPP path (wave_ops.h): 64 channels x 12 dependent ds_bpermute round trips were most of this
-        // kernel's time
-        const float mx = sgw::wave_max(h);
-        const double sm = sgw::wave_sum((double)h);
-        if (lane == 0) { out[ch] = mx; out[64 + ch] = (float)(sm / 64.0); }    // model.py:77-79
+        hs[ch * 65 + lane] = h;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const float* row = hs + lane * 65;                        // lane = channel
+        float mx = -INFINITY;
+        double sm = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) {
+            const float v = row[i];
+            mx = fmaxf(mx, v);
+            sm += (double)v;
+        }
+        out[lane] = mx;                                          // model.py:77-79: [max | mean] over the 64 samples
+        out[64 + lane] = (float)(sm / 64.0);
     }
 }
 __global__ __launch_bounds__(64) void k_mlp1_apply(const float* __restrict__ samples, const uint8_t* __restrict__ knn,
