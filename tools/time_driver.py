@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--segments", type=int, default=1000)
     ap.add_argument("--out-format", default="txt,npy")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--inflight", type=int, default=32)
+    ap.add_argument("--inflight", type=int, default=64)
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--out", default=None)
     ap.add_argument("--skip-loop", action="store_true", help="skip the per-scene loop legs (7 scenes/s: slow for many scenes)")
