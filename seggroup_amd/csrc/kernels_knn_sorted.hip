@@ -819,11 +819,11 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
 // fifth wave for the unseeded one (104 -> 96 VGPRs) costs 10 spilled registers and is slower (973 -> 991 us).
 template <int K, int kSlices, bool kSeeded>
 __global__ __launch_bounds__(64 * kSlices, kSlices == 1 && kSeeded ? 4 : 1) void k_cluster_knn_sorted_b(const sg::SlotCtx* __restrict__ cx) {
-    const sg::SlotCtx& c = cx[blockIdx.y];
-    if ((int)blockIdx.x >= c.T) return;
+    const sg::SlotCtx& c = cx[blockIdx.x];                    // grid = (scenes, tiles): one scene per XCD (kernels_edgeconv.hip, k_edgeconv_b)
+    if ((int)blockIdx.y >= c.T) return;
     cluster_knn_sorted_body<K, kSlices, kSeeded>(c.sxyzw, c.smpos, c.cl_pt_off, c.tile_cl, c.tile_lo, c.tile_hi, c.cl_seg_off, c.order, c.dst,
                                                  c.seg_off, c.seg_chunk_off, c.segbox, c.chunk_box, c.slot_of_pos, c.pos0, c.knn, 0, c.knn_seed,
-                                                 c.seg_prevcl, c.members, c.point_rec, blockIdx.x);
+                                                 c.seg_prevcl, c.members, c.point_rec, blockIdx.y);
 }
 
 
@@ -1097,7 +1097,7 @@ int b_layer_layout(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
 
 int b_cluster_knn(const SlotCtx* d_ctx, const BatchDims& bd, int waves_per_tile, bool seeded, hipStream_t st) {
     if (bd.nslots == 0 || bd.max_T == 0) return SG_OK;
-    const dim3 grid(bd.max_T, bd.nslots);
+    const dim3 grid(bd.nslots, bd.max_T);
     if (seeded) k_cluster_knn_sorted_b<20, 1, true><<<grid, 64, 0, st>>>(d_ctx);
     else if (waves_per_tile == 1) k_cluster_knn_sorted_b<20, 1, false><<<grid, 64, 0, st>>>(d_ctx);
     else if (waves_per_tile == 2) k_cluster_knn_sorted_b<20, 2, false><<<grid, 128, 0, st>>>(d_ctx);
