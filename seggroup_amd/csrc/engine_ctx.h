@@ -111,6 +111,8 @@ struct SlotCtx {
     float* ec_sh1;
     float* ec_w2f;                     // |a| of the last layer of MLP3
     float* ec_sh2;
+    float* ec_w2img;                   // S2X's conv2 weights, pre-split into fp16 pieces in LDS order (16 KB, k_bn_fold_moments)
+    float* ec_scale;                   // {1 / (S T), T, S}: the power-of-two scales of that pass
     float* pf;                         // [N,64] pre-activation maxima
     int K;                             // neighbours per point (20); a run-time value on purpose: as a literal the moments kernel unrolls all slots
     int ec_blocks;                     // ceil(ceil(N/32)/4)

@@ -62,6 +62,9 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 enum { S1X = 1, S2X = 2 };     // conv1 statistics + extremum (MLP2) | conv1' -> conv2 statistics + extremum (MLP3)
@@ -78,8 +81,9 @@ struct Lds {
     // W1[32t + (lane&31)][8 (lane>>5) + j], j = 0..7 (k >= 9: zero)
     u32x4 a1db[3][2][64];
     float4 a1x[2][2][64];    // a1x[t][s>>2][lane][s&3] = W1[32t + (lane&31)][9 + k]    the x_i columns, used once per point
-    // conv2, bf16 pieces: a2b[piece][ot][kb][lane] = 8 bf16 = piece of W2[32ot + (lane&31)][acc_channel(kb>>1, 8(kb&1) + j, lane>>5)], j = 0..7
-    u32x4 a2b[3][2][4][64];
+    // conv2, fp16 pieces (k_bn_fold_moments prepares the image once per scene): a2h[piece][ot][kb][lane] = 8 halves = piece of
+    // S * sgn(gamma2) * W2[32ot + (lane&31)][acc_channel(kb>>1, 8(kb&1) + j, lane>>5)], j = 0..7
+    u32x4 a2h[2][2][4][64];
     float sh1r[2][2][16];    // folded BN1 shift in accumulator-register order: sh1r[tile][half][reg] (b128 reads)
     double acc[kWaves][128]; // per-wave statistics: [0,64) sum, [64,128) sum of squares
 };
@@ -87,7 +91,8 @@ struct Lds {
 template <int MODE, bool REREAD_A>
 __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                               const float* __restrict__ w1, const float* __restrict__ shift1,
-                                              const float* __restrict__ w2, const float* __restrict__ gamma_last,
+                                              const u32x4* __restrict__ w2img, const float* __restrict__ scales,
+                                              const float* __restrict__ gamma_last,
                                               float* __restrict__ ext, double* __restrict__ partial, int bid) {
     __shared__ Lds lds;
     constexpr bool kTwo = MODE == S2X;
@@ -128,31 +133,7 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
         lds.a1db[2][t][l] = u32x4{p3[0], p3[1], p3[2], p3[3]};
     }
     if (kTwo) {
-        // one (ot, kb, lane) fragment per iteration: 8 weights, each cut into its three bf16 pieces
-        for (int i = tid; i < 2 * 4 * 64; i += 64 * kWaves) {
-            const int l = i & 63, kb = (i >> 6) & 3, ot = i >> 8;
-            const int ch = 32 * ot + (l & 31);
-            const bool neg = gamma_last[ch] < 0.f;
-            unsigned int p1[4], p2[4], p3[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                unsigned int h1[2], h2[2], h3[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    float v = w2[ch * 64 + acc_channel(kb >> 1, 8 * (kb & 1) + 2 * jj + u, l >> 5)];
-                    if (neg) v = -v;
-                    const float a = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
-                    const float r = v - a;
-                    const float b = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
-                    const float c = r - b;
-                    h1[u] = __float_as_uint(a) >> 16; h2[u] = __float_as_uint(b) >> 16; h3[u] = __float_as_uint(c) >> 16;
-                }
-                p1[jj] = h1[0] | (h1[1] << 16); p2[jj] = h2[0] | (h2[1] << 16); p3[jj] = h3[0] | (h3[1] << 16);
-            }
-            lds.a2b[0][ot][kb][l] = u32x4{p1[0], p1[1], p1[2], p1[3]};
-            lds.a2b[1][ot][kb][l] = u32x4{p2[0], p2[1], p2[2], p2[3]};
-            lds.a2b[2][ot][kb][l] = u32x4{p3[0], p3[1], p3[2], p3[3]};
-        }
+        for (int i = tid; i < 2 * 2 * 4 * 64; i += 64 * kWaves) (&lds.a2h[0][0][0][0])[i] = w2img[i];
     }
     if (tid < 64) {
         const int t_ = tid >> 5, h_ = (tid >> 4) & 1, q_ = tid & 15;
@@ -165,6 +146,8 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
     const int pt = tile * 32 + r;
     const bool valid = pt < N;
     const float vmask = valid ? 1.f : 0.f;
+    // S2X runs on scaled operands (conv1' x T, W2 x S, both powers of two: see k_bn_fold_moments); y2 comes out x S T
+    const float unscale = kTwo ? scales[0] : 1.f;
     const int ptc = valid ? pt : 0;
 
     if (tile * 32 < N) {
@@ -291,68 +274,56 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc1[t][q] = fmaxf(acc1[t][q], 0.2f * acc1[t][q]);
-                // conv2 on the bf16 matrix pipe (see the header): per 16-deep k block the 8 accumulator registers of this lane
-                // are cut into three bf16 pieces each and meet the pre-split weights in six MFMAs per output tile; the two
-                // output tiles are independent accumulator chains, interleaved
+                // conv2 on the fp16 matrix pipe (see the header): per 16-deep k block the 8 accumulator registers of this lane are cut
+                // into two fp16 pieces each (round-to-nearest: v_cvt_pk_f16_f32) and meet the pre-split weights in three MFMAs per
+                // output tile; the two output tiles are independent accumulator chains, interleaved
                 f32x16 acc2[2];
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc2[ot][q] = 0.f;
                 // The wave issues in order, and an MFMA that finds the matrix pipe busy blocks everything behind it: with the split
-                // of a k block written in front of its twelve MFMAs, split and MFMAs alternate and the pipe idles during every split
-                // (56 % busy, PMC).  The split of block kb + 1 only needs conv1's accumulator, so it is computed WHILE block kb's
-                // MFMAs run: one MFMA, then four of the next block's VALU instructions in its 32-cycle shadow, pinned with
-                // sched_group_barrier (0x8 = MFMA, 0x2 = VALU).  (Pipelining further -- the next slot's conv1 under this slot's
-                // statistics, the d split under the last k block -- needs both accumulators live across the loop edge: 100-300 B of
-                // scratch per lane at 2 waves/SIMD, and 1 wave/SIMD is 1.5x slower; measured, not kept.)
-                unsigned int q1[4], q2[4], q3[4];
-                auto split_block = [&](int kb, unsigned int (&o1)[4], unsigned int (&o2)[4], unsigned int (&o3)[4]) {
+                // of a k block written in front of its MFMAs, split and MFMAs alternate and the pipe idles during every split.
+                // The split of block kb + 1 only needs conv1's accumulator, so it is computed WHILE block kb's MFMAs run: one MFMA,
+                // then four of the next block's VALU instructions in its 32-cycle shadow, pinned with sched_group_barrier
+                // (0x8 = MFMA, 0x2 = VALU).  (Pipelining further -- the next slot's conv1 under this slot's statistics, the d split
+                // under the last k block -- needs both accumulators live across the loop edge: 100-300 B of scratch per lane at
+                // 2 waves/SIMD, and 1 wave/SIMD is 1.5x slower; measured, not kept.)
+                unsigned int q1[4], q2[4];
+                auto split_block = [&](int kb, unsigned int (&o1)[4], unsigned int (&o2)[4]) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        const float v0 = acc1[kb >> 1][8 * (kb & 1) + 2 * jj], v1 = acc1[kb >> 1][8 * (kb & 1) + 2 * jj + 1];
-                        const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u);
-                        const float r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
-                        const float c0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-                        const float c1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-                        // {low half: high 16 bits of the even value, high half: high 16 bits of the odd value}
-                        o1[jj] = __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);
-                        o2[jj] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-                        o3[jj] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
+                        const f32x2 v = {acc1[kb >> 1][8 * (kb & 1) + 2 * jj], acc1[kb >> 1][8 * (kb & 1) + 2 * jj + 1]};
+                        const f16x2 hi = __builtin_convertvector(v, f16x2);
+                        const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);     // v - hi is exact in fp32
+                        o1[jj] = __builtin_bit_cast(unsigned int, hi);
+                        o2[jj] = __builtin_bit_cast(unsigned int, lo);
                     }
                 };
-                split_block(0, q1, q2, q3);
+                split_block(0, q1, q2);
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
-                    const bf16x8 x1 = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
-                    const bf16x8 x2 = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
-                    const bf16x8 x3 = __builtin_bit_cast(bf16x8, u32x4{q3[0], q3[1], q3[2], q3[3]});
-                    const bf16x8 wa1 = __builtin_bit_cast(bf16x8, lds.a2b[0][0][kb][lane]), wb1 = __builtin_bit_cast(bf16x8, lds.a2b[0][1][kb][lane]);
-                    const bf16x8 wa2 = __builtin_bit_cast(bf16x8, lds.a2b[1][0][kb][lane]), wb2 = __builtin_bit_cast(bf16x8, lds.a2b[1][1][kb][lane]);
-                    const bf16x8 wa3 = __builtin_bit_cast(bf16x8, lds.a2b[2][0][kb][lane]), wb3 = __builtin_bit_cast(bf16x8, lds.a2b[2][1][kb][lane]);
-                    unsigned int n1[4], n2[4], n3[4];
-                    if (kb < 3) split_block(kb + 1, n1, n2, n3);
+                    const f16x8 x1 = __builtin_bit_cast(f16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
+                    const f16x8 x2 = __builtin_bit_cast(f16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+                    const f16x8 wa1 = __builtin_bit_cast(f16x8, lds.a2h[0][0][kb][lane]), wb1 = __builtin_bit_cast(f16x8, lds.a2h[0][1][kb][lane]);
+                    const f16x8 wa2 = __builtin_bit_cast(f16x8, lds.a2h[1][0][kb][lane]), wb2 = __builtin_bit_cast(f16x8, lds.a2h[1][1][kb][lane]);
+                    unsigned int n1[4], n2[4];
+                    if (kb < 3) split_block(kb + 1, n1, n2);
                     // smallest terms first
-                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa3, x1, acc2[0], 0, 0, 0);
-                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb3, x1, acc2[1], 0, 0, 0);
-                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2, x2, acc2[0], 0, 0, 0);
-                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb2, x2, acc2[1], 0, 0, 0);
-                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x3, acc2[0], 0, 0, 0);
-                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x3, acc2[1], 0, 0, 0);
-                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2, x1, acc2[0], 0, 0, 0);
-                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb2, x1, acc2[1], 0, 0, 0);
-                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x2, acc2[0], 0, 0, 0);
-                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x2, acc2[1], 0, 0, 0);
-                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x1, acc2[0], 0, 0, 0);
-                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x1, acc2[1], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2, x1, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb2, x1, acc2[1], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, x2, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb1, x2, acc2[1], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, x1, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb1, x1, acc2[1], 0, 0, 0);
                     if (kb < 3) {
 #pragma unroll
-                        for (int i = 0; i < 12; ++i) {
+                        for (int i = 0; i < 6; ++i) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                         }
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) { q1[jj] = n1[jj]; q2[jj] = n2[jj]; q3[jj] = n3[jj]; }
+                        for (int jj = 0; jj < 4; ++jj) { q1[jj] = n1[jj]; q2[jj] = n2[jj]; }
                     }
                 }
 #pragma unroll
@@ -376,8 +347,8 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
             for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o); v += __shfl_xor(v, o); }
             if (r == 0) {
                 const int ch = acc_channel(q >> 4, q & 15, half);
-                lds.acc[wave][ch] += (double)s;
-                lds.acc[wave][64 + ch] += (double)v;
+                lds.acc[wave][ch] += (double)s * (double)unscale;                                  // power of two: exact
+                lds.acc[wave][64 + ch] += (double)v * ((double)unscale * (double)unscale);
             }
         }
         if (valid) {
@@ -387,7 +358,8 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 v = make_float4(best[t][4 * g], best[t][4 * g + 1], best[t][4 * g + 2], best[t][4 * g + 3]);
+                    const float4 v = make_float4(best[t][4 * g] * unscale, best[t][4 * g + 1] * unscale, best[t][4 * g + 2] * unscale,
+                                                 best[t][4 * g + 3] * unscale);
                     *reinterpret_cast<float4*>(orow + 32 * t + 8 * g + 4 * half) = v;
                 }
         }
@@ -404,17 +376,19 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
 template <int MODE, bool REREAD_A = false>
 __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                                           const float* __restrict__ w1, const float* __restrict__ shift1,
-                                                          const float* __restrict__ w2, const float* __restrict__ gamma_last,
+                                                          const u32x4* __restrict__ w2img, const float* __restrict__ scales,
+                                                          const float* __restrict__ gamma_last,
                                                           float* __restrict__ ext, double* __restrict__ partial) {
-    edgeconv_body<MODE, REREAD_A>(x9m, knn, N, K, w1, shift1, w2, gamma_last, ext, partial, blockIdx.x);
+    edgeconv_body<MODE, REREAD_A>(x9m, knn, N, K, w1, shift1, w2img, scales, gamma_last, ext, partial, blockIdx.x);
 }
 // S1X: the scene's MLP2 weights as they are; S2X: its folded conv1 (ec_w1f, ec_sh1) + the raw conv2
 template <int MODE, bool REREAD_A>
 __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.ec_blocks) return;
-    if (MODE == S1X) edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, c.K, c.ec_w1, nullptr, nullptr, c.ec_g1, c.pf, c.ec_partial, blockIdx.x);
-    else edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, c.K, c.ec_w1f, c.ec_sh1, c.ec_w2, c.ec_g2, c.pf, c.ec_partial, blockIdx.x);
+    if (MODE == S1X) edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, c.K, c.ec_w1, nullptr, nullptr, nullptr, c.ec_g1, c.pf, c.ec_partial, blockIdx.x);
+    else edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, c.K, c.ec_w1f, c.ec_sh1, reinterpret_cast<const u32x4*>(c.ec_w2img), c.ec_scale, c.ec_g2, c.pf,
+                                       c.ec_partial, blockIdx.x);
 }
 
 // Batch statistics of conv1's output WITHOUT evaluating it (the inner BN of MLP3): y = W1 e is linear, so
@@ -514,10 +488,29 @@ __global__ __launch_bounds__(256) void k_edge_moments_b(const sg::SlotCtx* __res
 }
 
 // moments -> folded conv1 weights and shift (one block; fixed-order sum of the per-block partials)
+// ... and the operands of S2X's conv2 on the fp16 matrix pipe.  conv2 multiplies h = LReLU(conv1'(e)) by W2 as two fp16 pieces per
+// value (hi = rn16(v), lo = rn16(v - hi): 22+ significand bits; products hi*hi + hi*lo + lo*hi accumulated in fp32).  fp16 has a
+// narrow exponent range, so both operands are moved into it by POWERS OF TWO (exact; S2X divides them out again):
+//   T: |h_c| <= |beta_c| + |gamma_c| sqrt(rows)  (a standardised value is at most sqrt(rows - 1); LReLU only shrinks), so with
+//      T = 2^floor(log2(32768 / max_c bound_c)) no T h can overflow fp16 (65504) whatever the data is; T multiplies the folded conv1
+//      weights and shift (the accumulator of conv1' is then T x the unscaled one bit for bit);
+//   S: max |S W2| in [2^12, 2^13): the low pieces of all but vanishing weights are fp16 normals.
+// The pre-split weight image (the layout S2X copies to LDS, rows already carrying sgn(gamma2)) is written here, once per scene,
+// instead of once per workgroup.
+__device__ __forceinline__ float pow2_scale(float bound, float target) {      // largest power of two p with p * bound <= target
+    if (!(bound > 0.f) || !(bound < INFINITY)) return 1.f;
+    int e;
+    const float m = frexpf(target / bound, &e);                                // target / bound = m 2^e, m in [0.5, 1)
+    (void)m;
+    return ldexpf(1.f, min(max(e - 1, -40), 40));
+}
 __device__ __forceinline__ void bn_fold_moments_body(const double* __restrict__ partial, int nblocks, double rows,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift) {
+                                                     const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift,
+                                                     const float* __restrict__ w2, const float* __restrict__ gamma2,
+                                                     u32x4* __restrict__ w2img, float* __restrict__ scales) {
     __shared__ double part[4][256];
+    __shared__ float sbound[64], swmax[16], sT, sS;
     __shared__ double tot[kMom];
     __shared__ double mu[18], M[18][18];
     const int v = threadIdx.x & 255, g = threadIdx.x >> 8;
@@ -558,17 +551,60 @@ __device__ __forceinline__ void bn_fold_moments_body(const double* __restrict__ 
     }
     const double var = ey2 - mean * mean;
     const double a = (double)gamma[ch] / sqrt(var + 1e-5);
-    for (int k = threadIdx.x >> 6; k < 18; k += 16) w_folded[ch * 18 + k] = (float)(a * (double)w[ch * 18 + k]);
-    if (threadIdx.x < 64) shift[ch] = (float)((double)beta[ch] - a * mean);
+    float T = 1.f;
+    if (w2img) {
+        if (threadIdx.x < 64) sbound[ch] = fabsf(beta[ch]) + fabsf(gamma[ch]) * (float)sqrt(rows);
+        float wm = 0.f;
+        for (int i = threadIdx.x; i < 64 * 64; i += 1024) wm = fmaxf(wm, fabsf(w2[i]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+        if ((threadIdx.x & 63) == 0) swmax[threadIdx.x >> 6] = wm;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float b = 0.f, m = 0.f;
+            for (int c = 0; c < 64; ++c) b = fmaxf(b, sbound[c]);
+            for (int c = 0; c < 16; ++c) m = fmaxf(m, swmax[c]);
+            sT = pow2_scale(b, 32768.f);
+            sS = pow2_scale(m, 8191.f);
+            scales[0] = 1.f / (sT * sS);                           // what S2X multiplies its results by
+            scales[1] = sT;
+            scales[2] = sS;
+        }
+        __syncthreads();
+        T = sT;
+        const float S = sS;
+        if (threadIdx.x < 2 * 4 * 64) {                            // one (ot, kb, lane) fragment per thread: 8 weights -> hi | lo pieces
+            const int l = threadIdx.x & 63, kb = (threadIdx.x >> 6) & 3, ot = threadIdx.x >> 8;
+            const int oc = 32 * ot + (l & 31);
+            const float sgn = gamma2[oc] < 0.f ? -S : S;           // the last layer's rows carry the sign of its BN gamma (see the header)
+            unsigned int hi[4], lo[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x2 v = {sgn * w2[oc * 64 + acc_channel(kb >> 1, 8 * (kb & 1) + 2 * jj, l >> 5)],
+                                 sgn * w2[oc * 64 + acc_channel(kb >> 1, 8 * (kb & 1) + 2 * jj + 1, l >> 5)]};
+                const f16x2 h = __builtin_convertvector(v, f16x2);
+                const f16x2 r = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), f16x2);
+                hi[jj] = __builtin_bit_cast(unsigned int, h);
+                lo[jj] = __builtin_bit_cast(unsigned int, r);
+            }
+            w2img[threadIdx.x] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            w2img[512 + threadIdx.x] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+    }
+    for (int k = threadIdx.x >> 6; k < 18; k += 16) w_folded[ch * 18 + k] = (float)(a * (double)w[ch * 18 + k]) * T;
+    if (threadIdx.x < 64) shift[ch] = (float)((double)beta[ch] - a * mean) * T;
 }
 __global__ __launch_bounds__(1024) void k_bn_fold_moments(const double* __restrict__ partial, int nblocks, double rows,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift) {
-    bn_fold_moments_body(partial, nblocks, rows, gamma, beta, w, w_folded, shift);
+                                                          const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift,
+                                                          const float* __restrict__ w2, const float* __restrict__ gamma2,
+                                                          u32x4* __restrict__ w2img, float* __restrict__ scales) {
+    bn_fold_moments_body(partial, nblocks, rows, gamma, beta, w, w_folded, shift, w2, gamma2, w2img, scales);
 }
 __global__ __launch_bounds__(1024) void k_bn_fold_moments_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
-    bn_fold_moments_body(c.ec_partial, c.ec_mblocks, (double)c.N * 20.0, c.ec_g1, c.ec_b1, c.ec_w1, c.ec_w1f, c.ec_sh1);
+    bn_fold_moments_body(c.ec_partial, c.ec_mblocks, (double)c.N * 20.0, c.ec_g1, c.ec_b1, c.ec_w1, c.ec_w1f, c.ec_sh1, c.ec_w2, c.ec_g2,
+                         reinterpret_cast<u32x4*>(c.ec_w2img), c.ec_scale);
 }
 
 // last layer of an MLP: fixed-order reduction of the per-block partials -> |a| = |gamma| / sqrt(var + eps) and the shift.
@@ -669,20 +705,22 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     const int nblocks = sg::cdiv(sg::cdiv(N, 32), kWaves);
     sg::Carver cv(d_ws, ws_bytes);
     double* partial = cv.take<double>(std::max((size_t)nblocks * 128, (size_t)sg::cdiv(N, 256) * kMom));
-    float* fold = cv.take<float>(64 * 18 + 64 + 64 * 64 + 64 + 128);
+    float* fold = cv.take<float>(sg::kEdgeFoldFloats + 128);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_edgeconv_forward: workspace too small (%zu < %zu)", ws_bytes, sg_edgeconv_ws_bytes(N));
     float* w1f = fold;
     float* sh1 = w1f + 64 * 18;
     float* w2f = sh1 + 64;
     float* sh2 = w2f + 64 * 64;
-    float* stats_last = sh2 + 64;                                // batch mean | variance of the LAST BatchNorm's input
+    u32x4* w2img = reinterpret_cast<u32x4*>(sh2 + 64);           // S2X's pre-split conv2 weights + {1/(S T), T, S}
+    float* scales = sh2 + 64 + 4096;
+    float* stats_last = fold + sg::kEdgeFoldFloats;              // batch mean | variance of the LAST BatchNorm's input
     hipStream_t st = sg::as_stream(stream);
     const double rows = (double)N * (double)k;
     const dim3 grid(nblocks), block(64 * kWaves);
     const size_t n4 = (size_t)N * 16;
     const int egrid = (int)std::min<size_t>((n4 + 255) / 256, 2048);
     if (layers == 1) {
-        k_edgeconv<S1X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, d_g1, d_out, partial);
+        k_edgeconv<S1X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, d_g1, d_out, partial);
         k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, w1f, sh1, stats_last);
         if (mark) mark(0);
         if (d_affine) { d_affine[0] = w1f; d_affine[1] = sh1; d_affine[2] = stats_last; }        // the caller applies LReLU(|a| E + b') where it consumes E
@@ -691,9 +729,9 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     } else {
         const int mblocks = sg::cdiv(N, 256);
         k_edge_moments<<<mblocks, 256, 0, st>>>(d_x9m, d_knn, N, k, partial);
-        k_bn_fold_moments<<<1, 1024, 0, st>>>(partial, mblocks, rows, d_g1, d_b1, d_w1, w1f, sh1);
+        k_bn_fold_moments<<<1, 1024, 0, st>>>(partial, mblocks, rows, d_g1, d_b1, d_w1, w1f, sh1, d_w2, d_g2, w2img, scales);
         if (mark) mark(0);
-        k_edgeconv<S2X, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, d_w2, d_g2, d_out, partial);
+        k_edgeconv<S2X, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2img, scales, d_g2, d_out, partial);
         k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, w2f, sh2, stats_last);
         if (mark) mark(1);
         if (d_affine) { d_affine[0] = w2f; d_affine[1] = sh2; d_affine[2] = stats_last; }
@@ -740,7 +778,7 @@ extern "C" {
 size_t sg_edgeconv_ws_bytes(int N) {
     const size_t nblocks = (size_t)sg::cdiv(sg::cdiv(std::max(N, 1), 32), kWaves);
     const size_t mblocks = (size_t)sg::cdiv(std::max(N, 1), 256);
-    return sg::align_up(std::max(nblocks * 128, mblocks * 189) * 8) + sg::align_up((64 * 18 + 64 + 64 * 64 + 64 + 128) * 4);
+    return sg::align_up(std::max(nblocks * 128, mblocks * 189) * 8) + sg::align_up((sg::kEdgeFoldFloats + 128) * 4);
 }
 
 int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,

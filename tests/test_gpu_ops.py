@@ -302,6 +302,38 @@ def test_edgeconv_forward(env, N):
         assert np.abs(out.cpu().numpy() - ref).max() < 2e-5, which
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("g1_scale,w2_scale", [(1e3, 1e-3), (1e-3, 1e3), (3e4, 1e-4), (1.0, 1e-6)])
+def test_edgeconv_fp16_operand_scaling(env, g1_scale, w2_scale):
+    """MLP3's conv2 runs on fp16 pieces; the kernel moves both operands into fp16's exponent range by powers of two derived from
+    the weights (kernels_edgeconv.hip, k_bn_fold_moments).  Activations 1000x larger / smaller than usual and conv2 weights far
+    from O(0.1) must come out as accurate as the ordinary case (no overflow to inf, no fp16 subnormal loss)."""
+    lib, torch, hip = env
+    from oracle import cpu_ref as O
+    from seggroup_amd import weights
+    N, K = 3000, 20
+    rng = np.random.default_rng(77)
+    x9 = rng.uniform(-1, 1, (N, 9)).astype(np.float32)
+    knn = rng.integers(0, N, (N, K)).astype(np.int32)
+    W = weights.make_weights(1, 2.0, affine_jitter=0.3)
+    W["mlp_3.bn1.weight"] = (W["mlp_3.bn1.weight"] * g1_scale).astype(np.float32)
+    W["mlp_3.bn1.bias"] = (W["mlp_3.bn1.bias"] * g1_scale).astype(np.float32)
+    W["mlp_3.conv2.0.weight"] = (W["mlp_3.conv2.0.weight"] * w2_scale).astype(np.float32)
+    x12 = np.zeros((N, 12), np.float32)
+    x12[:, :9] = x9
+    d_x, d_k = _up(torch, x12), _up(torch, knn)
+    ws = _ws(torch, lib.sg_edgeconv_ws_bytes(N))
+    out = torch.zeros(N, 64, device="cuda:0")
+    t = {k: _up(torch, W[k]) for k in W}
+    hip.check(lib.sg_edgeconv_forward(d_x.data_ptr(), d_k.data_ptr(), N, K, 2, t["mlp_3.conv1.0.weight"].data_ptr(),
+                                      t["mlp_3.bn1.weight"].data_ptr(), t["mlp_3.bn1.bias"].data_ptr(), t["mlp_3.conv2.0.weight"].data_ptr(),
+                                      t["mlp_3.bn2.weight"].data_ptr(), t["mlp_3.bn2.bias"].data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), None))
+    ref = O.edgeconv_forward(x9, knn.astype(np.int64), W, "mlp_3")
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
 def test_gcn_forward(env):
     lib, torch, hip = env
     from oracle import cpu_ref as O
