@@ -47,9 +47,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak (64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
 MFMA_BF16_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md; 2495 TF measured)
-# what k_edgeconv<S2X> EXECUTES per edge row since round 2: fp32 operands split into three bf16 pieces -- conv2 as 6 products of
-# 64x64 (the three smallest cross terms are dropped), conv1 as 12 MFMAs of 32x32x16 per 32 rows x 64 outputs
-S2X_EXECUTED_BF16_FLOP_PER_ROW = 6 * 2 * 64 * 64 + 12 * 2 * 32 * 32 * 16 // 32
+# what k_edgeconv<S2X> EXECUTES per edge row since round 2: fp32 operands split into 16-bit pieces -- conv2 as 3 fp16 products of
+# 64x64 (hi*hi + hi*lo + lo*hi), conv1 as 12 bf16 MFMAs of 32x32x16 per 32 rows x 64 outputs
+S2X_EXECUTED_BF16_FLOP_PER_ROW = 3 * 2 * 64 * 64 + 12 * 2 * 32 * 32 * 16 // 32
 VALU_PEAK_GINST = 1024 * 2.4 / 2.0   # wave64 VALU instructions/ns: 1024 SIMD-32s, 2 cycles per wave64 op, 2.4 GHz
 PROFILE_TAG = "r02"
 
@@ -359,8 +359,9 @@ def main(argv=None):
         if d["ms_per_scene_launch"] > 0:
             ex = S2X_EXECUTED_BF16_FLOP_PER_ROW * 20.0 * args.points
             sm = solo_k.get(dom, {}).get("ms_per_scene_launch", 0.0)
-            roofline["executed"] = {"what": "the same launch priced by what it ISSUES: bf16 MFMA work of the three-piece split (fp32-accurate result; "
-                                            "'achieved' above is the algorithmic fp32 contraction against the fp32 MFMA peak, which a bf16x3 kernel can exceed)",
+            roofline["executed"] = {"what": "the same launch priced by what it ISSUES: 16-bit MFMA work of the split operands (fp16 hi/lo for conv2, three bf16 pieces "
+                                            "for conv1; fp32-accurate result; 'achieved' above is the algorithmic fp32 contraction against the fp32 MFMA peak, "
+                                            "which a split-operand kernel can exceed)",
                                     "bf16_flop_per_scene_launch": ex, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                                     "achieved": round(ex / (d["ms_per_scene_launch"] * 1e-3) / 1e12, 2),
                                     "frac": round(ex / (d["ms_per_scene_launch"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4),

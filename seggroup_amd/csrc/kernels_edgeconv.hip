@@ -7,10 +7,11 @@
 //   (infer.py never calls eval()).
 //
 // This is the only dense contraction on the hot path and it is MFMA-bound (39 GFLOP/scene, ~280
-// flop/B): it runs on v_mfma_f32_32x32x2_f32 (exact fp32, bit-equal to an fmaf chain).
+// flop/B): it runs on the matrix pipe -- the per-point part on v_mfma_f32_32x32x2_f32 (exact fp32, bit-equal to an fmaf chain),
+// the per-edge part on 16-bit MFMAs over split fp32 operands (below).
 //
 // The x_i half of the edge feature does not depend on the neighbour: its contribution to conv1 (plus the folded shift) is
-// evaluated once per point and seeds every slot's accumulator, so a slot costs 10 + 64 MFMAs (MLP3) or 10 (MLP2), not 18 + 64 / 18.
+// evaluated once per point and seeds every slot's accumulator, so conv1 contracts 9 inputs per slot, not 18.
 //
 // Mapping (one wave = one tile of 32 points, loop over the k=20 neighbour slots):
 //   D^T[ch][row] = sum_k W[ch][k] * E[row][k]:  A operand = weights (M = 32 channels per tile, two
@@ -37,18 +38,26 @@
 // Per-block fp64 partial sums are combined in fixed order by a one-block finalize kernel, so the
 // result is bit-reproducible run to run.
 //
-// conv2 of MLP3 (64 -> 64, 78 % of the stage's flops) runs on the bf16 matrix pipe at fp32 accuracy: the fp32 MFMA issues
-// at the fp32 VECTOR rate (64 cycles per 32x32x2 on a SIMD), v_mfma_f32_32x32x16_bf16 moves 8x the k-depth in half the
-// cycles.  Every fp32 operand is cut EXACTLY into three bf16 pieces by truncation (x = x1 + x2 + x3: 8 + 8 + 8 significand
-// bits; two ANDs and two subtractions per value, the pieces are the high halves of x, x - x1 and x - x1 - x2) and the
-// six products whose weight is >= 2^-16 of the leading one are accumulated in fp32 by the matrix pipe:
-//     w x ~= w1 x1 + (w1 x2 + w2 x1) + (w1 x3 + w2 x2 + w3 x1)        dropped: w2 x3 + w3 x2 + w3 x3 <= 3 * 2^-24 |w x|
-// Each bf16 x bf16 product is exact in fp32, so the result differs from the fp32 fmaf chain only by the order of the fp32
-// additions and the dropped 2^-24 terms: measured against the float64 oracle it is as close as the fp32 MFMA was (~1e-6;
-// tolerance 1e-4).  48 bf16 MFMAs (32 cycles each) + ~180 VALU replace 64 fp32 MFMAs (64 cycles each) per neighbour slot.
-// The accumulator of conv1 is still fed straight back as the B operand: a 16-deep k block of the bf16 MFMA takes 8
-// consecutive accumulator registers of a lane (lanes 0-31: k 0-7, lanes 32-63: k 8-15), and the weights are staged in LDS
-// in exactly that channel order, already split.
+// conv1 and conv2 run on the 16-bit matrix pipe at fp32 accuracy: the fp32 MFMA issues at the fp32 VECTOR rate (64 cycles per
+// 32x32x2 on a SIMD), v_mfma_f32_32x32x16_{bf16,f16} moves 8x the k-depth in half the cycles.  Every fp32 operand is cut into
+// 16-bit pieces whose products are exact in fp32, and the matrix pipe accumulates the products that matter in fp32:
+//   conv1 (d = x_j - x_i, raw data of unknown range): three bf16 pieces by truncation (x = x1 + x2 + x3, 8 + 8 + 8 significand
+//     bits, the full fp32 exponent range), six products
+//         w x ~= w1 x1 + (w1 x2 + w2 x1) + (w1 x3 + w2 x2 + w3 x1)        dropped: w2 x3 + w3 x2 + w3 x3 <= 3 * 2^-24 |w x|
+//   conv2 (64 -> 64, 78 % of the stage's flops; its operand h = LReLU(BN1(.)) has a PROVABLE bound): two fp16 pieces by
+//     round-to-nearest (hi = rn16(x), lo = rn16(x - hi): 11 + 11 bits and the sign of the remainder, |x - hi - lo| <= 2^-22 |x|),
+//     three products
+//         w x ~= w_hi x_hi + (w_hi x_lo + w_lo x_hi)                        dropped: w_lo x_lo ~ 2^-22 |w x|
+//     Half the MFMAs of the bf16 split and a cheaper cut (v_cvt_pk_f16_f32 rounds and packs a pair in one instruction).  fp16's
+//     exponent range is narrow, so both operands are moved into it by powers of two (exact; divided out of the statistics and
+//     the maxima at the end): see k_bn_fold_moments, which also writes the pre-split weight image once per scene.  The matrix
+//     pipe keeps fp16 subnormal inputs (tools/micro/mfma_f16_split.hip), so a small value's low piece costs at most 2^-25 / T
+//     of absolute error.  Measured (same micro test, |y| ~ 0.5, K = 64): max error 1.6e-7 vs 0.9e-7 (bf16 x 3, six products)
+//     and 1.3e-7 (plain fp32 fmaf chain); against the float64 oracle the point features stay within 2e-5 and every fixture's
+//     labels are unchanged.
+// The accumulator of conv1 is fed straight back as the B operand of conv2: a 16-deep k block takes 8 consecutive accumulator
+// registers of a lane (lanes 0-31: k 0-7, lanes 32-63: k 8-15), and the weights are staged in LDS in exactly that channel
+// order, already split.  Per neighbour slot: 12 (conv1) + 24 (conv2) MFMAs of 32 cycles instead of 10 + 64 fp32 MFMAs of 64.
 //
 // Conditioning: channels 0..2 of x_i are ABSOLUTE coordinates.  BatchNorm is invariant to a per-channel constant added to
 // its input, so every kernel here evaluates the x_i half of conv1 on x_i - [c, 0] with c = the XYZ of row 0 (any fixed point
