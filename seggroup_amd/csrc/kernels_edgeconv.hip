@@ -66,6 +66,7 @@
 // from the origin.  The differences d = x_j - x_i are formed from the raw coordinates exactly as the reference does.
 #include "engine_ctx.h"
 #include "sg_common.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -98,11 +99,12 @@ struct Lds {
 };
 
 template <int MODE, bool REREAD_A>
-__device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
-                                              const float* __restrict__ w1, const float* __restrict__ shift1,
-                                              const u32x4* __restrict__ w2img, const float* __restrict__ scales,
-                                              const float* __restrict__ gamma_last,
-                                              float* __restrict__ ext, double* __restrict__ partial, int bid) {
+__device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gptr<const int32_t> knn, int N, int K,
+                                              sg::gptr<const float> w1, sg::gptr<const float> shift1,
+                                              sg::gptr<const u32x4> w2img, sg::gptr<const float> scales,
+                                              sg::gptr<const float> gamma_last,
+                                              sg::gptr<float> ext, sg::gptr<double> partial, int bid) {
+    using sg::gptr;
     __shared__ Lds lds;
     constexpr bool kTwo = MODE == S2X;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -161,7 +163,7 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
 
     if (tile * 32 < N) {
         // x_i (9 of the 12 floats of the padded row)
-        const float4* xr = reinterpret_cast<const float4*>(x9m + (size_t)ptc * 12);
+        const gptr<const float4> xr = (gptr<const float4>)(x9m + (size_t)ptc * 12);
         const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
         const float xi[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
         // B operands, k = 2s + half: the x_i half of the edge feature is the same for all K neighbours of a point, so its
@@ -212,10 +214,12 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
 #pragma unroll
             for (int q = 0; q < 16; ++q) best[t][q] = -INFINITY;
 
-        const int32_t* krow = knn + (size_t)ptc * K;
-        // software pipeline: the next slot's neighbour row is requested before this slot's MFMAs start
+        const gptr<const int32_t> krow = knn + (size_t)ptc * K;
+        // software pipeline: the next slot's neighbour row is requested before this slot's MFMAs start.  (Hoisting the tile's
+        // first loads -- own row, first ids, first neighbour row: three dependent round trips -- in front of the weight staging
+        // and the base MFMAs measured SLOWER, S1X 421 -> 457 us: the co-resident wave of the other workgroup already covers them.)
         int nb_next = krow[0];
-        const float4* xp = reinterpret_cast<const float4*>(x9m + (size_t)nb_next * 12);
+        const gptr<const float4> xp = (gptr<const float4>)(x9m + (size_t)nb_next * 12);
         float4 p0 = xp[0], p1 = xp[1], p2 = xp[2];
         nb_next = K > 1 ? krow[1] : 0;
         for (int j = 0; j < K; ++j) {
@@ -225,7 +229,7 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
             if (REREAD_A) asm volatile("" ::: "memory");
             const float4 n0 = p0, n1 = p1, n2 = p2;
             if (j + 1 < K) {
-                const float4* xq = reinterpret_cast<const float4*>(x9m + (size_t)nb_next * 12);
+                const gptr<const float4> xq = (gptr<const float4>)(x9m + (size_t)nb_next * 12);
                 p0 = xq[0]; p1 = xq[1]; p2 = xq[2];
                 if (j + 2 < K) nb_next = krow[j + 2];
             }
@@ -347,14 +351,18 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
             }
         }
 
-        // sum over the 32 rows of this half (xor offsets < 32 keep the half), then one lane per half
-        // adds into the wave's fp64 LDS accumulators
+        // sum over the 32 rows of each half on the DPP path (wave_ops.h; `__shfl_xor` is an LDS round trip per step on gfx950): quads,
+        // 16-lane rows, then row_bcast15 folds row 0 into row 1 and row 2 into row 3 -- lanes 31 and 63 hold their half's sum and
+        // add it into the wave's fp64 LDS accumulators
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
             float s = stat_s[q] * vmask, v = stat_q[q] * vmask;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o); v += __shfl_xor(v, o); }
-            if (r == 0) {
+            s += sgw::dpp_f<sgw::kQuadXor1>(s, s); v += sgw::dpp_f<sgw::kQuadXor1>(v, v);
+            s += sgw::dpp_f<sgw::kQuadXor2>(s, s); v += sgw::dpp_f<sgw::kQuadXor2>(v, v);
+            s += sgw::dpp_f<sgw::kRowRor4>(s, s);  v += sgw::dpp_f<sgw::kRowRor4>(v, v);
+            s += sgw::dpp_f<sgw::kRowRor8>(s, s);  v += sgw::dpp_f<sgw::kRowRor8>(v, v);
+            s += sgw::dpp_f<sgw::kRowBcast15, 0xA>(0.f, s); v += sgw::dpp_f<sgw::kRowBcast15, 0xA>(0.f, v);
+            if (r == 31) {
                 const int ch = acc_channel(q >> 4, q & 15, half);
                 lds.acc[wave][ch] += (double)s * (double)unscale;                                  // power of two: exact
                 lds.acc[wave][64 + ch] += (double)v * ((double)unscale * (double)unscale);
@@ -362,14 +370,14 @@ __device__ __forceinline__ void edgeconv_body(const float* __restrict__ x9m, con
         }
         if (valid) {
             // E = max_j y'_j : 4 consecutive channels per float4 store
-            float* orow = ext + (size_t)pt * 64;
+            const gptr<float> orow = ext + (size_t)pt * 64;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 v = make_float4(best[t][4 * g] * unscale, best[t][4 * g + 1] * unscale, best[t][4 * g + 2] * unscale,
                                                  best[t][4 * g + 3] * unscale);
-                    *reinterpret_cast<float4*>(orow + 32 * t + 8 * g + 4 * half) = v;
+                    *(gptr<float4>)(orow + 32 * t + 8 * g + 4 * half) = v;
                 }
         }
     }
@@ -388,16 +396,22 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
                                                           const u32x4* __restrict__ w2img, const float* __restrict__ scales,
                                                           const float* __restrict__ gamma_last,
                                                           float* __restrict__ ext, double* __restrict__ partial) {
-    edgeconv_body<MODE, REREAD_A>(x9m, knn, N, K, w1, shift1, w2img, scales, gamma_last, ext, partial, blockIdx.x);
+    using sg::as_global;
+    edgeconv_body<MODE, REREAD_A>(as_global(x9m), as_global(knn), N, K, as_global(w1), as_global(shift1), as_global(w2img), as_global(scales),
+                                  as_global(gamma_last), as_global(ext), as_global(partial), blockIdx.x);
 }
 // S1X: the scene's MLP2 weights as they are; S2X: its folded conv1 (ec_w1f, ec_sh1) + the raw conv2
 template <int MODE, bool REREAD_A>
 __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.ec_blocks) return;
-    if (MODE == S1X) edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, c.K, c.ec_w1, nullptr, nullptr, nullptr, c.ec_g1, c.pf, c.ec_partial, blockIdx.x);
-    else edgeconv_body<MODE, REREAD_A>(c.x9m, c.knn, c.N, c.K, c.ec_w1f, c.ec_sh1, reinterpret_cast<const u32x4*>(c.ec_w2img), c.ec_scale, c.ec_g2, c.pf,
-                                       c.ec_partial, blockIdx.x);
+    // pointers read out of a SlotCtx are generic to the compiler (sg_common.h, gptr): hand them over as global memory
+    using sg::as_global;
+    if (MODE == S1X) edgeconv_body<MODE, REREAD_A>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global(c.ec_w1), nullptr, nullptr, nullptr,
+                                                   as_global(c.ec_g1), as_global(c.pf), as_global(c.ec_partial), blockIdx.x);
+    else edgeconv_body<MODE, REREAD_A>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global((const float*)c.ec_w1f), as_global((const float*)c.ec_sh1),
+                                       as_global(reinterpret_cast<const u32x4*>(c.ec_w2img)), as_global((const float*)c.ec_scale), as_global(c.ec_g2),
+                                       as_global(c.pf), as_global(c.ec_partial), blockIdx.x);
 }
 
 // Batch statistics of conv1's output WITHOUT evaluating it (the inner BN of MLP3): y = W1 e is linear, so

@@ -13,6 +13,25 @@
 
 namespace sg {
 
+// A pointer loaded from a descriptor struct (SlotCtx) is a GENERIC pointer to the compiler: every access through it is a
+// flat_load / flat_store -- counted on vmcnt AND lgkmcnt, so LDS waits and memory waits block each other, plus an aperture check
+// per access.  Device code that mixes LDS traffic with gathers therefore takes its pointers in address space 1 (gptr<T>):
+// global_load / global_store, vmcnt only.  (A cast back to a generic pointer loses the information again.)
+#if defined(__HIPCC__)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SG_GLOBAL __attribute__((address_space(1)))
+#define SG_LDS __attribute__((address_space(3)))
+#else
+#define SG_GLOBAL                    /* the host pass only parses device code */
+#define SG_LDS
+#endif
+template <class T>
+using gptr = SG_GLOBAL T*;
+template <class T>
+__host__ __device__ __forceinline__ gptr<T> as_global(T* p) { return (gptr<T>)p; }
+#endif
+
+
 char* err_buf();                       // thread-local message buffer (defined in capi.cpp)
 int fail(int code, const char* fmt, ...);
 
