@@ -474,12 +474,10 @@ __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m,
         xi[0] -= cx; xi[1] -= cy; xi[2] -= cz;                   // d is done with the raw coordinates; the x_i terms are centred
     }
     const float Kf = valid ? (float)K : 0.f;
-    // wave sums in fp32 over a fixed shuffle tree (as the MFMA statistics passes do), then doubles: the four waves
+    // wave sums in fp32 over a fixed DPP network (as the MFMA statistics passes do), then doubles: the four waves
     // in fixed order, the blocks in fixed order in k_bn_fold_moments
     auto wsum = [&](float v, int slot) {
-        float s = v;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float s = sgw::wave_sum(v);                           // DPP network (wave_ops.h): 189 sums per wave, no LDS round trips
         if (lane == 0) red[wave][slot] = (double)s;
     };
     int t = 0;

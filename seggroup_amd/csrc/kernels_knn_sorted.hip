@@ -497,13 +497,13 @@ __device__ unsigned long long g_knn5_stats[16];
 // and nobody skips them.
 template <int K, int kSlices, bool kSeeded>
 __device__ __forceinline__ void cluster_knn_sorted_body(
-    const float4* __restrict__ sxyzw, const int32_t* __restrict__ smpos, const int32_t* __restrict__ cl_off,
-    const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi,
-    const int32_t* __restrict__ cl_seg_off, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
-    const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off, const float* __restrict__ segbox,
-    const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg_arg,
-    const int32_t* __restrict__ seed, const int32_t* __restrict__ seg_prevcl, const int32_t* __restrict__ members,
-    const float4* __restrict__ point_rec, int t) {
+    sg::gptr<const float4> sxyzw, sg::gptr<const int32_t> smpos, sg::gptr<const int32_t> cl_off,
+    sg::gptr<const int32_t> tile_cl, sg::gptr<const int32_t> tile_lo, sg::gptr<const int32_t> tile_hi,
+    sg::gptr<const int32_t> cl_seg_off, sg::gptr<const int32_t> order, sg::gptr<const int32_t> dst,
+    sg::gptr<const int32_t> seg_off, sg::gptr<const int32_t> seg_chunk_off, sg::gptr<const float> segbox,
+    sg::gptr<const float> chunk_box, sg::gptr<const int32_t> slot_of_pos, int pos0, sg::gptr<int32_t> knn, int dbg_arg,
+    sg::gptr<const int32_t> seed, sg::gptr<const int32_t> seg_prevcl, sg::gptr<const int32_t> members,
+    sg::gptr<const float4> point_rec, int t) {
     static_assert(!kSeeded || kSlices == 1, "seeding is built for one wave per tile");
     const int dbg = kKnnProfile ? dbg_arg : 0;
     // LDS per wave decides how many tiles a CU keeps in flight, and this kernel waits on memory ~45 % of the time:
@@ -527,13 +527,14 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     const int myrow = active ? smpos[q] : 0;                  // member position = output row
     if (n <= K) {                                            // model.py:516-518 (block-uniform)
         if (active && wave == 0) {
-            int32_t* o = knn + (size_t)myrow * K;
+            const sg::gptr<int32_t> o = knn + (size_t)myrow * K;
 #pragma unroll
             for (int j = 0; j < K; ++j) o[j] = j < n ? clo + j : pos0;
         }
         return;
     }
-    const float4 me = active ? sxyzw[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) me = sxyzw[q];
     unsigned long long kv[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) kv[j] = 0ull;
@@ -542,7 +543,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     if (kSeeded && active) {
         myprev = seg_prevcl[order[slot_of_pos[myrow]]];
         if (myprev >= 0) {
-            const int32_t* sp = seed + (size_t)members[myrow] * K;
+            const sg::gptr<const int32_t> sp = seed + (size_t)members[myrow] * K;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const float4 rec = point_rec[sp[j]];              // XYZ + this layer's member position: one gather per seed
@@ -570,9 +571,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
         return pub > thr ? pub : thr;
     };
     auto drain = [&]() {
-        int mxc = cnt;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mxc = max(mxc, __shfl_xor(mxc, o));
+        const int mxc = sgw::wave_max(cnt);                    // DPP + readlane: wave-uniform (an SGPR drives the loop below)
         if (dbg & 32) {
             unsigned long long tot = cnt;
 #pragma unroll
@@ -605,7 +604,9 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
         __builtin_amdgcn_wave_barrier();
         if (lane < kChunkPts + kQuadS) {
             const bool in = lane < m;
-            cw[lane] = in ? sxyzw[p0 + lane] : make_float4(0.f, 0.f, 0.f, INFINITY);
+            float4 cand = make_float4(0.f, 0.f, 0.f, INFINITY);
+            if (in) cand = sxyzw[p0 + lane];
+            cw[lane] = cand;
             ci[lane] = in ? smpos[p0 + lane] - clo : 0x7fffffff;
         }
         __builtin_amdgcn_wave_barrier();
@@ -690,7 +691,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (lane < nb) {
-                    const float4* bp = reinterpret_cast<const float4*>(chunk_box + (size_t)(sg_c0 + mych) * 8);
+                    const sg::gptr<const float4> bp = (sg::gptr<const float4>)(chunk_box + (size_t)(sg_c0 + mych) * 8);
                     const float4 b0 = bp[0], b1 = bp[1];
                     reinterpret_cast<float4*>(cbx)[2 * lane] = b0;
                     reinterpret_cast<float4*>(cbx)[2 * lane + 1] = b1;
@@ -753,7 +754,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             st_c0[e] = seg_chunk_off[sg];
             st_d[e] = dst[slot];
             if (kSeeded) st_pc[e] = seg_prevcl[sg];
-            const float4* bp = reinterpret_cast<const float4*>(segbox + (size_t)sg * 8);
+            const sg::gptr<const float4> bp = (sg::gptr<const float4>)(segbox + (size_t)sg * 8);
             reinterpret_cast<float4*>(&st_box[e][0])[0] = bp[0];
             reinterpret_cast<float4*>(&st_box[e][0])[1] = bp[1];
         }
@@ -764,7 +765,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     const unsigned long long t3 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
     if (kSlices == 1) {
         if (active) {
-            int32_t* o = knn + (size_t)myrow * K;
+            const sg::gptr<int32_t> o = knn + (size_t)myrow * K;
 #pragma unroll
             for (int j = 0; j < K; ++j) o[j] = clo + key_index(kv[j]);
         }
@@ -779,7 +780,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             unsigned long long h[kSlices];
     #pragma unroll
             for (int w = 0; w < kSlices; ++w) { p[w] = 0; h[w] = lists[((size_t)w * K) * 64 + lane]; }
-            int32_t* o = knn + (size_t)myrow * K;
+            const sg::gptr<int32_t> o = knn + (size_t)myrow * K;
             for (int j = 0; j < K; ++j) {
                 int bw = 0;
                 unsigned long long bk = h[0];
@@ -810,9 +811,12 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
     const float* __restrict__ chunk_box, const int32_t* __restrict__ slot_of_pos, int pos0, int32_t* __restrict__ knn, int dbg_arg,
     const int32_t* __restrict__ seed = nullptr, const int32_t* __restrict__ seg_prevcl = nullptr, const int32_t* __restrict__ members = nullptr,
     const float4* __restrict__ point_rec = nullptr) {
-    cluster_knn_sorted_body<K, kSlices, kSeeded>(sxyzw, smpos, cl_off, tile_cl, tile_lo, tile_hi, cl_seg_off, order, dst, seg_off, seg_chunk_off,
-                                                 segbox, chunk_box, slot_of_pos, pos0, knn, dbg_arg, seed, seg_prevcl, members, point_rec,
-                                                 blockIdx.x);
+    using sg::as_global;
+    cluster_knn_sorted_body<K, kSlices, kSeeded>(as_global(sxyzw), as_global(smpos), as_global(cl_off), as_global(tile_cl), as_global(tile_lo),
+                                                 as_global(tile_hi), as_global(cl_seg_off), as_global(order), as_global(dst), as_global(seg_off),
+                                                 as_global(seg_chunk_off), as_global(segbox), as_global(chunk_box), as_global(slot_of_pos), pos0,
+                                                 as_global(knn), dbg_arg, as_global(seed), as_global(seg_prevcl), as_global(members),
+                                                 as_global(point_rec), blockIdx.x);
 }
 // one wave per tile: these waves wait on memory two thirds of their life (PMC: 35 % issuing).  The seeded kernel gets a
 // fourth resident wave per SIMD by capping it at 128 VGPRs (129 -> 118, no spill: 952 -> 848 us per launch of 8 scenes); a
@@ -821,9 +825,14 @@ template <int K, int kSlices, bool kSeeded>
 __global__ __launch_bounds__(64 * kSlices, kSlices == 1 && kSeeded ? 4 : 1) void k_cluster_knn_sorted_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.x];                    // grid = (scenes, tiles): one scene per XCD (kernels_edgeconv.hip, k_edgeconv_b)
     if ((int)blockIdx.y >= c.T) return;
-    cluster_knn_sorted_body<K, kSlices, kSeeded>(c.sxyzw, c.smpos, c.cl_pt_off, c.tile_cl, c.tile_lo, c.tile_hi, c.cl_seg_off, c.order, c.dst,
-                                                 c.seg_off, c.seg_chunk_off, c.segbox, c.chunk_box, c.slot_of_pos, c.pos0, c.knn, 0, c.knn_seed,
-                                                 c.seg_prevcl, c.members, c.point_rec, blockIdx.y);
+    // pointers read out of a SlotCtx are generic to the compiler (flat_load: vmcnt AND lgkmcnt); sg_common.h, gptr
+    using sg::as_global;
+    cluster_knn_sorted_body<K, kSlices, kSeeded>(as_global(c.sxyzw), as_global(c.smpos), as_global(c.cl_pt_off), as_global(c.tile_cl),
+                                                 as_global(c.tile_lo), as_global(c.tile_hi), as_global(c.cl_seg_off), as_global(c.order),
+                                                 as_global(c.dst), as_global(c.seg_off), as_global(c.seg_chunk_off), as_global(c.segbox),
+                                                 as_global(c.chunk_box), as_global(c.slot_of_pos), c.pos0, as_global(c.knn), 0,
+                                                 as_global(c.knn_seed), as_global(c.seg_prevcl), as_global(c.members), as_global(c.point_rec),
+                                                 blockIdx.y);
 }
 
 
@@ -913,7 +922,8 @@ __global__ __launch_bounds__(64) void k_cluster_knn_2pass(
         }
         return;
     }
-    const float4 me = active ? sxyzw[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) me = sxyzw[q];
     const int ch0 = cl_chunk_off[c], nch = cl_chunk_off[c + 1] - ch0;
     const int start = tile_chunk0[t];                         // cluster-relative chunk holding the tile's first query
     // the tile's query box (idle lanes repeat lane 0) and largest |q|^2, for the coarse chunk test
