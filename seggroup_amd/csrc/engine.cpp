@@ -478,7 +478,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     mark(sb + 2);
     struct MarkArg { Group* g; int sub0; } ma{this, layer == 0 ? 19 : 21};
     EG_CHECK(sg::b_edgeconv(d_ctx, bd, layer + 1, [](void* a, int i) { auto* m = static_cast<MarkArg*>(a); m->g->mark(m->sub0 + i); }, &ma, stream));
-    EG_CHECK(sg::b_segment_max(d_ctx, bd, layer + 1, stream));      // the last BN + LeakyReLU ride inside the segment max
+    // (the point -> cluster max rides inside the EdgeConv launches, the last BN + LeakyReLU in b_edgeconv's k_cluster_affine)
     mark(sb + 4);
     EG_CHECK(sg::b_gcn(d_ctx, bd, 0.125f, stream));
     EG_CHECK(sg::b_edge_distance(d_ctx, bd, stream));

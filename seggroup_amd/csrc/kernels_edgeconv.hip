@@ -98,12 +98,13 @@ struct Lds {
     double acc[kWaves][128]; // per-wave statistics: [0,64) sum, [64,128) sum of squares
 };
 
-template <int MODE, bool REREAD_A>
+template <int MODE, bool REREAD_A, bool kFused = false>
 __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gptr<const int32_t> knn, int N, int K,
                                               sg::gptr<const float> w1, sg::gptr<const float> shift1,
                                               sg::gptr<const u32x4> w2img, sg::gptr<const float> scales,
                                               sg::gptr<const float> gamma_last,
-                                              sg::gptr<float> ext, sg::gptr<double> partial, int bid) {
+                                              sg::gptr<float> ext, sg::gptr<double> partial, int bid,
+                                              sg::gptr<const int32_t> cluster_of_pos = nullptr, int ext_stride = 64) {
     using sg::gptr;
     __shared__ Lds lds;
     constexpr bool kTwo = MODE == S2X;
@@ -368,17 +369,50 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                 lds.acc[wave][64 + ch] += (double)v * ((double)unscale * (double)unscale);
             }
         }
-        if (valid) {
-            // E = max_j y'_j : 4 consecutive channels per float4 store
-            const gptr<float> orow = ext + (size_t)pt * 64;
+        if constexpr (!kFused) {
+            if (valid) {
+                // E = max_j y'_j : 4 consecutive channels per float4 store
+                const gptr<float> orow = ext + (size_t)pt * 64;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 v = make_float4(best[t][4 * g] * unscale, best[t][4 * g + 1] * unscale, best[t][4 * g + 2] * unscale,
+                                                     best[t][4 * g + 3] * unscale);
+                        *(gptr<float4>)(orow + 32 * t + 8 * g + 4 * half) = v;
+                    }
+            }
+        } else {
+            // Fused point -> cluster max (the scene engine): the consumer of E is max over each cluster's rows of LReLU(|a| E + b'),
+            // and that map is monotone, so the cluster maximum of E itself is enough -- the [N,64] array (38 MB per scene and
+            // layer, written here and read back by the segment-max kernel) never exists.  Rows are in member order (a tile spans
+            // one cluster, sometimes two or three): the wave parks its 32 x 64 maxima in LDS, then lane = channel walks the rows
+            // and leaves ONE atomic max per (cluster, channel) -- into the columns of the layer's feature matrix that the fill
+            // kernel set to -inf (`ext` = cat + gm_D, stride Dcat); k_cluster_affine applies the activation once the fold is known.
+            __shared__ float stage[kWaves][32 * 65];
+            float* st = &stage[wave][0];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 v = make_float4(best[t][4 * g] * unscale, best[t][4 * g + 1] * unscale, best[t][4 * g + 2] * unscale,
-                                                 best[t][4 * g + 3] * unscale);
-                    *(gptr<float4>)(orow + 32 * t + 8 * g + 4 * half) = v;
-                }
+                for (int q = 0; q < 16; ++q) st[r * 65 + acc_channel(t, q, half)] = best[t][q] * unscale;
+            const int myc = cluster_of_pos[ptc];
+            __builtin_amdgcn_wave_barrier();
+            const int rows_here = min(32, N - tile * 32);
+            int cprev = __builtin_amdgcn_readfirstlane(myc);
+            float m = -INFINITY;
+            auto flush = [&](int c, float v) {
+                float* addr = (float*)(ext + (size_t)c * ext_stride + lane);
+                // order-preserving integer view: non-negative floats compare as ints, negative floats reversed as uints
+                if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+                else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+            };
+            for (int rr = 0; rr < rows_here; ++rr) {
+                const int cr = __builtin_amdgcn_readlane(myc, rr);
+                const float v = st[rr * 65 + lane];
+                if (cr != cprev) { flush(cprev, m); m = v; cprev = cr; }
+                else m = fmaxf(m, v);
+            }
+            flush(cprev, m);
         }
     }
 
@@ -401,17 +435,37 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
                                   as_global(gamma_last), as_global(ext), as_global(partial), blockIdx.x);
 }
 // S1X: the scene's MLP2 weights as they are; S2X: its folded conv1 (ec_w1f, ec_sh1) + the raw conv2
+// the engine's launches: E goes straight into the clusters' maxima (kFused above), c.pf is not written
 template <int MODE, bool REREAD_A>
 __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.ec_blocks) return;
     // pointers read out of a SlotCtx are generic to the compiler (sg_common.h, gptr): hand them over as global memory
     using sg::as_global;
-    if (MODE == S1X) edgeconv_body<MODE, REREAD_A>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global(c.ec_w1), nullptr, nullptr, nullptr,
-                                                   as_global(c.ec_g1), as_global(c.pf), as_global(c.ec_partial), blockIdx.x);
-    else edgeconv_body<MODE, REREAD_A>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global((const float*)c.ec_w1f), as_global((const float*)c.ec_sh1),
-                                       as_global(reinterpret_cast<const u32x4*>(c.ec_w2img)), as_global((const float*)c.ec_scale), as_global(c.ec_g2),
-                                       as_global(c.pf), as_global(c.ec_partial), blockIdx.x);
+    if (MODE == S1X) edgeconv_body<MODE, REREAD_A, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global(c.ec_w1), nullptr, nullptr, nullptr,
+                                                         as_global(c.ec_g1), as_global(c.cat + c.gm_D), as_global(c.ec_partial), blockIdx.x,
+                                                         as_global(c.cluster_of_pos), c.Dcat);
+    else edgeconv_body<MODE, REREAD_A, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global((const float*)c.ec_w1f),
+                                             as_global((const float*)c.ec_sh1), as_global(reinterpret_cast<const u32x4*>(c.ec_w2img)),
+                                             as_global((const float*)c.ec_scale), as_global(c.ec_g2), as_global(c.cat + c.gm_D),
+                                             as_global(c.ec_partial), blockIdx.x, as_global(c.cluster_of_pos), c.Dcat);
+}
+// ... and the activation on the [C,64] maxima, in place, once the fold of the layer's last BatchNorm is known
+__global__ __launch_bounds__(256) void k_cluster_affine_b(const sg::SlotCtx* __restrict__ cx, int layers) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;                   // (cluster, channel quad)
+    if (i >= c.C * 16) return;
+    const float* a = layers == 1 ? c.ec_w1f : c.ec_w2f;
+    const float* b = layers == 1 ? c.ec_sh1 : c.ec_sh2;
+    const int ch = (i & 15) * 4;
+    float4* p = reinterpret_cast<float4*>(c.cat + c.gm_D + (size_t)(i >> 4) * c.Dcat + ch);
+    float4 v = *p;
+    float y;
+    y = __builtin_fmaf(a[ch], v.x, b[ch]);         v.x = fmaxf(y, 0.2f * y);
+    y = __builtin_fmaf(a[ch + 1], v.y, b[ch + 1]); v.y = fmaxf(y, 0.2f * y);
+    y = __builtin_fmaf(a[ch + 2], v.z, b[ch + 2]); v.z = fmaxf(y, 0.2f * y);
+    y = __builtin_fmaf(a[ch + 3], v.w, b[ch + 3]); v.w = fmaxf(y, 0.2f * y);
+    *p = v;
 }
 
 // Batch statistics of conv1's output WITHOUT evaluating it (the inner BN of MLP3): y = W1 e is linear, so
@@ -779,6 +833,7 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
     if (layers == 1) {
         k_edgeconv_b<S1X, false><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
         k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 1);
+        k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 1);
         if (mark) mark(mark_arg, 0);
     } else {
         k_edge_moments_b<<<dim3(sg::cdiv(bd.max_N, 256), bd.nslots), 256, 0, st>>>(d_ctx);
@@ -786,6 +841,7 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
         if (mark) mark(mark_arg, 0);
         k_edgeconv_b<S2X, true><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
         k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 2);
+        k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 2);
         if (mark) mark(mark_arg, 1);
     }
     SG_LAUNCH_CHECK();
