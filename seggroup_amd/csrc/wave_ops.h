@@ -15,9 +15,14 @@
 
 namespace sgw {
 
+// Full row mask: every lane receives a value (quad_perm / row_ror have no out-of-range source), so `old` is irrelevant -- and it
+// must not be a live register: with old = v the compiler emits copy + v_mov_b32_dpp + op (4 instructions per step with the
+// hazard nop); with old = 0 and bound_ctrl it folds the move into the consumer (`v_add_f32_dpp v, v, v quad_perm:...`: one).
+// A partial row mask (the row_bcast steps) keeps `old` for the lanes that are not written.
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ int dpp_i(int old, int v) {
-    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+    if constexpr (ROW_MASK == 0xF) return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+    else return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
 }
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_f(float old, float v) {
