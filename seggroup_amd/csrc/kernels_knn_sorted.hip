@@ -621,17 +621,23 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             // pairs the candidates' arithmetic into v_pk_mul / v_pk_fma_f32: same IEEE operations, fewer issue slots; a slab laid
             // out in candidate pairs to drop the packing moves measured no faster)
             float4 c4[kQuadS];
-            int id4[kQuadS];
 #pragma unroll
-            for (int u = 0; u < kQuadS; ++u) { c4[u] = cw[i + u]; id4[u] = ci[i + u]; }
+            for (int u = 0; u < kQuadS; ++u) c4[u] = cw[i + u];
+            // all kQuadS scores first, ONE branch for the group: late in a scan every lane turns every candidate away, and a taken
+            // `s_cbranch_execz` per candidate (7 VALU of work between two of them) costs about as much as the work itself
+            float sc4[kQuadS];
 #pragma unroll
-            for (int u = 0; u < kQuadS; ++u) {
-                const float sc = score4(me, c4[u]);
-                if (sc >= fbound) {
-                    const unsigned long long key = make_key(sc, id4[u]);
-                    if (key > use && key > thr) {
-                        buf[cnt][tid] = key;
-                        ++cnt;
+            for (int u = 0; u < kQuadS; ++u) sc4[u] = score4(me, c4[u]);
+            static_assert(kQuadS == 4, "the group test below is written for four candidates");
+            if (fmaxf(fmaxf(sc4[0], sc4[1]), fmaxf(sc4[2], sc4[3])) >= fbound) {
+#pragma unroll
+                for (int u = 0; u < kQuadS; ++u) {
+                    if (sc4[u] >= fbound) {
+                        const unsigned long long key = make_key(sc4[u], ci[i + u]);        // the index is only read for a survivor
+                        if (key > use && key > thr) {
+                            buf[cnt][tid] = key;
+                            ++cnt;
+                        }
                     }
                 }
             }
