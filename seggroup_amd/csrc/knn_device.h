@@ -23,14 +23,28 @@ __device__ inline int key_index(unsigned long long key) { return (int)(0xfffffff
 
 // Sorted insertion in PARALLEL form: every slot decides independently from two compares (no K-step chain):
 // new[j] = x > old[j] ? (x > old[j-1] ? old[j-1] : x) : old[j]
+// The K compares are made ONCE, as wave masks (an SGPR pair each), and the selects take the masks as they are.  Written with
+// plain bools the compiler keeps one VCC: it re-evaluates `x > old[j-1]` as a second 64-bit compare per slot and pays the
+// VALU-writes-VCC -> v_cndmask wait states behind every one of them (2 compares + 2 s_nop + 4 selects per slot).
+__device__ __forceinline__ unsigned int sel_mask(unsigned int if_clear, unsigned int if_set, unsigned long long mask) {
+    unsigned int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
 template <int K>
 __device__ inline void key_insert(unsigned long long (&kv)[K], unsigned long long x) {
-    bool c[K];
+    unsigned long long c[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) c[j] = x > kv[j];
+    for (int j = 0; j < K; ++j) c[j] = __builtin_amdgcn_uicmpl(x, kv[j], 34 /* ICMP_UGT */);
+    const unsigned int xl = (unsigned int)x, xh = (unsigned int)(x >> 32);
 #pragma unroll
-    for (int j = K - 1; j > 0; --j) kv[j] = c[j] ? (c[j - 1] ? kv[j - 1] : x) : kv[j];
-    kv[0] = c[0] ? x : kv[0];
+    for (int j = K - 1; j > 0; --j) {
+        const unsigned int pl = (unsigned int)kv[j - 1], ph = (unsigned int)(kv[j - 1] >> 32);
+        const unsigned int ol = (unsigned int)kv[j], oh = (unsigned int)(kv[j] >> 32);
+        const unsigned int tl = sel_mask(xl, pl, c[j - 1]), th = sel_mask(xh, ph, c[j - 1]);      // min(old[j-1], x)
+        kv[j] = ((unsigned long long)sel_mask(oh, th, c[j]) << 32) | sel_mask(ol, tl, c[j]);
+    }
+    kv[0] = ((unsigned long long)sel_mask((unsigned int)(kv[0] >> 32), xh, c[0]) << 32) | sel_mask((unsigned int)kv[0], xl, c[0]);
 }
 
 // upper bound of the score of ANY point inside an axis-aligned box {min xyz, max xyz, max |p|^2}:
