@@ -10,6 +10,7 @@
 // ((a - b) ** 2).sum(axis=2) on float32 (model.py:326): three individually rounded squares added as
 // (dx2 + dy2) + dz2 -- this translation unit is compiled with -ffp-contract=off so no FMA is formed.
 #include <climits>
+#include <type_traits>
 
 #include "engine_ctx.h"
 #include "sg_common.h"
@@ -80,8 +81,9 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
         // lane (point i = lane + 64 u, the same assignment as the strided loop below, so the first-index argmax is unchanged);
         // the newest pick's coordinates come from its owner lane through v_readlane.  The 64 dependent steps of a segment
         // were bound by LDS round trips (4 reads + 1 write per point and step, then 3 broadcast reads).
-        if (rem > 0 && n <= 256) {
-            constexpr int kU = 4;
+        // kU = points per lane, picked by the segment's size (wave-uniform): a 100-point segment steps over two slots, not four
+        auto in_registers = [&](auto ku) {
+            constexpr int kU = decltype(ku)::value;
             float X[kU], Y[kU], Z[kU], M[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
@@ -92,44 +94,56 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
                     X[u] = row[0]; Y[u] = row[1]; Z[u] = row[2];
                 }
             }
+            // branch-free on purpose: written with `if (i < n)` / `if (d > b.v)` the step compiled to 35 branches and 45 exec-mask
+            // saves for ~60 VALU of arithmetic, and a segment is a chain of 64 such steps.  A slot past the segment's end carries
+            // the running minimum -inf: it never wins the argmax (slot 0 always holds point 0, whose distance is >= 0).
+            bool in[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) in[u] = tid + 64 * u < n;
             auto pass = [&](float qx, float qy, float qz, bool reset) {
                 Best b{-INFINITY, INT_MAX};
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
                     const int i = tid + 64 * u;
-                    if (i < n) {
-                        const float dx = X[u] - qx, dy = Y[u] - qy, dz = Z[u] - qz;
-                        float d = (dx * dx + dy * dy) + dz * dz;
-                        if (!reset) d = fminf(M[u], d);
-                        M[u] = d;
-                        if (d > b.v) { b.v = d; b.i = i; }
-                    }
+                    const float dx = X[u] - qx, dy = Y[u] - qy, dz = Z[u] - qz;
+                    float d = (dx * dx + dy * dy) + dz * dz;
+                    d = reset ? d : fminf(M[u], d);
+                    d = in[u] ? d : -INFINITY;
+                    M[u] = d;
+                    const bool better_ = d > b.v;                 // strict: the lower index (u ascending) keeps a tie
+                    b.v = better_ ? d : b.v;
+                    b.i = better_ ? i : b.i;
                 }
                 sgw::wave_argmax(b.v, b.i);
                 return b;
             };
             auto coords = [&](int cur, float& qx, float& qy, float& qz) {     // cur is wave-uniform
                 const int u = cur >> 6, l = cur & 63;
-                const float sx = u == 0 ? X[0] : u == 1 ? X[1] : u == 2 ? X[2] : X[3];
-                const float sy = u == 0 ? Y[0] : u == 1 ? Y[1] : u == 2 ? Y[2] : Y[3];
-                const float sz = u == 0 ? Z[0] : u == 1 ? Z[1] : u == 2 ? Z[2] : Z[3];
+                float sx = X[0], sy = Y[0], sz = Z[0];
+#pragma unroll
+                for (int w = 1; w < kU; ++w) { sx = u == w ? X[w] : sx; sy = u == w ? Y[w] : sy; sz = u == w ? Z[w] : sz; }
                 qx = sgw::bcast(sx, l); qy = sgw::bcast(sy, l); qz = sgw::bcast(sz, l);
             };
             float qx, qy, qz;
             coords(0, qx, qy, qz);
             Best b = pass(qx, qy, qz, true);                          // start at member 0 (model.py:382-386)
-            int cur = b.i;
+            int cur = __builtin_amdgcn_readfirstlane(b.i);      // wave-uniform: say so, or `coords` becomes a branch tree
             if (tid == 0) picks[0] = cur;
             coords(cur, qx, qy, qz);
             b = pass(qx, qy, qz, true);
             for (int it = 1; it < rem; ++it) {                       // model.py:389-394
-                cur = b.i;
+                cur = __builtin_amdgcn_readfirstlane(b.i);
                 if (tid == 0) picks[it] = cur;
                 if (it + 1 < rem) {
                     coords(cur, qx, qy, qz);
                     b = pass(qx, qy, qz, false);
                 }
             }
+        };
+        if (rem > 0 && n <= 256) {
+            if (n <= 64) in_registers(std::integral_constant<int, 1>{});
+            else if (n <= 128) in_registers(std::integral_constant<int, 2>{});
+            else in_registers(std::integral_constant<int, 4>{});
             sampled = true;
         }
     }
@@ -172,6 +186,35 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
 
     // rows: members tiled rep times, then the picks (model.py:413-420)
     float* out = samples + (size_t)c * P * ch_out;
+    if constexpr (BLOCK == 64) {
+        // One wave, P = 64 rows, six channels (the structural layer): lane r owns row r, so the transform below runs on registers.
+        // The general path writes the rows, reads them back for the mean (12 threads, 16 DEPENDENT global loads each: as long as
+        // the 64 sampling steps themselves), rewrites them centred, rereads and rewrites them scaled.  The mean's association
+        // order -- four interleaved accumulators over the rows, added in order: see below -- is reproduced with v_readlane.
+        if (P == 64 && transform && ch_out == 6 && !sel) {
+            const int r = tid;
+            const int local = r < rep * n ? r % n : picks[r - rep * n];
+            const float* row = data + (size_t)members[lo + local] * ch_in;
+            float v[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[k] = row[k];
+            float mean[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] += sgw::bcast(v[ch], 4 * q + j);
+                mean[ch] = (((a[0] + a[1]) + a[2]) + a[3]) / (float)P;
+            }
+            const float x = v[0] - mean[0], y = v[1] - mean[1], z = v[2] - mean[2];
+            const float amax = sgw::wave_max(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
+            float* q = out + (size_t)r * 6;
+            q[0] = x / amax; q[1] = y / amax; q[2] = z / amax; q[3] = v[3]; q[4] = v[4]; q[5] = v[5];
+            return;
+        }
+    }
     for (int r = tid; r < P; r += BLOCK) {
         const int local = r < rep * n ? r % n : picks[r - rep * n];
         const int p = members[lo + local];

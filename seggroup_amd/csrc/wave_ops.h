@@ -79,26 +79,20 @@ __device__ __forceinline__ double wave_sum(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// argmax with "larger value wins, ties -> lower index" (np.argmax): a total order on (value, index), hence associative,
-// commutative and idempotent
+__device__ __forceinline__ int op_mini(int a, int b) { return min(a, b); }
+__device__ __forceinline__ int wave_min(int v) {
+    SGW_REDUCE(int, dpp_i, v, op_mini, v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// argmax with "larger value wins, ties -> lower index" (np.argmax), in two plain reductions: the wave's maximum (every step
+// folds into one v_max_f32_dpp), then the smallest index among the lanes that hold it (v_min_i32_dpp).  The pairwise network on
+// (value, index) pairs it replaces cost 9 instructions per step (two moves, three compares, two mask operations, two selects):
+// 54 of the ~105 instructions of an FPS step.  Values must not be NaN (a NaN equals nothing: no lane would own the maximum).
 __device__ __forceinline__ void wave_argmax(float& val, int& idx) {
-#define SGW_ARG_STEP(CTRL, MASK)                                                                           \
-    do {                                                                                                   \
-        const float ov = dpp_f<CTRL, MASK>(val, val);                                                      \
-        const int oi = dpp_i<CTRL, MASK>(idx, idx);                                                        \
-        const bool take = ov > val || (ov == val && oi < idx);                                             \
-        val = take ? ov : val;                                                                             \
-        idx = take ? oi : idx;                                                                             \
-    } while (0)
-    SGW_ARG_STEP(kQuadXor1, 0xF);
-    SGW_ARG_STEP(kQuadXor2, 0xF);
-    SGW_ARG_STEP(kRowRor4, 0xF);
-    SGW_ARG_STEP(kRowRor8, 0xF);
-    SGW_ARG_STEP(kRowBcast15, 0xA);
-    SGW_ARG_STEP(kRowBcast31, 0xC);
-#undef SGW_ARG_STEP
-    val = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), 63));
-    idx = __builtin_amdgcn_readlane(idx, 63);
+    const float m = wave_max(val);
+    idx = wave_min(val == m ? idx : 0x7fffffff);
+    val = m;
 }
 
 // lane `j` (wave-uniform) of v for every lane: v_readlane_b32 instead of a ds_bpermute round trip
