@@ -12,6 +12,7 @@
 //   3. k_mlp1_apply       : conv + affine + LeakyReLU + max_k, then wave-reduced max/mean over the lanes.
 #include "engine_ctx.h"
 #include "sg_common.h"
+#include "knn_device.h"
 #include "wave_ops.h"
 
 namespace {
@@ -44,19 +45,21 @@ __device__ __forceinline__ void mlp1_knn_moments_body(const float* __restrict__ 
     for (int j = 0; j < 64; ++j) {
         // candidate j is the same for every lane: v_readlane broadcasts instead of four ds_bpermute round trips
         const float s = knn_score(f[0], f[1], f[2], xx, sgw::bcast(f[0], j), sgw::bcast(f[1], j), sgw::bcast(f[2], j), sgw::bcast(xx, j));
-        if (s > bv[K1 - 1]) {                       // sorted insertion, earlier candidate first on ties
-            float v = s;
-            int id = j;
-            bool placed = false;                    // once placed, everything below shifts down (stable for ties)
+        // sorted insertion in parallel form (earlier candidate first on ties: the compares are strict): every slot decides from two
+        // wave masks, no `placed` chain and no exec-mask branches (the serial form compiled to ~180 mask operations per candidate)
+        unsigned long long cm[K1];
 #pragma unroll
-            for (int t = 0; t < K1; ++t) {
-                if (placed || v > bv[t]) {
-                    placed = true;
-                    const float tv = bv[t]; const int ti = bi[t];
-                    bv[t] = v; bi[t] = id; v = tv; id = ti;
-                }
-            }
+        for (int t = 0; t < K1; ++t) cm[t] = __builtin_amdgcn_fcmpf(s, bv[t], 2 /* FCMP_OGT */);
+        const unsigned int sb = __float_as_uint(s);
+#pragma unroll
+        for (int t = K1 - 1; t > 0; --t) {
+            const unsigned int tv = sgknn::sel_mask(sb, __float_as_uint(bv[t - 1]), cm[t - 1]);
+            const unsigned int ti = sgknn::sel_mask((unsigned int)j, (unsigned int)bi[t - 1], cm[t - 1]);
+            bv[t] = __uint_as_float(sgknn::sel_mask(__float_as_uint(bv[t]), tv, cm[t]));
+            bi[t] = (int)sgknn::sel_mask((unsigned int)bi[t], ti, cm[t]);
         }
+        bv[0] = __uint_as_float(sgknn::sel_mask(__float_as_uint(bv[0]), sb, cm[0]));
+        bi[0] = (int)sgknn::sel_mask((unsigned int)bi[0], (unsigned int)j, cm[0]);
     }
     uint8_t* ko = knn + ((size_t)c * 64 + lane) * K1;
 #pragma unroll
@@ -172,9 +175,16 @@ __device__ __forceinline__ void mlp1_apply_body(const float* __restrict__ sample
     // operations per value instead of a cross-lane network per channel (64 x ~50 DPP / readlane instructions were a third of this
     // kernel).  Row stride 65: the column write and the row read are both conflict-free.
     __shared__ float hs[64 * 65];
+    // the folded weights (384 + 64 floats) through LDS once: read per channel from global memory they were seven loads of one
+    // address per lane and channel (the pointer comes out of a SlotCtx: flat loads), each waited for inside the channel loop
+    __shared__ float wl[448];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) wl[lane + 64 * i] = folded[lane + 64 * i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
     for (int ch = 0; ch < 64; ++ch) {
-        const float w0 = folded[ch * 6 + 0], w1 = folded[ch * 6 + 1], w2 = folded[ch * 6 + 2], w3 = folded[ch * 6 + 3],
-                    w4 = folded[ch * 6 + 4], w5 = folded[ch * 6 + 5], b = folded[384 + ch];
+        const float w0 = wl[ch * 6 + 0], w1 = wl[ch * 6 + 1], w2 = wl[ch * 6 + 2], w3 = wl[ch * 6 + 3],
+                    w4 = wl[ch * 6 + 4], w5 = wl[ch * 6 + 5], b = wl[384 + ch];
         float h = -INFINITY;
 #pragma unroll
         for (int t = 0; t < K1; ++t) {
