@@ -95,6 +95,7 @@ struct Run {
     const char* out_dir = nullptr;
     sg_partition* part = nullptr;
     int max_ins = 1, max_seg = 0, cap1 = 0, out_rows = 0;
+    std::vector<int32_t> lay_big;
     int E = 0;
     std::vector<int32_t> adj, adj_next;
     std::vector<uint8_t> connected, keep;
@@ -370,6 +371,15 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
         }
         tiles_total += T;
         c.order = put(Ln.order.data(), S); c.dst = put(Ln.dst.data(), S);
+        {
+            std::vector<int32_t>& big = r.lay_big;                // a block lays out kLayoutPiece rows: list the rest of larger segments
+            big.clear();
+            if (r.max_seg > sg::kLayoutPiece)
+                for (int k = 0; k < S; ++k)
+                    for (int r0 = sg::kLayoutPiece; r0 < sc->h_seg_size[Ln.order[k]]; r0 += sg::kLayoutPiece) { big.push_back(k); big.push_back(r0); }
+            c.lay_big = put(big.data(), big.size()); c.lay_nbig = (int)(big.size() / 2);
+            bd.max_lay_big = std::max(bd.max_lay_big, c.lay_nbig);
+        }
         c.seg_chunk_off = put(r.chunk_off.data(), (size_t)S + 1);
         tmp.resize(S);
         for (int k = 0; k < S; ++k) tmp[k] = Ln.cl_of_seg[Ln.order[k]];
@@ -788,7 +798,7 @@ sg_engine* sg_engine_create(int maxN, int maxS, int maxE, int maxV, const sg_wei
         }
         // parameter arena: SlotCtx array + every slot's descriptors (the single-scene pipeline's descriptor capacity + tables)
         const size_t T = (size_t)maxN / 64 + S + 1;
-        const size_t par_slot = sizeof(SlotCtx) + (20 * S + 64 + 3 * T + 6 * maxE1 + 256) * 4 + SG_NUM_LABEL_VECTORS * S * 4 + 2048;
+        const size_t par_slot = sizeof(SlotCtx) + (20 * S + 64 + 3 * T + 6 * maxE1 + 256 + 2 * ((size_t)maxN / sg::kLayoutPiece + 1)) * 4 + SG_NUM_LABEL_VECTORS * S * 4 + 2048;
         const size_t box_slot = 256 + S * 24 + out_rows * 12 + S * 256 * 4 + (128 + 5 * (S + 2)) * 4 + 1024;
         grp->par.cap = par_slot * scenes_per_group;
         grp->box.cap = box_slot * scenes_per_group;

@@ -67,6 +67,8 @@ struct SlotCtx {
     // ---- layer layout (member arrays, centred rows, sorted kNN operands) ----
     const int32_t* order;              // params block
     const int32_t* dst;
+    const int32_t* lay_big;            // (slot, first row) pairs: the pieces of segments beyond kLayoutPiece rows
+    int lay_nbig;
     const int32_t* cl;
     const float* cl_mean;
     int32_t* members;
@@ -140,12 +142,15 @@ struct SlotCtx {
 };
 
 // ---- batched launchers: one launch per call, grid.y = nslots -------------------------------------------------------
+constexpr int kLayoutPiece = 1024;       // rows of a segment one layout block walks (k_layer_layout_b / _big_b)
+
 struct BatchDims {                       // maxima over the slots of a group (grid.x sizes)
     int nslots = 0;
     int max_N = 0, max_S = 0, max_E0 = 0, max_V = 0;
     int max_bits_blocks = 0, max_seg = 0;
     int max_C = 0, max_T = 0, max_E = 0, max_ins = 0;
     int max_prevC = 0;
+    int max_lay_big = 0;                 // pieces of segments beyond kLayoutPiece rows (layout kernel)
 };
 
 int b_contract(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);

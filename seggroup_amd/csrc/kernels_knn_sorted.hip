@@ -422,11 +422,11 @@ __device__ __forceinline__ void layer_layout_body(const float* __restrict__ data
                                                   const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
                                                   int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
                                                   float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos,
-                                                  float4* __restrict__ point_rec, int i) {
+                                                  float4* __restrict__ point_rec, int i, int r_begin = 0, int r_end = 0x7fffffff) {
     const int s = order[i];
-    const int lo = seg_off[s], n = seg_off[s + 1] - lo, d = dst[i], c = cl[i];
+    const int lo = seg_off[s], n = min(seg_off[s + 1] - lo, r_end), d = dst[i], c = cl[i];
     const float mx = cl_mean[3 * c], my = cl_mean[3 * c + 1], mz = cl_mean[3 * c + 2];
-    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+    for (int r = r_begin + threadIdx.x; r < n; r += blockDim.x) {
         const int p = seg_points[lo + r];
         members[d + r] = p;
         pos_of_point[p] = d + r;
@@ -454,11 +454,21 @@ __global__ void k_layer_layout(const float* __restrict__ data, const int32_t* __
     layer_layout_body(data, seg_points, seg_off, sperm, order, dst, cl, cl_mean, members, pos_of_point, cluster_of_pos, slot_of_pos, x9m, sxyzw,
                       smpos, point_rec, blockIdx.x);
 }
+// The engine's launches: a block lays out the first kLayoutPiece rows of its segment; the rest of a larger segment (ScanNet floors
+// and walls: 10k-40k points) is cut into pieces of kLayoutPiece rows that the host lists per layer (lay_big = (slot, first row)
+// pairs) and a second launch spreads over the GPU -- one block walking 40k rows alone was 0.46 ms per launch.
 __global__ void k_layer_layout_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.S) return;
     layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, c.pos_of_point, c.cluster_of_pos,
-                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, blockIdx.x);
+                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, blockIdx.x, 0, sg::kLayoutPiece);
+}
+__global__ void k_layer_layout_big_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.lay_nbig) return;
+    const int i = c.lay_big[2 * blockIdx.x], r0 = c.lay_big[2 * blockIdx.x + 1];
+    layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, c.pos_of_point, c.cluster_of_pos,
+                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, i, r0, r0 + sg::kLayoutPiece);
 }
 
 // per layer: block i = i-th segment in member order; writes the operand and the member position in SORTED order
@@ -1113,6 +1123,7 @@ int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
 int b_layer_layout(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
     if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
     k_layer_layout_b<<<dim3(bd.max_S, bd.nslots), 128, 0, st>>>(d_ctx);
+    if (bd.max_lay_big > 0) k_layer_layout_big_b<<<dim3(bd.max_lay_big, bd.nslots), 128, 0, st>>>(d_ctx);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }
