@@ -275,10 +275,10 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
     mark(-1);
     EG_CHECK(sg::b_contract(d_ctx, bd, stream));
     mark(0);
-    EG_CHECK(sg::b_fps64(d_ctx, bd, stream));
     if (mode == SG_MODE_INS_INFER) {
-        EG_CHECK(sg::b_sort_boxes(d_ctx, bd, stream));
+        EG_CHECK(sg::b_sort_boxes(d_ctx, bd, stream));              // first: the sampling of the largest segments walks its chunk boxes
     }
+    EG_CHECK(sg::b_fps64(d_ctx, bd, stream, mode == SG_MODE_INS_INFER));
     mark(1);
     sg_pipeline* p0 = runs_[0].pl;
     EG_CHECK(sg::b_mlp1(d_ctx, p0->w.p + p0->o_m1w, p0->w.p + p0->o_m1g, p0->w.p + p0->o_m1b, bd, stream));

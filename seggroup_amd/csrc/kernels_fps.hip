@@ -65,7 +65,8 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
                                                 const int32_t* __restrict__ members, const int32_t* __restrict__ cl_off,
                                                 int P, int ch_out, int transform, int n_lo, int n_hi, int lds_pts,
                                                 float* __restrict__ samples, int32_t* __restrict__ sel,
-                                                float* __restrict__ ws, int c) {
+                                                float* __restrict__ ws, int c, const int32_t* __restrict__ sperm = nullptr,
+                                                const float* __restrict__ chunk_box = nullptr, const int32_t* __restrict__ seg_chunk_off = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lo = cl_off[c], n = cl_off[c + 1] - lo;
     if (n < n_lo || n > n_hi || n <= 0) return;
@@ -144,6 +145,113 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
             if (n <= 64) in_registers(std::integral_constant<int, 1>{});
             else if (n <= 128) in_registers(std::integral_constant<int, 2>{});
             else in_registers(std::integral_constant<int, 4>{});
+            sampled = true;
+        }
+    }
+    if constexpr (BLOCK == 1024) {
+        // Segments that do not fit the LDS carve (ScanNet floors and walls: 10k-40k points) with the Morton order and the 32-point
+        // chunk boxes of k_bigseg_sort_boxes at hand: a sampling step only has to touch the chunks the new pick can still
+        // improve.  Per chunk the running maximum of its points' min-distances is kept (cm, with the member index ci that
+        // np.argmax would return for it and its sorted position cr); a chunk whose box is farther from the pick than cm keeps
+        // every minimum (d >= box distance >= cm >= M_i: the 1e-6 margin covers the fp32 rounding of both sides), and the step's
+        // argmax is the argmax over the chunk maxima (ties -> lowest member index, as in the plain pass).  The first two passes
+        // (start point, then the reset to the first pick: model.py:382-386) visit everything.  One block walking 40k points 64 times
+        // through L2 was 0.55 ms per launch.
+        if (rem > 0 && !sampled && n > lds_pts && sperm && (n + 31) / 32 <= lds_pts) {
+            const int nch = (n + 31) / 32, c0 = seg_chunk_off[c];
+            float* cm = lds_f;                                                     // the carve is unused on this path: 4 x lds_pts words
+            int* ci = reinterpret_cast<int*>(lds_f + lds_pts);
+            int* cr = reinterpret_cast<int*>(lds_f + 2 * (size_t)lds_pts);
+            int* wl = reinterpret_cast<int*>(lds_f + 3 * (size_t)lds_pts);
+            __shared__ int wl_n;
+            __shared__ float rv[16];
+            __shared__ int ri[16], rr[16];
+            float* Xs = ws + lo; float* Ys = ws + (size_t)N + lo; float* Zs = ws + 2 * (size_t)N + lo; float* Ms = ws + 3 * (size_t)N + lo;
+            for (int r = tid; r < n; r += BLOCK) {
+                const float* row = data + (size_t)members[sperm[lo + r]] * ch_in;
+                Xs[r] = row[0]; Ys[r] = row[1]; Zs[r] = row[2];
+            }
+            __syncthreads();
+            const int lane = tid & 63, wave = tid >> 6, hl = lane & 31, half = lane >> 5;
+            // one chunk per half wave: distances to q, running minima, the chunk's (max, member index, sorted position)
+            auto visit = [&](int ch, float qx, float qy, float qz, bool reset) {
+                const int r = 32 * ch + hl;
+                const bool in = r < n;
+                float d = -INFINITY;
+                int li = INT_MAX;
+                if (in) {
+                    const float dx = Xs[r] - qx, dy = Ys[r] - qy, dz = Zs[r] - qz;
+                    d = (dx * dx + dy * dy) + dz * dz;
+                    if (!reset) d = fminf(Ms[r], d);
+                    Ms[r] = d;
+                    li = sperm[lo + r] - lo;
+                }
+                // maxima / minima of the 32 lanes of each half: rows of 16 on the DPP path, row 0 -> 1 and 2 -> 3, then lanes 31 / 63
+                float m = d;
+                m = fmaxf(m, sgw::dpp_f<sgw::kQuadXor1>(m, m)); m = fmaxf(m, sgw::dpp_f<sgw::kQuadXor2>(m, m));
+                m = fmaxf(m, sgw::dpp_f<sgw::kRowRor4>(m, m));  m = fmaxf(m, sgw::dpp_f<sgw::kRowRor8>(m, m));
+                m = fmaxf(m, sgw::dpp_f<sgw::kRowBcast15, 0xA>(m, m));
+                const float mh = half ? sgw::bcast(m, 63) : sgw::bcast(m, 31);
+                int k = d == mh ? li : INT_MAX;
+                k = min(k, sgw::dpp_i<sgw::kQuadXor1>(k, k)); k = min(k, sgw::dpp_i<sgw::kQuadXor2>(k, k));
+                k = min(k, sgw::dpp_i<sgw::kRowRor4>(k, k));  k = min(k, sgw::dpp_i<sgw::kRowRor8>(k, k));
+                k = min(k, sgw::dpp_i<sgw::kRowBcast15, 0xA>(k, k));
+                const int kh = half ? sgw::bcast(k, 63) : sgw::bcast(k, 31);
+                if (in && li == kh) { cm[ch] = mh; ci[ch] = kh; cr[ch] = r; }     // exactly one lane of the half
+            };
+            // argmax over the chunk maxima: larger value, ties -> lower member index; every thread returns the winner
+            auto pick = [&](float& bv, int& bi, int& br) {
+                float v = -INFINITY; int i = INT_MAX, r = 0;
+                for (int ch = tid; ch < nch; ch += BLOCK) {
+                    const float cv = cm[ch]; const int cix = ci[ch];
+                    if (cv > v || (cv == v && cix < i)) { v = cv; i = cix; r = cr[ch]; }
+                }
+                const float wm = sgw::wave_max(v);
+                const int wi = sgw::wave_min(v == wm ? i : INT_MAX);
+                const int wr = sgw::wave_min(v == wm && i == wi ? r : INT_MAX);
+                if (lane == 0) { rv[wave] = wm; ri[wave] = wi; rr[wave] = wr; }
+                __syncthreads();
+                bv = rv[0]; bi = ri[0]; br = rr[0];
+#pragma unroll
+                for (int w = 1; w < 16; ++w)
+                    if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; br = rr[w]; }
+                __syncthreads();
+            };
+            auto full_pass = [&](float qx, float qy, float qz) {
+                for (int e = 2 * wave; e < nch; e += 32) visit(min(e + half, nch - 1), qx, qy, qz, true);   // both halves together (see below)
+                __syncthreads();
+            };
+            float bv; int bi, br;
+            {
+                const float* row0 = data + (size_t)members[lo] * ch_in;           // start at member 0 (model.py:382-386)
+                full_pass(row0[0], row0[1], row0[2]);
+                pick(bv, bi, br);
+            }
+            int cur = bi;
+            if (tid == 0) picks[0] = cur;
+            full_pass(Xs[br], Ys[br], Zs[br]);                                    // reset to the first pick
+            pick(bv, bi, br);
+            for (int it = 1; it < rem; ++it) {                                    // model.py:389-394
+                cur = bi;
+                if (tid == 0) { picks[it] = cur; wl_n = 0; }
+                if (it + 1 < rem) {
+                    const float qx = Xs[br], qy = Ys[br], qz = Zs[br];
+                    __syncthreads();
+                    for (int ch = tid; ch < nch; ch += BLOCK) {
+                        const float* bx = chunk_box + (size_t)(c0 + ch) * 8;
+                        const float gx = fmaxf(fmaxf(bx[0] - qx, qx - bx[3]), 0.f), gy = fmaxf(fmaxf(bx[1] - qy, qy - bx[4]), 0.f),
+                                    gz = fmaxf(fmaxf(bx[2] - qz, qz - bx[5]), 0.f);
+                        if (((gx * gx + gy * gy) + gz * gz) * 0.999999f < cm[ch]) wl[atomicAdd(&wl_n, 1)] = ch;
+                    }
+                    __syncthreads();
+                    const int nw = wl_n;
+                    // both halves of a wave must run visit() together (its reductions are wave-wide DPP networks): an odd tail
+                    // revisits the last listed chunk, which changes nothing
+                    for (int e = 2 * wave; e < nw; e += 32) visit(wl[min(e + half, nw - 1)], qx, qy, qz, false);
+                    __syncthreads();
+                    pick(bv, bi, br);
+                }
+            }
             sampled = true;
         }
     }
@@ -276,10 +384,11 @@ __global__ __launch_bounds__(BLOCK) void k_fps_sample(const float* __restrict__ 
 
 // structural layer of several scenes: FPS-64 over the original over-segments, all six channels, transformed
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_fps_sample_b(const sg::SlotCtx* __restrict__ cx, int n_lo, int n_hi, int lds_pts) {
+__global__ __launch_bounds__(BLOCK) void k_fps_sample_b(const sg::SlotCtx* __restrict__ cx, int n_lo, int n_hi, int lds_pts, int sorted) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.S) return;
-    fps_sample_body<BLOCK>(c.data, c.N, 6, c.seg_points, c.seg_off, 64, 6, 1, n_lo, n_hi, lds_pts, c.samples, nullptr, c.ws_fps, blockIdx.x);
+    fps_sample_body<BLOCK>(c.data, c.N, 6, c.seg_points, c.seg_off, 64, 6, 1, n_lo, n_hi, lds_pts, c.samples, nullptr, c.ws_fps, blockIdx.x,
+                           sorted ? c.sperm : nullptr, c.chunk_box, c.seg_chunk_off);
 }
 
 }  // namespace
@@ -318,7 +427,7 @@ int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_memb
     return SG_OK;
 }
 
-int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
+int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, bool sorted) {
     if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
     const int P = 64;
     const size_t head = (size_t)P * 4 + 16 * sizeof(Best);
@@ -329,10 +438,10 @@ int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
         attr_set = true;
     }
     const int small_pts = std::max(64, std::min(bd.max_seg, kSmallMax));
-    k_fps_sample_b<64><<<dim3(bd.max_S, bd.nslots), 64, head + (size_t)small_pts * 16, st>>>(d_ctx, 1, kSmallMax, small_pts);
+    k_fps_sample_b<64><<<dim3(bd.max_S, bd.nslots), 64, head + (size_t)small_pts * 16, st>>>(d_ctx, 1, kSmallMax, small_pts, 0);
     if (bd.max_seg > kSmallMax) {
         const int big_pts = std::min(bd.max_seg, kLdsCap);
-        k_fps_sample_b<1024><<<dim3(bd.max_S, bd.nslots), 1024, head + (size_t)big_pts * 16, st>>>(d_ctx, kSmallMax + 1, INT_MAX, big_pts);
+        k_fps_sample_b<1024><<<dim3(bd.max_S, bd.nslots), 1024, head + (size_t)big_pts * 16, st>>>(d_ctx, kSmallMax + 1, INT_MAX, big_pts, sorted ? 1 : 0);
     }
     SG_LAUNCH_CHECK();
     return SG_OK;
