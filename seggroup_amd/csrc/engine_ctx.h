@@ -166,7 +166,6 @@ int b_cluster_knn(const SlotCtx* d_ctx, const BatchDims& bd, int waves_per_tile,
 int b_knn_seed_points(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);
 // layers == 1: S1X + fold.  layers == 2: moments + fold, S2X + fold.  `mark(i)` after step i (stage timing).
 int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mark)(void*, int), void* mark_arg, hipStream_t st);
-int b_segment_max(const SlotCtx* d_ctx, const BatchDims& bd, int layers, hipStream_t st);
 int b_gcn(const SlotCtx* d_ctx, const BatchDims& bd, float alpha, hipStream_t st);
 int b_export_eval(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);
 

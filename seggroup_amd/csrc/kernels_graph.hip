@@ -308,13 +308,7 @@ __global__ __launch_bounds__(256) void k_segment_max64(const float* __restrict__
                                                        const float* __restrict__ shift) {
     segment_max64_body(rows, N, cluster_of_pos, out, out_stride, a, shift, blockIdx.x);
 }
-// layers selects which folded affine of the EdgeConv applies (MLP2: w1f/sh1 hold |a|, b'; MLP3: w2f/sh2)
-__global__ __launch_bounds__(256) void k_segment_max64_b(const SlotCtx* __restrict__ cx, int layers) {
-    const SlotCtx& c = cx[blockIdx.y];
-    if ((int)blockIdx.x * kRowsPerBlock >= c.N) return;
-    segment_max64_body(c.pf, c.N, c.cluster_of_pos, c.cat + c.gm_D, c.Dcat, layers == 1 ? c.ec_w1f : c.ec_w2f, layers == 1 ? c.ec_sh1 : c.ec_sh2,
-                       blockIdx.x);
-}
+// (the engine has no batched twin of this kernel: its EdgeConv launches reduce E to the clusters' maxima themselves, kernels_edgeconv.hip)
 
 // ------------------------------------------------------------------------------------------------
 // a16: label export gather (model.py:525-605)
@@ -493,13 +487,6 @@ int b_edge_distance(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
 int b_group_max_fill(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
     if (bd.nslots == 0 || bd.max_C == 0) return SG_OK;
     k_group_max_rows_b<<<dim3(bd.max_C, bd.nslots), 256, 0, st>>>(d_ctx);
-    SG_LAUNCH_CHECK();
-    return SG_OK;
-}
-
-int b_segment_max(const SlotCtx* d_ctx, const BatchDims& bd, int layers, hipStream_t st) {
-    if (bd.nslots == 0 || bd.max_N == 0) return SG_OK;
-    k_segment_max64_b<<<dim3(sg::cdiv(bd.max_N, kRowsPerBlock), bd.nslots), 256, 0, st>>>(d_ctx, layers);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }
