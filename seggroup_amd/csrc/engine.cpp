@@ -483,8 +483,9 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     if (variant == 0) variant = 8;                                  // the two-pass kernel has no batched twin
     const bool seeded = variant == 8 && layer == 1;
     const int waves = variant == 8 ? 1 : variant;
-    EG_CHECK(sg::b_cluster_knn(d_ctx, bd, waves, seeded, stream));
-    if (layer == 0) EG_CHECK(sg::b_knn_seed_points(d_ctx, bd, stream));
+    bool wrote_seed = false;
+    EG_CHECK(sg::b_cluster_knn(d_ctx, bd, waves, seeded, stream, layer == 0, &wrote_seed));
+    if (layer == 0 && !wrote_seed) EG_CHECK(sg::b_knn_seed_points(d_ctx, bd, stream));
     mark(sb + 2);
     struct MarkArg { Group* g; int sub0; } ma{this, layer == 0 ? 19 : 21};
     EG_CHECK(sg::b_edgeconv(d_ctx, bd, layer + 1, [](void* a, int i) { auto* m = static_cast<MarkArg*>(a); m->g->mark(m->sub0 + i); }, &ma, stream));

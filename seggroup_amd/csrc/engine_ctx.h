@@ -162,7 +162,8 @@ int b_mlp1(const SlotCtx* d_ctx, const float* d_w, const float* d_g, const float
 int b_edge_distance(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);
 int b_layer_layout(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);
 int b_group_max_fill(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);
-int b_cluster_knn(const SlotCtx* d_ctx, const BatchDims& bd, int waves_per_tile, bool seeded, hipStream_t st);
+int b_cluster_knn(const SlotCtx* d_ctx, const BatchDims& bd, int waves_per_tile, bool seeded, hipStream_t st, bool write_seed = false,
+                  bool* wrote_seed = nullptr);
 int b_knn_seed_points(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);
 // layers == 1: S1X + fold.  layers == 2: moments + fold, S2X + fold.  `mark(i)` after step i (stage timing).
 int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mark)(void*, int), void* mark_arg, hipStream_t st);

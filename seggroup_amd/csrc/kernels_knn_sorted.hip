@@ -513,7 +513,9 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     sg::gptr<const int32_t> seg_off, sg::gptr<const int32_t> seg_chunk_off, sg::gptr<const float> segbox,
     sg::gptr<const float> chunk_box, sg::gptr<const int32_t> slot_of_pos, int pos0, sg::gptr<int32_t> knn, int dbg_arg,
     sg::gptr<const int32_t> seed, sg::gptr<const int32_t> seg_prevcl, sg::gptr<const int32_t> members,
-    sg::gptr<const float4> point_rec, int t) {
+    sg::gptr<const float4> point_rec, int t, sg::gptr<int32_t> seed_out = nullptr) {
+    // seed_out (one wave per tile): the table once more with rows and entries as POINT ids -- what the next layer's seeded launch
+    // reads (a separate pass over the finished table re-read 12 MB per scene for it)
     static_assert(!kSeeded || kSlices == 1, "seeding is built for one wave per tile");
     const int dbg = kKnnProfile ? dbg_arg : 0;
     // LDS per wave decides how many tiles a CU keeps in flight, and this kernel waits on memory ~45 % of the time:
@@ -540,6 +542,11 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             const sg::gptr<int32_t> o = knn + (size_t)myrow * K;
 #pragma unroll
             for (int j = 0; j < K; ++j) o[j] = j < n ? clo + j : pos0;
+            if (seed_out) {
+                const sg::gptr<int32_t> so = seed_out + (size_t)members[myrow] * K;
+#pragma unroll
+                for (int j = 0; j < K; ++j) so[j] = members[j < n ? clo + j : pos0];
+            }
         }
         return;
     }
@@ -790,6 +797,11 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             const sg::gptr<int32_t> o = knn + (size_t)myrow * K;
 #pragma unroll
             for (int j = 0; j < K; ++j) o[j] = clo + key_index(kv[j]);
+            if (seed_out) {
+                const sg::gptr<int32_t> so = seed_out + (size_t)members[myrow] * K;
+#pragma unroll
+                for (int j = 0; j < K; ++j) so[j] = members[clo + key_index(kv[j])];
+            }
         }
     } else {
         __syncthreads();                                          // every wave is done with its append buffer
@@ -844,7 +856,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
 // fourth resident wave per SIMD by capping it at 128 VGPRs (129 -> 118, no spill: 952 -> 848 us per launch of 8 scenes); a
 // fifth wave for the unseeded one (104 -> 96 VGPRs) costs 10 spilled registers and is slower (973 -> 991 us).
 template <int K, int kSlices, bool kSeeded>
-__global__ __launch_bounds__(64 * kSlices, kSlices == 1 && kSeeded ? 4 : 1) void k_cluster_knn_sorted_b(const sg::SlotCtx* __restrict__ cx) {
+__global__ __launch_bounds__(64 * kSlices, kSlices == 1 && kSeeded ? 4 : 1) void k_cluster_knn_sorted_b(const sg::SlotCtx* __restrict__ cx, int write_seed) {
     const sg::SlotCtx& c = cx[blockIdx.x];                    // grid = (scenes, tiles): one scene per XCD (kernels_edgeconv.hip, k_edgeconv_b)
     if ((int)blockIdx.y >= c.T) return;
     // pointers read out of a SlotCtx are generic to the compiler (flat_load: vmcnt AND lgkmcnt); sg_common.h, gptr
@@ -854,7 +866,7 @@ __global__ __launch_bounds__(64 * kSlices, kSlices == 1 && kSeeded ? 4 : 1) void
                                                  as_global(c.dst), as_global(c.seg_off), as_global(c.seg_chunk_off), as_global(c.segbox),
                                                  as_global(c.chunk_box), as_global(c.slot_of_pos), c.pos0, as_global(c.knn), 0,
                                                  as_global(c.knn_seed), as_global(c.seg_prevcl), as_global(c.members), as_global(c.point_rec),
-                                                 blockIdx.y);
+                                                 blockIdx.y, kSlices == 1 && !kSeeded && write_seed ? as_global(c.knn_seed) : nullptr);
 }
 
 
@@ -1128,13 +1140,18 @@ int b_layer_layout(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
     return SG_OK;
 }
 
-int b_cluster_knn(const SlotCtx* d_ctx, const BatchDims& bd, int waves_per_tile, bool seeded, hipStream_t st) {
+// write_seed: also emit the table in point ids (knn_seed) for the next layer's seeded launch; the one-wave-per-tile kernel does it
+// in its output stage, the multi-wave variants leave it to b_knn_seed_points (*wrote_seed tells the caller)
+int b_cluster_knn(const SlotCtx* d_ctx, const BatchDims& bd, int waves_per_tile, bool seeded, hipStream_t st, bool write_seed, bool* wrote_seed) {
+    if (wrote_seed) *wrote_seed = false;
     if (bd.nslots == 0 || bd.max_T == 0) return SG_OK;
     const dim3 grid(bd.nslots, bd.max_T);
-    if (seeded) k_cluster_knn_sorted_b<20, 1, true><<<grid, 64, 0, st>>>(d_ctx);
-    else if (waves_per_tile == 1) k_cluster_knn_sorted_b<20, 1, false><<<grid, 64, 0, st>>>(d_ctx);
-    else if (waves_per_tile == 2) k_cluster_knn_sorted_b<20, 2, false><<<grid, 128, 0, st>>>(d_ctx);
-    else k_cluster_knn_sorted_b<20, 4, false><<<grid, 256, 0, st>>>(d_ctx);
+    if (seeded) k_cluster_knn_sorted_b<20, 1, true><<<grid, 64, 0, st>>>(d_ctx, 0);
+    else if (waves_per_tile == 1) {
+        k_cluster_knn_sorted_b<20, 1, false><<<grid, 64, 0, st>>>(d_ctx, write_seed ? 1 : 0);
+        if (wrote_seed) *wrote_seed = write_seed;
+    } else if (waves_per_tile == 2) k_cluster_knn_sorted_b<20, 2, false><<<grid, 128, 0, st>>>(d_ctx, 0);
+    else k_cluster_knn_sorted_b<20, 4, false><<<grid, 256, 0, st>>>(d_ctx, 0);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }
