@@ -429,7 +429,7 @@ __device__ __forceinline__ void layer_layout_body(const float* __restrict__ data
     for (int r = r_begin + threadIdx.x; r < n; r += blockDim.x) {
         const int p = seg_points[lo + r];
         members[d + r] = p;
-        pos_of_point[p] = d + r;
+        if (pos_of_point) pos_of_point[p] = d + r;                // (the engine passes null: its kernels read point_rec instead)
         cluster_of_pos[d + r] = c;
         slot_of_pos[d + r] = i;
         const float* row = data + (size_t)p * 6;
@@ -460,14 +460,14 @@ __global__ void k_layer_layout(const float* __restrict__ data, const int32_t* __
 __global__ void k_layer_layout_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.S) return;
-    layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, c.pos_of_point, c.cluster_of_pos,
+    layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, nullptr, c.cluster_of_pos,
                       c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, blockIdx.x, 0, sg::kLayoutPiece);
 }
 __global__ void k_layer_layout_big_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.lay_nbig) return;
     const int i = c.lay_big[2 * blockIdx.x], r0 = c.lay_big[2 * blockIdx.x + 1];
-    layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, c.pos_of_point, c.cluster_of_pos,
+    layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, nullptr, c.cluster_of_pos,
                       c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, i, r0, r0 + sg::kLayoutPiece);
 }
 
