@@ -7,6 +7,7 @@
 // fp64 so the decision distances that follow are as close to exact arithmetic as fp32 features allow.
 #include "engine_ctx.h"
 #include "sg_common.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -55,8 +56,12 @@ __device__ __forceinline__ void gcn_aggregate_body(const float* __restrict__ x, 
                 acc = fma(d, d, acc);
             }
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        // 16 lanes per edge = one DPP row: quad, quad pairs, then two row rotations leave the row's sum in every lane (a
+        // `__shfl_xor` step is an LDS round trip, twice for a double)
+        acc += sgw::dpp_d<sgw::kQuadXor1>(acc, acc);
+        acc += sgw::dpp_d<sgw::kQuadXor2>(acc, acc);
+        acc += sgw::dpp_d<sgw::kRowRor4>(acc, acc);
+        acc += sgw::dpp_d<sgw::kRowRor8>(acc, acc);
         if (t < deg && sub == 0) {
             const float df = (float)sqrt(acc);
             dist[id] = df;
@@ -98,11 +103,13 @@ constexpr int kRows = 8;
 // out2 (may be null): a second copy of the result (the engine's outbox)
 __device__ __forceinline__ void gcn_fc_body(const float* __restrict__ agg, int S, int D, const float* __restrict__ wt, float* __restrict__ out,
                                             float* __restrict__ out2, int bid) {
-    __shared__ float rows[kRows][256];
+    // the block's rows once as DOUBLES in LDS (every thread used to convert the same row values again, per k and per row, behind a
+    // 4-byte broadcast read each: 8 LDS reads + 8 conversions per 8 FMAs); two k per 16-byte broadcast read
+    __shared__ __attribute__((aligned(16))) double rows[kRows][256];
     const int r0 = bid * kRows;
     for (int i = threadIdx.x; i < kRows * D; i += blockDim.x) {
         const int rr = i / D, k = i % D;
-        rows[rr][k] = (r0 + rr < S) ? agg[(size_t)(r0 + rr) * D + k] : 0.f;
+        rows[rr][k] = (r0 + rr < S) ? (double)agg[(size_t)(r0 + rr) * D + k] : 0.0;
     }
     __syncthreads();
     const int o = threadIdx.x;
@@ -110,10 +117,20 @@ __device__ __forceinline__ void gcn_fc_body(const float* __restrict__ agg, int S
     double acc[kRows];
 #pragma unroll
     for (int rr = 0; rr < kRows; ++rr) acc[rr] = 0.0;
-    for (int k = 0; k < D; ++k) {
-        const double w = (double)wt[(size_t)k * D + o];
+    // the k order of the sum is unchanged (D is 192 or 256 on the hot path; an odd D takes the last k alone)
+    for (int k = 0; k + 1 < D; k += 2) {
+        const double w0 = (double)wt[(size_t)k * D + o], w1 = (double)wt[(size_t)(k + 1) * D + o];
 #pragma unroll
-        for (int rr = 0; rr < kRows; ++rr) acc[rr] = fma((double)rows[rr][k], w, acc[rr]);
+        for (int rr = 0; rr < kRows; ++rr) {
+            const double2 x = *reinterpret_cast<const double2*>(&rows[rr][k]);
+            acc[rr] = fma(x.x, w0, acc[rr]);
+            acc[rr] = fma(x.y, w1, acc[rr]);
+        }
+    }
+    if (D & 1) {
+        const double w = (double)wt[(size_t)(D - 1) * D + o];
+#pragma unroll
+        for (int rr = 0; rr < kRows; ++rr) acc[rr] = fma(rows[rr][D - 1], w, acc[rr]);
     }
 #pragma unroll
     for (int rr = 0; rr < kRows; ++rr)
