@@ -2,6 +2,7 @@
 // gathering (a2/a10), edge distance (a8), row/segment max (a10), label export (a16), metric counts (a17).
 #include "engine_ctx.h"
 #include "sg_common.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -186,8 +187,7 @@ __device__ __forceinline__ void edge_distance_one(const float* __restrict__ feat
         const double d = (double)a[k] - (double)b[k] + 1e-6;
         acc = fma(d, d, acc);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    acc = sgw::wave_sum(acc);                                   // DPP network (wave_ops.h), fixed order
     if (lane == 0) {
         const float v = (float)sqrt(acc);
         dist[e] = v;
