@@ -135,17 +135,13 @@ __device__ __forceinline__ void segment_sort_boxes_body(const float* __restrict_
         for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], r[k]); mx[k] = fmaxf(mx[k], r[k]); sm[k] += (double)r[k]; }
         xx = fmaxf(xx, (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
     }
+    // wave reductions on the DPP path (wave_ops.h; a `__shfl_xor` step is an LDS round trip, twice for a double)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
-        xx = fmaxf(xx, __shfl_xor(xx, o));
-    }
+    for (int k = 0; k < 3; ++k) { mn[k] = sgw::wave_min(mn[k]); mx[k] = sgw::wave_max(mx[k]); }
+    xx = sgw::wave_max(xx);
     if (seg_sums) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) sm[k] += __shfl_xor(sm[k], o);
+        for (int k = 0; k < 3; ++k) sm[k] = sgw::wave_sum(sm[k]);
         if (lane == 0) { dred[wave][0] = sm[0]; dred[wave][1] = sm[1]; dred[wave][2] = sm[2]; }
     }
     if (lane == 0) { red[wave][0] = mn[0]; red[wave][1] = mn[1]; red[wave][2] = mn[2]; red[wave][3] = mx[0]; red[wave][4] = mx[1]; red[wave][5] = mx[2]; red[wave][6] = xx; }
@@ -197,11 +193,8 @@ __device__ __forceinline__ void segment_sort_boxes_body(const float* __restrict_
             cxx = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
         }
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { cmn[k] = fminf(cmn[k], __shfl_xor(cmn[k], o)); cmx[k] = fmaxf(cmx[k], __shfl_xor(cmx[k], o)); }
-            cxx = fmaxf(cxx, __shfl_xor(cxx, o));
-        }
+        for (int k = 0; k < 3; ++k) { cmn[k] = sgw::half_min(cmn[k], lane); cmx[k] = sgw::half_max(cmx[k], lane); }
+        cxx = sgw::half_max(cxx, lane);
         if (l == 0) {
             float* b = chunk_box + (size_t)(c0 + j) * 8;
             b[0] = cmn[0]; b[1] = cmn[1]; b[2] = cmn[2]; b[3] = cmx[0]; b[4] = cmx[1]; b[5] = cmx[2]; b[6] = cxx; b[7] = 0.f;
@@ -368,11 +361,8 @@ __device__ __forceinline__ void bigseg_sort_boxes_body(const float* __restrict__
             cxx = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
         }
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { cmn[k] = fminf(cmn[k], __shfl_xor(cmn[k], o)); cmx[k] = fmaxf(cmx[k], __shfl_xor(cmx[k], o)); }
-            cxx = fmaxf(cxx, __shfl_xor(cxx, o));
-        }
+        for (int k = 0; k < 3; ++k) { cmn[k] = sgw::half_min(cmn[k], lane); cmx[k] = sgw::half_max(cmx[k], lane); }
+        cxx = sgw::half_max(cxx, lane);
         if (l == 0) {
             float* b = chunk_box + (size_t)(c0 + j) * 8;
             b[0] = cmn[0]; b[1] = cmn[1]; b[2] = cmn[2]; b[3] = cmx[0]; b[4] = cmx[1]; b[5] = cmx[2]; b[6] = cxx; b[7] = 0.f;

@@ -95,6 +95,26 @@ __device__ __forceinline__ void wave_argmax(float& val, int& idx) {
     val = m;
 }
 
+// reductions over the 32 lanes of each HALF of the wave (two 32-point chunks per wave step): rows of 16 on the DPP path, row 0 -> 1
+// and row 2 -> 3 with row_bcast15, then the half's result is read from its last lane (31 / 63) for every lane of the half
+__device__ __forceinline__ float half_reduce_pick(float v, int lane) {
+    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return (lane & 32) ? hi : lo;
+}
+__device__ __forceinline__ float half_max(float v, int lane) {
+    v = fmaxf(v, dpp_f<kQuadXor1>(v, v)); v = fmaxf(v, dpp_f<kQuadXor2>(v, v));
+    v = fmaxf(v, dpp_f<kRowRor4>(v, v));  v = fmaxf(v, dpp_f<kRowRor8>(v, v));
+    v = fmaxf(v, dpp_f<kRowBcast15, 0xA>(v, v));
+    return half_reduce_pick(v, lane);
+}
+__device__ __forceinline__ float half_min(float v, int lane) {
+    v = fminf(v, dpp_f<kQuadXor1>(v, v)); v = fminf(v, dpp_f<kQuadXor2>(v, v));
+    v = fminf(v, dpp_f<kRowRor4>(v, v));  v = fminf(v, dpp_f<kRowRor8>(v, v));
+    v = fminf(v, dpp_f<kRowBcast15, 0xA>(v, v));
+    return half_reduce_pick(v, lane);
+}
+
 // lane `j` (wave-uniform) of v for every lane: v_readlane_b32 instead of a ds_bpermute round trip
 __device__ __forceinline__ float bcast(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
 __device__ __forceinline__ int bcast(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
