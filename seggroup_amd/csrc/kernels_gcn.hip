@@ -118,7 +118,24 @@ __device__ __forceinline__ void gcn_fc_body(const float* __restrict__ agg, int S
 #pragma unroll
     for (int rr = 0; rr < kRows; ++rr) acc[rr] = 0.0;
     // the k order of the sum is unchanged (D is 192 or 256 on the hot path; an odd D takes the last k alone)
-    for (int k = 0; k + 1 < D; k += 2) {
+    // two pairs per trip: the four weight loads and the sixteen row reads of a trip are issued together (left to itself the compiler
+    // waited out every load on its own; one scene = ~130 workgroups has nothing else to hide them with)
+    int k = 0;
+    for (; k + 3 < D; k += 4) {
+        const float f0 = wt[(size_t)k * D + o], f1 = wt[(size_t)(k + 1) * D + o], f2 = wt[(size_t)(k + 2) * D + o], f3 = wt[(size_t)(k + 3) * D + o];
+        double2 xa[kRows], xb[kRows];
+#pragma unroll
+        for (int rr = 0; rr < kRows; ++rr) { xa[rr] = *reinterpret_cast<const double2*>(&rows[rr][k]); xb[rr] = *reinterpret_cast<const double2*>(&rows[rr][k + 2]); }
+        const double w0 = (double)f0, w1 = (double)f1, w2 = (double)f2, w3 = (double)f3;
+#pragma unroll
+        for (int rr = 0; rr < kRows; ++rr) {
+            acc[rr] = fma(xa[rr].x, w0, acc[rr]);
+            acc[rr] = fma(xa[rr].y, w1, acc[rr]);
+            acc[rr] = fma(xb[rr].x, w2, acc[rr]);
+            acc[rr] = fma(xb[rr].y, w3, acc[rr]);
+        }
+    }
+    for (; k + 1 < D; k += 2) {
         const double w0 = (double)wt[(size_t)k * D + o], w1 = (double)wt[(size_t)(k + 1) * D + o];
 #pragma unroll
         for (int rr = 0; rr < kRows; ++rr) {
