@@ -468,7 +468,13 @@ int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_o
 int b_contract(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
     if (bd.nslots == 0) return SG_OK;
     const dim3 gy(1, bd.nslots);
-    if (bd.max_E0 > 0) k_mark_pairs_b<<<dim3(std::min(sg::cdiv(bd.max_E0, kBlock), 1024), bd.nslots), kBlock, 0, st>>>(d_ctx);
+    // ~1,024 workgroups per launch, each walking ~14 edges per thread: measured per launch of 8 scenes, blocks per scene 4,096 /
+    // 1,024 / 512 / 256 / 128 / 64 -> 124 / 97 / 71 / 63 / 57 / 66 us (the edge rows stream, the two segment-id gathers per edge and
+    // the bitmap atomics do better with fewer, longer-lived waves)
+    if (bd.max_E0 > 0) {
+        const int per_scene = std::min(sg::cdiv(bd.max_E0, kBlock), std::max(128, 1024 / std::max(bd.nslots, 1)));
+        k_mark_pairs_b<<<dim3(per_scene, bd.nslots), kBlock, 0, st>>>(d_ctx);
+    }
     k_count_bits_b<<<dim3(bd.max_bits_blocks, bd.nslots), kBlock, 0, st>>>(d_ctx);
     k_scan_blocks_b<<<gy, kBlock, 0, st>>>(d_ctx);
     k_emit_pairs_b<<<dim3(bd.max_bits_blocks, bd.nslots), kBlock, 0, st>>>(d_ctx);
