@@ -499,7 +499,7 @@ int b_group_max_fill(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) 
 
 int b_export_eval(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
     if (bd.nslots == 0) return SG_OK;
-    k_export_b<<<dim3(std::max(1, std::min(sg::cdiv(bd.max_V, 256), 1024)), bd.nslots), 256, 0, st>>>(d_ctx);
+    k_export_b<<<dim3(std::max(1, std::min(sg::cdiv(bd.max_V, 256), std::max(128, 1024 / std::max(bd.nslots, 1)))), bd.nslots), 256, 0, st>>>(d_ctx);
     const size_t dyn = (size_t)std::min(std::max(bd.max_ins, 1), kInsLds) * 16;     // every scene with max_ins <= kInsLds fits
     k_eval_counts_b<<<dim3(std::max(1, std::min(sg::cdiv(bd.max_V, 1024), 256)), bd.nslots), 256, dyn, st>>>(d_ctx);
     k_eval_first_sem_b<<<dim3(sg::cdiv(std::max(bd.max_ins, 1), 256), bd.nslots), 256, 0, st>>>(d_ctx);
