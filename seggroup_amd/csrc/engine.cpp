@@ -457,7 +457,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
         c.ec_partial = r.ec_partial; c.ec_w1f = r.ec_fold; c.ec_sh1 = c.ec_w1f + 64 * 18; c.ec_w2f = c.ec_sh1 + 64; c.ec_sh2 = c.ec_w2f + 64 * 64;
         c.ec_w2img = c.ec_sh2 + 64; c.ec_scale = c.ec_w2img + 4096;
         c.K = 20;
-        c.pf = pl->pf.p; c.ec_blocks = sg::cdiv(sg::cdiv(N, 32), 4); c.ec_mblocks = sg::cdiv(N, 256);
+        c.pf = pl->pf.p; c.ec_blocks = sg::cdiv(sg::cdiv(N, 32), sg::kEdgeWaves); c.ec_mblocks = sg::cdiv(N, 256);
         c.g_wt = W + (layer == 0 ? pl->o_g2t : pl->o_g3t); c.g_dist = r.g_dist; c.g_agg = r.g_agg; c.g_out = pl->featB.p;
         // outbox: decision distances (+ the GCN output of layer 3, which the final clustering reads on the host)
         r.dist_in_outbox = E <= r.out_rows;
@@ -788,7 +788,7 @@ sg_engine* sg_engine_create(int maxN, int maxS, int maxE, int maxV, const sg_wei
             r.m1_partial = cm.take<double>(S * 27);
             r.m1_folded = cm.take<float>(448);
             sg::Carver ce(pl->ws_edge.p, pl->ws_edge.n);
-            const size_t nb = (size_t)sg::cdiv(sg::cdiv(maxN, 32), 4), mb = (size_t)sg::cdiv(maxN, 256);
+            const size_t nb = (size_t)sg::cdiv(sg::cdiv(maxN, 32), sg::kEdgeWaves), mb = (size_t)sg::cdiv(maxN, 256);
             r.ec_partial = ce.take<double>(std::max(nb * 128, mb * 189));
             r.ec_fold = ce.take<float>(sg::kEdgeFoldFloats);
             sg::Carver cg(pl->ws_gcn.p, pl->ws_gcn.n);

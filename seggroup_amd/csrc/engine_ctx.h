@@ -142,6 +142,7 @@ struct SlotCtx {
 };
 
 // ---- batched launchers: one launch per call, grid.y = nslots -------------------------------------------------------
+constexpr int kEdgeWaves = 4;             // tiles (waves) per EdgeConv workgroup: grid and partial-sum sizing (kernels_edgeconv.hip)
 constexpr int kLayoutPiece = 1024;       // rows of a segment one layout block walks (k_layer_layout_b / _big_b)
 
 struct BatchDims {                       // maxima over the slots of a group (grid.x sizes)

@@ -79,7 +79,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 enum { S1X = 1, S2X = 2 };     // conv1 statistics + extremum (MLP2) | conv1' -> conv2 statistics + extremum (MLP3)
 
-constexpr int kWaves = 4;
+constexpr int kWaves = sg::kEdgeWaves;
 
 
 __device__ inline int acc_channel(int tile, int reg, int half) { return 32 * tile + (reg & 3) + 8 * (reg >> 2) + 4 * half; }
@@ -425,7 +425,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     }
 }
 template <int MODE, bool REREAD_A = false>
-__global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
+__global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                                           const float* __restrict__ w1, const float* __restrict__ shift1,
                                                           const u32x4* __restrict__ w2img, const float* __restrict__ scales,
                                                           const float* __restrict__ gamma_last,
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv(const float* __rest
 // S1X: the scene's MLP2 weights as they are; S2X: its folded conv1 (ec_w1f, ec_sh1) + the raw conv2
 // the engine's launches: E goes straight into the clusters' maxima (kFused above), c.pf is not written
 template <int MODE, bool REREAD_A>
-__global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx) {
+__global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.ec_blocks) return;
     // pointers read out of a SlotCtx are generic to the compiler (sg_common.h, gptr): hand them over as global memory
