@@ -51,7 +51,15 @@ __device__ __forceinline__ void gcn_aggregate_body(const float* __restrict__ x, 
             id = staged ? s_id[t] : eid[lo + t];
             const float* a = x + (size_t)(staged ? s_a[t] : adj[2 * id]) * D;
             const float* b = x + (size_t)(staged ? s_b[t] : adj[2 * id + 1]) * D;
-            for (int k = sub; k < D; k += 16) {
+            int k = sub;
+            for (; k + 48 < D; k += 64) {                         // four strides per trip, their eight loads in flight together
+                const float a0 = a[k], a1 = a[k + 16], a2 = a[k + 32], a3 = a[k + 48], b0 = b[k], b1 = b[k + 16], b2 = b[k + 32], b3 = b[k + 48];
+                double d = (double)a0 - (double)b0 + 1e-6; acc = fma(d, d, acc);
+                d = (double)a1 - (double)b1 + 1e-6; acc = fma(d, d, acc);
+                d = (double)a2 - (double)b2 + 1e-6; acc = fma(d, d, acc);
+                d = (double)a3 - (double)b3 + 1e-6; acc = fma(d, d, acc);
+            }
+            for (; k < D; k += 16) {
                 const double d = (double)a[k] - (double)b[k] + 1e-6;
                 acc = fma(d, d, acc);
             }

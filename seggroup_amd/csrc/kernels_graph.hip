@@ -183,7 +183,13 @@ __device__ __forceinline__ void edge_distance_one(const float* __restrict__ feat
     const float* a = feat + (size_t)adj[2 * e] * stride;
     const float* b = feat + (size_t)adj[2 * e + 1] * stride;
     double acc = 0.0;
-    for (int k = lane; k < D; k += 64) {
+    int k = lane;
+    for (; k + 64 < D; k += 128) {                                // two strides per trip, their four loads in flight together
+        const float a0 = a[k], a1 = a[k + 64], b0 = b[k], b1 = b[k + 64];
+        double d = (double)a0 - (double)b0 + 1e-6; acc = fma(d, d, acc);
+        d = (double)a1 - (double)b1 + 1e-6; acc = fma(d, d, acc);
+    }
+    for (; k < D; k += 64) {
         const double d = (double)a[k] - (double)b[k] + 1e-6;
         acc = fma(d, d, acc);
     }
@@ -219,7 +225,14 @@ __device__ __forceinline__ void group_max_rows_body(const float* __restrict__ ro
     const int lo = goff[g], hi = goff[g + 1];
     for (int k = threadIdx.x; k < D; k += blockDim.x) {
         float m = -INFINITY;
-        for (int i = lo; i < hi; ++i) m = fmaxf(m, rows[(size_t)gidx[i] * row_stride + k]);
+        int i = lo;
+        for (; i + 3 < hi; i += 4) {                              // four child ids, then their four rows, in flight together
+            const int a = gidx[i], b = gidx[i + 1], c = gidx[i + 2], d = gidx[i + 3];
+            const float va = rows[(size_t)a * row_stride + k], vb = rows[(size_t)b * row_stride + k], vc = rows[(size_t)c * row_stride + k],
+                        vd = rows[(size_t)d * row_stride + k];
+            m = fmaxf(fmaxf(m, fmaxf(va, vb)), fmaxf(vc, vd));
+        }
+        for (; i < hi; ++i) m = fmaxf(m, rows[(size_t)gidx[i] * row_stride + k]);
         out[(size_t)g * out_stride + k] = m;
     }
     for (int k = threadIdx.x; k < fill_cols; k += blockDim.x) out[(size_t)g * out_stride + D + k] = -INFINITY;
