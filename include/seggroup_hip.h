@@ -164,21 +164,19 @@ int sg_cluster_knn_pruned(const float* d_xyzw, int N, const int32_t* d_cl_off,
                           const int32_t* d_seg_off, const float* d_segbox, const int32_t* d_slot_of_pos,
                           int k, int pos0, int32_t* d_knn, void* stream);
 
-/* Fastest variant (same tables again).  Once per scene sg_segment_spatial_sort puts the points of every original
- * segment in Morton order (d_sperm[N]: sorted position -> index into d_seg_points) and boxes every run of 32
- * sorted points (d_chunk_box [(sum_s ceil(size_s/32)), 8]; d_seg_chunk_off[S+1] = first chunk of each segment,
- * computed by the caller from the segment sizes).  Per layer sg_knn_operands lays the kNN operand out in that
- * order (d_sxyzw [N,4], d_smpos [N] = member position of each sorted position) and sg_cluster_knn_sorted scans
- * only chunks whose box can still beat a lane's 20th best.  Tiles hold <= 64 SORTED positions of one cluster
- * (same ranges as member order: sorting only permutes inside a segment). */
-size_t sg_spatial_sort_ws_bytes(int N);
-int sg_segment_spatial_sort(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off,
-                            const int32_t* d_seg_of_point, int S, const float* d_segbox, const int32_t* d_seg_chunk_off,
-                            int32_t* d_sperm, float* d_chunk_box, void* d_ws, size_t ws_bytes, void* stream);
-/* sg_segment_boxes + sg_segment_spatial_sort in ONE launch when the largest segment (max_seg points, known to the
- * host) fits a block's LDS (2048 points); otherwise exactly those two calls (d_ws as for sg_segment_spatial_sort,
- * unused on the fast path).  Identical outputs: d_segbox [S,8], d_sperm [N], d_chunk_box.  d_seg_sums (may be NULL):
- * [S,3] double, the sum of every segment's xyz -- layer-invariant, so the host can form any cluster's centroid from it. */
+/* Fastest variant (same tables again).  Once per scene sg_segment_sort_boxes puts the points of every original
+ * segment in Morton order (d_sperm[N]: sorted position -> index into d_seg_points; key = 30-bit Morton code inside the
+ * segment's box, ties by CSR index) and boxes every run of 32 sorted points (d_chunk_box [(sum_s ceil(size_s/32)), 8];
+ * d_seg_chunk_off[S+1] = first chunk of each segment, computed by the caller from the segment sizes).  Per layer
+ * sg_knn_operands lays the kNN operand out in that order (d_sxyzw [N,4], d_smpos [N] = member position of each sorted
+ * position) and sg_cluster_knn_sorted scans only chunks whose box can still beat a lane's 20th best.  Tiles hold <= 64
+ * SORTED positions of one cluster (same ranges as member order: sorting only permutes inside a segment).
+ * One launch (a block per segment: box, LDS bitonic sort, chunk boxes) when the largest segment (max_seg points, known
+ * to the host) fits a block's LDS (2048 points); segments beyond that take a second launch that buckets by the top 12
+ * Morton bits in d_ws (sg_segment_sort_ws_bytes(N) = 16 N bytes; unused otherwise) and sorts every run of cells in LDS.
+ * Outputs: d_segbox [S,8], d_sperm [N], d_chunk_box.  d_seg_sums (may be NULL): [S,3] double, the sum of every
+ * segment's xyz -- layer-invariant, so the host can form any cluster's centroid from it. */
+size_t sg_segment_sort_ws_bytes(int N);
 int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off,
                           const int32_t* d_seg_of_point, int S, const int32_t* d_seg_chunk_off, int max_seg, float* d_segbox,
                           int32_t* d_sperm, float* d_chunk_box, double* d_seg_sums, void* d_ws, size_t ws_bytes, void* stream);

@@ -13,7 +13,6 @@
 // index wins"), whatever order candidates arrive in.
 #include <cstdlib>
 
-#include <hipcub/hipcub.hpp>
 
 #include "engine_ctx.h"
 #include "knn_device.h"
@@ -64,52 +63,7 @@ __device__ inline unsigned int spread10(unsigned int v) {      // 10 bits -> eve
     return v;
 }
 
-// i indexes the ascending CSR of the over-segmentation (seg_points); key = segment << 32 | morton30 in its box
-__global__ void k_morton_keys(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
-                              const int32_t* __restrict__ seg_of_point, const float* __restrict__ segbox, int N,
-                              unsigned long long* __restrict__ keys, int32_t* __restrict__ vals) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int p = seg_points[i];
-    const int s = seg_of_point[p];
-    const float* b = segbox + (size_t)s * 8;
-    const float* r = data + (size_t)p * 6;
-    const unsigned int m = morton30(r, b);
-    keys[i] = ((unsigned long long)(unsigned int)s << 32) | m;
-    vals[i] = i;
-}
-
-// one wave per segment: boxes of its 32-point chunks in sorted order
-__global__ __launch_bounds__(64) void k_chunk_boxes(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
-                                                    const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
-                                                    const int32_t* __restrict__ sperm, float* __restrict__ chunk_box) {
-    const int s = blockIdx.x, lane = threadIdx.x;
-    const int lo = seg_off[s], n = seg_off[s + 1] - lo;
-    const int c0 = seg_chunk_off[s];
-    const int half = lane >> 5, l = lane & 31;                 // two chunks per iteration
-    for (int j = half; j * kChunkPts < n; j += 2) {
-        const int t = j * kChunkPts + l;
-        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, xx = 0.f;
-        if (t < n) {
-            const float* r = data + (size_t)seg_points[sperm[lo + t]] * 6;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { mn[k] = r[k]; mx[k] = r[k]; }
-            xx = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
-        }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
-            xx = fmaxf(xx, __shfl_xor(xx, o));
-        }
-        if (l == 0) {
-            float* b = chunk_box + (size_t)(c0 + j) * 8;
-            b[0] = mn[0]; b[1] = mn[1]; b[2] = mn[2]; b[3] = mx[0]; b[4] = mx[1]; b[5] = mx[2]; b[6] = xx; b[7] = 0.f;
-        }
-    }
-}
-
-// One launch for what sg_segment_boxes + k_morton_keys + the device radix sort (9 launches) + k_chunk_boxes do, for scenes
+// Segment box + Morton sort + chunk boxes in one launch (round 1: a key kernel, a library radix sort = 9 launches, a box kernel), for scenes
 // whose largest segment has <= kSortCap points: block s owns segment s, computes its box, sorts (morton30 << 32 | local
 // index) in LDS with a bitonic network -- the local index in the low bits reproduces the radix sort's stable order exactly
 // -- and boxes its 32-point chunks.  At ~1000 scenes/s the pipelines issue ~100k runtime calls per second, so launches
@@ -155,7 +109,7 @@ __device__ __forceinline__ void segment_sort_boxes_body(const float* __restrict_
     if (tid == 7) segbox[(size_t)s * 8 + 7] = 0.f;
     if (seg_sums && tid >= 8 && tid < 11) seg_sums[(size_t)s * 3 + (tid - 8)] = ((dred[0][tid - 8] + dred[1][tid - 8]) + dred[2][tid - 8]) + dred[3][tid - 8];
     __syncthreads();
-    // 2. keys (same quantisation as k_morton_keys), padded to a power of two with ~0
+    // 2. keys (morton30 inside the box just computed), padded to a power of two with ~0
     int m2 = 64;
     while (m2 < n) m2 <<= 1;
     for (int i = tid; i < m2; i += 256) {
@@ -1173,45 +1127,7 @@ int sg_debug_knn5_stats(unsigned long long* h_out) {
 }
 #endif
 
-size_t sg_spatial_sort_ws_bytes(int N) {
-    size_t temp = 0;
-    hipcub::DoubleBuffer<unsigned long long> dk(nullptr, nullptr);
-    hipcub::DoubleBuffer<int32_t> dv(nullptr, nullptr);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, dk, dv, std::max(N, 1), 0, 64, (hipStream_t)0);
-    const size_t n = (size_t)std::max(N, 1);
-    return sg::align_up(temp) + 2 * sg::align_up(n * 8) + 2 * sg::align_up(n * 4) + 256;
-}
-
-int sg_segment_spatial_sort(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off,
-                            const int32_t* d_seg_of_point, int S, const float* d_segbox, const int32_t* d_seg_chunk_off,
-                            int32_t* d_sperm, float* d_chunk_box, void* d_ws, size_t ws_bytes, void* stream) {
-    SG_REQUIRE(N >= 0 && S >= 0 && d_sperm && d_chunk_box && d_ws, "sg_segment_spatial_sort: bad arguments");
-    if (N == 0 || S == 0) return SG_OK;
-    hipStream_t st = sg::as_stream(stream);
-    size_t temp = 0;
-    {
-        hipcub::DoubleBuffer<unsigned long long> dk(nullptr, nullptr);
-        hipcub::DoubleBuffer<int32_t> dv(nullptr, nullptr);
-        SG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp, dk, dv, N, 0, 64, st));
-    }
-    sg::Carver cv(d_ws, ws_bytes);
-    char* tmp = cv.take<char>(temp);
-    unsigned long long* k0 = cv.take<unsigned long long>(N);
-    unsigned long long* k1 = cv.take<unsigned long long>(N);
-    int32_t* v0 = cv.take<int32_t>(N);
-    int32_t* v1 = cv.take<int32_t>(N);
-    if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_segment_spatial_sort: workspace too small (%zu < %zu)", ws_bytes, sg_spatial_sort_ws_bytes(N));
-    k_morton_keys<<<sg::cdiv(N, 256), 256, 0, st>>>(d_data, d_seg_points, d_seg_of_point, d_segbox, N, k0, v0);
-    int seg_bits = 1;
-    while ((1 << seg_bits) < S) ++seg_bits;
-    hipcub::DoubleBuffer<unsigned long long> dk(k0, k1);
-    hipcub::DoubleBuffer<int32_t> dv(v0, v1);
-    SG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, temp, dk, dv, N, 0, 32 + seg_bits, st));
-    SG_HIP(hipMemcpyAsync(d_sperm, dv.Current(), (size_t)N * 4, hipMemcpyDeviceToDevice, st));
-    k_chunk_boxes<<<S, 64, 0, st>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_sperm, d_chunk_box);
-    SG_LAUNCH_CHECK();
-    return SG_OK;
-}
+size_t sg_segment_sort_ws_bytes(int N) { return (size_t)std::max(N, 1) * 16; }   // two N-key scratch arrays of k_bigseg_sort_boxes
 
 int sg_layer_layout(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl, const float* d_cl_mean, int32_t* d_members,
@@ -1235,7 +1151,7 @@ int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_point
     k_segment_sort_boxes<<<S, 256, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_segbox, d_sperm, d_chunk_box,
                                                                d_seg_sums);
     if (max_seg > kSortCap) {                                  // segments beyond one block's LDS: cell-bucketed LDS sort, scratch = 2 x N keys
-        if (!d_ws || ws_bytes < (size_t)N * 16) return sg::fail(SG_ENOMEM, "sg_segment_sort_boxes: workspace too small (%zu < %zu)", ws_bytes, (size_t)N * 16);
+        if (!d_ws || ws_bytes < sg_segment_sort_ws_bytes(N)) return sg::fail(SG_ENOMEM, "sg_segment_sort_boxes: workspace too small (%zu < %zu)", ws_bytes, sg_segment_sort_ws_bytes(N));
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(d_ws);
         k_bigseg_sort_boxes<<<S, kBigBlock, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_segbox, d_sperm,
                                                                       d_chunk_box, d_seg_sums, keys, keys + N);

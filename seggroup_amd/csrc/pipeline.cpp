@@ -129,7 +129,7 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
     D(pl->feat1, S * 128); D(pl->featA, S * 256); D(pl->featB, S * 256);
     D(pl->seg_sums, S * 3); P(pl->h_seg_sums, S * 3); D(pl->segbox, S * 8); D(pl->chunk_box, (N / 32 + S + 1) * 8); D(pl->chunk_table, (N / 32 + S + 1) * 8); D(pl->sperm, N); D(pl->smpos, N); D(pl->seg_chunk_off, S + 1);
-    D(pl->ws_sort, sg_spatial_sort_ws_bytes(maxN)); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64); D(pl->point_rec, N * 4);
+    D(pl->ws_sort, sg_segment_sort_ws_bytes(maxN)); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64); D(pl->point_rec, N * 4);
     P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4); P(pl->h_chunk_off, S + 1);
     P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
     if (bad) { sg::fail(SG_ENOMEM, "sg_pipeline_create: device/pinned allocation failed (N=%d S=%d E=%d V=%d)", maxN, maxS, maxE, maxV); return nullptr; }

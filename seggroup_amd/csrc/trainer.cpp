@@ -70,7 +70,7 @@ void sg_trainer_destroy(sg_trainer* tr) {
 
 sg_trainer* sg_trainer_create(int maxN, int maxS, int maxE, int maxV, float* d_params, float* d_grads, void* stream) {
     if (!d_params || !d_grads) { sg::fail(SG_EINVAL, "sg_trainer_create: null parameter / gradient vector"); return nullptr; }
-    std::unique_ptr<sg_trainer> tr(new sg_trainer());
+    std::unique_ptr<sg_trainer, void (*)(sg_trainer*)> tr(new sg_trainer(), sg_trainer_destroy);   // a failed allocation below also frees tr->pl
     // the pipeline wants host weights at creation; they are replaced from d_params before every forward
     std::vector<float> zero(65536, 0.f);
     sg_weights w;

@@ -82,8 +82,7 @@ SIGNATURES = {
     "sg_cluster_knn": (_I, [vp, _I, vp, vp, vp, vp, _I, _I, _I, vp, vp]),
     "sg_segment_boxes": (_I, [vp, vp, vp, _I, vp, vp]),
     "sg_cluster_knn_pruned": (_I, [vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
-    "sg_spatial_sort_ws_bytes": (_Z, [_I]),
-    "sg_segment_spatial_sort": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),
+    "sg_segment_sort_ws_bytes": (_Z, [_I]),
     "sg_knn_operands": (_I, [vp, vp, vp, vp, _I, vp, vp, vp, vp, vp]),
     "sg_cluster_knn_sorted": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
     "sg_segment_sort_boxes": (_I, [vp, _I, vp, vp, vp, _I, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),

@@ -294,10 +294,11 @@ def main(argv=None):
         print('seggroup_amd runs on MI355X only: no CPU fallback (use oracle/cpu_ref.py for testing)')
         raise SystemExit(1)
     np.seterr(divide='ignore', invalid='ignore')
-    io = IOStream(os.path.join(args.root, 'checkpoints', args.exp_name, 'run_infer.log'))
-    io.cprint(str(args))
-    io.cprint("Let's use " + str(torch.cuda.device_count()) + " GPUs!")
-    io.close()
+    if int(os.environ.get('RANK', '0')) == 0:                              # once, like the reference (under torchrun every rank runs main())
+        io = IOStream(os.path.join(args.root, 'checkpoints', args.exp_name, 'run_infer.log'))
+        io.cprint(str(args))
+        io.cprint("Let's use " + str(torch.cuda.device_count()) + " GPUs!")
+        io.close()
     torch.manual_seed(args.seed)
     np.random.seed(1)
     if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:              # launched by torchrun

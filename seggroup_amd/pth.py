@@ -24,6 +24,15 @@ def _rebuild_tensor_v2(storage, offset, size, stride, requires_grad=False, backw
     arr, dtype = storage
     flat = np.frombuffer(arr, dtype=dtype)
     item = np.dtype(dtype).itemsize
+    size, stride, offset = tuple(int(v) for v in size), tuple(int(v) for v in stride), int(offset)
+    # the pickle is untrusted input: the view must stay inside the storage it names (a truncated or hostile file would
+    # otherwise read out of bounds); the caller falls back to torch.load on ValueError
+    if offset < 0 or len(size) != len(stride) or any(v < 0 for v in size) or any(v < 0 for v in stride):
+        raise ValueError("tensor view with a negative offset / size / stride")
+    if all(v > 0 for v in size) and offset + sum((n - 1) * st for n, st in zip(size, stride)) >= flat.size:
+        raise ValueError("tensor view reaches beyond its storage")
+    if any(v == 0 for v in size):
+        return np.zeros(size, dtype=dtype)
     view = np.lib.stride_tricks.as_strided(flat[offset:], shape=tuple(size), strides=tuple(s * item for s in stride), writeable=False)
     return np.ascontiguousarray(view)
 

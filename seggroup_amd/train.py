@@ -181,13 +181,13 @@ def run_worker(rank: int, world: int, args, make_trainer: Optional[Callable] = N
         from . import cache
         from .scene import DeviceScene
         from .trainer import Trainer
+        torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))       # before the first collective: RCCL binds to the current device
+        dev = torch.device('cuda', torch.cuda.current_device())
         if not args.no_cache:
             per_rank = max(1, -(-int(args.workers) // max(world, 1)))
             cache.build_missing(args.root, names[rank::world], args.label_style, workers=per_rank)
             if world > 1:
                 dist.barrier()                             # every rank reads packs other ranks built
-        torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))
-        dev = torch.device('cuda', torch.cuda.current_device())
 
         def stage(name):   # noqa: F811
             if args.no_cache:
@@ -239,10 +239,11 @@ def run_worker(rank: int, world: int, args, make_trainer: Optional[Callable] = N
             if hasattr(tr, "fits") and not tr.fits(sc):
                 # a scene beyond the trainer's capacities: same parameters / optimizer state / BatchNorm buffers, larger buffers
                 bigger = tuple(max(a, b) for a, b in zip(tr.caps, (sc.N, sc.S, sc.E0, sc.V)))
-                grown = Trainer(tr.state_dict(), bigger, device=dev, use_sgd=args.use_sgd, lr=args.lr, momentum=args.momentum, seed=args.seed + rank)
-                grown.load_optimizer_state(tr.optimizer_state())
+                # the old trainer's device buffers go first: two pipelines of the larger size need not fit together
+                state_now, opt_now = tr.state_dict(), tr.optimizer_state()
                 tr.close()
-                tr = grown
+                tr = Trainer(state_now, bigger, device=dev, use_sgd=args.use_sgd, lr=args.lr, momentum=args.momentum, seed=args.seed + rank)
+                tr.load_optimizer_state(opt_now)
             try:
                 loss, res, summed = tr.step(sc)
             except Exception as e:                                                   # e.g. a scene with one weak instance: BatchNorm1d raises
@@ -298,10 +299,11 @@ def main(argv=None):
     for d in ('checkpoints', os.path.join('checkpoints', args.exp_name), os.path.join('checkpoints', args.exp_name, 'models'), 'results',
               os.path.join('results', args.exp_name)):
         os.makedirs(os.path.join(args.root, d), exist_ok=True)                          # train.py:_init_
-    io = IOStream(os.path.join(args.root, 'checkpoints', args.exp_name, 'run.log'))
-    io.cprint(str(args))
-    io.cprint("Let's use " + str(torch.cuda.device_count()) + " GPUs!")
-    io.close()
+    if int(os.environ.get('RANK', '0')) == 0:                              # once, like the reference (under torchrun every rank runs main())
+        io = IOStream(os.path.join(args.root, 'checkpoints', args.exp_name, 'run.log'))
+        io.cprint(str(args))
+        io.cprint("Let's use " + str(torch.cuda.device_count()) + " GPUs!")
+        io.close()
     if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:              # launched by torchrun
         import torch.distributed as dist
         rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])

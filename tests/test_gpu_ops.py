@@ -39,6 +39,51 @@ def _ws(torch, nbytes):
     return torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device="cuda:0")
 
 
+def _morton_sort_oracle(data, seg_points, seg_off):
+    """NumPy statement of what sg_segment_sort_boxes defines (include/seggroup_hip.h): per over-segment its box [min xyz | max xyz |
+    max |p|^2 | 0], the order of its points by (30-bit Morton code inside that box, CSR index) and the boxes of every run of 32
+    sorted points.  Every axis is quantised to 10 bits by its own extent unless that is < 1/4 of the largest (then by the largest);
+    all arithmetic in float32 like the kernel."""
+    f = np.float32
+    xyz = data[seg_points, :3].astype(f)
+    S = len(seg_off) - 1
+    n = np.diff(seg_off)
+    seg = np.repeat(np.arange(S), n)
+    xx = (xyz[:, 0] * xyz[:, 0] + xyz[:, 1] * xyz[:, 1]) + xyz[:, 2] * xyz[:, 2]
+    box = np.zeros((S, 8), f)
+    nz = n > 0
+    st = seg_off[:-1][nz]
+    box[nz, 0:3] = np.minimum.reduceat(xyz, st, axis=0)
+    box[nz, 3:6] = np.maximum.reduceat(xyz, st, axis=0)
+    box[nz, 6] = np.maximum.reduceat(xx, st)
+    e = box[:, 3:6] - box[:, 0:3]
+    emax = e.max(axis=1, keepdims=True)
+    ext = np.where(e >= f(0.25) * emax, e, emax)[seg]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(ext > 0, (xyz - box[seg, 0:3]) / ext, f(0)).astype(f)
+    q = np.minimum(np.maximum(t * f(1023.0), f(0)), f(1023.0)).astype(np.uint32)
+
+    def spread(v):
+        v = v & 0x3ff
+        v = (v | (v << 16)) & 0x030000ff
+        v = (v | (v << 8)) & 0x0300f00f
+        v = (v | (v << 4)) & 0x030c30c3
+        return (v | (v << 2)) & 0x09249249
+    m = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    idx = np.arange(len(seg))
+    sperm = np.lexsort((idx, m, seg)).astype(np.int32)
+    sx, sxx = xyz[sperm], xx[sperm]
+    chunk_off = np.concatenate([[0], np.cumsum((n + 31) // 32)])
+    cstart = np.concatenate([seg_off[s] + 32 * np.arange((n[s] + 31) // 32) for s in range(S)]).astype(np.int64) if S else np.zeros(0, np.int64)
+    cbox = np.zeros((int(chunk_off[-1]), 8), f)
+    if len(cstart):
+        cbox[:, 0:3] = np.minimum.reduceat(sx, cstart, axis=0)
+        cbox[:, 3:6] = np.maximum.reduceat(sx, cstart, axis=0)
+        cbox[:, 6] = np.maximum.reduceat(sxx, cstart)
+    return box, sperm, cbox
+
+
+
 def _layer_arrays(layer):
     """member CSR of an oracle Layer"""
     members = np.concatenate(layer.members).astype(np.int32)
@@ -449,15 +494,15 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         d_co = _up(torch, chunk_off)
         sperm = torch.zeros(N, dtype=torch.int32, device="cuda:0")
         cbox = torch.zeros(int(chunk_off[-1]) + 1, 8, device="cuda:0")
-        wss = _ws(torch, lib.sg_spatial_sort_ws_bytes(N))
+        wss = _ws(torch, lib.sg_segment_sort_ws_bytes(N))
         d_sop = _up(torch, sc.seg)
-        hip.check(lib.sg_segment_spatial_sort(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), d_sop.data_ptr(), S,
-                                              box.data_ptr(), d_co.data_ptr(), sperm.data_ptr(), cbox.data_ptr(), wss.data_ptr(),
-                                              wss.numel(), None))
-        # the single-launch form (segment box + Morton sort in LDS + chunk boxes) gives the same three arrays bit for bit
+        obox, osperm, ocbox = _morton_sort_oracle(sc.data, segorder, seg_off)
+        assert np.array_equal(obox, box.cpu().numpy())                 # sg_segment_boxes: the same boxes
+        sperm.copy_(torch.from_numpy(osperm)); cbox[:len(ocbox)].copy_(torch.from_numpy(ocbox))
+        # the single-launch kernel (segment box + Morton sort in LDS + chunk boxes) against the NumPy statement, bit for bit
         box2 = torch.full((S, 8), 7.0, device="cuda:0"); sperm2 = torch.full((N,), -1, dtype=torch.int32, device="cuda:0")
         cbox2 = torch.zeros_like(cbox)
-        for max_seg in (int(np.diff(seg_off).max()), 1 << 20):      # fits a block / forces the library-sort fallback
+        for max_seg in (int(np.diff(seg_off).max()), 1 << 20):      # fits a block / also launches the big-segment kernel (nothing for it to do)
             box2.fill_(7.0); sperm2.fill_(-1); cbox2.zero_()
             sums = torch.zeros(S, 3, dtype=torch.float64, device="cuda:0")
             hip.check(lib.sg_segment_sort_boxes(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), d_sop.data_ptr(), S,
@@ -565,9 +610,12 @@ def _knn_layer_setup(lib, torch, hip, sc, L):
     hip.check(lib.sg_segment_boxes(d["data"].data_ptr(), d["segpts"].data_ptr(), d["segoff"].data_ptr(), S, box.data_ptr(), None))
     sperm = torch.zeros(N, dtype=torch.int32, device="cuda:0")
     cbox = torch.zeros(int(chunk_off[-1]) + 1, 8, device="cuda:0")
-    wss = _ws(torch, lib.sg_spatial_sort_ws_bytes(N))
-    hip.check(lib.sg_segment_spatial_sort(d["data"].data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), d["sop"].data_ptr(), S,
-                                          box.data_ptr(), d["co"].data_ptr(), sperm.data_ptr(), cbox.data_ptr(), wss.data_ptr(), wss.numel(), None))
+    wss = _ws(torch, lib.sg_segment_sort_ws_bytes(N))
+    box_s = torch.zeros_like(box)
+    hip.check(lib.sg_segment_sort_boxes(d["data"].data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), d["sop"].data_ptr(), S,
+                                        d["co"].data_ptr(), int(np.diff(seg_off).max()), box_s.data_ptr(), sperm.data_ptr(), cbox.data_ptr(), None,
+                                        wss.data_ptr(), wss.numel(), None))
+    assert torch.equal(box_s, box)
     sxyzw = torch.zeros(N, 4, device="cuda:0"); smpos = torch.zeros(N, dtype=torch.int32, device="cuda:0")
     hip.check(lib.sg_knn_operands(d["data"].data_ptr(), d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S, d["order"].data_ptr(),
                                   d["dst"].data_ptr(), sxyzw.data_ptr(), smpos.data_ptr(), None))
@@ -628,8 +676,8 @@ def test_seeded_knn_equals_bruteforce(env, golden_index, name, fine, coarse):
                          ids=["5k-point-segments", "scannet-subsampled", "scannet-tiled", "7k-segments-30pct-duplicates"])
 def test_segments_beyond_the_lds_sort_cap(env, cfg):
     """Over-segments of more than 2,048 points (floors and walls of a real scan: 10k-30k points) are Morton-sorted by
-    k_bigseg_sort_boxes (cells of the top 12 Morton bits, every run of cells sorted in LDS) instead of a library radix
-    sort: segment boxes, sorted order, chunk boxes and coordinate sums must equal the library path's bit for bit."""
+    k_bigseg_sort_boxes (cells of the top 12 Morton bits, every run of cells sorted in LDS): segment boxes, sorted order, chunk
+    boxes and coordinate sums must equal the NumPy statement of the order (`_morton_sort_oracle`) bit for bit."""
     lib, torch, hip = env
     from seggroup_amd import synthetic
     n, s, seed, kw = cfg
@@ -642,18 +690,14 @@ def test_segments_beyond_the_lds_sort_cap(env, cfg):
     chunk_off = np.concatenate([[0], np.cumsum((counts + 31) // 32)]).astype(np.int32)
     d_data, d_pts, d_off, d_sop, d_co = (_up(torch, x) for x in (sc.data, order, seg_off, sc.seg, chunk_off))
     nchunk = int(chunk_off[-1])
-    # library path: boxes, then radix sort of (segment | morton30) pairs, then chunk boxes
-    box = torch.zeros(S, 8, device="cuda:0")
-    hip.check(lib.sg_segment_boxes(d_data.data_ptr(), d_pts.data_ptr(), d_off.data_ptr(), S, box.data_ptr(), None))
-    sperm = torch.zeros(N, dtype=torch.int32, device="cuda:0")
-    cbox = torch.zeros(nchunk + 1, 8, device="cuda:0")
-    wss = _ws(torch, lib.sg_spatial_sort_ws_bytes(N))
-    hip.check(lib.sg_segment_spatial_sort(d_data.data_ptr(), N, d_pts.data_ptr(), d_off.data_ptr(), d_sop.data_ptr(), S, box.data_ptr(),
-                                          d_co.data_ptr(), sperm.data_ptr(), cbox.data_ptr(), wss.data_ptr(), wss.numel(), None))
+    # the order the header defines, evaluated in NumPy: boxes, (segment, morton30, CSR index) order, chunk boxes
+    obox, osperm, ocbox = _morton_sort_oracle(sc.data, order, seg_off)
+    box, sperm = _up(torch, obox), _up(torch, osperm)
+    cbox = torch.zeros(nchunk + 1, 8, device="cuda:0"); cbox[:nchunk].copy_(torch.from_numpy(ocbox))
     # the pipeline's path
     box2 = torch.full((S, 8), 7.0, device="cuda:0"); sperm2 = torch.full((N,), -1, dtype=torch.int32, device="cuda:0")
     cbox2 = torch.zeros_like(cbox); sums = torch.zeros(S, 3, dtype=torch.float64, device="cuda:0")
-    ws2 = _ws(torch, 16 * N)
+    ws2 = _ws(torch, lib.sg_segment_sort_ws_bytes(N))
     for rep in range(2):                                        # twice: the scratch keeps stale keys from the first run
         hip.check(lib.sg_segment_sort_boxes(d_data.data_ptr(), N, d_pts.data_ptr(), d_off.data_ptr(), d_sop.data_ptr(), S, d_co.data_ptr(),
                                             int(counts.max()), box2.data_ptr(), sperm2.data_ptr(), cbox2.data_ptr(), sums.data_ptr(),

@@ -27,3 +27,13 @@ def test_pth_reader_refuses_anything_but_a_plain_tensor(tmp_path):
     open(q, "wb").write(b"not a zip")
     with pytest.raises(Exception):
         pth.load_tensor(q)
+
+
+def test_pth_reader_refuses_a_view_beyond_its_storage():
+    from seggroup_amd import pth
+    store = (np.arange(12, dtype=np.float32).tobytes(), np.float32)
+    assert pth._rebuild_tensor_v2(store, 2, (2, 5), (5, 1)).shape == (2, 5)          # last element = flat[11]
+    for off, size, stride in ((3, (2, 5), (5, 1)), (0, (4, 4), (4, 1)), (-1, (2,), (1,)), (0, (2,), (-1,)), (12, (1,), (1,)), (0, (2, 2), (1,))):
+        with pytest.raises(ValueError):
+            pth._rebuild_tensor_v2(store, off, size, stride)
+    assert pth._rebuild_tensor_v2(store, 12, (0, 3), (3, 1)).shape == (0, 3)
