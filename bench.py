@@ -17,13 +17,18 @@ of the 14 label vectors and metrics) except writing the label files (reported se
 `with_label_files_scenes_per_s`, through the asynchronous native writer pool).
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job scenes/s, plus
-  roofline     - the dominant MFMA kernel measured with HIP events on the engine's own streams inside
-                 the timed region (algorithmic flops per launch from DESIGN.md section 4), the VALU roof
-                 of the in-cluster kNN, and the whole-GPU MFMA figure;
+  roofline     - the dominant MFMA kernel, k_edgeconv<S2X>: the 16-bit MFMA work the launch EXECUTES
+                  / the duration of the batched launch with ONE engine group on the
+                 GPU ("solo batched", HIP events on the group's stream, measured in this process after the
+                 timed region; `profiles/rNN_solo_batched_kernel_stats.csv` is the rocprofv3 view of the same
+                 configuration) / the 2.5 PF dense 16-bit MFMA peak; the algorithmic fp32 contraction and
+                 the whole-GPU figure as secondary keys;
   cpu_baseline - the NumPy oracle ("port", faithful per-edge loops) timed on this box's host cores on a
                  bounded sample (one scene of the same workload, repeated), rank 0 at N=1 only;
-  parity_check - after the timed region, label digests of >= 8 scenes of the last batch against the same
-                 scenes through a single default-stream pipeline.
+  parity_check - after the timed region, label digests of EVERY scene of the last batch against the same
+                 scenes through a single default-stream pipeline;
+  extra        - strong_1201 (BASELINE configs[3] at W = 1), latency (configs[1] / configs[4]: one scene alone),
+                 the ScanNet-shaped profile, the training step.
 """
 from __future__ import annotations
 
@@ -47,52 +52,31 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak (64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
 MFMA_BF16_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md; 2495 TF measured)
-# what k_edgeconv<S2X> EXECUTES per edge row since round 2: fp32 operands split into 16-bit pieces -- conv2 as 3 fp16 products of
-# 64x64 (hi*hi + hi*lo + lo*hi), conv1 as 12 bf16 MFMAs of 32x32x16 per 32 rows x 64 outputs
-S2X_EXECUTED_BF16_FLOP_PER_ROW = 3 * 2 * 64 * 64 + 12 * 2 * 32 * 32 * 16 // 32
+# what the EdgeConv launches EXECUTE per edge row (one of the 20 neighbour slots of a point): fp32 operands split into 16-bit
+# pieces that meet on v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation.  An MFMA of 32x32x16 is
+# 2 * 32 * 32 * 16 flop for 32 rows; CONV1_MFMAS = MFMAs per neighbour slot and 32-row tile for the 9-deep conv1 (two 32-channel
+# output tiles), conv2 = three fp16 products of 64x64 per row (hi*hi + hi*lo + lo*hi).
+CONV1_MFMAS_PER_SLOT = 12
+CONV1_EXEC_FLOP_PER_ROW = CONV1_MFMAS_PER_SLOT * 2 * 32 * 32 * 16 // 32
+S1X_EXECUTED_FLOP_PER_ROW = CONV1_EXEC_FLOP_PER_ROW
+S2X_EXECUTED_FLOP_PER_ROW = 3 * 2 * 64 * 64 + CONV1_EXEC_FLOP_PER_ROW
 VALU_PEAK_GINST = 1024 * 2.4 / 2.0   # wave64 VALU instructions/ns: 1024 SIMD-32s, 2 cycles per wave64 op, 2.4 GHz
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
+DTYPE = "f32 (fp32 accumulate; operands split 3 x bf16 / 2 x fp16 on v_mfma_f32_32x32x16; kNN / FPS scores in exact fp32 order)"
 
 
 def kernel_model(n_points: int, k: int = 20):
-    """Hot kernels: the engine stages that time them (HIP events), launches per scene and the ALGORITHMIC
-    work of one scene's share of a launch."""
+    """Hot kernels: the engine stages that time them (HIP events), launches per scene, and per SCENE-launch the ALGORITHMIC work
+    (fp32 contraction flops / bytes) and the EXECUTED 16-bit MFMA flops."""
     n = float(n_points)
     c1, c12 = 2.0 * k * n * (18 * 64), 2.0 * k * n * (18 * 64 + 64 * 64)
     return {
-        # name: (stages, launches per scene, bound, units per scene-launch, unit, peak, scale)
-        "k_edgeconv<S2X>": (["l3.edgeconv.stats2"], 1, "mfma", c12, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
-        "k_edgeconv<S1X>": (["l2.edgeconv.stats1"], 1, "mfma", c1, "TFLOP/s", MFMA_F32_PEAK_TF, 1e12),
-        # kNN: reads [N,4] f32, writes [N,20] i32; VALU-bound (selection), its HBM figure is nominal
-        "k_cluster_knn_sorted": (["l2.knn", "l3.knn"], 2, "hbm", 96.0 * n, "GB/s", HBM_PEAK_GBS, 1e9),
+        # name: (stages, launches per scene, bound, algorithmic units, unit, executed MFMA flop)
+        "k_edgeconv<S2X>": (["l3.edgeconv.stats2"], 1, "mfma", c12, "TFLOP/s", S2X_EXECUTED_FLOP_PER_ROW * k * n),
+        "k_edgeconv<S1X>": (["l2.edgeconv.stats1"], 1, "mfma", c1, "TFLOP/s", S1X_EXECUTED_FLOP_PER_ROW * k * n),
+        # kNN: reads [N,4] f32, writes [N,20] i32; VALU-bound (selection): priced against the VALU issue roof from the PMC pass
+        "k_cluster_knn_sorted": (["l2.knn", "l3.knn"], 2, "valu", 96.0 * n, "GB/s", 0.0),
     }
-
-
-def parse_args(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="distinct scenes per GPU per step (BASELINE.json configs[2]: 64)")
-    ap.add_argument("--scenes-total", type=int, default=0,
-                    help="strong scaling: ONE set of this many scenes sharded i mod W over the ranks (configs[3]: 1201); "
-                         "a step = one pass over the rank's shard in batches of --batch")
-    ap.add_argument("--groups", type=int, default=8, help="engine groups per GPU (host thread + HIP stream each)")
-    ap.add_argument("--per-group", type=int, default=8, help="scenes a group advances in lock-step through batched launches")
-    ap.add_argument("--points", type=int, default=150000)
-    ap.add_argument("--segments", type=int, default=1500)
-    ap.add_argument("--seg-profile", default="voronoi", help="synthetic segment-size profile: voronoi (SURVEY 8d recipe) | scannet (heavy-tailed)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline leg")
-    ap.add_argument("--no-files", action="store_true", help="skip the separate with-files measurement")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra leg (scenes/s on the ScanNet-shaped segment profile)")
-    ap.add_argument("--extra-train", type=int, default=8, help="training steps timed in the extra leg (rank 0, N = 1; 0 = skip)")
-    ap.add_argument("--extra-scannet", type=int, default=48, help="scenes of the ScanNet-shaped profile in the extra leg (rank 0, N = 1)")
-    ap.add_argument("--writer-threads", type=int, default=16, help="native writer threads for the with-files leg")
-    ap.add_argument("--gen-workers", type=int, default=0, help="scene generator processes (0 = min(16, cores))")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU rehearsals of the reduction)")
-    ap.add_argument("--parity-scenes", type=int, default=8, help="scenes of the last batch re-run on a single pipeline and compared")
-    return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -135,15 +119,26 @@ def launch_ranks(args, argv) -> int:
 # scene generation in worker processes (NumPy / SciPy only: nothing there touches the GPU)
 # ------------------------------------------------------------------------------------------------------------------
 def _gen_job(job):
-    points, segments, seed, profile = job
+    points, segments, seed, profile, cache = job
     from seggroup_amd import synthetic
+    path = os.path.join(cache, f"scene_{profile}_{points}_{segments}_{seed}.npz") if cache else None
+    if path and os.path.exists(path):
+        z = np.load(path)
+        return synthetic.Scene(name=str(z["name"]), **{k: z[k] for k in ("data", "weak_label", "seg", "adj", "unmap", "gt")})
     kw = {} if profile == "voronoi" else {"seg_profile": profile}
-    return synthetic.make_scene(points, segments, seed, **kw)
+    sc = synthetic.make_scene(points, segments, seed, **kw)
+    if path:
+        os.makedirs(cache, exist_ok=True)
+        tmp = path + f".{os.getpid()}.tmp.npz"
+        np.savez(tmp, name=sc.name, data=sc.data, weak_label=sc.weak_label, seg=sc.seg, adj=sc.adj, unmap=sc.unmap, gt=sc.gt)
+        os.replace(tmp, path)
+    return sc
 
 
 def generate_scenes(jobs, workers):
     """Ordered iterator over host scenes; the pool's processes are started (spawn context) by the submits below,
-    i.e. before the caller initialises the GPU."""
+    i.e. before the caller initialises the GPU.  workers <= 1 (profiled runs: nothing may be spawned under rocprofv3)
+    generates -- or reads from --scene-cache -- inline."""
     if workers <= 1 or len(jobs) < 4:
         return (_gen_job(j) for j in jobs), None
     import multiprocessing as mp
@@ -178,6 +173,13 @@ def reduce_accumulators(vec: np.ndarray, world: int, backend: str, dev=None) -> 
     return t.cpu().numpy()
 
 
+def digest_of_digests(results) -> str:
+    h = hashlib.sha256()
+    for r in results:
+        h.update(label_digest(r).encode())
+    return h.hexdigest()
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -193,16 +195,28 @@ def main(argv=None):
     # ---- synthetic input, generated in worker processes BEFORE this process initialises the GPU ----
     t_gen = time.time()
     cores = os.cpu_count() or 1
-    workers = args.gen_workers or max(1, min(16, cores // max(world, 1)))
+    extras_on = not (args.no_extras or world > 1 or args.seg_profile != "voronoi" or args.scenes_total > 0)
+    n_strong = max(0, args.extra_strong) if extras_on else 0
+    workers = args.gen_workers or max(1, min(64 if n_strong else 16, cores // (2 * max(world, 1)) or 1))
+    cache = args.scene_cache
     if args.scenes_total > 0:
         mine = list(range(rank, args.scenes_total, world))              # scene i -> rank i mod W
-        jobs = [(args.points, args.segments, 40000 + i, args.seg_profile) for i in mine]
+        jobs = [(args.points, args.segments, 40000 + i, args.seg_profile, cache) for i in mine]
     else:
-        jobs = [(args.points, args.segments, 30000 + 1000 * rank + i, args.seg_profile) for i in range(args.batch)]
+        jobs = [(args.points, args.segments, 30000 + 1000 * rank + i, args.seg_profile, cache) for i in range(args.batch)]
     n_main = len(jobs)
-    n_extra = 0 if (args.no_extras or world > 1 or args.seg_profile != "voronoi") else max(0, args.extra_scannet)
-    jobs += [(args.points, args.segments, 70100 + i, "scannet") for i in range(n_extra)]
+    n_scannet = max(0, args.extra_scannet) if extras_on else 0
+    jobs += [(args.points, args.segments, 70100 + i, "scannet", cache) for i in range(n_scannet)]
+    jobs += [(args.points, args.segments, 40000 + i, args.seg_profile, cache) for i in range(n_strong)]     # the set `--scenes-total` shards
+    n_stress = 1 if (extras_on and args.extra_stress > 0) else 0
+    jobs += [(args.extra_stress, args.extra_stress // 100, 50005, "voronoi", cache)] * n_stress
     scene_iter, pool = generate_scenes(jobs, workers)
+    if args.generate_only:
+        n_gen = sum(1 for _ in scene_iter)
+        if pool is not None:
+            pool.shutdown()
+        print(f"bench.py: {n_gen} scenes in {args.scene_cache or '(no cache directory given)'} ({time.time() - t_gen:.1f} s)", file=sys.stderr)
+        return
 
     import torch
     import torch.distributed as dist
@@ -234,73 +248,85 @@ def main(argv=None):
     if pool is not None:
         pool.shutdown()
     gen_s = time.time() - t_gen
+    stress_scenes = scenes[len(scenes) - n_stress:] if n_stress else []
+    scenes = scenes[:len(scenes) - n_stress] if n_stress else scenes
+    strong_scenes, scenes = scenes[n_main + n_scannet:], scenes[:n_main + n_scannet]
     extra_scenes, scenes = scenes[n_main:], scenes[:n_main]
 
-    from seggroup_amd.model import Engine
-    every = scenes + extra_scenes
+    from seggroup_amd.model import Engine, Pipeline
+    every = scenes + extra_scenes + strong_scenes
     caps = (max(s.N for s in every), max(s.S for s in every), max(s.E0 for s in every), max(s.V for s in every))
     # stage timing: a handful of HIP events per batched launch sequence (per group of scenes, not per scene)
     runner = Engine(W, caps, groups=args.groups, per_group=args.per_group, device=dev, timing=1)
     acc = {"iou_sem": np.zeros(80), "iou_ins": np.zeros(80), "acc": np.zeros(4), "n": 0}
     batches = [scenes[k:k + args.batch] for k in range(0, len(scenes), args.batch)]
 
-    def run_steps(k, record=True):
-        """k steps; a step = every scene of the rank's batch (or shard) through SegModel.forward.  Batches are queued two
-        ahead (submit k+2, then wait for k), as a driver with a stream of scenes does: the engine's groups never drain
-        between two batches.  Every batch is waited for and its results consumed inside the call."""
+    def run_batches(bl, k, sink=None):
+        """k passes over the batches `bl`, queued two ahead (submit k+2, then wait for k) as a driver with a stream of scenes does:
+        the engine's groups never drain between two batches.  Every batch is waited for and its results handed to `sink` (which
+        must consume them before the third submit after theirs: the label buffers are a ring) inside the call."""
         last, pending = None, []
-
-        def consume(res):
-            if record:
-                for r in res:
-                    acc["iou_sem"] += r.iou_sem.reshape(-1)
-                    acc["iou_ins"] += r.iou_ins.reshape(-1)
-                    acc["acc"] += np.nan_to_num(r.acc)
-                    acc["n"] += 1
-            return res
-
         for _ in range(k):
-            for b in batches:
+            for b in bl:
                 pending.append(runner.submit(b, hip.MODE_INS_INFER))
                 if len(pending) > 2:
-                    last = consume(runner.wait(pending.pop(0)))
+                    last = runner.wait(pending.pop(0))
+                    if sink:
+                        sink(last)
         while pending:
-            last = consume(runner.wait(pending.pop(0)))
+            last = runner.wait(pending.pop(0))
+            if sink:
+                sink(last)
         return last
+
+    def record(res):
+        for r in res:
+            acc["iou_sem"] += r.iou_sem.reshape(-1)
+            acc["iou_ins"] += r.iou_ins.reshape(-1)
+            acc["acc"] += np.nan_to_num(r.acc)
+            acc["n"] += 1
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(k, sink):
+        barrier()
+        t0_ = time.perf_counter()
+        last_ = run_batches(batches, k, sink)
+        barrier()
+        el = time.perf_counter() - t0_
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, last_
+
     runner.profile(enable=True)
-    run_steps(args.warmup, record=False)
+    run_batches(batches, args.warmup)
     runner.reset_stage_stats()
-    barrier()
-    t0 = time.perf_counter()
-    last_results = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, last_results = timed(args.steps, record)           # THE timed region: exactly --steps steps
     engine_profile = {k_: round(v, 3) for k_, v in runner.profile().items()}
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    mean_ms = runner.mean_stage_ms()
     scenes_per_step = args.scenes_total if args.scenes_total > 0 else world * args.batch
     value = scenes_per_step * args.steps / elapsed
-
-    vec = reduce_accumulators(np.concatenate([acc["iou_sem"], acc["iou_ins"], acc["acc"], [acc["n"]]]), world, args.backend, dev)
-
-    # ---- parity of the concurrent path: scenes of the LAST batch vs a single default-stream pipeline ----
+    # labels of the last timed batch, digested before anything else is submitted (their buffers are a ring)
     last_batch = batches[-1]
     n_par = min(args.parity_scenes, len(last_batch))
     batch_digests = [label_digest(last_results[i]) for i in range(n_par)]
     batch_trace0 = list(last_results[0].trace)
-    from seggroup_amd.model import Pipeline
+    repeat_values = [round(value, 3)]
+    for _ in range(max(0, args.repeats - 1)):                   # run-to-run spread; `value` stays the first region
+        el, _ = timed(args.steps, None)
+        repeat_values.append(round(scenes_per_step * args.steps / el, 3))
+
+    vec = reduce_accumulators(np.concatenate([acc["iou_sem"], acc["iou_ins"], acc["acc"], [acc["n"]]]), world, args.backend, dev)
+
+    # ---- parity of the concurrent path: EVERY scene of the LAST timed batch vs a single default-stream pipeline ----
     solo = Pipeline(W, *caps, stream=None, device=dev)
     solo.set_timing(0)
     solo_digests = [label_digest(solo.forward(last_batch[i], hip.MODE_INS_INFER)) for i in range(n_par)]
-    solo.close()
     parity_ok = batch_digests == solo_digests
     ok = torch.tensor([1.0 if parity_ok else 0.0], dtype=torch.float64)
     if world > 1:
@@ -311,71 +337,78 @@ def main(argv=None):
 
     rc = 0
     if rank == 0:
-        mean_ms = runner.mean_stage_ms()
         model = kernel_model(args.points)
-        per_scene = {kn: sum(mean_ms.get(st, 0.0) for st in m[0]) for kn, m in model.items()}
 
-        def priced(ms_by_kernel):
-            out = {}
-            for kn, m in model.items():
-                ms = ms_by_kernel.get(kn, 0.0)
-                if ms <= 0:
-                    continue
-                ach = m[3] / (ms / m[1] * 1e-3) / m[6]
-                out[kn] = {"bound": m[2], "ms_per_scene_launch": round(ms / m[1], 4), "achieved": round(ach, 3), "peak": m[5], "unit": m[4],
-                           "frac": round(ach / m[5], 5)}
-            return out
+        def per_kernel(ms):
+            return {kn: sum(ms.get(st, 0.0) for st in m[0]) / m[1] for kn, m in model.items()}        # ms per scene-launch
 
-        all_k = priced(per_scene)
-        # the same kernels with ONE scene in flight (outside the timed region): with several streams sharing the GPU a
-        # launch's duration says how long it shared the machine, not how well it uses it
-        solo_runner = Engine(W, caps, groups=1, per_group=1, device=dev, timing=1)
-        solo_runner.run(scenes[:2], hip.MODE_INS_INFER)
-        solo_runner.reset_stage_stats()
-        solo_runner.run(scenes[:4], hip.MODE_INS_INFER)
-        solo_ms = solo_runner.mean_stage_ms()
-        solo_runner.close()
-        solo_k = priced({kn: sum(solo_ms.get(st, 0.0) for st in m[0]) for kn, m in model.items()})
+        in_region = per_kernel(mean_ms)
+        # ---- "solo batched": ONE group of --per-group scenes alone on the GPU, the same batched launches, HIP events on the group's
+        # stream.  Under the timed region's load the groups' launches overlap and a launch's duration includes the time it shares the
+        # device, so the roofline is taken from this configuration (rocprofv3 view: profiles/rNN_solo_batched_kernel_stats.csv).
+        sb = Engine(W, caps, groups=1, per_group=args.per_group, device=dev, timing=1)
+        sb.run(scenes[:args.per_group], hip.MODE_INS_INFER)
+        sb.reset_stage_stats()
+        for k0 in range(0, len(scenes), args.per_group):
+            sb.run(scenes[k0:k0 + args.per_group], hip.MODE_INS_INFER)
+        sb_ms = sb.mean_stage_ms()
+        sb.close()
+        solo_b = per_kernel(sb_ms)
+        sb_sum = sum(v for k_, v in sb_ms.items() if k_.count(".") <= 1)          # names with two dots are sub-passes of a stage
 
-        # PMC-derived per-launch figures of the committed profile (tools/summarise_profiles.py writes the file)
         pmc = {}
         ppath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_kernels.json")
         if os.path.exists(ppath) and args.points == 150000:
             pmc = json.load(open(ppath))
-        dom = "k_edgeconv<S2X>"                                  # the kernel with a flop roof and the most algorithmic work
-        d = all_k.get(dom, {"achieved": 0.0, "frac": 0.0, "ms_per_scene_launch": 0.0})
-        f_scene = sum(m[3] for kn, m in model.items() if m[2] == "mfma")          # 38.4 GFLOP of dense contraction per scene
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": d["achieved"], "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": d["frac"], "traffic": (pmc.get("hbm_bytes_per_scene_launch", {}) or {}).get(dom),
-                    "traffic_source": pmc.get("configuration"),
-                    "ms_per_scene_launch": d["ms_per_scene_launch"], "launches_per_scene": 1,
-                    "measured_with": "HIP events on the engine's streams, inside the timed region (duration of the batched launch / scenes in it); "
-                                     "the groups' launches overlap on the GPU, so a launch's duration includes the time it shares the device -- "
-                                     "single_stream (one launch alone) and whole_gpu (all MFMA work of the step / its wall time) are the undiluted views",
-                    "whole_gpu": {"mfma_tflops": round(f_scene * value / world / 1e12, 2), "frac_of_fp32_mfma_peak": round(f_scene * value / world / 1e12 / MFMA_F32_PEAK_TF, 4),
-                                  "flop_per_scene": f_scene},
-                    "all_kernels": all_k, "single_stream": solo_k,
-                    "stage_ms": {k_: round(v, 4) for k_, v in mean_ms.items() if v > 0}}
-        if d["ms_per_scene_launch"] > 0:
-            ex = S2X_EXECUTED_BF16_FLOP_PER_ROW * 20.0 * args.points
-            sm = solo_k.get(dom, {}).get("ms_per_scene_launch", 0.0)
-            roofline["executed"] = {"what": "the same launch priced by what it ISSUES: 16-bit MFMA work of the split operands (fp16 hi/lo for conv2, three bf16 pieces "
-                                            "for conv1; fp32-accurate result; 'achieved' above is the algorithmic fp32 contraction against the fp32 MFMA peak, "
-                                            "which a split-operand kernel can exceed)",
-                                    "bf16_flop_per_scene_launch": ex, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                                    "achieved": round(ex / (d["ms_per_scene_launch"] * 1e-3) / 1e12, 2),
-                                    "frac": round(ex / (d["ms_per_scene_launch"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4),
-                                    "frac_single_stream": round(ex / (sm * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4) if sm > 0 else None}
+        dom = "k_edgeconv<S2X>"                                  # the kernel with the most MFMA work
+        ex_all = sum(m[5] for m in model.values())               # executed 16-bit MFMA flop per scene (S1X + S2X)
+        alg_all = sum(m[3] for m in model.values() if m[2] == "mfma")
+        t_dom = solo_b.get(dom, 0.0) * 1e-3
+        m_dom = model[dom]
+        ach = m_dom[5] / t_dom / 1e12 if t_dom > 0 else 0.0
+        kernels = {}
+        for kn, m in model.items():
+            t = solo_b.get(kn, 0.0) * 1e-3
+            if t <= 0:
+                continue
+            e = {"ms_per_scene_launch_solo_batched": round(t * 1e3, 4), "ms_per_scene_launch_in_timed_region": round(in_region.get(kn, 0.0), 4),
+                 "launches_per_scene": m[1]}
+            if m[2] == "mfma":
+                e.update({"executed_tflops": round(m[5] / t / 1e12, 1), "frac_of_16bit_mfma_peak": round(m[5] / t / 1e12 / MFMA_BF16_PEAK_TF, 4),
+                          "algorithmic_fp32_tflops": round(m[3] / t / 1e12, 1)})
+            kernels[kn] = e
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
+                    "traffic": (pmc.get("hbm_bytes_per_scene_launch", {}) or {}).get(dom), "traffic_source": pmc.get("configuration"),
+                    "basis": "EXECUTED 16-bit MFMA flop of one scene's share of the batched launch (fp32 operands split into bf16 x 3 / fp16 x 2 pieces, "
+                             "fp32 accumulate: DESIGN.md section 4) / the launch's duration with one engine group alone on the GPU (HIP events on the "
+                             "group's stream, after the timed region; profiles/%s_solo_batched_kernel_stats.csv is rocprofv3's view of the same "
+                             "configuration) / the dense bf16 / fp16 MFMA peak" % PROFILE_TAG,
+                    "executed_flop_per_scene_launch": m_dom[5], "algorithmic_flop_per_scene_launch": m_dom[3],
+                    "ms_per_scene_launch": round(t_dom * 1e3, 4), "launches_per_scene": 1,
+                    "algorithmic_fp32_tflops": round(m_dom[3] / t_dom / 1e12, 1) if t_dom > 0 else None,
+                    "algorithmic_vs_fp32_mfma_peak_157tf": round(m_dom[3] / t_dom / 1e12 / MFMA_F32_PEAK_TF, 3) if t_dom > 0 else None,
+                    "whole_gpu": {"executed_mfma_tflops": round(ex_all * value / world / 1e12, 1),
+                                  "frac_of_16bit_mfma_peak": round(ex_all * value / world / 1e12 / MFMA_BF16_PEAK_TF, 4),
+                                  "algorithmic_fp32_tflops": round(alg_all * value / world / 1e12, 1),
+                                  "executed_flop_per_scene": ex_all, "algorithmic_flop_per_scene": alg_all},
+                    "kernels": kernels,
+                    "solo_batched_device_ms_per_scene": round(sb_sum, 4),
+                    "check_device_time_fits_step": {"solo_batched_ms_per_scene_x_scenes_per_step": round(sb_sum * scenes_per_step / world, 3),
+                                                    "ms_per_step": round(elapsed / args.steps * 1e3, 3)},
+                    "stage_ms_solo_batched": {k_: round(v, 4) for k_, v in sb_ms.items() if v > 0},
+                    "stage_ms_in_timed_region": {k_: round(v, 4) for k_, v in mean_ms.items() if v > 0}}
         # VALU roof of the in-cluster kNN: SQ_INSTS_VALU per scene-launch (PMC pass, committed) / (1024 SIMDs x 2.4 GHz / 2 cycles)
         vmap = pmc.get("valu_insts_per_scene_launch", {}) or {}
         vi = sum(vmap.get(k_, 0) for k_ in ("k_cluster_knn_sorted<unseeded>", "k_cluster_knn_sorted<seeded>"))
-        if vi and "k_cluster_knn_sorted" in all_k:
-            ms2 = 2.0 * all_k["k_cluster_knn_sorted"]["ms_per_scene_launch"]                       # both launches of a scene
-            sms2 = 2.0 * solo_k.get("k_cluster_knn_sorted", {}).get("ms_per_scene_launch", 0.0)
-            roofline["knn_valu"] = {"valu_insts_per_scene": vi, "peak_ginst_per_s": VALU_PEAK_GINST,
+        if vi and solo_b.get("k_cluster_knn_sorted", 0) > 0:
+            ms2 = 2.0 * solo_b["k_cluster_knn_sorted"]                                             # both launches of a scene
+            hb = pmc.get("hbm_bytes_per_scene_launch", {}) or {}
+            roofline["knn_valu"] = {"valu_insts_per_scene": vi, "peak_ginst_per_s": VALU_PEAK_GINST, "ms_per_scene_both_launches_solo_batched": round(ms2, 4),
                                     "valu_frac": round(vi / (ms2 * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
-                                    "valu_frac_single_stream": round(vi / (sms2 * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if sms2 > 0 else None,
-                                    "source": f"profiles/{PROFILE_TAG}_pmc_kernels.json (SQ_INSTS_VALU of the two kNN launches of a scene, separate PMC pass)"}
+                                    "hbm_bytes_per_scene_launch": {k_: hb.get(k_) for k_ in ("k_cluster_knn_sorted<unseeded>", "k_cluster_knn_sorted<seeded>")},
+                                    "algorithmic_bytes_per_scene_launch": 96.0 * args.points,
+                                    "source": f"profiles/{PROFILE_TAG}_pmc_kernels.json (SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE of the two kNN launches, separate PMC passes)"}
         mb = (pmc.get("mfma_busy_share", {}) or {}).get(dom)
         if mb is not None:
             roofline["mfma_busy_share_pmc"] = {"value": mb, "source": f"profiles/{PROFILE_TAG}_pmc_kernels.json (SQ_VALU_MFMA_BUSY_CYCLES, solo batched)"}
@@ -396,9 +429,56 @@ def main(argv=None):
                         runner.run(sub, hip.MODE_INS_INFER, writer=writer, out_dirs=dirs, formats=fmts)
                     writer.flush()
                     with_files["+".join(fmts)] = round(2 * len(sub) / (time.perf_counter() - t1), 3)
+            with_files["filesystem"] = "tempfile.gettempdir() = %s" % tempfile.gettempdir()
             writer.close()
 
         extras = {}
+        if strong_scenes:
+            # BASELINE configs[3] at W = 1: the 1201-scene set that `--scenes-total 1201` shards i mod W, ONE pass per step in batches of
+            # --batch, everything resident; two passes must give the same labels (digest of the per-scene digests), and a strided sample is
+            # checked against the single pipeline
+            sb_batches = [strong_scenes[k:k + args.batch] for k in range(0, len(strong_scenes), args.batch)]
+            dig = []
+            run_batches(sb_batches[:2], 1)
+            passes = []
+            for _ in range(2):
+                got = []
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                run_batches(sb_batches, 1, lambda res: got.extend(label_digest(r_) for r_ in res))
+                torch.cuda.synchronize()
+                passes.append(time.perf_counter() - t1)
+                dig.append(got)
+            idx = list(range(0, len(strong_scenes), 50))
+            same_s = all(dig[0][i] == label_digest(solo.forward(strong_scenes[i], hip.MODE_INS_INFER)) for i in idx)
+            h = hashlib.sha256("".join(dig[0]).encode()).hexdigest()
+            extras["strong_1201"] = {"scenes": len(strong_scenes), "scenes_per_s": round(len(strong_scenes) / min(passes), 3),
+                                     "ms_per_pass": [round(p_ * 1e3, 2) for p_ in passes], "passes_equal": dig[0] == dig[1],
+                                     "parity_digest_ok": bool(same_s and dig[0] == dig[1]), "checked_against_single_pipeline": len(idx),
+                                     "digest_of_digests": h,
+                                     "what": "python bench.py --gpus 1 --scenes-total %d on the same engine: scene i of seeds 40000+i, the N = 1 point of the "
+                                             "strong-scaling curve" % len(strong_scenes)}
+            if not (same_s and dig[0] == dig[1]):
+                parity_all = False
+        if extras_on:
+            # configs[1] / configs[4]: ONE scene alone on the GPU (sg_pipeline_forward, default stream): wall time per forward incl. the
+            # host grouping and the D2H of the 14 label vectors
+            lat = {}
+            for tag, sc_, pl in (("150k", scenes[0], solo),) + ((("%dk" % (args.extra_stress // 1000), stress_scenes[0], None),) if stress_scenes else ()):
+                own = pl is None
+                if own:
+                    pl = Pipeline(W, sc_.N, sc_.S, sc_.E0, sc_.V, stream=None, device=dev)
+                    pl.set_timing(0)
+                ts = []
+                for it in range(7):
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    pl.forward(sc_, hip.MODE_INS_INFER)
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                lat[tag] = {"points": sc_.N, "segments": sc_.S, "ms_median": round(float(np.median(ts[2:])), 3), "ms_min": round(min(ts[2:]), 3)}
+                if own:
+                    pl.close()
+            extras["latency_ms_single_scene"] = lat
+        solo.close()
         if extra_scenes:
             # the same engine on ScanNet-shaped scenes (synthetic.make_scannet_scene: surfaces, 10k-30k-point floor / wall segments,
             # median segment ~55 points, V != N, every other scene with 15 % duplicated points); each scene checked against a
@@ -432,7 +512,8 @@ def main(argv=None):
             from seggroup_amd import train as _train, trainer as _trainer
             st = _train.initial_state(1)
             st.update({k_: (v.numpy() if hasattr(v, "numpy") else np.asarray(v)) for k_, v in weights.to_state_dict(W, prefix="").items()})
-            trn = _trainer.Trainer(st, caps, device=dev)
+            caps_t = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+            trn = _trainer.Trainer(st, caps_t, device=dev)
             tt = {"forward": 0.0, "loss": 0.0, "backward": 0.0, "optimizer": 0.0}
             for it in range(-2, args.extra_train):
                 sc_ = scenes[it % len(scenes)]
@@ -488,15 +569,18 @@ def main(argv=None):
         out = {
             "metric": "pseudo-label scenes/sec (150k pts, 1.5k segs)", "value": round(value, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong" if args.scenes_total > 0 else "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if args.scenes_total > 0 else "weak", "vs_baseline": None, "dtype": DTYPE,
             "data": "synthetic",
             "config": {"workload": workload, "mode": "ins_infer", "scenes_per_step_per_gpu": len(scenes), "scenes_in_flight": args.groups * args.per_group,
                        "engine": f"{args.groups} groups x {args.per_group} scenes per batched launch",
                        "seg_profile": args.seg_profile, "weights": "tests/golden/weights_g2.npz", "parallelism": f"scene-parallel x{world}"},
+            "timed_region_s": round(elapsed, 3),
+            "repeat_values": {"scenes_per_s": repeat_values, "min": min(repeat_values), "median": float(np.median(repeat_values)),
+                              "what": f"{len(repeat_values)} timed regions of {args.steps} steps each, back to back; `value` is the first"},
             "roofline": roofline, "cpu_baseline": cpu,
             "parity_check": {"scenes_per_rank": n_par, "ranks_equal": parity_all,
-                             "what": "sha256 over the 14 label vectors + metric tensors + cluster trace of scenes of the last timed batch "
-                                     "== the same scenes through one default-stream pipeline"},
+                             "what": "sha256 over the 14 label vectors + metric tensors + cluster trace of every checked scene of the last timed batch "
+                                     "== the same scenes through one default-stream pipeline (and the extra legs' own checks)"},
             "with_label_files_scenes_per_s": with_files or None,
             "pseudo_label_mIoU": {"semantic": round(miou_sem, 4), "instance": round(miou_ins, 4), "scenes": int(vec[164])},
             "extra": extras or None,
@@ -507,6 +591,8 @@ def main(argv=None):
         if not parity_all:
             print("bench.py: PARITY FAILURE -- the concurrent path's labels differ from the single-pipeline path", file=sys.stderr)
             rc = 4
+    else:
+        solo.close()
     runner.close()
     if world > 1:
         dist.barrier()

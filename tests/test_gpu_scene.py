@@ -127,6 +127,65 @@ def test_150k_scene_matches_reference_digests_and_oracle(golden_index, weight_se
     assert np.array_equal(res.iou_sem, g["ins.metric.0"]) and np.array_equal(res.iou_ins, g["ins.metric.1"])
 
 
+def test_150k_scene_float_stages_match_reference_capture_and_oracle(golden_index, weight_sets):
+    """Floats at full size (VERDICT round 2, weak #1b).  scene_150k.npz holds every 64th point row of the REAL reference's MLP2 / MLP3
+    outputs (capture B), its GCN outputs and decision distances, the rows of its in-cluster kNN tables that differ from the
+    defined tie rule (exact score ties: tests/test_oracle_golden.py), and the oracle's GCN outputs / distances.  The HIP path must
+      * produce the defined-tie-rule kNN tables bit for bit (sha256 of the full [N,20] tables) -- patched with the stored rows they
+        ARE the reference's tables;
+      * match the reference's point features within 1e-4 on every sampled row that is not a tie row (the split-operand EdgeConv:
+        bf16 x 3 / fp16 x 2 pieces on the 16-bit matrix pipe);
+      * match the oracle's GCN outputs and decision distances within 1e-4 EVERYWHERE, and the reference's on > 90 % of the entries
+        (a tie row moves its cluster's maximum and, through the GCN, its neighbours')."""
+    name = "scene_150k"
+    e = golden_index[name]
+    g = load_golden(name)
+    scene = make_fixture_scene(golden_index, name)
+    res, t, _ = _run(scene, weight_sets["ins_infer"], "ins_infer", debug=True)
+    assert res.trace[1:5] == e["ins_infer"]["nclusters"]
+    stride = e["taps_stride"]
+    assert np.abs(t["feat1"].cpu().numpy() - g["ins.tap.mlp_1"]).max() < FLOAT_TOL
+    for i, nm in enumerate(("mlp_2", "mlp_3")):
+        members = t["members"][i].cpu().numpy()
+        knn_pts = np.empty((scene.num_points, 20), np.int32)
+        knn_pts[members] = members[t["knn"][i].cpu().numpy()]
+        assert hashlib.sha256(knn_pts.tobytes()).hexdigest() == e["knn_sha"][nm]["defined_tie_rule"], f"{nm}: kNN table"
+        rows = g[f"ins.tap.knn_tie_rows.{nm}"]
+        knn_pts[rows] = g[f"ins.tap.knn_tie_ref.{nm}"]
+        assert hashlib.sha256(knn_pts.tobytes()).hexdigest() == e["knn_sha"][nm]["reference"], f"{nm}: kNN table vs the reference's"
+        pf = np.empty((scene.num_points, 64), np.float32)
+        pf[members] = t["pf"][i].cpu().numpy()
+        sampled = np.arange(0, scene.num_points, stride)
+        clean = ~np.isin(sampled, rows)
+        d = np.abs(pf[::stride] - g[f"ins.tap.{nm}"]).max(axis=1)
+        assert d[clean].max() < FLOAT_TOL, (nm, float(d[clean].max()))
+        C, D = res.trace[1 + i], (192, 256)[i]
+        gcn = t["gcn"][i].reshape(-1)[:C * D].reshape(C, D)
+        assert np.abs(gcn - g[f"ins.oracle.gcn_{nm[-1]}"]).max() < FLOAT_TOL, nm
+        assert (np.abs(gcn - g[f"ins.tap.gcn_{nm[-1]}"]).max(axis=1) < FLOAT_TOL).mean() > 0.9, nm
+    for i in range(3):
+        want, ref = g[f"ins.oracle.dists.{i}"], g[f"ins.tap.dists.{i}"]
+        got = t["dist"][i][:want.shape[0]]
+        assert np.abs(got - want).max() < FLOAT_TOL, f"decision distances {i} vs the oracle"
+        assert (np.abs(got - ref) < FLOAT_TOL).mean() > 0.9, f"decision distances {i} vs the reference"
+
+
+def test_150k_scene_sem_infer_matches_reference_digests(golden_index, weight_sets):
+    """sem_infer above 20k points: the 6 label vectors of the 150k fixture (weights_g1, th = 3) against the reference capture's and the
+    oracle's sha256 digests."""
+    from seggroup_amd import hip
+    e = golden_index["scene_150k"]["sem_infer"]
+    scene = make_fixture_scene(golden_index, "scene_150k")
+    res, _, _ = _run(scene, weight_sets["sem_infer"], "sem_infer")
+    assert e["labels_A_equal_B"] and e["oracle_equals_reference"] and res.n_vectors == 6
+    assert res.trace[:2] == e["oracle_trace"] and res.trace[1] == e["nclusters"][0]
+    for i in range(6):
+        nm = hip.LABEL_NAMES[i]
+        assert hashlib.sha256(np.ascontiguousarray(res.labels[i]).tobytes()).hexdigest() == e["label_sha"][nm], nm
+    g = load_golden("scene_150k")
+    assert np.array_equal(res.iou_sem, g["sem.metric.0"]) and np.array_equal(res.iou_ins, g["sem.metric.1"])
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 4])
 def test_150k_scene_labels_do_not_depend_on_the_knn_kernel(golden_index, weight_sets, variant):
     """The pipeline's alternative in-cluster kNN kernels (two-pass over the chunk table; 1 / 2 / 4 waves per tile, none
@@ -444,7 +503,7 @@ def _digest(res):
 
 def test_batch_of_64_full_size_scenes_through_the_concurrent_path(golden_index, weight_sets):
     """BASELINE.json configs[2]: 64 distinct 150k-point / 1.5k-segment scenes through the CONCURRENT path (the scene engine,
-    4 groups x 8 scenes advancing through batched launches -- what bench.py times), twice.  Every scene's 14 label vectors, metric tensors and cluster trace
+    8 groups x 8 scenes advancing through batched launches -- the shape bench.py times), twice.  Every scene's 14 label vectors, metric tensors and cluster trace
     must equal (i) the same scene through a single default-stream pipeline and (ii), for the `scene_150k` fixture seed that
     rides in the batch, the digests of the reference capture in tests/golden/index.json.  A race on a shared buffer, a
     stream-ordering slip or cross-scene state would show here and nowhere in the single-pipeline tests."""
@@ -461,7 +520,8 @@ def test_batch_of_64_full_size_scenes_through_the_concurrent_path(golden_index, 
     want = [_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
     solo.close()
     assert len(set(want)) == 64                                    # the scenes really are distinct
-    runner = BatchRunner(W, scenes, inflight=32, device="cuda:0", timing=1)        # the engine: 4 groups x 8 scenes in lock-step
+    runner = BatchRunner(W, scenes, inflight=64, device="cuda:0", timing=1)        # the engine in bench.py's shape: 8 groups x 8 scenes in lock-step
+    assert (runner.groups, runner.per_group) == (8, 8)
     for rep in range(2):
         order = list(range(64)) if rep == 0 else list(range(63, -1, -1))      # second pass: other scene -> slot assignment
         res = runner.run([scenes[i] for i in order], hip.MODE_INS_INFER)
@@ -510,7 +570,7 @@ def _scan_book():
     return json.load(open(p)) if os.path.exists(p) else {}
 
 
-@pytest.mark.parametrize("workload", ["uniform_150k", "scannet_150k", "scannet_60k"])
+@pytest.mark.parametrize("workload", ["uniform_150k", "scannet_150k", "scannet_60k", "uniform_500k"])
 def test_every_scanned_seed_matches_oracle_and_the_stable_ones_match_the_reference(weight_sets, workload):
     """tests/golden/seed_scan.json (tools/seed_scan.py, build container): for EVERY seed of a workload -- not only the ones a
     fixture screen would keep -- the digests of the oracle's 14 label vectors, of the real reference's (capture B), whether

@@ -41,7 +41,8 @@ FIXTURES = {
     "tiny_dup_4k": dict(n=4000, s=40, seed=12, kw=dict(dup_frac=0.05, raw_vertices=4500), full=True),
     "island_20k": dict(n=20000, s=200, seed=10013, kw=dict(island_radius=1.2), full=True),
     "small_20k": dict(n=20000, s=200, seed=10000, kw={}, full=True),
-    "scene_150k": dict(n=150000, s=1500, seed=20004, kw={}, full=False),
+    # full-size fixture: digests of the label vectors + (taps) a strided subsample of the float stages + (sem) a sem_infer run
+    "scene_150k": dict(n=150000, s=1500, seed=20004, kw={}, full=False, taps=64, sem=True),
     "stress_500k": dict(n=500000, s=5000, seed=50005, kw={}, full=False),
 }
 
@@ -239,7 +240,7 @@ def main():
                      "e0": int(scene.adj.shape[0])}
             blobs = {}
             for mode in ("ins_infer", "sem_infer"):
-                if mode == "sem_infer" and not fx["full"]:
+                if mode == "sem_infer" and not (fx["full"] or fx.get("sem")):
                     continue
                 runs = {}
                 for variant, contig in (("B", True), ("A", False)):
@@ -269,6 +270,36 @@ def main():
                         blobs[f"{pre}.label.{k}"] = v
                 for i, t in enumerate(b["metrics"]):
                     blobs[f"{pre}.metric.{i}"] = t
+                if fx.get("taps") and mode == "ins_infer":
+                    # float-parity targets at full size (capture B): every `taps`-th point row of the EdgeConv outputs, the GCN
+                    # outputs and the three decision-distance vectors
+                    st_ = int(fx["taps"])
+                    for nm in ("mlp_2", "mlp_3"):
+                        blobs[f"ins.tap.{nm}"] = np.ascontiguousarray(b["feats"][nm][0].T[::st_])
+                    for nm in ("mlp_1", "gcn_2", "gcn_3"):
+                        blobs[f"ins.tap.{nm}"] = b["feats"][nm]
+                    for i_, j_ in enumerate((0, 2, 4)):
+                        blobs[f"ins.tap.dists.{i_}"] = b["cap"]["dists"][j_]
+                    entry["taps_stride"] = st_
+                    # torch.topk leaves the order of EQUAL scores open; the build defines "lower index wins" (oracle/cpu_ref.py:topk_desc).
+                    # Rows of the reference's in-cluster kNN tables that differ from the defined rule are stored (row ids + the
+                    # reference's rows) with the sha256 of both full tables: tests rebuild the reference's table from the oracle's
+                    # (or the HIP path's) by patching exactly these rows, and check that each of them is an exact score tie.  Such a
+                    # row changes one point's feature by O(1) and everything downstream of its cluster a little, so the oracle's
+                    # own GCN outputs / distances (defined tie rule, float64) are stored beside the reference's.
+                    from oracle import cpu_ref
+                    o_ = cpu_ref.forward_scene(scene, wsets[mode], mode, keep=True)
+                    assert o_["trace"][1:5] == b["nclusters"]
+                    entry["knn_sha"] = {}
+                    for li_, nm in enumerate(("mlp_2", "mlp_3")):
+                        rk, ok = b["cap"]["knn"][li_].astype(np.int32), o_["stages"][nm]["knn"].astype(np.int32)
+                        rows = np.nonzero(np.any(rk != ok, axis=1))[0].astype(np.int32)
+                        blobs[f"ins.tap.knn_tie_rows.{nm}"] = rows
+                        blobs[f"ins.tap.knn_tie_ref.{nm}"] = rk[rows]
+                        entry["knn_sha"][nm] = {"reference": sha(rk), "defined_tie_rule": sha(ok), "rows_that_differ": int(rows.size)}
+                        blobs[f"ins.oracle.gcn_{nm[-1]}"] = o_["stages"][nm]["gcn"].astype(np.float32)
+                    for i_, d_ in enumerate((o_["stages"]["d1"], o_["stages"]["mlp_2"]["d"], o_["stages"]["mlp_3"]["d"])):
+                        blobs[f"ins.oracle.dists.{i_}"] = np.asarray(d_, np.float32)
                 if fx["full"]:
                     for k, v in b["feats"].items():
                         if v.size <= 300000:      # point-level [1,64,N] tensors only for the tiny fixtures

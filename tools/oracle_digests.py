@@ -21,4 +21,12 @@ for name in sys.argv[1:] or ["scene_150k", "stress_500k"]:
     e["ins_infer"]["oracle_trace"] = r["trace"]
     e["ins_infer"]["oracle_equals_reference"] = e["ins_infer"]["oracle_label_sha"] == e["ins_infer"]["label_sha"]
     print(name, "oracle", round(time.time() - t, 1), "s  trace", r["trace"], " == reference digests:", e["ins_infer"]["oracle_equals_reference"], flush=True)
+    if "sem_infer" in e:                                           # fixtures captured with sem=True (weights_g1, th = 3: returns after the structural layer)
+        W1 = weights.load_npz(os.path.join(ROOT, "tests", "golden", "weights_g1.npz"))
+        r = cpu_ref.forward_scene(sc, W1, "sem_infer")
+        e["sem_infer"]["oracle_label_sha"] = {k: hashlib.sha256(np.ascontiguousarray(v.astype(np.int32)).tobytes()).hexdigest()
+                                              for k, v in r["labels"].items()}
+        e["sem_infer"]["oracle_trace"] = r["trace"]
+        e["sem_infer"]["oracle_equals_reference"] = e["sem_infer"]["oracle_label_sha"] == e["sem_infer"]["label_sha"]
+        print(name, "sem_infer oracle trace", r["trace"], " == reference digests:", e["sem_infer"]["oracle_equals_reference"], flush=True)
     json.dump(idx, open(idx_path, "w"), indent=1, sort_keys=True)

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: PMC counters per kernel for the bench's batched launches, one counter set per pass (never combined
-# with trace domains other than --kernel-trace).  Default shape 1 group x 8 scenes ("solo batched": nothing else on the GPU);
-#   gpurun -- 'bash tools/pmc_engine.sh r02 1 8'      -> gpurun_out/<tag>_pmc_<pass>.json (per-kernel averages per launch)
+# with trace domains other than --kernel-trace).  The profiled process spawns nothing: --gen-workers 1 + the scene cache.  Default shape 1 group x 8 scenes ("solo batched": nothing else on the GPU);
+#   gpurun -- 'bash tools/pmc_engine.sh r03 1 8'      -> gpurun_out/<tag>_pmc_<pass>.json (per-kernel averages per launch)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}; G=${2:-1}; B=${3:-8}
+TAG=${1:-r03}; G=${2:-1}; B=${3:-8}; CACHE=${SG_SCENE_CACHE:-/tmp/sg_scenes}
 cd /tmp && export TMPDIR=/tmp
 pass() {   # name, counters...
   local name=$1; shift
   local out=$R/gpurun_out/${TAG}_pmc_raw_$name
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-files --groups $G --per-group $B --parity-scenes 1 --no-extras > $out.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-files --groups $G --per-group $B --parity-scenes 1 --no-extras --repeats 1 --gen-workers 1 --scene-cache $CACHE > $out.log 2>&1
   python3 - "$out" "$R/gpurun_out/${TAG}_pmc_$name.json" "$G" "$B" <<'PY'
 import csv, glob, json, sys, collections, re
 src, dst, G, B = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])

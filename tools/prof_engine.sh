@@ -1,9 +1,10 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: rocprofv3 kernel stats of the bench with a given engine shape (default 1 group x 8: batched launches, nothing else on the GPU)
+# Runs ON THE GPU BOX: rocprofv3 kernel stats of the bench with a given engine shape (default 1 group x 8: batched launches, nothing else on the GPU).
+# The profiled process spawns nothing (--gen-workers 1): its scenes come from the cache tools/collect_round.sh filled beforehand.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-solo8}; G=${2:-1}; B=${3:-8}
+TAG=${1:-solo8}; G=${2:-1}; B=${3:-8}; CACHE=${SG_SCENE_CACHE:-/tmp/sg_scenes}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-files --groups $G --per-group $B --no-extras > $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-files --groups $G --per-group $B --no-extras --gen-workers 1 --scene-cache $CACHE > $R/gpurun_out/prof_$TAG.log 2>&1
 f=$(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys
