@@ -55,8 +55,8 @@ MFMA_BF16_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MIC
 # what the EdgeConv launches EXECUTE per edge row (one of the 20 neighbour slots of a point): fp32 operands split into 16-bit
 # pieces that meet on v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation.  An MFMA of 32x32x16 is
 # 2 * 32 * 32 * 16 flop for 32 rows; CONV1_MFMAS = MFMAs per neighbour slot and 32-row tile for the 9-deep conv1 (two 32-channel
-# output tiles), conv2 = three fp16 products of 64x64 per row (hi*hi + hi*lo + lo*hi).
-CONV1_MFMAS_PER_SLOT = 12
+# output tiles; the six products of the bf16 x 3 split packed along K: round 3, 12 before), conv2 = three fp16 products of 64x64 per row (hi*hi + hi*lo + lo*hi).
+CONV1_MFMAS_PER_SLOT = 8
 CONV1_EXEC_FLOP_PER_ROW = CONV1_MFMAS_PER_SLOT * 2 * 32 * 32 * 16 // 32
 S1X_EXECUTED_FLOP_PER_ROW = CONV1_EXEC_FLOP_PER_ROW
 S2X_EXECUTED_FLOP_PER_ROW = 3 * 2 * 64 * 64 + CONV1_EXEC_FLOP_PER_ROW
@@ -72,11 +72,46 @@ def kernel_model(n_points: int, k: int = 20):
     c1, c12 = 2.0 * k * n * (18 * 64), 2.0 * k * n * (18 * 64 + 64 * 64)
     return {
         # name: (stages, launches per scene, bound, algorithmic units, unit, executed MFMA flop)
-        "k_edgeconv<S2X>": (["l3.edgeconv.stats2"], 1, "mfma", c12, "TFLOP/s", S2X_EXECUTED_FLOP_PER_ROW * k * n),
-        "k_edgeconv<S1X>": (["l2.edgeconv.stats1"], 1, "mfma", c1, "TFLOP/s", S1X_EXECUTED_FLOP_PER_ROW * k * n),
+        "k_edgeconv<S2X>": (["kernel.l3.edgeconv"], 1, "mfma", c12, "TFLOP/s", S2X_EXECUTED_FLOP_PER_ROW * k * n),
+        "k_edgeconv<S1X>": (["kernel.l2.edgeconv"], 1, "mfma", c1, "TFLOP/s", S1X_EXECUTED_FLOP_PER_ROW * k * n),
         # kNN: reads [N,4] f32, writes [N,20] i32; VALU-bound (selection): priced against the VALU issue roof from the PMC pass
         "k_cluster_knn_sorted": (["l2.knn", "l3.knn"], 2, "valu", 96.0 * n, "GB/s", 0.0),
     }
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=80, help="timed steps (80 x 64 scenes: a timed region of > 2 s)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each: `value` is the FIRST (the contract's K steps), "
+                                                            "the others are reported as repeat_values (run-to-run spread)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="distinct scenes per GPU per step (BASELINE.json configs[2]: 64)")
+    ap.add_argument("--scenes-total", type=int, default=0,
+                    help="strong scaling: ONE set of this many scenes sharded i mod W over the ranks (configs[3]: 1201); "
+                         "a step = one pass over the rank's shard in batches of --batch")
+    ap.add_argument("--groups", type=int, default=8, help="engine groups per GPU (host thread + HIP stream each)")
+    ap.add_argument("--per-group", type=int, default=8, help="scenes a group advances in lock-step through batched launches")
+    ap.add_argument("--points", type=int, default=150000)
+    ap.add_argument("--segments", type=int, default=1500)
+    ap.add_argument("--seg-profile", default="voronoi", help="synthetic segment-size profile: voronoi (SURVEY 8d recipe) | scannet (heavy-tailed)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline leg")
+    ap.add_argument("--no-files", action="store_true", help="skip the separate with-files measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra leg (scenes/s on the ScanNet-shaped segment profile)")
+    ap.add_argument("--extra-train", type=int, default=8, help="training steps timed in the extra leg (rank 0, N = 1; 0 = skip)")
+    ap.add_argument("--extra-scannet", type=int, default=48, help="scenes of the ScanNet-shaped profile in the extra leg (rank 0, N = 1)")
+    ap.add_argument("--writer-threads", type=int, default=16, help="native writer threads for the with-files leg")
+    ap.add_argument("--gen-workers", type=int, default=0, help="scene generator processes (0 = min(16, cores))")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU rehearsals of the reduction)")
+    ap.add_argument("--parity-scenes", type=int, default=64, help="scenes of the last batch re-run on a single pipeline and compared (default: all 64)")
+    ap.add_argument("--extra-strong", type=int, default=1201, help="extra leg (rank 0, N = 1): ONE pass over this many distinct scenes = BASELINE configs[3] "
+                                                                    "at W = 1 (0 = skip)")
+    ap.add_argument("--extra-stress", type=int, default=500000, help="extra leg: single-scene latency of a scene with this many points / 100 (0 = skip)")
+    ap.add_argument("--generate-only", action="store_true", help="fill --scene-cache (worker pool, no GPU call) and exit")
+    ap.add_argument("--scene-cache", default="", help="directory of generated scenes (.npz per scene): read when present, written otherwise; "
+                                                      "profiled runs use it with --gen-workers 1 so that the profiled process spawns nothing")
+    return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -438,16 +473,18 @@ def main(argv=None):
             # --batch, everything resident; two passes must give the same labels (digest of the per-scene digests), and a strided sample is
             # checked against the single pipeline
             sb_batches = [strong_scenes[k:k + args.batch] for k in range(0, len(strong_scenes), args.batch)]
-            dig = []
             run_batches(sb_batches[:2], 1)
             passes = []
-            for _ in range(2):
-                got = []
+            for _ in range(2):                                     # timed: results consumed (waited for, metric tensors read) like the main loop
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                run_batches(sb_batches, 1, lambda res: got.extend(label_digest(r_) for r_ in res))
+                run_batches(sb_batches, 1, lambda res: [r_.acc for r_ in res])
                 torch.cuda.synchronize()
                 passes.append(time.perf_counter() - t1)
+            dig = []
+            for _ in range(2):                                     # untimed: sha256 over 8.4 MB of labels per scene is ~4 ms of host time each
+                got = []
+                run_batches(sb_batches, 1, lambda res: got.extend(label_digest(r_) for r_ in res))
                 dig.append(got)
             idx = list(range(0, len(strong_scenes), 50))
             same_s = all(dig[0][i] == label_digest(solo.forward(strong_scenes[i], hip.MODE_INS_INFER)) for i in idx)

@@ -487,8 +487,13 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     EG_CHECK(sg::b_cluster_knn(d_ctx, bd, waves, seeded, stream, layer == 0, &wrote_seed));
     if (layer == 0 && !wrote_seed) EG_CHECK(sg::b_knn_seed_points(d_ctx, bd, stream));
     mark(sb + 2);
-    struct MarkArg { Group* g; int sub0; } ma{this, layer == 0 ? 19 : 21};
-    EG_CHECK(sg::b_edgeconv(d_ctx, bd, layer + 1, [](void* a, int i) { auto* m = static_cast<MarkArg*>(a); m->g->mark(m->sub0 + i); }, &ma, stream));
+    // marks 0 / 1 close the sub-passes (statistics pass(es)), 2 / 3 bracket the EdgeConv launch itself: an interval that starts at mark 2
+    // belongs to the stage in front of it (the kNN), the one that ends at mark 3 is the kernel alone
+    struct MarkArg { Group* g; int sub0, before, kernel; } ma{this, layer == 0 ? 19 : 21, sb + 2, 24 + layer};
+    EG_CHECK(sg::b_edgeconv(d_ctx, bd, layer + 1, [](void* a, int i) {
+        auto* m = static_cast<MarkArg*>(a);
+        m->g->mark(i == 2 ? m->before : i == 3 ? m->kernel : m->sub0 + i);
+    }, &ma, stream));
     // (the point -> cluster max rides inside the EdgeConv launches, the last BN + LeakyReLU in b_edgeconv's k_cluster_affine)
     mark(sb + 4);
     EG_CHECK(sg::b_gcn(d_ctx, bd, 0.125f, stream));
@@ -617,6 +622,8 @@ void sg_engine::Group::collect_times(int n) {
         if (ev_stage[i] >= 0 && ev_stage[i] < kNumStages && hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) ms_stage[ev_stage[i]] += ms;
     }
     n_ev = 0;
+    ms_stage[19] += ms_stage[24];                                // the kernel's own interval is part of its statistics sub-pass
+    ms_stage[22] += ms_stage[25];
     ms_stage[7] = ms_stage[19] + ms_stage[20];
     ms_stage[13] = ms_stage[21] + ms_stage[22] + ms_stage[23];
     std::lock_guard<std::mutex> g(eng->mu_times);

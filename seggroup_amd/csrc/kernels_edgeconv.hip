@@ -57,7 +57,8 @@
 //     labels are unchanged.
 // The accumulator of conv1 is fed straight back as the B operand of conv2: a 16-deep k block takes 8 consecutive accumulator
 // registers of a lane (lanes 0-31: k 0-7, lanes 32-63: k 8-15), and the weights are staged in LDS in exactly that channel
-// order, already split.  Per neighbour slot: 12 (conv1) + 24 (conv2) MFMAs of 32 cycles instead of 10 + 64 fp32 MFMAs of 64.
+// order, already split.  conv1's six products are packed along K (struct Lds, a1p): 54 of 64 k-slots of four MFMAs per output tile instead of
+// six MFMAs with 9 of 16.  Per neighbour slot: 8 (conv1) + 24 (conv2) MFMAs of 32 cycles instead of 10 + 64 fp32 MFMAs of 64.
 //
 // Conditioning: channels 0..2 of x_i are ABSOLUTE coordinates.  BatchNorm is invariant to a per-channel constant added to
 // its input, so every kernel here evaluates the x_i half of conv1 on x_i - [c, 0] with c = the XYZ of row 0 (any fixed point
@@ -86,10 +87,13 @@ __device__ inline int acc_channel(int tile, int reg, int half) { return 32 * til
 
 struct Lds {
     // A fragments, four MFMA steps per ds_read_b128 (conflict-free: consecutive lanes, 16 B each)
-    // conv1, split by input half (e = [d, x_i], d = x_j - x_i): five K=2 steps each, k = 2s + (lane>>5) < 9 (k = 9: zero)
-    // conv1, d columns (used every neighbour slot), bf16 pieces: a1db[piece][t][lane] = 8 bf16 = piece of
-    // W1[32t + (lane&31)][8 (lane>>5) + j], j = 0..7 (k >= 9: zero)
-    u32x4 a1db[3][2][64];
+    // conv1, d columns (used every neighbour slot): the six (weight piece, d piece) products of the bf16 x 3 split PACKED along K -- 54 of
+    // the 64 k-slots of four 16-deep MFMAs per output tile carry a product (the 9-deep contraction alone fills 9 of 16).  Lanes 0-31
+    // (k 0..7) own d0..d3, lanes 32-63 (k 8..15) own d4..d7, both own d8; per lane and MFMA m four units of two bf16:
+    //   m = 0: (w1 | w1)   m = 1: (w2 | w1)   m = 2: (w2 | w3)   meeting B = (x1 | x2), (x1 | x3), (x2 | x1) of the lane's four values
+    //   m = 3: d8's products -- lanes 0-31: w1, w1, w1, w2 ; lanes 32-63: w3, w2, 0, 0   meeting B = (x1, x2, x3, x1) of d8
+    // a1p[m][t][lane] = the 8 bf16 of W1[32t + (lane&31)][.] in that order (pieces by truncation: w = w1 + w2 + w3)
+    u32x4 a1p[4][2][64];
     float4 a1x[2][2][64];    // a1x[t][s>>2][lane][s&3] = W1[32t + (lane&31)][9 + k]    the x_i columns, used once per point
     // conv2, fp16 pieces (k_bn_fold_moments prepares the image once per scene): a2h[piece][ot][kb][lane] = 8 halves = piece of
     // S * sgn(gamma2) * W2[32ot + (lane&31)][acc_channel(kb>>1, 8(kb&1) + j, lane>>5)], j = 0..7
@@ -119,30 +123,32 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         if (MODE == S1X && gamma_last[ch] < 0.f) v = -v;
         (&lds.a1x[t][s >> 2][l].x)[s & 3] = v;
     }
-    for (int i = tid; i < 2 * 64; i += 64 * kWaves) {               // d columns, cut into bf16 pieces (see conv2 below)
-        const int l = i & 63, t = i >> 6;
-        const int ch = 32 * t + (l & 31);
+    for (int i = tid; i < 4 * 2 * 64; i += 64 * kWaves) {           // d columns: the packed product image (struct Lds)
+        const int l = i & 63, t = (i >> 6) & 1, m = i >> 7;
+        const int ch = 32 * t + (l & 31), hf = l >> 5;
         const bool neg = MODE == S1X && gamma_last[ch] < 0.f;
-        unsigned int p1[4], p2[4], p3[4];
+        auto piece = [&](int k, int p) -> unsigned int {              // bf16 bits of piece p (1..3) of W1[ch][k], 0 for p == 0
+            if (p == 0) return 0u;
+            float v = w1[ch * 18 + k];
+            if (neg) v = -v;
+            const float a1 = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+            const float r1 = v - a1;
+            const float a2 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+            const float r2 = r1 - a2;
+            return __float_as_uint(p == 1 ? a1 : p == 2 ? a2 : r2) >> 16;
+        };
+        unsigned int u[4];
+        if (m < 3) {
+            const int pa = m == 0 ? 1 : 2, pb = m == 2 ? 3 : 1;       // weight piece of units 0-1 | units 2-3
+            const int c0 = 4 * hf;
+            u[0] = piece(c0, pa) | (piece(c0 + 1, pa) << 16); u[1] = piece(c0 + 2, pa) | (piece(c0 + 3, pa) << 16);
+            u[2] = piece(c0, pb) | (piece(c0 + 1, pb) << 16); u[3] = piece(c0 + 2, pb) | (piece(c0 + 3, pb) << 16);
+        } else {
+            const int pw[2][4] = {{1, 1, 1, 2}, {3, 2, 0, 0}};
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            unsigned int h1[2], h2[2], h3[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k = 8 * (l >> 5) + 2 * jj + u;
-                float v = k < 9 ? w1[ch * 18 + k] : 0.f;
-                if (neg) v = -v;
-                const float a = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
-                const float r = v - a;
-                const float b = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
-                const float c = r - b;
-                h1[u] = __float_as_uint(a) >> 16; h2[u] = __float_as_uint(b) >> 16; h3[u] = __float_as_uint(c) >> 16;
-            }
-            p1[jj] = h1[0] | (h1[1] << 16); p2[jj] = h2[0] | (h2[1] << 16); p3[jj] = h3[0] | (h3[1] << 16);
+            for (int q = 0; q < 4; ++q) u[q] = piece(8, pw[hf][q]);  // (w[8] piece, 0)
         }
-        lds.a1db[0][t][l] = u32x4{p1[0], p1[1], p1[2], p1[3]};
-        lds.a1db[1][t][l] = u32x4{p2[0], p2[1], p2[2], p2[3]};
-        lds.a1db[2][t][l] = u32x4{p3[0], p3[1], p3[2], p3[3]};
+        lds.a1p[m][t][l] = u32x4{u[0], u[1], u[2], u[3]};
     }
     if (kTwo) {
         for (int i = tid; i < 2 * 2 * 4 * 64; i += 64 * kWaves) (&lds.a2h[0][0][0][0])[i] = w2img[i];
@@ -171,9 +177,8 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         // contribution W1[:, 9:18] x_i (+ the folded BN1 shift) is evaluated ONCE into `base` and every slot's accumulator
         // starts from it (first MFMA: C = base, D = acc1) -- 10 instead of 18 conv1 MFMAs per slot
         const float xsel[5] = {half ? xi[1] : xi[0], half ? xi[3] : xi[2], half ? xi[5] : xi[4], half ? xi[7] : xi[6], half ? 0.f : xi[8]};
-        // d = x_j - x_i as the B operand of ONE 16-deep bf16 k block: lanes 0-31 carry k = 0..7, lanes 32-63 k = 8 (+ zeros)
-        const float xs[8] = {half ? xi[8] : xi[0], half ? 0.f : xi[1], half ? 0.f : xi[2], half ? 0.f : xi[3],
-                             half ? 0.f : xi[4], half ? 0.f : xi[5], half ? 0.f : xi[6], half ? 0.f : xi[7]};
+        // d = x_j - x_i: lanes 0-31 cut d0..d3, lanes 32-63 d4..d7, both d8 (struct Lds, a1p)
+        const float xs[5] = {half ? xi[4] : xi[0], half ? xi[5] : xi[1], half ? xi[6] : xi[2], half ? xi[7] : xi[3], xi[8]};
         // the x_i half sees coordinates relative to row 0 (see "Conditioning" in the header); d below uses the raw ones
         const float xcen[5] = {half ? xi[1] - x9m[1] : xi[0] - x9m[0], half ? xi[3] : xi[2] - x9m[2], xsel[2], xsel[3], xsel[4]};
         f32x16 base[2];
@@ -234,42 +239,41 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                 p0 = xq[0]; p1 = xq[1]; p2 = xq[2];
                 if (j + 2 < K) nb_next = krow[j + 2];
             }
-            // conv1 on the bf16 pipe like conv2: d (8 values per lane) cut into three bf16 pieces, six products per output tile
-            // on top of the point's base accumulator (12 MFMAs of 32 cycles instead of 10 fp32 MFMAs of 64)
+            // conv1 on the bf16 pipe: the lane's five d values cut into three bf16 pieces by truncation (d = x1 + x2 + x3), the six products
+            // that matter packed along K (struct Lds): 8 MFMAs of 32 cycles on top of the point's base accumulator
             f32x16 acc1[2];
             {
-                const float nv[8] = {half ? n2.x : n0.x, half ? 0.f : n0.y, half ? 0.f : n0.z, half ? 0.f : n0.w,
-                                     half ? 0.f : n1.x, half ? 0.f : n1.y, half ? 0.f : n1.z, half ? 0.f : n1.w};
-                unsigned int q1[4], q2[4], q3[4];
+                const float nv[5] = {half ? n1.x : n0.x, half ? n1.y : n0.y, half ? n1.z : n0.z, half ? n1.w : n0.w, n2.x};
+                unsigned int v1[5], v2[5], v3[5];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const float v0 = nv[2 * jj] - xs[2 * jj], v1 = nv[2 * jj + 1] - xs[2 * jj + 1];
-                    const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u);
-                    const float r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
-                    const float c0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-                    const float c1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-                    q1[jj] = __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);
-                    q2[jj] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-                    q3[jj] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
+                for (int q = 0; q < 5; ++q) {
+                    const float v = nv[q] - xs[q];
+                    const float r = v - __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+                    const float c = r - __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+                    v1[q] = __float_as_uint(v); v2[q] = __float_as_uint(r); v3[q] = __float_as_uint(c);
                 }
-                const bf16x8 x1 = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
-                const bf16x8 x2 = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
-                const bf16x8 x3 = __builtin_bit_cast(bf16x8, u32x4{q3[0], q3[1], q3[2], q3[3]});
-                const bf16x8 wa1 = __builtin_bit_cast(bf16x8, lds.a1db[0][0][lane]), wb1 = __builtin_bit_cast(bf16x8, lds.a1db[0][1][lane]);
-                const bf16x8 wa2 = __builtin_bit_cast(bf16x8, lds.a1db[1][0][lane]), wb2 = __builtin_bit_cast(bf16x8, lds.a1db[1][1][lane]);
-                const bf16x8 wa3 = __builtin_bit_cast(bf16x8, lds.a1db[2][0][lane]), wb3 = __builtin_bit_cast(bf16x8, lds.a1db[2][1][lane]);
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa3, x1, base[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb3, x1, base[1], 0, 0, 0);
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2, x2, acc1[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb2, x2, acc1[1], 0, 0, 0);
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x3, acc1[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x3, acc1[1], 0, 0, 0);
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2, x1, acc1[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb2, x1, acc1[1], 0, 0, 0);
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x2, acc1[0], 0, 0, 0);
-                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x2, acc1[1], 0, 0, 0);
+                // units of two bf16 = the top halves of two registers (v_perm_b32)
+                const unsigned int a1 = __builtin_amdgcn_perm(v1[1], v1[0], 0x07060302u), b1 = __builtin_amdgcn_perm(v1[3], v1[2], 0x07060302u);
+                const unsigned int a2 = __builtin_amdgcn_perm(v2[1], v2[0], 0x07060302u), b2 = __builtin_amdgcn_perm(v2[3], v2[2], 0x07060302u);
+                const unsigned int a3 = __builtin_amdgcn_perm(v3[1], v3[0], 0x07060302u), b3 = __builtin_amdgcn_perm(v3[3], v3[2], 0x07060302u);
+                const unsigned int c1 = v1[4] >> 16, c2 = v2[4] >> 16, c3 = v3[4] >> 16;
+                const bf16x8 x0 = __builtin_bit_cast(bf16x8, u32x4{a1, b1, a2, b2});       // (x1 | x2)
+                const bf16x8 x1 = __builtin_bit_cast(bf16x8, u32x4{a1, b1, a3, b3});       // (x1 | x3)
+                const bf16x8 x2 = __builtin_bit_cast(bf16x8, u32x4{a2, b2, a1, b1});       // (x2 | x1)
+                const bf16x8 x3 = __builtin_bit_cast(bf16x8, u32x4{c1, c2, c3, c1});       // d8: x1, x2, x3, x1
+                const bf16x8 wa0 = __builtin_bit_cast(bf16x8, lds.a1p[0][0][lane]), wb0 = __builtin_bit_cast(bf16x8, lds.a1p[0][1][lane]);
+                const bf16x8 wa1 = __builtin_bit_cast(bf16x8, lds.a1p[1][0][lane]), wb1 = __builtin_bit_cast(bf16x8, lds.a1p[1][1][lane]);
+                const bf16x8 wa2 = __builtin_bit_cast(bf16x8, lds.a1p[2][0][lane]), wb2 = __builtin_bit_cast(bf16x8, lds.a1p[2][1][lane]);
+                const bf16x8 wa3 = __builtin_bit_cast(bf16x8, lds.a1p[3][0][lane]), wb3 = __builtin_bit_cast(bf16x8, lds.a1p[3][1][lane]);
+                // smallest terms first: (w2 x2, w3 x1), (w2 x1, w1 x3), d8's six, (w1 x1, w1 x2)
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa2, x2, base[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb2, x2, base[1], 0, 0, 0);
                 acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1, x1, acc1[0], 0, 0, 0);
                 acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, x1, acc1[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa3, x3, acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb3, x3, acc1[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa0, x0, acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb0, x0, acc1[1], 0, 0, 0);
             }
             if (!kTwo) {
 #pragma unroll
@@ -831,7 +835,9 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
     const int nblocks = sg::cdiv(sg::cdiv(bd.max_N, 32), kWaves);
     const dim3 grid(nblocks, bd.nslots), one(1, bd.nslots);
     if (layers == 1) {
+        if (mark) mark(mark_arg, 2);                                  // 2 / 3: in front of / behind the EdgeConv launch itself
         k_edgeconv_b<S1X, false><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
+        if (mark) mark(mark_arg, 3);
         k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 1);
         k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 1);
         if (mark) mark(mark_arg, 0);
@@ -840,6 +846,7 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
         k_bn_fold_moments_b<<<one, 1024, 0, st>>>(d_ctx);
         if (mark) mark(mark_arg, 0);
         k_edgeconv_b<S2X, true><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
+        if (mark) mark(mark_arg, 3);
         k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 2);
         k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 2);
         if (mark) mark(mark_arg, 1);

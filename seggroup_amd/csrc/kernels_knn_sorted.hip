@@ -496,9 +496,10 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     }
     float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) me = sxyzw[q];
-    unsigned long long kv[K];
+    // the running top K in LIST form (knn_device.h): doubles whose order is the keys' order, inserted with v_min_f64 / v_max_f64
+    double kv[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) kv[j] = 0ull;
+    for (int j = 0; j < K; ++j) kv[j] = list_empty();
     unsigned long long thr = active ? 0ull : ~0ull;          // idle lanes never accept
     int myprev = -1;                                          // former cluster whose candidates are already in kv
     if (kSeeded && active) {
@@ -508,10 +509,10 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const float4 rec = point_rec[sp[j]];              // XYZ + this layer's member position: one gather per seed
-                kv[j] = make_key(score4(me, make_float4(rec.x, rec.y, rec.z, (rec.x * rec.x + rec.y * rec.y) + rec.z * rec.z)),
-                                 __float_as_int(rec.w) - clo);
+                kv[j] = to_list(make_key(score4(me, make_float4(rec.x, rec.y, rec.z, (rec.x * rec.x + rec.y * rec.y) + rec.z * rec.z)),
+                                         __float_as_int(rec.w) - clo));
             }
-            thr = kv[K - 1];
+            thr = from_list(kv[K - 1]);
         }
     }
     thr_pub[wave][lane] = (unsigned int)(thr >> 32);
@@ -544,13 +545,13 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
         for (int u = 0; u < mxc; ++u) {
             const unsigned long long cur = u < cnt ? nxt : 0ull;
             nxt = buf[min(u + 1, kBufS - 1)][tid];
-            key_insert<K>(kv, cur);
+            list_insert<K>(kv, cur);
         }
         cnt = 0;
         if (active) {
-            thr = kv[K - 1];
+            thr = from_list(kv[K - 1]);
             thr_pub[wave][lane] = (unsigned int)(thr >> 32);
-            thr5_pub[wave][lane] = (unsigned int)(kv[K / kSlices - 1] >> 32);
+            thr5_pub[wave][lane] = (unsigned int)(from_list(kv[K / kSlices - 1]) >> 32);
         }
     };
     bool ok = true;                                           // seeded: false while the segment at hand belongs to my former cluster
@@ -740,18 +741,18 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
         if (active) {
             const sg::gptr<int32_t> o = knn + (size_t)myrow * K;
 #pragma unroll
-            for (int j = 0; j < K; ++j) o[j] = clo + key_index(kv[j]);
+            for (int j = 0; j < K; ++j) o[j] = clo + list_index(kv[j]);
             if (seed_out) {
                 const sg::gptr<int32_t> so = seed_out + (size_t)members[myrow] * K;
 #pragma unroll
-                for (int j = 0; j < K; ++j) so[j] = members[clo + key_index(kv[j])];
+                for (int j = 0; j < K; ++j) so[j] = members[clo + list_index(kv[j])];
             }
         }
     } else {
         __syncthreads();                                          // every wave is done with its append buffer
         unsigned long long* lists = &buf[0][0];
     #pragma unroll
-        for (int j = 0; j < K; ++j) lists[((size_t)wave * K + j) * 64 + lane] = kv[j];
+        for (int j = 0; j < K; ++j) lists[((size_t)wave * K + j) * 64 + lane] = from_list(kv[j]);
         __syncthreads();
         if (wave == 0 && active) {
             int p[kSlices];
@@ -1089,6 +1090,7 @@ int b_layer_layout(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
 int b_cluster_knn(const SlotCtx* d_ctx, const BatchDims& bd, int waves_per_tile, bool seeded, hipStream_t st, bool write_seed, bool* wrote_seed) {
     if (wrote_seed) *wrote_seed = false;
     if (bd.nslots == 0 || bd.max_T == 0) return SG_OK;
+    if (bd.max_N > sgknn::kListMaxPoints) return sg::fail(SG_EUNSUP, "in-cluster kNN: %d points in a scene, the list keys carry 20 index bits (N <= %d)", bd.max_N, sgknn::kListMaxPoints);
     const dim3 grid(bd.nslots, bd.max_T);
     if (seeded) k_cluster_knn_sorted_b<20, 1, true><<<grid, 64, 0, st>>>(d_ctx, 0);
     else if (waves_per_tile == 1) {
@@ -1186,6 +1188,7 @@ int sg_cluster_knn_seeded(const float* d_sxyzw, const int32_t* d_smpos, int N, c
                           int k, int pos0, int32_t* d_knn, void* stream) {
     SG_REQUIRE(N >= 0 && T >= 0 && d_knn && d_sxyzw && d_smpos && d_seed && d_seg_prevcl && d_members && d_point_rec,
                "sg_cluster_knn_seeded: bad arguments");
+    SG_REQUIRE(N <= sgknn::kListMaxPoints, "sg_cluster_knn_seeded: the list keys carry 20 index bits (N <= 2^20)");
     if (k != 20) return sg::fail(SG_EUNSUP, "sg_cluster_knn_seeded: only k == 20 is built (model.py:788,829), got %d", k);
     if (T == 0) return SG_OK;
     k_cluster_knn_sorted<20, 1, true><<<T, 64, 0, sg::as_stream(stream)>>>(
@@ -1225,6 +1228,7 @@ int sg_cluster_knn_sorted_w(const float* d_sxyzw, const int32_t* d_smpos, int N,
                             const float* d_segbox, const float* d_chunk_box, const int32_t* d_slot_of_pos, int k, int pos0,
                             int waves_per_tile, int32_t* d_knn, void* stream) {
     SG_REQUIRE(N >= 0 && T >= 0 && d_knn && d_sxyzw && d_smpos, "sg_cluster_knn_sorted: bad arguments");
+    SG_REQUIRE(N <= sgknn::kListMaxPoints, "sg_cluster_knn_sorted: the list keys carry 20 index bits (N <= 2^20)");
     if (k != 20) return sg::fail(SG_EUNSUP, "sg_cluster_knn_sorted: only k == 20 is built (model.py:788,829), got %d", k);
     if (T == 0) return SG_OK;
     const int slices = (waves_per_tile == 1 || waves_per_tile == 2 || waves_per_tile == 4) ? waves_per_tile : (T >= 2048 ? 1 : T >= 1024 ? 2 : 4);

@@ -47,6 +47,35 @@ __device__ inline void key_insert(unsigned long long (&kv)[K], unsigned long lon
     kv[0] = ((unsigned long long)sel_mask((unsigned int)(kv[0] >> 32), xh, c[0]) << 32) | sel_mask((unsigned int)kv[0], xl, c[0]);
 }
 
+// LIST form of a key (round 3): the same key as a double in [2^52, 2^53) -- exponent 0x433, payload = ordered score << 20 | the low
+// 20 bits of ~index -- so that integer order == floating-point order and a sorted insertion is two plain instructions per slot,
+//     new[j] = max(old[j], min(old[j-1], x)),
+// instead of a 64-bit compare and four selects (tools/micro/key_insert_rates.hip: 248 vs 560 cycles per insertion into 20 slots,
+// identical lists).  All keys share one exponent: no NaN, no denormal, no -0 can appear.  20 index bits: member positions inside one
+// cluster, i.e. N <= 2^20 points per scene (the host entry points check it).  Key 0 ("nothing yet") <-> kListEmpty, the smallest.
+constexpr int kListIndexBits = 20;
+constexpr int kListMaxPoints = 1 << kListIndexBits;
+__device__ __forceinline__ double list_empty() { return __hiloint2double(0x43300000, 0); }
+__device__ __forceinline__ double to_list(unsigned long long key) {
+    const unsigned int o = (unsigned int)(key >> 32), lo = (unsigned int)key;
+    return __hiloint2double((int)(0x43300000u | (o >> 12)), (int)((o << 20) | (lo & 0xfffffu)));
+}
+__device__ __forceinline__ unsigned long long from_list(double d) {              // exact inverse for indices < 2^20 (empty -> a key below every real one)
+    const unsigned int hi = (unsigned int)__double2hiint(d), lo = (unsigned int)__double2loint(d);
+    return ((unsigned long long)((hi << 12) | (lo >> 20)) << 32) | (0xfff00000u | lo);
+}
+__device__ __forceinline__ int list_index(double d) { return (int)(0xfffffu - ((unsigned int)__double2loint(d) & 0xfffffu)); }
+// plain v_max_f64 / v_min_f64: fmax() / fmin() would put a canonicalising v_max_f64 x, x in front of every operand
+__device__ __forceinline__ double list_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double list_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int K>
+__device__ __forceinline__ void list_insert(double (&kv)[K], unsigned long long key) {
+    const double x = to_list(key);
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) kv[j] = list_max(kv[j], list_min(kv[j - 1], x));
+    kv[0] = list_max(kv[0], x);
+}
+
 // upper bound of the score of ANY point inside an axis-aligned box {min xyz, max xyz, max |p|^2}:
 // -dmin^2 (shrunk by 1e-6) + 16 eps (|q|^2 + max |p|^2) -- the margin covers the fp32 rounding of score4()
 __device__ inline float box_score_bound(const float4& me, const float* bx) {

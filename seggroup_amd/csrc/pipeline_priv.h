@@ -12,7 +12,10 @@ static const char* const kStageNames[] = {"contract_edges", "fps64", "mlp1", "di
                              "fallback_fps1024", "export", "evaluate",
                              // sub-passes of the two EdgeConv stages (their sum is l2.edgeconv / l3.edgeconv)
                              "l2.edgeconv.stats1", "l2.edgeconv.final", "l3.edgeconv.stats1", "l3.edgeconv.stats2",
-                             "l3.edgeconv.final"};
+                             "l3.edgeconv.final",
+                             // the scene engine only: the EdgeConv launch ALONE (events right before and right after it; its stage above also
+                             // holds the fold and affine launches behind it)
+                             "kernel.l2.edgeconv", "kernel.l3.edgeconv"};
 constexpr int kNumStages = sizeof(kStageNames) / sizeof(kStageNames[0]);
 
 template <class T>
