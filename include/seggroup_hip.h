@@ -183,12 +183,16 @@ int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_point
 /* One launch for what sg_gather_members + sg_center_clusters + sg_knn_operands produce for a layer (same arrays, same
  * bits): d_cl[i] = cluster of the i-th segment in member order, d_cl_mean [C,3] = the clusters' centroids as fp32
  * (= (float)(sum of the members' xyz in double / count), e.g. from sg_segment_sort_boxes' d_seg_sums).
- * d_point_rec (may be NULL): [N,4] indexed by POINT id = {x, y, z, bits of the point's member position in this layer}: the
- * 16-byte record sg_cluster_knn_seeded gathers per seed (instead of a row of d_data and an entry of d_pos_of_point). */
+ * d_point_rec (may be NULL): [N,4] = {x, y, z, bits of the point's member position in this layer}: the 16-byte record
+ * sg_cluster_knn_seeded gathers per seed (instead of a row of d_data and an entry of d_pos_of_point).
+ * d_seed_id (may be NULL): [N] by member position = the point's SEED ID, its place in the Morton-sorted CSR of the
+ * over-segmentation (d_seg_off[s] + rank inside segment s): the same in every layer, consecutive for the queries of a kNN tile,
+ * close for points that are close in space.  With d_seed_id the records are indexed by seed id (written in order), without by
+ * point id.  Seed tables may use either id space -- whatever map the caller hands to sg_knn_seed_points / sg_cluster_knn_seeded. */
 int sg_layer_layout(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl, const float* d_cl_mean, int32_t* d_members,
                     int32_t* d_pos_of_point, int32_t* d_cluster_of_pos, int32_t* d_slot_of_pos, float* d_x9m, float* d_sxyzw,
-                    int32_t* d_smpos, float* d_point_rec, void* stream);
+                    int32_t* d_smpos, float* d_point_rec, int32_t* d_seed_id, void* stream);
 int sg_knn_operands(const float* d_data, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, float* d_sxyzw, int32_t* d_smpos, void* stream);
 int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off,
@@ -199,9 +203,10 @@ int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, c
 /* Seeded variant for a layer whose clusters are unions of the clusters of the PREVIOUS kNN layer (model.py:829 after
  * 788: the score of a pair depends on raw coordinates only and union() appends whole member lists, so a query's
  * previous list is the exact top k inside its former cluster).  sg_knn_seed_points turns the previous table (rows and
- * entries = member positions of that layer, d_members = its position -> point map) into d_seed [N,k] indexed by and
- * holding POINT ids.  sg_cluster_knn_seeded = sg_cluster_knn_sorted with one wave per tile that starts every query
- * from its seeds (d_members: THIS layer's position -> point map, d_point_rec: sg_layer_layout's records of THIS layer) and skips the chunks of
+ * entries = member positions of that layer, d_members = its position -> id map: point ids (sg_layer_layout's d_members)
+ * or seed ids (its d_seed_id: what the pipeline and the engine pass)) into d_seed [N,k] indexed by and holding those ids.
+ * sg_cluster_knn_seeded = sg_cluster_knn_sorted with one wave per tile that starts every query from its seeds (d_members:
+ * THIS layer's position -> id map in the same id space, d_point_rec: sg_layer_layout's records of THIS layer by id) and skips the chunks of
  * segments whose former cluster (d_seg_prevcl[S]) is the query's own; d_seg_prevcl = -1 marks segments of former
  * clusters with <= k points, which have no kNN list (model.py:516-518).  Same table as every other variant. */
 int sg_knn_seed_points(const int32_t* d_knn, const int32_t* d_members, int N, int k, int32_t* d_seed, void* stream);

@@ -444,7 +444,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
             c.rowptr = d_rp; c.col = d_col; c.eid = d_eid;
         }
         c.E = E; c.C = C; c.Dcat = Dcat;
-        c.members = pl->members.p; c.pos_of_point = pl->pos_of_point.p; c.point_rec = layer == 1 ? reinterpret_cast<float4*>(pl->point_rec.p) : nullptr;   /* only the seeded (layer-3) kNN reads the records */ c.cluster_of_pos = pl->cluster_of_pos.p; c.slot_of_pos = pl->slot_of_pos.p;
+        c.members = pl->members.p; c.pos_of_point = pl->pos_of_point.p; c.point_rec = layer == 1 ? reinterpret_cast<float4*>(pl->point_rec.p) : nullptr;   /* only the seeded (layer-3) kNN reads the records */ c.cluster_of_pos = pl->cluster_of_pos.p; c.slot_of_pos = pl->slot_of_pos.p; c.seed_id = pl->seed_id.p;
         c.x9m = pl->x9m.p; c.sxyzw = reinterpret_cast<float4*>(pl->xyzw.p); c.smpos = pl->smpos.p;
         c.gm_rows = r.feat_prev; c.gm_stride = r.feat_prev_stride; c.gm_D = r.feat_prev_dim; c.cat = pl->featA.p;
         // point 0 is the first member of segment 0; its member-order position is that segment's dst

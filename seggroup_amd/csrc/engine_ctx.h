@@ -73,7 +73,8 @@ struct SlotCtx {
     const float* cl_mean;
     int32_t* members;
     int32_t* pos_of_point;
-    float4* point_rec;                 // [N] by point id: xyz + this layer's member position (seeded kNN)
+    float4* point_rec;                 // [N] by seed id: xyz + this layer's member position (seeded kNN)
+    int32_t* seed_id;                  // [N] by member position: the point's id in the seed tables = its place in the Morton-sorted CSR of the over-segmentation
     int32_t* cluster_of_pos;
     int32_t* slot_of_pos;
     float* x9m;                        // [N,12]
@@ -98,7 +99,7 @@ struct SlotCtx {
     const int32_t* cl_seg_off;
     int pos0;
     int32_t* knn;                      // [N,20]
-    int32_t* knn_seed;                 // [N,20] point ids (written after layer 2, read by layer 3)
+    int32_t* knn_seed;                 // [N,20] seed ids, rows by seed id (written after layer 2, read by layer 3)
     const int32_t* seg_prevcl;
 
     // ---- a13: EdgeConv ----

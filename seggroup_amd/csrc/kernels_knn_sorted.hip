@@ -366,7 +366,8 @@ __device__ __forceinline__ void layer_layout_body(const float* __restrict__ data
                                                   const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
                                                   int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
                                                   float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos,
-                                                  float4* __restrict__ point_rec, int i, int r_begin = 0, int r_end = 0x7fffffff) {
+                                                  float4* __restrict__ point_rec, int32_t* __restrict__ seed_id, int i, int r_begin = 0,
+                                                  int r_end = 0x7fffffff) {
     const int s = order[i];
     const int lo = seg_off[s], n = min(seg_off[s + 1] - lo, r_end), d = dst[i], c = cl[i];
     const float mx = cl_mean[3 * c], my = cl_mean[3 * c + 1], mz = cl_mean[3 * c + 2];
@@ -379,7 +380,8 @@ __device__ __forceinline__ void layer_layout_body(const float* __restrict__ data
         const float* row = data + (size_t)p * 6;
         const float x = row[0], y = row[1], z = row[2];
         // XYZ + this layer's member position of the point in ONE 16-byte record: what the seeded kNN of the layer gathers per seed
-        if (point_rec) point_rec[p] = make_float4(x, y, z, __int_as_float(d + r));
+        // (indexed by point id without seed ids -- the records then scatter over the whole array)
+        if (point_rec && !seed_id) point_rec[p] = make_float4(x, y, z, __int_as_float(d + r));
         float4* o = reinterpret_cast<float4*>(x9m + (size_t)(d + r) * 12);
         o[0] = make_float4(x, y, z, row[3]);
         o[1] = make_float4(row[4], row[5], x - mx, y - my);
@@ -388,15 +390,24 @@ __device__ __forceinline__ void layer_layout_body(const float* __restrict__ data
         const float* q = data + (size_t)seg_points[ci] * 6;
         sxyzw[d + r] = make_float4(q[0], q[1], q[2], (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);     // torch.sum(x**2, dim=1)
         smpos[d + r] = d + (ci - lo);
+        // Seed ids (round 3): the id of a point in the seed tables = its position in the Morton-sorted CSR of the over-segmentation,
+        // lo + r -- the same in every layer, consecutive for the queries of a tile and close for points that are close in space.  The
+        // records are then written in order (coalesced; by point id they scattered 16 bytes per point) and a query's 20 seed gathers
+        // hit a few neighbouring lines (by point id: 51 MB fetched per scene for 14 MB of kNN operands).
+        if (seed_id) {
+            seed_id[d + (ci - lo)] = lo + r;
+            if (point_rec) point_rec[lo + r] = make_float4(q[0], q[1], q[2], __int_as_float(d + (ci - lo)));
+        }
     }
 }
 __global__ void k_layer_layout(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
                                const int32_t* __restrict__ sperm, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
                                const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
                                int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
-                               float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos, float4* __restrict__ point_rec) {
+                               float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos, float4* __restrict__ point_rec,
+                               int32_t* __restrict__ seed_id) {
     layer_layout_body(data, seg_points, seg_off, sperm, order, dst, cl, cl_mean, members, pos_of_point, cluster_of_pos, slot_of_pos, x9m, sxyzw,
-                      smpos, point_rec, blockIdx.x);
+                      smpos, point_rec, seed_id, blockIdx.x);
 }
 // The engine's launches: a block lays out the first kLayoutPiece rows of its segment; the rest of a larger segment (ScanNet floors
 // and walls: 10k-40k points) is cut into pieces of kLayoutPiece rows that the host lists per layer (lay_big = (slot, first row)
@@ -405,14 +416,14 @@ __global__ void k_layer_layout_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.S) return;
     layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, nullptr, c.cluster_of_pos,
-                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, blockIdx.x, 0, sg::kLayoutPiece);
+                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, c.seed_id, blockIdx.x, 0, sg::kLayoutPiece);
 }
 __global__ void k_layer_layout_big_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.lay_nbig) return;
     const int i = c.lay_big[2 * blockIdx.x], r0 = c.lay_big[2 * blockIdx.x + 1];
     layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, nullptr, c.cluster_of_pos,
-                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, i, r0, r0 + sg::kLayoutPiece);
+                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, c.seed_id, i, r0, r0 + sg::kLayoutPiece);
 }
 
 // per layer: block i = i-th segment in member order; writes the operand and the member position in SORTED order
@@ -810,7 +821,7 @@ __global__ __launch_bounds__(64 * kSlices, kSlices == 1 && kSeeded ? 4 : 1) void
                                                  as_global(c.tile_lo), as_global(c.tile_hi), as_global(c.cl_seg_off), as_global(c.order),
                                                  as_global(c.dst), as_global(c.seg_off), as_global(c.seg_chunk_off), as_global(c.segbox),
                                                  as_global(c.chunk_box), as_global(c.slot_of_pos), c.pos0, as_global(c.knn), 0,
-                                                 as_global(c.knn_seed), as_global(c.seg_prevcl), as_global(c.members), as_global(c.point_rec),
+                                                 as_global(c.knn_seed), as_global(c.seg_prevcl), as_global(c.seed_id), as_global(c.point_rec),
                                                  blockIdx.y, kSlices == 1 && !kSeeded && write_seed ? as_global(c.knn_seed) : nullptr);
 }
 
@@ -826,7 +837,7 @@ __global__ void k_knn_seed_points_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.N * 20) return;
-    c.knn_seed[(size_t)c.members[i / 20] * 20 + i % 20] = c.members[c.knn[i]];
+    c.knn_seed[(size_t)c.seed_id[i / 20] * 20 + i % 20] = c.seed_id[c.knn[i]];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1134,13 +1145,13 @@ size_t sg_segment_sort_ws_bytes(int N) { return (size_t)std::max(N, 1) * 16; }  
 int sg_layer_layout(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl, const float* d_cl_mean, int32_t* d_members,
                     int32_t* d_pos_of_point, int32_t* d_cluster_of_pos, int32_t* d_slot_of_pos, float* d_x9m, float* d_sxyzw,
-                    int32_t* d_smpos, float* d_point_rec, void* stream) {
+                    int32_t* d_smpos, float* d_point_rec, int32_t* d_seed_id, void* stream) {
     SG_REQUIRE(N >= 0 && S >= 0 && d_sperm && d_cl_mean && d_members && d_pos_of_point && d_cluster_of_pos && d_slot_of_pos && d_x9m &&
                    d_sxyzw && d_smpos, "sg_layer_layout: bad arguments");
     if (S == 0) return SG_OK;
     k_layer_layout<<<S, 128, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_sperm, d_order, d_dst, d_cl, d_cl_mean, d_members,
                                                         d_pos_of_point, d_cluster_of_pos, d_slot_of_pos, d_x9m,
-                                                        reinterpret_cast<float4*>(d_sxyzw), d_smpos, reinterpret_cast<float4*>(d_point_rec));
+                                                        reinterpret_cast<float4*>(d_sxyzw), d_smpos, reinterpret_cast<float4*>(d_point_rec), d_seed_id);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

@@ -37,30 +37,21 @@ __device__ __forceinline__ void mlp1_knn_moments_body(const float* __restrict__ 
     for (int k = 0; k < 6; ++k) f[k] = row[k];
     const float xx = sqnorm3(f[0], f[1], f[2]);
 
-    float bv[K1];
-    int bi[K1];
+    // top 10 in LIST form (knn_device.h): keys = (ordered score, ~candidate) as doubles of one exponent, a sorted insertion = 19 plain
+    // v_min_f64 / v_max_f64 (round 2: 10 compares into wave masks + 40 selects per candidate).  Order: score descending, the EARLIER
+    // candidate first among equal scores -- what the strict compares of the serial form gave.
+    double kvl[K1];
 #pragma unroll
-    for (int t = 0; t < K1; ++t) { bv[t] = -INFINITY; bi[t] = 0; }
+    for (int t = 0; t < K1; ++t) kvl[t] = sgknn::list_empty();
 #pragma unroll 8
     for (int j = 0; j < 64; ++j) {
         // candidate j is the same for every lane: v_readlane broadcasts instead of four ds_bpermute round trips
         const float s = knn_score(f[0], f[1], f[2], xx, sgw::bcast(f[0], j), sgw::bcast(f[1], j), sgw::bcast(f[2], j), sgw::bcast(xx, j));
-        // sorted insertion in parallel form (earlier candidate first on ties: the compares are strict): every slot decides from two
-        // wave masks, no `placed` chain and no exec-mask branches (the serial form compiled to ~180 mask operations per candidate)
-        unsigned long long cm[K1];
-#pragma unroll
-        for (int t = 0; t < K1; ++t) cm[t] = __builtin_amdgcn_fcmpf(s, bv[t], 2 /* FCMP_OGT */);
-        const unsigned int sb = __float_as_uint(s);
-#pragma unroll
-        for (int t = K1 - 1; t > 0; --t) {
-            const unsigned int tv = sgknn::sel_mask(sb, __float_as_uint(bv[t - 1]), cm[t - 1]);
-            const unsigned int ti = sgknn::sel_mask((unsigned int)j, (unsigned int)bi[t - 1], cm[t - 1]);
-            bv[t] = __uint_as_float(sgknn::sel_mask(__float_as_uint(bv[t]), tv, cm[t]));
-            bi[t] = (int)sgknn::sel_mask((unsigned int)bi[t], ti, cm[t]);
-        }
-        bv[0] = __uint_as_float(sgknn::sel_mask(__float_as_uint(bv[0]), sb, cm[0]));
-        bi[0] = (int)sgknn::sel_mask((unsigned int)bi[0], (unsigned int)j, cm[0]);
+        sgknn::list_insert<K1>(kvl, sgknn::make_key(s, j));
     }
+    int bi[K1];
+#pragma unroll
+    for (int t = 0; t < K1; ++t) bi[t] = sgknn::list_index(kvl[t]);
     uint8_t* ko = knn + ((size_t)c * 64 + lane) * K1;
 #pragma unroll
     for (int t = 0; t < K1; ++t) ko[t] = (uint8_t)bi[t];

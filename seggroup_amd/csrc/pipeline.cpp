@@ -123,7 +123,7 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->ws_eval, sg_eval_ws_bytes(maxS + 2));
     D(pl->adj1, 2 * maxE1); D(pl->count, 4);
     D(pl->members, N); D(pl->pos_of_point, N); D(pl->cluster_of_pos, N); D(pl->slot_of_pos, N);
-    D(pl->knn, N * 20); D(pl->knn_seed, N * 20);
+    D(pl->knn, N * 20); D(pl->knn_seed, N * 20); D(pl->seed_id, N);
     D(pl->desc, 15 * S + 16 + 4 * T + 2 * maxE1 + 4 * maxE1 + 128);
     D(pl->tables, SG_NUM_LABEL_VECTORS * S); D(pl->labels, SG_NUM_LABEL_VECTORS * V);
     D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
@@ -392,7 +392,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             // member arrays + centred rows + sorted kNN operands of the layer: one launch
             PL_CHECK(sg_layer_layout(sc->d_data, N, sc->d_seg_points, sc->d_seg_off, pl->sperm.p, S, dd + o.order, dd + o.dst, dd + o.cl,
                                      reinterpret_cast<const float*>(dd + o.cl_mean), pl->members.p, pl->pos_of_point.p, pl->cluster_of_pos.p,
-                                     pl->slot_of_pos.p, pl->x9m.p, pl->xyzw.p, pl->smpos.p, pl->point_rec.p, stv));
+                                     pl->slot_of_pos.p, pl->x9m.p, pl->xyzw.p, pl->smpos.p, pl->point_rec.p, pl->seed_id.p, stv));
             // + -inf into the 64 columns the point->cluster max fills below
             PL_CHECK(sg::group_max_rows_fill(feat_prev, feat_prev_stride, feat_prev_dim, dd + o.goff, dd + o.gidx, C, cat, Dcat, 64, stv));
             pl->mark(sb + 0);
@@ -409,7 +409,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             } else if (seeded) {
                 PL_CHECK(sg_cluster_knn_seeded(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
                                                dd + o.cl_seg_off, dd + o.order, dd + o.dst, sc->d_seg_off, pl->seg_chunk_off.p, pl->segbox.p,
-                                               pl->chunk_box.p, pl->slot_of_pos.p, pl->knn_seed.p, dd + o.seg_prevcl, pl->members.p,
+                                               pl->chunk_box.p, pl->slot_of_pos.p, pl->knn_seed.p, dd + o.seg_prevcl, pl->seed_id.p,
                                                pl->point_rec.p, 20, pos0, pl->knn.p, stv));
             } else {
                 PL_CHECK(sg_cluster_knn_sorted_w(pl->xyzw.p, pl->smpos.p, N, dd + o.cl_pt_off, dd + o.tile_cl, dd + o.tile_lo, dd + o.tile_hi, T,
@@ -417,7 +417,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                                                  pl->chunk_box.p, pl->slot_of_pos.p, 20, pos0, waves_per_tile, pl->knn.p, stv));
             }
             if (layer == 0) {                              // the next kNN layer may start from this table
-                PL_CHECK(sg_knn_seed_points(pl->knn.p, pl->members.p, N, 20, pl->knn_seed.p, stv));
+                PL_CHECK(sg_knn_seed_points(pl->knn.p, pl->seed_id.p, N, 20, pl->knn_seed.p, stv));
                 have_seed = true;
             }
             pl->mark(sb + 2);

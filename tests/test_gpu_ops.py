@@ -534,10 +534,22 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         hip.check(lib.sg_layer_layout(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S,
                                       d["order"].data_ptr(), d["dst"].data_ptr(), d_cls.data_ptr(), d_mean.data_ptr(), lay["members"].data_ptr(),
                                       lay["pop"].data_ptr(), lay["cop"].data_ptr(), lay["sop"].data_ptr(), lay["x9m"].data_ptr(),
-                                      lay["sx"].data_ptr(), lay["sm"].data_ptr(), lay["rec"].data_ptr(), None))
+                                      lay["sx"].data_ptr(), lay["sm"].data_ptr(), lay["rec"].data_ptr(), None, None))
         assert np.array_equal(lay["members"].cpu().numpy(), members) and np.array_equal(lay["pop"].cpu().numpy(), pos_of_point)
         rec = lay["rec"].cpu().numpy()                          # by point id: xyz + the bits of the point's member position
         assert np.array_equal(rec[:, :3], d_data.cpu().numpy()[:, :3]) and np.array_equal(rec[:, 3].copy().view(np.int32), pos_of_point.astype(np.int32))
+        # with seed ids: id of a point = its place in the Morton-sorted CSR of the over-segmentation (the same in every layer);
+        # the records are indexed by it
+        sid = torch.full((N,), -1, dtype=torch.int32, device="cuda:0")
+        rec2 = torch.zeros(N, 4, device="cuda:0")
+        hip.check(lib.sg_layer_layout(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S,
+                                      d["order"].data_ptr(), d["dst"].data_ptr(), d_cls.data_ptr(), d_mean.data_ptr(), lay["members"].data_ptr(),
+                                      lay["pop"].data_ptr(), lay["cop"].data_ptr(), lay["sop"].data_ptr(), lay["x9m"].data_ptr(),
+                                      lay["sx"].data_ptr(), lay["sm"].data_ptr(), rec2.data_ptr(), sid.data_ptr(), None))
+        sid_np, rec2_np = sid.cpu().numpy(), rec2.cpu().numpy()
+        sorted_pts = segorder[sperm.cpu().numpy()]                # seed id -> point id
+        assert sorted(sid_np.tolist()) == list(range(N)) and np.array_equal(sorted_pts[sid_np], members)
+        assert np.array_equal(rec2_np[:, :3], sc.data[sorted_pts, :3]) and np.array_equal(rec2_np[:, 3].copy().view(np.int32), pos_of_point[sorted_pts].astype(np.int32))
         assert np.array_equal(lay["cop"].cpu().numpy(), np.repeat(np.arange(L.count), np.diff(off)))
         assert np.array_equal(lay["sop"].cpu().numpy(), slot_of_pos)
         assert torch.equal(lay["x9m"], x9m) and torch.equal(lay["sx"], sxyzw) and torch.equal(lay["sm"], smpos)
