@@ -81,6 +81,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 enum { S1X = 1, S2X = 2 };     // conv1 statistics + extremum (MLP2) | conv1' -> conv2 statistics + extremum (MLP3)
 
 constexpr int kWaves = sg::kEdgeWaves;
+constexpr int kStagger1 = 0, kStagger2 = 0;    // defaults of the start offset between the two waves of a SIMD (see edgeconv_body)
 
 
 __device__ inline int acc_channel(int tile, int reg, int half) { return 32 * tile + (reg & 3) + 8 * (reg >> 2) + 4 * half; }
@@ -108,7 +109,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                                               sg::gptr<const u32x4> w2img, sg::gptr<const float> scales,
                                               sg::gptr<const float> gamma_last,
                                               sg::gptr<float> ext, sg::gptr<double> partial, int bid,
-                                              sg::gptr<const int32_t> cluster_of_pos = nullptr, int ext_stride = 64) {
+                                              sg::gptr<const int32_t> cluster_of_pos = nullptr, int ext_stride = 64, int stagger = 0) {
     using sg::gptr;
     __shared__ Lds lds;
     constexpr bool kTwo = MODE == S2X;
@@ -160,6 +161,13 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     for (int i = tid; i < kWaves * 128; i += 64 * kWaves) (&lds.acc[0][0])[i] = 0.0;
     __syncthreads();
 
+    // Two waves share a SIMD (different workgroups, started together, running the same loop): they fall into lockstep -- both in
+    // their MFMA phase, then both in their VALU phase -- and the matrix pipe idles while both cut operands and add statistics.  The
+    // wave in the odd slot of its SIMD (HW_ID.wave_id) starts `stagger` x 64 cycles late, about half a neighbour slot, so that one
+    // wave's MFMA phase meets the other's VALU phase.
+    if (stagger > 0 && (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1)) {
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     const int tile = bid * kWaves + wave;
     const int pt = tile * 32 + r;
     const bool valid = pt < N;
@@ -288,10 +296,16 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                     }
             } else {
                 // LeakyReLU(BN1(.)) in place -> B operand of conv2
+                // (the 0.2 x as v_pk_mul_f32, two values per issue slot: every VALU instruction costs a SIMD ~4 cycles whatever it does,
+                // tools/micro/issue_rates.hip, and this kernel is bound by its instruction count)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc1[t][q] = fmaxf(acc1[t][q], 0.2f * acc1[t][q]);
+                    for (int q = 0; q < 16; q += 2) {
+                        const f32x2 v = {acc1[t][q], acc1[t][q + 1]};
+                        const f32x2 w = v * f32x2{0.2f, 0.2f};
+                        acc1[t][q] = fmaxf(v.x, w.x); acc1[t][q + 1] = fmaxf(v.y, w.y);
+                    }
                 // conv2 on the fp16 matrix pipe (see the header): per 16-deep k block the 8 accumulator registers of this lane are cut
                 // into two fp16 pieces each (round-to-nearest: v_cvt_pk_f16_f32) and meet the pre-split weights in three MFMAs per
                 // output tile; the two output tiles are independent accumulator chains, interleaved
@@ -441,18 +455,18 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv(const floa
 // S1X: the scene's MLP2 weights as they are; S2X: its folded conv1 (ec_w1f, ec_sh1) + the raw conv2
 // the engine's launches: E goes straight into the clusters' maxima (kFused above), c.pf is not written
 template <int MODE, bool REREAD_A>
-__global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx) {
+__global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx, int stagger) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.ec_blocks) return;
     // pointers read out of a SlotCtx are generic to the compiler (sg_common.h, gptr): hand them over as global memory
     using sg::as_global;
     if (MODE == S1X) edgeconv_body<MODE, REREAD_A, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global(c.ec_w1), nullptr, nullptr, nullptr,
                                                          as_global(c.ec_g1), as_global(c.cat + c.gm_D), as_global(c.ec_partial), blockIdx.x,
-                                                         as_global(c.cluster_of_pos), c.Dcat);
+                                                         as_global(c.cluster_of_pos), c.Dcat, stagger);
     else edgeconv_body<MODE, REREAD_A, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global((const float*)c.ec_w1f),
                                              as_global((const float*)c.ec_sh1), as_global(reinterpret_cast<const u32x4*>(c.ec_w2img)),
                                              as_global((const float*)c.ec_scale), as_global(c.ec_g2), as_global(c.cat + c.gm_D),
-                                             as_global(c.ec_partial), blockIdx.x, as_global(c.cluster_of_pos), c.Dcat);
+                                             as_global(c.ec_partial), blockIdx.x, as_global(c.cluster_of_pos), c.Dcat, stagger);
 }
 // ... and the activation on the [C,64] maxima, in place, once the fold of the layer's last BatchNorm is known
 __global__ __launch_bounds__(256) void k_cluster_affine_b(const sg::SlotCtx* __restrict__ cx, int layers) {
@@ -834,9 +848,12 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
     if (bd.nslots == 0 || bd.max_N == 0) return SG_OK;
     const int nblocks = sg::cdiv(sg::cdiv(bd.max_N, 32), kWaves);
     const dim3 grid(nblocks, bd.nslots), one(1, bd.nslots);
+    // development knobs: SG_EC_STAGGER1 / SG_EC_STAGGER2 = start offset of the odd wave slot in units of 64 cycles
+    static const int stagger1 = getenv("SG_EC_STAGGER1") ? atoi(getenv("SG_EC_STAGGER1")) : kStagger1;
+    static const int stagger2 = getenv("SG_EC_STAGGER2") ? atoi(getenv("SG_EC_STAGGER2")) : kStagger2;
     if (layers == 1) {
         if (mark) mark(mark_arg, 2);                                  // 2 / 3: in front of / behind the EdgeConv launch itself
-        k_edgeconv_b<S1X, false><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
+        k_edgeconv_b<S1X, false><<<grid, 64 * kWaves, 0, st>>>(d_ctx, stagger1);
         if (mark) mark(mark_arg, 3);
         k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 1);
         k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 1);
@@ -845,7 +862,7 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
         k_edge_moments_b<<<dim3(sg::cdiv(bd.max_N, 256), bd.nslots), 256, 0, st>>>(d_ctx);
         k_bn_fold_moments_b<<<one, 1024, 0, st>>>(d_ctx);
         if (mark) mark(mark_arg, 0);
-        k_edgeconv_b<S2X, true><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
+        k_edgeconv_b<S2X, true><<<grid, 64 * kWaves, 0, st>>>(d_ctx, stagger2);
         if (mark) mark(mark_arg, 3);
         k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 2);
         k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 2);
