@@ -460,10 +460,15 @@ def main(argv=None):
                     t1 = time.perf_counter()
                     sub = scenes[:min(len(scenes), 64)]          # a bounded sample: txt is ~7 MB per scene
                     dirs = [os.path.join(td, sc_.name) for sc_ in sub]
-                    for _ in range(2):
-                        runner.run(sub, hip.MODE_INS_INFER, writer=writer, out_dirs=dirs, formats=fmts)
+                    reps_f, pend_f = 4, []
+                    for _ in range(reps_f):                        # queued two ahead like the timed loop; the files of a pass overwrite the last
+                        pend_f.append(runner.submit(sub, hip.MODE_INS_INFER, writer=writer, out_dirs=dirs, formats=fmts))
+                        if len(pend_f) > 2:
+                            runner.wait(pend_f.pop(0))
+                    while pend_f:
+                        runner.wait(pend_f.pop(0))
                     writer.flush()
-                    with_files["+".join(fmts)] = round(2 * len(sub) / (time.perf_counter() - t1), 3)
+                    with_files["+".join(fmts)] = round(reps_f * len(sub) / (time.perf_counter() - t1), 3)
             with_files["filesystem"] = "tempfile.gettempdir() = %s" % tempfile.gettempdir()
             writer.close()
 

@@ -490,6 +490,12 @@ int sg_write_label_npy(const char* path, const int32_t* h_vec, int V);
 typedef struct sg_writer sg_writer;
 sg_writer* sg_writer_create(int threads, int max_queue);
 int  sg_writer_submit(sg_writer* w, const char* path_without_ext, const int32_t* h_vec, int V, int formats);
+/* A whole scene BY REFERENCE (model.py:533-547: the 14 files of one export directory): h_labels = nvec vectors of V values, stride V,
+ * written as <out_dir>/<layer_1.seg ... final.sem>.{txt,npy} by one worker (openat on the directory's descriptor, writev).  Nothing is
+ * copied: the buffer must stay untouched until sg_writer_wait_tag(w, tag) or sg_writer_flush returned.  tag >= 0, ascending over time
+ * (the engine passes its ticket number); sg_writer_wait_tag blocks until every scene with a tag <= `tag` is on disk. */
+int  sg_writer_submit_scene(sg_writer* w, const char* out_dir, const int32_t* h_labels, int V, int nvec, int formats, long long tag);
+int  sg_writer_wait_tag(sg_writer* w, long long tag);
 int  sg_writer_flush(sg_writer* w);
 void sg_writer_destroy(sg_writer* w);
 

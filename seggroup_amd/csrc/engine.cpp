@@ -153,7 +153,7 @@ struct sg_engine {
             (void)hipEventRecord(ev[n_ev], stream);
             ev_stage[n_ev++] = stage;
         }
-        int superstep(Run* r, int n, int mode, sg_writer* writer, int formats);
+        int superstep(Run* r, int n, int mode, sg_writer* writer, int formats, long long tag);
         int phase_p0(Run* r, int n, int mode);
         int phase_layer(Run* r, int n, int layer);
         int phase_end(Run* r, int n, int mode);
@@ -631,7 +631,7 @@ void sg_engine::Group::collect_times(int n) {
     eng->scenes_timed += n;
 }
 
-int sg_engine::Group::superstep(Run* r, int n, int mode, sg_writer* writer, int formats) {
+int sg_engine::Group::superstep(Run* r, int n, int mode, sg_writer* writer, int formats, long long tag) {
     n_ev = 0;
     int rc = phase_p0(r, n, mode);
     if (rc >= 0) collect_times(0);                               // phases are timed one by one: the event pool is small
@@ -647,10 +647,8 @@ int sg_engine::Group::superstep(Run* r, int n, int mode, sg_writer* writer, int 
         const int nvec = mode == SG_MODE_INS_INFER ? SG_NUM_LABEL_VECTORS : 6;
         for (int i = 0; i < n && rc >= 0; ++i) {
             if (!r[i].out_dir) continue;
-            for (int v = 0; v < nvec && rc >= 0; ++v) {
-                const std::string base = std::string(r[i].out_dir) + "/" + kLabelNames[v];
-                rc = sg_writer_submit(writer, base.c_str(), r[i].out->h_labels + (size_t)v * r[i].sc->V, r[i].sc->V, formats);
-            }
+            // by reference: the vectors stay in the caller's buffer, which the caller reuses only behind sg_writer_wait_tag(ticket)
+            rc = sg_writer_submit_scene(writer, r[i].out_dir, r[i].out->h_labels, r[i].sc->V, nvec, formats, tag);
         }
     }
     for (int i = 0; i < n; ++i) {
@@ -711,7 +709,7 @@ void sg_engine::Group::loop() {
                               sc->E0, sc->V, eng->maxN, eng->maxS, eng->maxE, eng->maxV);
             else if (!runs[i].out->h_labels) rc = sg::fail(SG_EINVAL, "sg_engine: results[%d].h_labels is null", first + i);
         }
-        if (rc >= 0) rc = superstep(runs.data(), take, job->mode, job->writer, job->formats);
+        if (rc >= 0) rc = superstep(runs.data(), take, job->mode, job->writer, job->formats, job->id);
         if (g_profile) { eng->ns_step += now_ns() - t_step; eng->ns_sync += tl_ns_sync; ++eng->n_steps; eng->n_step_scenes += take; }
         {
             std::lock_guard<std::mutex> lk(eng->mu);

@@ -171,6 +171,8 @@ SIGNATURES = {
     "sg_write_label_npy": (_I, [C.c_char_p, vp, _I]),
     "sg_writer_create": (vp, [_I, _I]),
     "sg_writer_submit": (_I, [vp, C.c_char_p, vp, _I, _I]),
+    "sg_writer_submit_scene": (_I, [vp, C.c_char_p, vp, _I, _I, _I, C.c_longlong]),
+    "sg_writer_wait_tag": (_I, [vp, C.c_longlong]),
     "sg_writer_flush": (_I, [vp]),
     "sg_writer_destroy": (None, [vp]),
 }

@@ -221,6 +221,7 @@ class Engine:
         self.lib.sg_engine_set_timing(self.handle, int(timing))
         self.ring = 3
         self._labels = [None] * self.ring
+        self._slot_writer = [None] * self.ring            # (writer, ticket id) of the files still being written out of a ring slot
         self._turn = 0
         self._names = [self.lib.sg_pipeline_stage_name(i).decode() for i in range(32) if self.lib.sg_pipeline_stage_name(i)]
 
@@ -234,10 +235,12 @@ class Engine:
             raise ValueError("Engine.submit: a scene exceeds the capacities this engine was created with")
         slot = self._turn
         self._turn = (self._turn + 1) % self.ring
+        self._release_slot(slot)                          # the writer pool reads the label vectors in place (sg_writer_submit_scene)
         if self._labels[slot] is None or self._labels[slot].shape[0] < n:
             # pinning hundreds of MB takes ~0.1 s: every ring slot is (re)sized at once, not one per submit
             for k in range(self.ring):
                 if self._labels[k] is None or self._labels[k].shape[0] < n:
+                    self._release_slot(k)
                     self._labels[k] = torch.empty((max(n, 1), hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32).pin_memory()
         buf = self._labels[slot]
         c_scenes = (hip.Scene * n)(*[s.c_struct for s in scenes])
@@ -254,7 +257,18 @@ class Engine:
         with torch.cuda.device(self.device):
             tid = self.lib.sg_engine_submit(self.handle, c_scenes, n, mode, c_res, wh, c_dirs, fm)
         hip.check(tid)
+        if wh is not None:
+            self._slot_writer[slot] = (writer, tid)
         return Ticket(tid, list(scenes), c_scenes, c_res, c_dirs, buf, mode)
+
+    def _release_slot(self, slot: int) -> None:
+        """Block until the writer pool has written the files whose label vectors still sit in ring slot `slot`."""
+        pending = self._slot_writer[slot]
+        if pending is not None:
+            w, tid = pending
+            if getattr(w, "handle", None):
+                hip.check(self.lib.sg_writer_wait_tag(w.handle, tid))
+            self._slot_writer[slot] = None
 
     def wait(self, t: Ticket) -> List[SceneResult]:
         hip.check(self.lib.sg_engine_wait(self.handle, t.id))
@@ -295,6 +309,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "handle", None):
+            for k in range(self.ring):                    # the label buffers die with this object: the writers must be done with them
+                self._release_slot(k)
             self.lib.sg_engine_destroy(self.handle)
             self.handle = None
 
