@@ -60,7 +60,11 @@ CONV1_MFMAS_PER_SLOT = 8
 CONV1_EXEC_FLOP_PER_ROW = CONV1_MFMAS_PER_SLOT * 2 * 32 * 32 * 16 // 32
 S1X_EXECUTED_FLOP_PER_ROW = CONV1_EXEC_FLOP_PER_ROW
 S2X_EXECUTED_FLOP_PER_ROW = 3 * 2 * 64 * 64 + CONV1_EXEC_FLOP_PER_ROW
-VALU_PEAK_GINST = 1024 * 2.4 / 2.0   # wave64 VALU instructions/ns: 1024 SIMD-32s, 2 cycles per wave64 op, 2.4 GHz
+# VALU issue roof, MEASURED (tools/micro/issue_rates.hip, 8 waves per SIMD, every SIMD busy): one wave64 instruction costs a SIMD 1.96-2.07 ns
+# for v_max_f32 / v_max_f64 / v_cvt_pk_f16_f32 / v_pk_fma_f32 alike (1.37 ns for v_fma_f32) -- about four cycles at the clock the chip
+# sustains, not the two of the SIMD-32 data path (round 2 priced the kNN against 1,229 G instructions/s).  1024 SIMDs / 2.0 ns:
+VALU_ISSUE_NS = 2.0
+VALU_PEAK_GINST = 1024 / VALU_ISSUE_NS
 PROFILE_TAG = "r03"
 DTYPE = "f32 (fp32 accumulate; operands split 3 x bf16 / 2 x fp16 on v_mfma_f32_32x32x16; kNN / FPS scores in exact fp32 order)"
 
@@ -85,7 +89,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=80, help="timed steps (80 x 64 scenes: a timed region of > 2 s)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each: `value` is the FIRST (the contract's K steps), "
                                                             "the others are reported as repeat_values (run-to-run spread)")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps in front of the timed region (clocks and caches settle over the first ~0.2 s)")
     ap.add_argument("--batch", type=int, default=64, help="distinct scenes per GPU per step (BASELINE.json configs[2]: 64)")
     ap.add_argument("--scenes-total", type=int, default=0,
                     help="strong scaling: ONE set of this many scenes sharded i mod W over the ranks (configs[3]: 1201); "
@@ -439,7 +443,9 @@ def main(argv=None):
         if vi and solo_b.get("k_cluster_knn_sorted", 0) > 0:
             ms2 = 2.0 * solo_b["k_cluster_knn_sorted"]                                             # both launches of a scene
             hb = pmc.get("hbm_bytes_per_scene_launch", {}) or {}
-            roofline["knn_valu"] = {"valu_insts_per_scene": vi, "peak_ginst_per_s": VALU_PEAK_GINST, "ms_per_scene_both_launches_solo_batched": round(ms2, 4),
+            roofline["knn_valu"] = {"valu_insts_per_scene": vi, "peak_ginst_per_s": VALU_PEAK_GINST,
+                                    "peak_basis": "measured issue cost of a wave64 VALU instruction per SIMD with 8 waves per SIMD: ~2.0 ns (tools/micro/issue_rates.hip)",
+                                    "ms_per_scene_both_launches_solo_batched": round(ms2, 4),
                                     "valu_frac": round(vi / (ms2 * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
                                     "hbm_bytes_per_scene_launch": {k_: hb.get(k_) for k_ in ("k_cluster_knn_sorted<unseeded>", "k_cluster_knn_sorted<seeded>")},
                                     "algorithmic_bytes_per_scene_launch": 96.0 * args.points,

@@ -321,26 +321,27 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                 // (0x8 = MFMA, 0x2 = VALU).  (Pipelining further -- the next slot's conv1 under this slot's statistics, the d split
                 // under the last k block -- needs both accumulators live across the loop edge: 100-300 B of scratch per lane at
                 // 2 waves/SIMD, and 1 wave/SIMD is 1.5x slower; measured, not kept.)
-                unsigned int q1[4], q2[4];
-                auto split_block = [&](int kb, unsigned int (&o1)[4], unsigned int (&o2)[4]) {
+                // ALL of the operand's pieces first (one VALU phase), then the 24 MFMAs back to back (one matrix phase): with the cut of block
+                // kb + 1 interleaved into block kb's MFMAs (round 2) the two waves of a SIMD were both in mixed MFMA / VALU streams all the
+                // time and the matrix pipe sat half idle; pure phases let one wave's VALU phase run beside the other's MFMA burst -- the way
+                // the statistics behind the last MFMA always did (leaving them out changed nothing, leaving the cut out saved 14 %).
+                unsigned int xh[4][4], xl[4][4];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const f32x2 v = {acc1[kb >> 1][8 * (kb & 1) + 2 * jj], acc1[kb >> 1][8 * (kb & 1) + 2 * jj + 1]};
                         const f16x2 hi = __builtin_convertvector(v, f16x2);
                         const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);     // v - hi is exact in fp32
-                        o1[jj] = __builtin_bit_cast(unsigned int, hi);
-                        o2[jj] = __builtin_bit_cast(unsigned int, lo);
+                        xh[kb][jj] = __builtin_bit_cast(unsigned int, hi);
+                        xl[kb][jj] = __builtin_bit_cast(unsigned int, lo);
                     }
-                };
-                split_block(0, q1, q2);
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
-                    const f16x8 x1 = __builtin_bit_cast(f16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
-                    const f16x8 x2 = __builtin_bit_cast(f16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+                    const f16x8 x1 = __builtin_bit_cast(f16x8, u32x4{xh[kb][0], xh[kb][1], xh[kb][2], xh[kb][3]});
+                    const f16x8 x2 = __builtin_bit_cast(f16x8, u32x4{xl[kb][0], xl[kb][1], xl[kb][2], xl[kb][3]});
                     const f16x8 wa1 = __builtin_bit_cast(f16x8, lds.a2h[0][0][kb][lane]), wb1 = __builtin_bit_cast(f16x8, lds.a2h[0][1][kb][lane]);
                     const f16x8 wa2 = __builtin_bit_cast(f16x8, lds.a2h[1][0][kb][lane]), wb2 = __builtin_bit_cast(f16x8, lds.a2h[1][1][kb][lane]);
-                    unsigned int n1[4], n2[4];
-                    if (kb < 3) split_block(kb + 1, n1, n2);
                     // smallest terms first
                     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa2, x1, acc2[0], 0, 0, 0);
                     acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb2, x1, acc2[1], 0, 0, 0);
@@ -348,15 +349,6 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                     acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb1, x2, acc2[1], 0, 0, 0);
                     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, x1, acc2[0], 0, 0, 0);
                     acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb1, x1, acc2[1], 0, 0, 0);
-                    if (kb < 3) {
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) { q1[jj] = n1[jj]; q2[jj] = n2[jj]; }
-                    }
                 }
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot)

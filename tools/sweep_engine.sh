@@ -1,16 +1,12 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: bench throughput for several engine shapes (groups x scenes per batched launch)
+# Runs ON THE GPU BOX: scenes/s of the bench for a few engine shapes (groups x scenes per batched launch); scenes come from a cache filled once
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for gb in "$@"; do
-  g=${gb%x*}; b=${gb#*x}
-  SG_ENGINE_PROFILE=1 timeout 300 python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-files --no-extras --groups $g --per-group $b > /tmp/o.json 2> /tmp/o.err
-  python3 - <<PY
-import json
-try:
-    d=json.load(open('/tmp/o.json'))
-    print("$gb", d['value'], 'scenes/s', d.get('engine_profile'), {k:round(v,3) for k,v in d['roofline']['stage_ms'].items() if k in ('l2.knn','l3.knn','l2.edgeconv','l3.edgeconv','evaluate','mlp1','fps64')})
-except Exception as e:
-    print("$gb", 'failed', e)
-PY
-  grep "engine profile" /tmp/o.err | tail -1
+export SG_SCENE_CACHE=/tmp/sg_scenes
+cd $R
+python3 bench.py --generate-only --no-extras --scene-cache $SG_SCENE_CACHE 2>&1 | tail -1
+for shape in ${@:-"8 8" "10 8" "12 8" "8 12" "6 12" "16 4" "12 6"}; do
+  set -- $shape
+  python3 bench.py --groups $1 --per-group $2 --steps 40 --repeats 2 --no-extras --no-files --no-cpu-baseline --parity-scenes 8 --scene-cache $SG_SCENE_CACHE 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1 x $2', d['repeat_values']['scenes_per_s'], d['engine_profile'])"
 done
