@@ -1,4 +1,4 @@
 export SG_SCENE_CACHE=/tmp/sg_scenes
 python3 bench.py --generate-only --no-extras --batch 16 --scene-cache $SG_SCENE_CACHE 2>&1 | tail -1
-for s2 in 0 4 8 12 16 24; do SG_EC_STAGGER2=$s2 python3 tools/time_engine.py --tag s2=$s2 --rounds 3 2>/dev/null | tail -1 | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['tag'], 'S2X', d['us_per_scene']['kernel.l3.edgeconv'], 'S1X', d['us_per_scene']['kernel.l2.edgeconv'])"; done
+python3 tools/time_engine.py --tag ${1:-x} --rounds 3 2>/dev/null | tail -1 | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['tag'], {k: d['us_per_scene'][k] for k in ('l2.knn','l3.knn','kernel.l2.edgeconv','kernel.l3.edgeconv','mlp1','fps64')})"

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Work counters of the in-cluster kNN kernels (profiling build only: make -C seggroup_amd/csrc PROFILE=1, SG_KNN_DEBUG=32):
+tiles, chunk box tests, chunks scanned, segment tests, keys appended, drain steps -- per scene, for the unseeded pair of layers
+(variant 1) and the default (layer 3 seeded)."""
+import ctypes as C
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("SG_KNN_DEBUG", "48")
+import torch  # noqa: E402
+from seggroup_amd import hip, synthetic, weights  # noqa: E402
+from seggroup_amd.model import Pipeline  # noqa: E402
+from seggroup_amd.scene import DeviceScene  # noqa: E402
+lib = hip.lib()
+if not hasattr(lib, "sg_debug_knn5_stats"):
+    raise SystemExit("release build: make -C seggroup_amd/csrc clean && make -C seggroup_amd/csrc PROFILE=1")
+W = weights.load_npz(os.path.join(ROOT, "tests/golden/weights_g2.npz"))
+sc = synthetic.make_scene(150000, 1500, 30000)
+ds = DeviceScene.from_synthetic(sc, "cuda:0")
+pl = Pipeline(W, ds.N, ds.S, ds.E0, ds.V, device="cuda:0")
+buf = (C.c_ulonglong * 16)()
+for variant, what in ((1, "both layers unseeded"), (8, "layer 2 unseeded + layer 3 seeded")):
+    pl.lib.sg_pipeline_set_knn_variant(pl.handle, variant)
+    pl.forward(ds, hip.MODE_INS_INFER)
+    lib.sg_debug_knn5_stats(buf)
+    res = pl.forward(ds, hip.MODE_INS_INFER)
+    torch.cuda.synchronize()
+    lib.sg_debug_knn5_stats(buf)
+    v = list(buf)
+    t = max(v[0], 1)
+    print(f"{what}: tiles {v[0]} | per tile: chunk tests {v[6] / t:.1f}, chunks scanned {v[5] / t:.1f} (= {32 * v[5] / t:.0f} candidates), segment tests {v[7] / t:.1f}, "
+          f"keys appended per lane {v[8] / t / 64:.1f}, drain steps {v[9] / t:.1f} | cycles per tile: phase A {v[1] / t:.0f}, B {v[3] / t:.0f}, out {v[4] / t:.0f}; trace {res.trace}")
