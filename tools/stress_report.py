@@ -56,10 +56,11 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 out = []
 with open(os.path.join(P, f"{tag}_stress_500k_kernel_stats.csv"), "w") as o:
     o.write(f"# python tools/time_scene.py {N} {S}: one scene at a time through sg_pipeline_forward, {iters} forwards\n")
-    o.write("kernel,calls,total_ms,avg_us,min_us,max_us,pct\n")
+    w = csv.writer(o)
+    w.writerow(["kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct"])
     for r in rows:
-        o.write("%s,%s,%.3f,%.2f,%.2f,%.2f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
-                                                 float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+        w.writerow([short(r["Name"]), r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6), "%.2f" % (float(r["AverageNs"]) / 1e3),
+                    "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3), r["Percentage"]])
 for r in rows:
     k = short(r["Name"])
     us = float(r["AverageNs"]) / 1e3

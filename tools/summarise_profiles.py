@@ -35,10 +35,11 @@ def stats(src_dir, dst, title):
     rows = list(csv.DictReader(open(fs[0])))
     with open(os.path.join(P, dst), "w") as o:
         o.write(f"# {title}\n# source: rocprofv3 --kernel-trace --stats ({os.path.basename(fs[0])})\n")
-        o.write("kernel,calls,total_ms,avg_us,min_us,max_us,pct\n")
+        w = csv.writer(o)                                      # kernel names carry commas (template arguments): quoted
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct"])
         for r in rows:
-            o.write("%s,%s,%.3f,%.2f,%.2f,%.2f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
-                                                     float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+            w.writerow([short(r["Name"]), r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6), "%.2f" % (float(r["AverageNs"]) / 1e3),
+                        "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3), r["Percentage"]])
     return {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
 
 
