@@ -48,6 +48,9 @@ int  sg_device_count(void);
 /* device self-test of the DPP wave reductions the structural-layer kernels use (csrc/wave_ops.h) against the ds_bpermute
  * butterflies they replace; *h_mismatches = 0 on a healthy build.  Synchronises the stream. */
 int  sg_selftest_wave_ops(int* h_mismatches, void* stream);
+/* device self-test: the kNN's top-K list in double form (v_min_f64 / v_max_f64 insertion) against the 64-bit integer form, ties, signed
+ * zeros, tiny positive scores and the empty key included; *h_mismatches = 0 when they agree */
+int  sg_selftest_list_insert(int* h_mismatches, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a3  update_adj, first call (model.py:291-302 with model.py:724-733): contract the point-level

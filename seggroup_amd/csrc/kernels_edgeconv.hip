@@ -490,7 +490,7 @@ constexpr int kMom = 189;
 
 __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                                   double* __restrict__ partial, int bid) {
-    __shared__ double red[4][kMom];
+    __shared__ double red[16][kMom];                            // one partial per 16-lane row (4 waves x 4 rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pt = bid * 256 + tid;
     const bool valid = pt < N;
@@ -538,11 +538,16 @@ __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m,
         xi[0] -= cx; xi[1] -= cy; xi[2] -= cz;                   // d is done with the raw coordinates; the x_i terms are centred
     }
     const float Kf = valid ? (float)K : 0.f;
-    // wave sums in fp32 over a fixed DPP network (as the MFMA statistics passes do), then doubles: the four waves
-    // in fixed order, the blocks in fixed order in k_bn_fold_moments
+    // 189 sums per wave: fp32 over the 16 lanes of a row on a fixed DPP network (four steps: every lane of the row ends up with the row's
+    // sum), then doubles -- the block's 16 rows in fixed order below, the blocks in fixed order in k_bn_fold_moments.  (Round 2 carried every
+    // sum on to lane 63 and read it back: two more DPP steps and a v_readlane per value, a sixth of this kernel's instructions.)
+    const int row16 = tid >> 4;
     auto wsum = [&](float v, int slot) {
-        const float s = sgw::wave_sum(v);                           // DPP network (wave_ops.h): 189 sums per wave, no LDS round trips
-        if (lane == 0) red[wave][slot] = (double)s;
+        v += sgw::dpp_f<sgw::kQuadXor1>(v, v);
+        v += sgw::dpp_f<sgw::kQuadXor2>(v, v);
+        v += sgw::dpp_f<sgw::kRowRor4>(v, v);
+        v += sgw::dpp_f<sgw::kRowRor8>(v, v);
+        if ((lane & 15) == 0) red[row16][slot] = (double)v;
     };
     int t = 0;
 #pragma unroll
@@ -560,7 +565,12 @@ __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m,
 #pragma unroll
         for (int l = k; l < 9; ++l) { wsum(Kf * xi[k] * xi[l], 144 + t); ++t; }
     __syncthreads();
-    if (tid < kMom) partial[(size_t)bid * kMom + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    if (tid < kMom) {
+        double t16 = red[0][tid];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t16 += red[i][tid];
+        partial[(size_t)bid * kMom + tid] = t16;
+    }
 }
 __global__ __launch_bounds__(256) void k_edge_moments(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                                       double* __restrict__ partial) {

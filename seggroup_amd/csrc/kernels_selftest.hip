@@ -1,4 +1,5 @@
 // Device self-test of the DPP wave reductions (wave_ops.h) against the ds_bpermute butterflies they replace.
+#include "knn_device.h"
 #include "sg_common.h"
 #include "wave_ops.h"
 
@@ -51,7 +52,61 @@ __global__ __launch_bounds__(64) void k_selftest_wave_ops(int* __restrict__ mism
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// The top-K list in double form (knn_device.h: list_insert with v_min_f64 / v_max_f64) against the integer form it replaced
+// (key_insert: one 64-bit compare and four selects per slot): 64 lanes x 512 blocks, 300 keys each -- scores drawn from a handful of
+// values (many exact ties, decided by the index), negative / zero / tiny positive scores, the empty key.
+__global__ __launch_bounds__(64) void k_selftest_list_insert(int* __restrict__ mismatches) {
+    using namespace sgknn;
+    constexpr int K = 20;
+    unsigned long long ki[K];
+    double kd[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { ki[j] = 0ull; kd[j] = list_empty(); }
+    int bad = 0;
+    unsigned int r = mix(blockIdx.x * 64u + threadIdx.x + 12345u);
+    for (int i = 0; i < 300; ++i) {
+        r = mix(r + i);
+        float sc;
+        switch (r & 7) {
+            case 0: sc = -(float)((r >> 8) & 7) * 0.125f; break;                 // eight values: ties
+            case 1: sc = __uint_as_float(0x33000000u | ((r >> 9) & 0xffu)); break;    // tiny positive (the expanded score of a coincident pair)
+            case 2: sc = -0.f; break;
+            default: sc = -__uint_as_float(0x3a000000u + ((r >> 5) & 0x03ffffffu)); break;
+        }
+        const int idx = (int)((r >> 11) % (unsigned)kListMaxPoints);
+        const unsigned long long key = (r & 0x700u) == 0x700u ? 0ull : make_key(sc, idx);
+        key_insert<K>(ki, key);
+        list_insert<K>(kd, key);
+        if ((i & 15) == 15) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const bool empty = ki[j] == 0ull;
+                bad += empty ? __double_as_longlong(kd[j]) != __double_as_longlong(list_empty())
+                             : (from_list(kd[j]) != ki[j] || list_index(kd[j]) != key_index(ki[j]) || to_list(ki[j]) != kd[j]);
+            }
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace
+
+extern "C" int sg_selftest_list_insert(int* h_mismatches, void* stream) {
+    SG_REQUIRE(h_mismatches, "sg_selftest_list_insert: null argument");
+    int* d = nullptr;
+    SG_HIP(hipMalloc((void**)&d, 4));
+    hipStream_t st = sg::as_stream(stream);
+    hipError_t e = hipMemsetAsync(d, 0, 4, st);
+    if (e == hipSuccess) {
+        k_selftest_list_insert<<<512, 64, 0, st>>>(d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_mismatches, d, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    SG_HIP(e);
+    return SG_OK;
+}
 
 extern "C" int sg_selftest_wave_ops(int* h_mismatches, void* stream) {
     SG_REQUIRE(h_mismatches, "sg_selftest_wave_ops: null argument");

@@ -67,6 +67,7 @@ SIGNATURES = {
     "sg_version": (_I, []),
     "sg_device_count": (_I, []),
     "sg_selftest_wave_ops": (_I, [C.POINTER(C.c_int), vp]),
+    "sg_selftest_list_insert": (_I, [C.POINTER(C.c_int), vp]),
     "sg_contract_ws_bytes": (_Z, [_I]),
     "sg_contract_point_edges": (_I, [vp, _I, vp, _I, _I, vp, _I, vp, vp, _Z, vp]),
     "sg_gather_members": (_I, [vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp]),

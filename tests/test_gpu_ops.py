@@ -734,3 +734,23 @@ def test_dpp_wave_reductions_selftest(env):
     bad = C.c_int(-1)
     hip.check(lib.sg_selftest_wave_ops(C.byref(bad), None))
     assert bad.value == 0
+
+
+def test_list_form_insertion_selftest(env):
+    """csrc/knn_device.h: the top-20 list as doubles of one exponent (two v_min_f64 / v_max_f64 per slot) holds the same keys in the same
+    order as the 64-bit integer list it replaced -- 32k lanes x 300 keys with exact score ties, signed zeros, tiny positive scores, the
+    empty key, indices up to 2^20 - 1."""
+    lib, torch, hip = env
+    bad = C.c_int(-1)
+    hip.check(lib.sg_selftest_list_insert(C.byref(bad), None))
+    assert bad.value == 0
+
+
+def test_knn_refuses_scenes_beyond_the_list_index_bits(env):
+    """The list keys carry 20 index bits: a table for more than 2^20 points must be refused loudly, not computed wrongly."""
+    lib, torch, hip = env
+    z = torch.zeros(64, dtype=torch.int32, device="cuda:0")
+    f = torch.zeros(64, 4, device="cuda:0")
+    with pytest.raises(hip.SgError):
+        hip.check(lib.sg_cluster_knn_sorted(f.data_ptr(), z.data_ptr(), (1 << 20) + 1, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, z.data_ptr(),
+                                            z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), f.data_ptr(), f.data_ptr(), z.data_ptr(), 20, 0, z.data_ptr(), None))

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int mixed_mfma) 
     float a0 = threadIdx.x, a1 = 1.f, a2 = 2.f, a3 = 3.f, a4 = 4.f, a5 = 5.f, a6 = 6.f, a7 = 7.f, b = 1.0001f, c = 0.5f;
     double d0 = threadIdx.x, d1 = 1., d2 = 2., d3 = 3., d4 = 4., d5 = 5., d6 = 6., d7 = 7., e = 2.5;
     unsigned long long p0 = threadIdx.x, p1 = 1, p2 = 2, p3 = 3, p4 = 4, p5 = 5, p6 = 6, p7 = 7;
-    f32x16 acc = {0};
+    f32x16 acc = {0}, acc_b = {0};
     f16x8 fa = {1, 1, 1, 1, 1, 1, 1, 1};
     __shared__ float4 lds[256];
     lds[threadIdx.x] = make_float4(1, 2, 3, 4);
@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int mixed_mfma) 
     const bool do_mfma = mixed_mfma && ((threadIdx.x >> 6) + blockIdx.x) % 2 == 0;      // mixed mode: half of the waves run MFMAs only
     for (int i = 0; i < iters; ++i) {
         if (KIND == 9 || do_mfma) {
-            R8(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fa, acc, 0, 0, 0);)
+            // two independent accumulator chains, kept alive by asm: eight MFMAs per trip
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %2, %0\nv_mfma_f32_32x32x16_f16 %1, %2, %2, %1\nv_mfma_f32_32x32x16_f16 %0, %2, %2, %0\nv_mfma_f32_32x32x16_f16 %1, %2, %2, %1\n"
+                         "v_mfma_f32_32x32x16_f16 %0, %2, %2, %0\nv_mfma_f32_32x32x16_f16 %1, %2, %2, %1\nv_mfma_f32_32x32x16_f16 %0, %2, %2, %0\nv_mfma_f32_32x32x16_f16 %1, %2, %2, %1"
+                         : "+v"(acc), "+v"(acc_b) : "v"(fa));
             continue;
         }
         if (KIND == 0) { asm volatile("v_fma_f32 %0, %0, %8, %9\nv_fma_f32 %1, %1, %8, %9\nv_fma_f32 %2, %2, %8, %9\nv_fma_f32 %3, %3, %8, %9\nv_fma_f32 %4, %4, %8, %9\nv_fma_f32 %5, %5, %8, %9\nv_fma_f32 %6, %6, %8, %9\nv_fma_f32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); }
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int mixed_mfma) 
         if (KIND == 8) { asm volatile("v_fma_mixlo_f16 %0, %8, -1.0, %9 op_sel_hi:[1,0,0]\nv_fma_mixlo_f16 %1, %8, -1.0, %9 op_sel_hi:[1,0,0]\nv_fma_mixlo_f16 %2, %8, -1.0, %9 op_sel_hi:[1,0,0]\nv_fma_mixlo_f16 %3, %8, -1.0, %9 op_sel_hi:[1,0,0]\nv_fma_mixhi_f16 %4, %8, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\nv_fma_mixhi_f16 %5, %8, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\nv_fma_mixhi_f16 %6, %8, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\nv_fma_mixhi_f16 %7, %8, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) + (float)(p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7) +
-                                          acc[0] + l0.x + l1.x + l2.x + l3.x;
+                                          acc[0] + acc_b[1] + l0.x + l1.x + l2.x + l3.x;
 }
 template <int KIND>
 double run(int wps, int iters, int mixed, float* d, int cus) {
