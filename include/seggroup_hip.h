@@ -191,11 +191,14 @@ int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_point
  * d_seed_id (may be NULL): [N] by member position = the point's SEED ID, its place in the Morton-sorted CSR of the
  * over-segmentation (d_seg_off[s] + rank inside segment s): the same in every layer, consecutive for the queries of a kNN tile,
  * close for points that are close in space.  With d_seed_id the records are indexed by seed id (written in order), without by
- * point id.  Seed tables may use either id space -- whatever map the caller hands to sg_knn_seed_points / sg_cluster_knn_seeded. */
+ * point id.  Seed tables may use either id space -- whatever map the caller hands to sg_knn_seed_points / sg_cluster_knn_seeded.
+ * d_range_bits (may be NULL): SG_RANGE_WORDS words, atomically raised to the bits of the largest |centred coordinate| / |feature| laid out
+ * (the atomics are spread over the words; the range is their maximum, and 2 * range bounds every edge difference of the layer): the scale
+ * sg_edgeconv_forward_r cuts conv1's operand with. */
 int sg_layer_layout(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl, const float* d_cl_mean, int32_t* d_members,
                     int32_t* d_pos_of_point, int32_t* d_cluster_of_pos, int32_t* d_slot_of_pos, float* d_x9m, float* d_sxyzw,
-                    int32_t* d_smpos, float* d_point_rec, int32_t* d_seed_id, void* stream);
+                    int32_t* d_smpos, float* d_point_rec, int32_t* d_seed_id, unsigned int* d_range_bits, void* stream);
 int sg_knn_operands(const float* d_data, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, float* d_sxyzw, int32_t* d_smpos, void* stream);
 int sg_cluster_knn_sorted(const float* d_sxyzw, const int32_t* d_smpos, int N, const int32_t* d_cl_off,
@@ -258,6 +261,16 @@ int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, 
                         const float* d_w1, const float* d_g1, const float* d_b1,
                         const float* d_w2, const float* d_g2, const float* d_b2,
                         float* d_out, void* d_ws, size_t ws_bytes, void* stream);
+/* The same with conv1's operand on fp16 pieces scaled by the layer's range (MLP2: 4 instead of 8 MFMAs per neighbour slot, same
+ * accuracy: the pieces keep 22 bits and the scale is a power of two).  d_range_bits: SG_RANGE_WORDS (256) words whose maximum is the bits
+ * of a float R with |x_j - x_i| <= 2 R for every edge and channel -- sg_layer_layout raises them while it writes d_x9m, sg_edge_range
+ * computes one from d_x9m alone (max |x9m[p][c] - x9m[0][c]|; the words must be 0 or smaller bounds before).  The op clears the words when it is done.
+ * NULL = sg_edgeconv_forward.  (MLP3 ignores the range so far and only clears it.) */
+int sg_edgeconv_forward_r(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
+                          const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
+                          size_t ws_bytes, unsigned int* d_range_bits, void* stream);
+#define SG_RANGE_WORDS 256
+int sg_edge_range(const float* d_x9m, int N, unsigned int* d_range_bits, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a14  calculate_similarity + build_similarity_matrix + GCN (model.py:262-265,305-309,141-151):

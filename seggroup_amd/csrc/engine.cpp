@@ -455,7 +455,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
         if (layer == 0) { c.ec_w1 = W + pl->o_m2w; c.ec_g1 = W + pl->o_m2g; c.ec_b1 = W + pl->o_m2b; c.ec_w2 = nullptr; c.ec_g2 = nullptr; c.ec_b2 = nullptr; }
         else { c.ec_w1 = W + pl->o_m3w1; c.ec_g1 = W + pl->o_m3g1; c.ec_b1 = W + pl->o_m3b1; c.ec_w2 = W + pl->o_m3w2; c.ec_g2 = W + pl->o_m3g2; c.ec_b2 = W + pl->o_m3b2; }
         c.ec_partial = r.ec_partial; c.ec_w1f = r.ec_fold; c.ec_sh1 = c.ec_w1f + 64 * 18; c.ec_w2f = c.ec_sh1 + 64; c.ec_sh2 = c.ec_w2f + 64 * 64;
-        c.ec_w2img = c.ec_sh2 + 64; c.ec_scale = c.ec_w2img + 4096;
+        c.ec_w2img = c.ec_sh2 + 64; c.ec_scale = c.ec_w2img + 4096; c.ec_range = pl->ec_range.p;
         c.K = 20;
         c.pf = pl->pf.p; c.ec_blocks = sg::cdiv(sg::cdiv(N, 32), sg::kEdgeWaves); c.ec_mblocks = sg::cdiv(N, 256);
         c.g_wt = W + (layer == 0 ? pl->o_g2t : pl->o_g3t); c.g_dist = r.g_dist; c.g_agg = r.g_agg; c.g_out = pl->featB.p;

@@ -116,6 +116,7 @@ struct SlotCtx {
     float* ec_sh2;
     float* ec_w2img;                   // S2X's conv2 weights, pre-split into fp16 pieces in LDS order (16 KB, k_bn_fold_moments)
     float* ec_scale;                   // {1 / (S T), T, S}: the power-of-two scales of that pass
+    unsigned int* ec_range;            // bits of the largest |centred coordinate| / |feature| of the layer (k_layer_layout writes, the last fold kernel of the layer clears)
     float* pf;                         // [N,64] pre-activation maxima
     int K;                             // neighbours per point (20); a run-time value on purpose: as a literal the moments kernel unrolls all slots
     int ec_blocks;                     // ceil(ceil(N/32)/4)

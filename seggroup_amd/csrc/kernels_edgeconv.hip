@@ -103,18 +103,53 @@ struct Lds {
     double acc[kWaves][128]; // per-wave statistics: [0,64) sum, [64,128) sum of squares
 };
 
-template <int MODE, bool REREAD_A, bool kFused = false>
+__device__ __forceinline__ float pow2_scale(float bound, float target) {      // largest power of two p with p * bound <= target
+    if (!(bound > 0.f) || !(bound < INFINITY)) return 1.f;
+    int e;
+    const float m = frexpf(target / bound, &e);                                // target / bound = m 2^e, m in [0.5, 1)
+    (void)m;
+    return ldexpf(1.f, min(max(e - 1, -40), 40));
+}
+
+// kF16 (MLP2, round 3): conv1's operand d = x_j - x_i on TWO fp16 pieces (round to nearest: hi = rn16(d), lo = rn16(d - hi), three
+// products w_hi d_hi + w_hi d_lo + w_lo d_hi) instead of three bf16 pieces and six products: 27 k-slots = two MFMAs per output tile
+// (4 per neighbour slot instead of 8) and 20 instead of 38 VALU for the cut.  fp16's narrow exponent range is handled with powers of
+// two, which are exact: d is scaled by Sd with 2 Sd * (largest |centred coordinate| / |feature| of the layer: `range_bits`, raised by
+// the layout kernel) <= 2^12 -- every difference inside a cluster is bounded by twice that value, so no piece can overflow; small
+// differences land on fp16 subnormals, which the matrix pipe keeps (absolute error 2^-25 / Sd: 1e-11 of the range) -- and the weights by
+// Sw with max |Sw w| in [2^11, 2^12); 1 / (Sw Sd) is divided out of the statistics and the maxima like S2X's scales.
+template <int MODE, bool REREAD_A, bool kFused = false, bool kF16 = false>
 __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gptr<const int32_t> knn, int N, int K,
                                               sg::gptr<const float> w1, sg::gptr<const float> shift1,
                                               sg::gptr<const u32x4> w2img, sg::gptr<const float> scales,
                                               sg::gptr<const float> gamma_last,
                                               sg::gptr<float> ext, sg::gptr<double> partial, int bid,
-                                              sg::gptr<const int32_t> cluster_of_pos = nullptr, int ext_stride = 64, int stagger = 0) {
+                                              sg::gptr<const int32_t> cluster_of_pos = nullptr, int ext_stride = 64, int stagger = 0,
+                                              sg::gptr<const unsigned int> range_bits = nullptr) {
     using sg::gptr;
     __shared__ Lds lds;
     constexpr bool kTwo = MODE == S2X;
+    static_assert(!kF16 || MODE == S1X, "the fp16 conv1 is built for MLP2");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
+    // the two scales of the fp16 conv1
+    float Sd = 1.f, Sw = 1.f;
+    if (kF16) {
+        __shared__ float wred[kWaves], rred[kWaves];
+        static_assert(sg::kRangeWords == 64 * kWaves, "one range word per thread");
+        float rm = __uint_as_float(range_bits[tid]);              // non-negative floats: the largest word is the range
+        float wm = 0.f;
+        for (int i = tid; i < 64 * 9; i += 64 * kWaves) wm = fmaxf(wm, fabsf(w1[(i / 9) * 18 + i % 9]));
+        wm = sgw::wave_max(wm);
+        rm = sgw::wave_max(rm);
+        if (lane == 0) { wred[wave] = wm; rred[wave] = rm; }
+        __syncthreads();
+        wm = wred[0]; rm = rred[0];
+#pragma unroll
+        for (int w_ = 1; w_ < kWaves; ++w_) { wm = fmaxf(wm, wred[w_]); rm = fmaxf(rm, rred[w_]); }
+        Sw = pow2_scale(wm, 4095.f);
+        Sd = pow2_scale(2.f * rm, 4096.f);
+    }
 
     // the last layer's rows carry the sign of its BN gamma (see the header): y' = sgn(gamma) * y exactly
     for (int i = tid; i < 2 * 8 * 64; i += 64 * kWaves) {           // x_i columns: [t][step 0..7][lane]; steps 5..7 and k = 9 stay zero
@@ -122,8 +157,31 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         const int ch = 32 * t + (l & 31), k = 2 * s + (l >> 5);
         float v = (s < 5 && k < 9) ? w1[ch * 18 + 9 + k] : 0.f;
         if (MODE == S1X && gamma_last[ch] < 0.f) v = -v;
+        if (kF16) v *= Sw * Sd;                                     // the x_i half joins an accumulator that runs at Sw Sd
         (&lds.a1x[t][s >> 2][l].x)[s & 3] = v;
     }
+    if (kF16) {
+        // fp16 image, two MFMAs per output tile: m = 0: (w_hi | w_hi) meeting B = (d_hi | d_lo) of the lane's four values;
+        // m = 1: (w_lo | d8's products) meeting B = (d_hi | d8_hi, d8_lo): lanes 0-31 w_hi[8], w_hi[8]; lanes 32-63 w_lo[8], 0
+        for (int i = tid; i < 2 * 2 * 64; i += 64 * kWaves) {
+            const int l = i & 63, t = (i >> 6) & 1, m = i >> 7;
+            const int ch = 32 * t + (l & 31), hf = l >> 5, c0 = 4 * hf;
+            const float sg_ = gamma_last[ch] < 0.f ? -Sw : Sw;
+            auto piece = [&](int k, int p) -> unsigned int {          // fp16 bits of the high (p = 1) / low (p = 2) piece of Sw W1[ch][k]
+                if (p == 0) return 0u;
+                const float v = sg_ * w1[ch * 18 + k];
+                const _Float16 h = (_Float16)v;
+                const _Float16 lo_ = (_Float16)(v - (float)h);
+                return (unsigned int)__builtin_bit_cast(unsigned short, p == 1 ? h : lo_);
+            };
+            unsigned int u[4];
+            const int pa = m == 0 ? 1 : 2;
+            u[0] = piece(c0, pa) | (piece(c0 + 1, pa) << 16); u[1] = piece(c0 + 2, pa) | (piece(c0 + 3, pa) << 16);
+            if (m == 0) { u[2] = u[0]; u[3] = u[1]; }
+            else { u[2] = piece(8, hf ? 2 : 1); u[3] = piece(8, hf ? 0 : 1); }
+            lds.a1p[m][t][l] = u32x4{u[0], u[1], u[2], u[3]};
+        }
+    } else
     for (int i = tid; i < 4 * 2 * 64; i += 64 * kWaves) {           // d columns: the packed product image (struct Lds)
         const int l = i & 63, t = (i >> 6) & 1, m = i >> 7;
         const int ch = 32 * t + (l & 31), hf = l >> 5;
@@ -173,7 +231,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     const bool valid = pt < N;
     const float vmask = valid ? 1.f : 0.f;
     // S2X runs on scaled operands (conv1' x T, W2 x S, both powers of two: see k_bn_fold_moments); y2 comes out x S T
-    const float unscale = kTwo ? scales[0] : 1.f;
+    const float unscale = kTwo ? scales[0] : kF16 ? 1.f / (Sw * Sd) : 1.f;
     const int ptc = valid ? pt : 0;
 
     if (tile * 32 < N) {
@@ -187,6 +245,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         const float xsel[5] = {half ? xi[1] : xi[0], half ? xi[3] : xi[2], half ? xi[5] : xi[4], half ? xi[7] : xi[6], half ? 0.f : xi[8]};
         // d = x_j - x_i: lanes 0-31 cut d0..d3, lanes 32-63 d4..d7, both d8 (struct Lds, a1p)
         const float xs[5] = {half ? xi[4] : xi[0], half ? xi[5] : xi[1], half ? xi[6] : xi[2], half ? xi[7] : xi[3], xi[8]};
+        const float xs_s[5] = {xs[0] * Sd, xs[1] * Sd, xs[2] * Sd, xs[3] * Sd, xs[4] * Sd};        // kF16 only
         // the x_i half sees coordinates relative to row 0 (see "Conditioning" in the header); d below uses the raw ones
         const float xcen[5] = {half ? xi[1] - x9m[1] : xi[0] - x9m[0], half ? xi[3] : xi[2] - x9m[2], xsel[2], xsel[3], xsel[4]};
         f32x16 base[2];
@@ -229,28 +288,45 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
             for (int q = 0; q < 16; ++q) best[t][q] = -INFINITY;
 
         const gptr<const int32_t> krow = knn + (size_t)ptc * K;
-        // software pipeline: the next slot's neighbour row is requested before this slot's MFMAs start.  (Hoisting the tile's
-        // first loads -- own row, first ids, first neighbour row: three dependent round trips -- in front of the weight staging
-        // and the base MFMAs measured SLOWER, S1X 421 -> 457 us: the co-resident wave of the other workgroup already covers them.)
-        int nb_next = krow[0];
-        const gptr<const float4> xp = (gptr<const float4>)(x9m + (size_t)nb_next * 12);
-        float4 p0 = xp[0], p1 = xp[1], p2 = xp[2];
-        nb_next = K > 1 ? krow[1] : 0;
-        for (int j = 0; j < K; ++j) {
+        // the fp16 conv1's four A fragments stay in registers for the whole tile (MLP2 has the room: no conv2 accumulators)
+        u32x4 fr16[4] = {};
+        if (kF16) { fr16[0] = lds.a1p[0][0][lane]; fr16[1] = lds.a1p[0][1][lane]; fr16[2] = lds.a1p[1][0][lane]; fr16[3] = lds.a1p[1][1][lane]; }
+        // one neighbour slot, given the neighbour's row
+        auto slot_body = [&](const float4& n0, const float4& n1, const float4& n2) {
             // S2X holds 64 statistics + 32 maxima + 48 accumulator registers: do not let the compiler also park the 82
             // loop-invariant A fragments in VGPRs (it then spills ~60 of them to scratch: 0.56 vs 0.48 ms per MLP3 at
             // 150k points); re-read them from LDS per slot
             if (REREAD_A) asm volatile("" ::: "memory");
-            const float4 n0 = p0, n1 = p1, n2 = p2;
-            if (j + 1 < K) {
-                const gptr<const float4> xq = (gptr<const float4>)(x9m + (size_t)nb_next * 12);
-                p0 = xq[0]; p1 = xq[1]; p2 = xq[2];
-                if (j + 2 < K) nb_next = krow[j + 2];
-            }
             // conv1 on the bf16 pipe: the lane's five d values cut into three bf16 pieces by truncation (d = x1 + x2 + x3), the six products
             // that matter packed along K (struct Lds): 8 MFMAs of 32 cycles on top of the point's base accumulator
             f32x16 acc1[2];
-            {
+            if constexpr (kF16) {
+                // d scaled by Sd (fma(n, Sd, -x_i Sd) = (n - x_i) Sd exactly: Sd is a power of two), cut into fp16 hi / lo, three products
+                // packed into two MFMAs per output tile (see the image above).  n0 = the 16 bytes of the neighbour's row this lane's half
+                // works on (the loads below fetch exactly those), n2.x = channel 8
+                const float nv[5] = {n0.x, n0.y, n0.z, n0.w, n2.x};
+                float ds[6];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) ds[q] = __builtin_fmaf(nv[q], Sd, -xs_s[q]);
+                ds[5] = 0.f;
+                unsigned int ph[3], pl_[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const f32x2 v = {ds[2 * u], ds[2 * u + 1]};
+                    const f16x2 hi = __builtin_convertvector(v, f16x2);
+                    const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);      // v - hi is exact in fp32
+                    ph[u] = __builtin_bit_cast(unsigned int, hi);
+                    pl_[u] = __builtin_bit_cast(unsigned int, lo);
+                }
+                const f16x8 x0 = __builtin_bit_cast(f16x8, u32x4{ph[0], ph[1], pl_[0], pl_[1]});      // (d_hi | d_lo) of the lane's four values
+                const f16x8 x1 = __builtin_bit_cast(f16x8, u32x4{ph[0], ph[1], ph[2], pl_[2]});       // (d_hi | d8_hi, d8_lo)
+                const f16x8 wa0 = __builtin_bit_cast(f16x8, fr16[0]), wb0 = __builtin_bit_cast(f16x8, fr16[1]);
+                const f16x8 wa1 = __builtin_bit_cast(f16x8, fr16[2]), wb1 = __builtin_bit_cast(f16x8, fr16[3]);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, x1, base[0], 0, 0, 0);           // the smaller terms first
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb1, x1, base[1], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, x0, acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb0, x0, acc1[1], 0, 0, 0);
+            } else {
                 const float nv[5] = {half ? n1.x : n0.x, half ? n1.y : n0.y, half ? n1.z : n0.z, half ? n1.w : n0.w, n2.x};
                 unsigned int v1[5], v2[5], v3[5];
 #pragma unroll
@@ -287,12 +363,16 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        // rows past N (the last tile) are masked when the lanes are summed, not here
-                        const float y = acc1[t][q];
-                        stat_s[16 * t + q] += y;
-                        stat_q[16 * t + q] = __builtin_fmaf(y, y, stat_q[16 * t + q]);
-                        best[t][q] = fmaxf(best[t][q], y);
+                    for (int q = 0; q < 16; q += 2) {
+                        // rows past N (the last tile) are masked when the lanes are summed, not here; register pairs written out so that
+                        // the packed adds / fmas sit on aligned pairs (left to the vectoriser they came out shifted by one, with a move
+                        // per operand)
+                        const f32x2 y = {acc1[t][q], acc1[t][q + 1]};
+                        const f32x2 s2 = f32x2{stat_s[16 * t + q], stat_s[16 * t + q + 1]} + y;
+                        const f32x2 q2 = __builtin_elementwise_fma(y, y, f32x2{stat_q[16 * t + q], stat_q[16 * t + q + 1]});
+                        stat_s[16 * t + q] = s2.x; stat_s[16 * t + q + 1] = s2.y;
+                        stat_q[16 * t + q] = q2.x; stat_q[16 * t + q + 1] = q2.y;
+                        best[t][q] = fmaxf(best[t][q], y.x); best[t][q + 1] = fmaxf(best[t][q + 1], y.y);
                     }
             } else {
                 // LeakyReLU(BN1(.)) in place -> B operand of conv2
@@ -359,6 +439,62 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                         stat_q[16 * ot + q] = __builtin_fmaf(z, z, stat_q[16 * ot + q]);
                         best[ot][q] = fmaxf(best[ot][q], z);
                     }
+            }
+        };
+        // software pipeline: the next slot's neighbour row is requested before this slot's MFMAs start.  (Hoisting the tile's
+        // first loads -- own row, first ids, first neighbour row: three dependent round trips -- in front of the weight staging
+        // and the base MFMAs measured SLOWER, S1X 421 -> 457 us: the co-resident wave of the other workgroup already covers them.)
+        auto load_row = [&](int nb, float4& r0, float4& r1, float4& r2) {
+            const gptr<const float4> xq = (gptr<const float4>)(x9m + (size_t)nb * 12);
+            r0 = xq[0]; r1 = xq[1]; r2 = xq[2];
+        };
+        if constexpr (kF16) {
+            // two row buffers that take turns: with one buffer handed over at the loop edge the register allocator copied freshly loaded
+            // registers right behind their load (a memory round trip per slot); requests beyond the last slot re-read it
+            // A lane needs the four values of its half (d0..d3 | d4..d7) and d8 of the neighbour's row: one 16-byte and one 4-byte load, plus
+            // the id of the neighbour after next.  The three requests of a slot are written as instructions: left to the compiler they are
+            // SUNK to their first use (register pressure), which turns the one-slot lookahead into a memory round trip per slot.  `arrive`
+            // waits for everything requested a slot ago and ties the registers to the wait.
+            using f32x4 = __attribute__((ext_vector_type(4))) float;
+            // (`cur` = the row the coming slot works on: re-defined by the request so that the slot's code cannot be scheduled in front of
+            // it; `done` = a statistic the finished slot wrote: re-defined by the wait so that the wait cannot be scheduled in front of it)
+            auto request = [&](int nb, f32x4& r0, float& e8, int& id_next, int j_next, f32x4& cur) {
+                const gptr<const float> row = x9m + (size_t)nb * 12;
+                const gptr<const float> p16 = row + 4 * half, p4 = row + 8;
+                const gptr<const int32_t> pid = krow + j_next;
+                asm volatile("global_load_dwordx4 %0, %2, off" : "=v"(r0), "+v"(cur) : "v"(p16));
+                asm volatile("global_load_dword %0, %1, off" : "=v"(e8) : "v"(p4));
+                asm volatile("global_load_dword %0, %1, off" : "=v"(id_next) : "v"(pid));
+            };
+            auto arrive = [&](f32x4& r0, float& e8, int& id_next, float& done) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(e8), "+v"(id_next), "+v"(done));
+            };
+            f32x4 ra, rb;
+            float ea, eb;
+            int ida, idb;
+            f32x4 none = {0.f, 0.f, 0.f, 0.f};
+            request(krow[0], ra, ea, ida, min(1, K - 1), none);    // slot 0's row, slot 1's id
+            for (int j = 0; j < K; j += 2) {
+                arrive(ra, ea, ida, stat_q[31]);
+                request(ida, rb, eb, idb, min(j + 2, K - 1), ra);   // slot j + 1's row, slot j + 2's id (requests beyond the last slot re-read it)
+                slot_body(make_float4(ra.x, ra.y, ra.z, ra.w), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(ea, 0.f, 0.f, 0.f));
+                arrive(rb, eb, idb, stat_q[31]);
+                request(idb, ra, ea, ida, min(j + 3, K - 1), rb);
+                if (j + 1 < K) slot_body(make_float4(rb.x, rb.y, rb.z, rb.w), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(eb, 0.f, 0.f, 0.f));
+            }
+            arrive(ra, ea, ida, stat_q[31]);                        // nothing may still be in flight into registers the code below reuses
+        } else {
+            int nb_next = krow[0];
+            float4 p0, p1, p2;
+            load_row(nb_next, p0, p1, p2);
+            nb_next = K > 1 ? krow[1] : 0;
+            for (int j = 0; j < K; ++j) {
+                const float4 n0 = p0, n1 = p1, n2 = p2;
+                if (j + 1 < K) {
+                    load_row(nb_next, p0, p1, p2);
+                    if (j + 2 < K) nb_next = krow[j + 2];
+                }
+                slot_body(n0, n1, n2);
             }
         }
 
@@ -434,15 +570,17 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         partial[(size_t)bid * 128 + tid] = s;
     }
 }
-template <int MODE, bool REREAD_A = false>
+template <int MODE, bool REREAD_A = false, bool kF16 = false>
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                                           const float* __restrict__ w1, const float* __restrict__ shift1,
                                                           const u32x4* __restrict__ w2img, const float* __restrict__ scales,
                                                           const float* __restrict__ gamma_last,
-                                                          float* __restrict__ ext, double* __restrict__ partial) {
+                                                          float* __restrict__ ext, double* __restrict__ partial,
+                                                          const unsigned int* __restrict__ range_bits = nullptr) {
     using sg::as_global;
-    edgeconv_body<MODE, REREAD_A>(as_global(x9m), as_global(knn), N, K, as_global(w1), as_global(shift1), as_global(w2img), as_global(scales),
-                                  as_global(gamma_last), as_global(ext), as_global(partial), blockIdx.x);
+    edgeconv_body<MODE, REREAD_A, false, kF16>(as_global(x9m), as_global(knn), N, K, as_global(w1), as_global(shift1), as_global(w2img),
+                                               as_global(scales), as_global(gamma_last), as_global(ext), as_global(partial), blockIdx.x, nullptr, 64,
+                                               0, as_global(range_bits));
 }
 // S1X: the scene's MLP2 weights as they are; S2X: its folded conv1 (ec_w1f, ec_sh1) + the raw conv2
 // the engine's launches: E goes straight into the clusters' maxima (kFused above), c.pf is not written
@@ -452,9 +590,9 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv_b(const sg
     if ((int)blockIdx.x >= c.ec_blocks) return;
     // pointers read out of a SlotCtx are generic to the compiler (sg_common.h, gptr): hand them over as global memory
     using sg::as_global;
-    if (MODE == S1X) edgeconv_body<MODE, REREAD_A, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global(c.ec_w1), nullptr, nullptr, nullptr,
-                                                         as_global(c.ec_g1), as_global(c.cat + c.gm_D), as_global(c.ec_partial), blockIdx.x,
-                                                         as_global(c.cluster_of_pos), c.Dcat, stagger);
+    if constexpr (MODE == S1X) edgeconv_body<MODE, REREAD_A, true, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global(c.ec_w1), nullptr, nullptr, nullptr,
+                                                               as_global(c.ec_g1), as_global(c.cat + c.gm_D), as_global(c.ec_partial), blockIdx.x,
+                                                               as_global(c.cluster_of_pos), c.Dcat, stagger, as_global((const unsigned int*)c.ec_range));
     else edgeconv_body<MODE, REREAD_A, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global((const float*)c.ec_w1f),
                                              as_global((const float*)c.ec_sh1), as_global(reinterpret_cast<const u32x4*>(c.ec_w2img)),
                                              as_global((const float*)c.ec_scale), as_global(c.ec_g2), as_global(c.cat + c.gm_D),
@@ -491,7 +629,7 @@ constexpr int kMom = 189;
 __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                                   double* __restrict__ partial, int bid) {
     __shared__ double red[16][kMom];                            // one partial per 16-lane row (4 waves x 4 rows)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int pt = bid * 256 + tid;
     const bool valid = pt < N;
     float a[9], D[45], xi[9];
@@ -592,13 +730,6 @@ __global__ __launch_bounds__(256) void k_edge_moments_b(const sg::SlotCtx* __res
 //   S: max |S W2| in [2^12, 2^13): the low pieces of all but vanishing weights are fp16 normals.
 // The pre-split weight image (the layout S2X copies to LDS, rows already carrying sgn(gamma2)) is written here, once per scene,
 // instead of once per workgroup.
-__device__ __forceinline__ float pow2_scale(float bound, float target) {      // largest power of two p with p * bound <= target
-    if (!(bound > 0.f) || !(bound < INFINITY)) return 1.f;
-    int e;
-    const float m = frexpf(target / bound, &e);                                // target / bound = m 2^e, m in [0.5, 1)
-    (void)m;
-    return ldexpf(1.f, min(max(e - 1, -40), 40));
-}
 __device__ __forceinline__ void bn_fold_moments_body(const double* __restrict__ partial, int nblocks, double rows,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift,
@@ -747,14 +878,28 @@ __device__ __forceinline__ void bn_fold_body(const double* __restrict__ partial,
 }
 __global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ partial, int nblocks, double rows,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  float* __restrict__ a_out, float* __restrict__ shift, float* __restrict__ stats) {
+                                                  float* __restrict__ a_out, float* __restrict__ shift, float* __restrict__ stats,
+                                                  unsigned int* __restrict__ range_bits) {
     bn_fold_body(partial, nblocks, rows, gamma, beta, a_out, shift, stats);
+    if (range_bits && threadIdx.x < sg::kRangeWords) range_bits[threadIdx.x] = 0u;      // the layer is done with its range words: the next layout starts from zero
 }
 // layers == 1: MLP2's only BN (-> ec_w1f = |a|, ec_sh1); layers == 2: MLP3's last BN (-> ec_w2f, ec_sh2)
 __global__ __launch_bounds__(1024) void k_bn_fold_b(const sg::SlotCtx* __restrict__ cx, int layers) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if (layers == 1) bn_fold_body(c.ec_partial, c.ec_blocks, (double)c.N * 20.0, c.ec_g1, c.ec_b1, c.ec_w1f, c.ec_sh1);
     else bn_fold_body(c.ec_partial, c.ec_blocks, (double)c.N * 20.0, c.ec_g2, c.ec_b2, c.ec_w2f, c.ec_sh2);
+    if (threadIdx.x < sg::kRangeWords) c.ec_range[threadIdx.x] = 0u;      // the layer is done with its range words (k_layer_layout raises them again)
+}
+
+// a caller without sg_layer_layout's range word: the largest |x9m[p][c] - x9m[0][c]| over all rows and the 9 channels (twice that bounds
+// every difference between two rows), raised into *range_bits like the layout kernel does
+__global__ __launch_bounds__(256) void k_edge_range(const float* __restrict__ x9m, int N, unsigned int* __restrict__ range_bits) {
+    float m = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < N; p += gridDim.x * 256)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) m = fmaxf(m, fabsf(x9m[(size_t)p * 12 + c] - x9m[c]));
+    m = sgw::wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(range_bits, __float_as_uint(m));
 }
 
 // epilogue of the last layer, in place: out = LReLU(|a| * E + b')
@@ -793,7 +938,8 @@ int edgeconv_apply(const float* d_e, int N, const float* d_a, const float* d_shi
 
 int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
                             const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
-                            size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine) {
+                            size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine,
+                            unsigned int* d_range_bits) {
     SG_REQUIRE(N >= 0 && k > 0 && (layers == 1 || layers == 2) && d_ws, "sg_edgeconv_forward: bad arguments");
     if (d_affine) { d_affine[0] = nullptr; d_affine[1] = nullptr; d_affine[2] = nullptr; }
     if (N == 0) return SG_OK;
@@ -815,8 +961,9 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     const size_t n4 = (size_t)N * 16;
     const int egrid = (int)std::min<size_t>((n4 + 255) / 256, 2048);
     if (layers == 1) {
-        k_edgeconv<S1X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, d_g1, d_out, partial);
-        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, w1f, sh1, stats_last);
+        if (d_range_bits) k_edgeconv<S1X, false, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, d_g1, d_out, partial, d_range_bits);
+        else k_edgeconv<S1X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, d_g1, d_out, partial);
+        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, w1f, sh1, stats_last, d_range_bits);
         if (mark) mark(0);
         if (d_affine) { d_affine[0] = w1f; d_affine[1] = sh1; d_affine[2] = stats_last; }        // the caller applies LReLU(|a| E + b') where it consumes E
         else k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w1f, sh1);
@@ -827,7 +974,7 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
         k_bn_fold_moments<<<1, 1024, 0, st>>>(partial, mblocks, rows, d_g1, d_b1, d_w1, w1f, sh1, d_w2, d_g2, w2img, scales);
         if (mark) mark(0);
         k_edgeconv<S2X, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2img, scales, d_g2, d_out, partial);
-        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, w2f, sh2, stats_last);
+        k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, w2f, sh2, stats_last, d_range_bits);
         if (mark) mark(1);
         if (d_affine) { d_affine[0] = w2f; d_affine[1] = sh2; d_affine[2] = stats_last; }
         else k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w2f, sh2);
@@ -889,6 +1036,21 @@ int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, 
                         size_t ws_bytes, void* stream) {
     return sg::edgeconv_forward_marked(d_x9m, d_knn, N, k, layers, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, d_out, d_ws, ws_bytes, stream,
                                        nullptr, nullptr);
+}
+
+int sg_edgeconv_forward_r(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
+                          const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
+                          size_t ws_bytes, unsigned int* d_range_bits, void* stream) {
+    return sg::edgeconv_forward_marked(d_x9m, d_knn, N, k, layers, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, d_out, d_ws, ws_bytes, stream,
+                                       nullptr, nullptr, d_range_bits);
+}
+
+int sg_edge_range(const float* d_x9m, int N, unsigned int* d_range_bits, void* stream) {
+    SG_REQUIRE(N >= 0 && d_x9m && d_range_bits, "sg_edge_range: bad arguments");
+    if (N == 0) return SG_OK;
+    k_edge_range<<<std::min(sg::cdiv(N, 256), 1024), 256, 0, sg::as_stream(stream)>>>(d_x9m, N, d_range_bits);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
 }
 
 }  // extern "C"

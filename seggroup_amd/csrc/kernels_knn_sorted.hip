@@ -366,11 +366,12 @@ __device__ __forceinline__ void layer_layout_body(const float* __restrict__ data
                                                   const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
                                                   int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
                                                   float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos,
-                                                  float4* __restrict__ point_rec, int32_t* __restrict__ seed_id, int i, int r_begin = 0,
-                                                  int r_end = 0x7fffffff) {
+                                                  float4* __restrict__ point_rec, int32_t* __restrict__ seed_id, unsigned int* __restrict__ range_bits,
+                                                  int i, int r_begin = 0, int r_end = 0x7fffffff) {
     const int s = order[i];
     const int lo = seg_off[s], n = min(seg_off[s + 1] - lo, r_end), d = dst[i], c = cl[i];
     const float mx = cl_mean[3 * c], my = cl_mean[3 * c + 1], mz = cl_mean[3 * c + 2];
+    float amax = 0.f;                                           // largest |centred xyz| / |feature| of the rows this thread lays out
     for (int r = r_begin + threadIdx.x; r < n; r += blockDim.x) {
         const int p = seg_points[lo + r];
         members[d + r] = p;
@@ -386,6 +387,7 @@ __device__ __forceinline__ void layer_layout_body(const float* __restrict__ data
         o[0] = make_float4(x, y, z, row[3]);
         o[1] = make_float4(row[4], row[5], x - mx, y - my);
         o[2] = make_float4(z - mz, 0.f, 0.f, 0.f);
+        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(x - mx)), fmaxf(fabsf(y - my), fabsf(z - mz))), fmaxf(fmaxf(fabsf(row[3]), fabsf(row[4])), fabsf(row[5])));
         const int ci = sperm[lo + r];                          // r-th point of the segment in Morton order
         const float* q = data + (size_t)seg_points[ci] * 6;
         sxyzw[d + r] = make_float4(q[0], q[1], q[2], (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);     // torch.sum(x**2, dim=1)
@@ -399,15 +401,25 @@ __device__ __forceinline__ void layer_layout_body(const float* __restrict__ data
             if (point_rec) point_rec[lo + r] = make_float4(q[0], q[1], q[2], __int_as_float(d + (ci - lo)));
         }
     }
+    // EdgeConv's range (kernels_edgeconv.hip, conv1 on fp16 pieces): every difference x_j - x_i inside a cluster is bounded by twice the
+    // largest |centred coordinate| / |feature| of the layer (raw and centred XYZ differ by the cluster's mean: the same differences).
+    // Non-negative floats order like their bits: one atomic max per wave.
+    if (range_bits) {
+        amax = sgw::wave_max(amax);
+        // 48,000 waves per launch: the range is kept as sg::kRangeWords words (their maximum counts) so that the atomics spread over
+        // as many addresses -- one word per scene serialised them in L2 (layout 57 -> 134 us per launch of 8)
+        if ((threadIdx.x & 63) == 0 && amax > 0.f)
+            atomicMax(range_bits + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (sg::kRangeWords - 1)), __float_as_uint(amax));
+    }
 }
 __global__ void k_layer_layout(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
                                const int32_t* __restrict__ sperm, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
                                const int32_t* __restrict__ cl, const float* __restrict__ cl_mean, int32_t* __restrict__ members,
                                int32_t* __restrict__ pos_of_point, int32_t* __restrict__ cluster_of_pos, int32_t* __restrict__ slot_of_pos,
                                float* __restrict__ x9m, float4* __restrict__ sxyzw, int32_t* __restrict__ smpos, float4* __restrict__ point_rec,
-                               int32_t* __restrict__ seed_id) {
+                               int32_t* __restrict__ seed_id, unsigned int* __restrict__ range_bits) {
     layer_layout_body(data, seg_points, seg_off, sperm, order, dst, cl, cl_mean, members, pos_of_point, cluster_of_pos, slot_of_pos, x9m, sxyzw,
-                      smpos, point_rec, seed_id, blockIdx.x);
+                      smpos, point_rec, seed_id, range_bits, blockIdx.x);
 }
 // The engine's launches: a block lays out the first kLayoutPiece rows of its segment; the rest of a larger segment (ScanNet floors
 // and walls: 10k-40k points) is cut into pieces of kLayoutPiece rows that the host lists per layer (lay_big = (slot, first row)
@@ -416,14 +428,14 @@ __global__ void k_layer_layout_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.S) return;
     layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, nullptr, c.cluster_of_pos,
-                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, c.seed_id, blockIdx.x, 0, sg::kLayoutPiece);
+                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, c.seed_id, c.ec_range, blockIdx.x, 0, sg::kLayoutPiece);
 }
 __global__ void k_layer_layout_big_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.lay_nbig) return;
     const int i = c.lay_big[2 * blockIdx.x], r0 = c.lay_big[2 * blockIdx.x + 1];
     layer_layout_body(c.data, c.seg_points, c.seg_off, c.sperm, c.order, c.dst, c.cl, c.cl_mean, c.members, nullptr, c.cluster_of_pos,
-                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, c.seed_id, i, r0, r0 + sg::kLayoutPiece);
+                      c.slot_of_pos, c.x9m, c.sxyzw, c.smpos, c.point_rec, c.seed_id, c.ec_range, i, r0, r0 + sg::kLayoutPiece);
 }
 
 // per layer: block i = i-th segment in member order; writes the operand and the member position in SORTED order
@@ -1145,13 +1157,13 @@ size_t sg_segment_sort_ws_bytes(int N) { return (size_t)std::max(N, 1) * 16; }  
 int sg_layer_layout(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl, const float* d_cl_mean, int32_t* d_members,
                     int32_t* d_pos_of_point, int32_t* d_cluster_of_pos, int32_t* d_slot_of_pos, float* d_x9m, float* d_sxyzw,
-                    int32_t* d_smpos, float* d_point_rec, int32_t* d_seed_id, void* stream) {
+                    int32_t* d_smpos, float* d_point_rec, int32_t* d_seed_id, unsigned int* d_range_bits, void* stream) {
     SG_REQUIRE(N >= 0 && S >= 0 && d_sperm && d_cl_mean && d_members && d_pos_of_point && d_cluster_of_pos && d_slot_of_pos && d_x9m &&
                    d_sxyzw && d_smpos, "sg_layer_layout: bad arguments");
     if (S == 0) return SG_OK;
     k_layer_layout<<<S, 128, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_sperm, d_order, d_dst, d_cl, d_cl_mean, d_members,
                                                         d_pos_of_point, d_cluster_of_pos, d_slot_of_pos, d_x9m,
-                                                        reinterpret_cast<float4*>(d_sxyzw), d_smpos, reinterpret_cast<float4*>(d_point_rec), d_seed_id);
+                                                        reinterpret_cast<float4*>(d_sxyzw), d_smpos, reinterpret_cast<float4*>(d_point_rec), d_seed_id, d_range_bits);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

@@ -123,7 +123,7 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->ws_eval, sg_eval_ws_bytes(maxS + 2));
     D(pl->adj1, 2 * maxE1); D(pl->count, 4);
     D(pl->members, N); D(pl->pos_of_point, N); D(pl->cluster_of_pos, N); D(pl->slot_of_pos, N);
-    D(pl->knn, N * 20); D(pl->knn_seed, N * 20); D(pl->seed_id, N);
+    D(pl->knn, N * 20); D(pl->knn_seed, N * 20); D(pl->seed_id, N); D(pl->ec_range, sg::kRangeWords);
     D(pl->desc, 15 * S + 16 + 4 * T + 2 * maxE1 + 4 * maxE1 + 128);
     D(pl->tables, SG_NUM_LABEL_VECTORS * S); D(pl->labels, SG_NUM_LABEL_VECTORS * V);
     D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
@@ -133,6 +133,7 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4); P(pl->h_chunk_off, S + 1);
     P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
     if (bad) { sg::fail(SG_ENOMEM, "sg_pipeline_create: device/pinned allocation failed (N=%d S=%d E=%d V=%d)", maxN, maxS, maxE, maxV); return nullptr; }
+    if (hipMemset(pl->ec_range.p, 0, sg::kRangeWords * sizeof(unsigned int)) != hipSuccess) { sg::fail(SG_EHIP, "sg_pipeline_create: hipMemset failed"); return nullptr; }
     pl->dev_bytes = dev; pl->pin_bytes = pin;
     return pl.release();
 }
@@ -392,7 +393,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             // member arrays + centred rows + sorted kNN operands of the layer: one launch
             PL_CHECK(sg_layer_layout(sc->d_data, N, sc->d_seg_points, sc->d_seg_off, pl->sperm.p, S, dd + o.order, dd + o.dst, dd + o.cl,
                                      reinterpret_cast<const float*>(dd + o.cl_mean), pl->members.p, pl->pos_of_point.p, pl->cluster_of_pos.p,
-                                     pl->slot_of_pos.p, pl->x9m.p, pl->xyzw.p, pl->smpos.p, pl->point_rec.p, pl->seed_id.p, stv));
+                                     pl->slot_of_pos.p, pl->x9m.p, pl->xyzw.p, pl->smpos.p, pl->point_rec.p, pl->seed_id.p, pl->ec_range.p, stv));
             // + -inf into the 64 columns the point->cluster max fills below
             PL_CHECK(sg::group_max_rows_fill(feat_prev, feat_prev_stride, feat_prev_dim, dd + o.goff, dd + o.gidx, C, cat, Dcat, 64, stv));
             pl->mark(sb + 0);
@@ -429,11 +430,11 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             const float* affine[3];
             if (layer == 0)
                 PL_CHECK(sg::edgeconv_forward_marked(pl->x9m.p, pl->knn.p, N, 20, 1, W + pl->o_m2w, W + pl->o_m2g, W + pl->o_m2b, nullptr,
-                                                     nullptr, nullptr, pl->pf.p, pl->ws_edge.p, pl->ws_edge.n, stv, mark_pass, affine));
+                                                     nullptr, nullptr, pl->pf.p, pl->ws_edge.p, pl->ws_edge.n, stv, mark_pass, affine, pl->ec_range.p));
             else
                 PL_CHECK(sg::edgeconv_forward_marked(pl->x9m.p, pl->knn.p, N, 20, 2, W + pl->o_m3w1, W + pl->o_m3g1, W + pl->o_m3b1,
                                                      W + pl->o_m3w2, W + pl->o_m3g2, W + pl->o_m3b2, pl->pf.p, pl->ws_edge.p,
-                                                     pl->ws_edge.n, stv, mark_pass, affine));
+                                                     pl->ws_edge.n, stv, mark_pass, affine, pl->ec_range.p));
             PL_CHECK(sg::segment_max_prefilled(pl->pf.p, N, pl->cluster_of_pos.p, cat + feat_prev_dim, Dcat, stv, affine[0], affine[1]));
             pl->mark(sb + 4);
             PL_CHECK(sg::gcn_forward_wt(cat, C, Dcat, dd + o.adj, E, dd + o.rowptr, dd + o.col, dd + o.eid, W + (layer == 0 ? pl->o_g2t : pl->o_g3t),

@@ -54,6 +54,7 @@ struct sg_pipeline {
     // device work buffers
     sgp::DevBuf<char> ws_contract, ws_fps, ws_mlp1, ws_edge, ws_gcn, ws_eval, ws_sort;
     sgp::DevBuf<int32_t> adj1, count, members, pos_of_point, cluster_of_pos, slot_of_pos, sperm, smpos, seg_chunk_off, knn, knn_seed, seed_id, desc, tables, labels;
+    sgp::DevBuf<unsigned int> ec_range;     // one word: the layer's EdgeConv range (k_layer_layout raises it, the layer's last fold kernel clears it)
     sgp::DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf, segbox, chunk_box, chunk_table, point_rec;
 
     // pinned host staging

@@ -67,7 +67,10 @@ int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_memb
 // moments + fold, 1 = S2X + fold, 2 = epilogue.
 int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
                             const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
-                            size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine);
+                            size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine,
+                            unsigned int* d_range_bits = nullptr);
+// d_range_bits != nullptr (sg_layer_layout's range word, or sg_edge_range's): MLP2's conv1 runs on fp16 pieces scaled by that range
+// (4 instead of 8 MFMAs per neighbour slot); the word is cleared when the op is done with it.
 // d_affine != nullptr: the last BatchNorm + LeakyReLU is NOT applied; d_out holds E = max_k sgn(gamma) y_k and
 // d_affine[0..2] receive the device pointers of |a| [64], b' [64] and the last BatchNorm's batch mean | variance [128] (inside d_ws) for a consumer that applies
 // LReLU(|a| E + b') itself (segment_max_prefilled does); edgeconv_apply is the epilogue on its own.
@@ -83,6 +86,7 @@ int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, 
                    const int32_t* d_eid, const float* d_wt, float alpha, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
 
 // EdgeConv's fold buffer: w1f [64*18] | sh1 [64] | w2f [64*64] | sh2 [64] | S2X's fp16 weight image [4096] | its scales [4]
+constexpr int kRangeWords = 256;          // EdgeConv's range: the maximum of this many words (k_layer_layout spreads its atomics over them)
 constexpr int kEdgeFoldFloats = 64 * 18 + 64 + 64 * 64 + 64 + 4096 + 4;
 int edge_moments_partials(const float* d_x9m, const int32_t* d_knn, int N, int K, double* d_partial, hipStream_t st);   // kernels_edgeconv.hip, [cdiv(N,256)][189]
 int reduce_partials(const double* d_partial, int nblocks, int stride, int count, double* d_out, hipStream_t st);   // kernels_train_edge.hip

@@ -87,7 +87,7 @@ SIGNATURES = {
     "sg_knn_operands": (_I, [vp, vp, vp, vp, _I, vp, vp, vp, vp, vp]),
     "sg_cluster_knn_sorted": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
     "sg_segment_sort_boxes": (_I, [vp, _I, vp, vp, vp, _I, vp, _I, vp, vp, vp, vp, vp, _Z, vp]),
-    "sg_layer_layout": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "sg_layer_layout": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "sg_cluster_knn_sorted_w": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, _I, vp, vp]),
     "sg_knn_seed_points": (_I, [vp, vp, _I, _I, vp, vp]),
     "sg_cluster_knn_seeded": (_I, [vp, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, _I, _I, vp, vp]),
@@ -133,6 +133,8 @@ SIGNATURES = {
     "sg_stage_segments": (_I, [vp, _I, _I, vp, vp, vp, vp]),
     "sg_edgeconv_ws_bytes": (_Z, [_I]),
     "sg_edgeconv_forward": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
+    "sg_edgeconv_forward_r": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp, vp]),
+    "sg_edge_range": (_I, [vp, _I, vp, vp]),
     "sg_gcn_ws_bytes": (_Z, [_I, _I, _I]),
     "sg_gcn_forward": (_I, [vp, _I, _I, vp, _I, vp, vp, vp, vp, C.c_float, vp, vp, _Z, vp]),
     "sg_export_labels": (_I, [vp, _I, vp, _I, vp, _I, _I, vp, vp]),

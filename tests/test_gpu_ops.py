@@ -345,6 +345,47 @@ def test_edgeconv_forward(env, N):
                                           ws.data_ptr(), ws.numel(), None))
         ref = O.edgeconv_forward(x9, knn.astype(np.int64), W, which)
         assert np.abs(out.cpu().numpy() - ref).max() < 2e-5, which
+        # the ranged entry: conv1's operand on fp16 pieces scaled by the range word (MLP2), the word cleared afterwards
+        rng_bits = torch.zeros(256, dtype=torch.int32, device="cuda:0")
+        hip.check(lib.sg_edge_range(d_x.data_ptr(), N, rng_bits.data_ptr(), None))
+        assert rng_bits.cpu().numpy().view(np.float32).max() == np.abs(x9 - x9[0]).max()
+        out2 = torch.zeros(N, 64, device="cuda:0")
+        hip.check(lib.sg_edgeconv_forward_r(d_x.data_ptr(), d_k.data_ptr(), N, K, layers, t[f"{which}.conv1.0.weight"].data_ptr(),
+                                            t[f"{which}.bn1.weight"].data_ptr(), t[f"{which}.bn1.bias"].data_ptr(), *p2, out2.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), rng_bits.data_ptr(), None))
+        assert np.abs(out2.cpu().numpy() - ref).max() < 2e-5, which
+        assert int(rng_bits.cpu().abs().sum()) == 0
+
+
+@pytest.mark.parametrize("spread,offset", [(1e-3, 0.0), (50.0, 0.0), (4.0, 900.0), (1e-6, 3.0)])
+def test_edgeconv_fp16_conv1_ranges(env, spread, offset):
+    """MLP2's conv1 on fp16 pieces (sg_edgeconv_forward_r): clouds of 1 mm, 50 m and 4 m extent -- the last 900 m from the origin -- and one
+    that is constant up to 1e-6: the power-of-two scale keeps the pieces inside fp16 whatever the data's magnitude (a difference can be
+    1e-6 of the range: it lands on fp16 subnormals, which the matrix pipe keeps), the result stays within 2e-5 of the float64 oracle."""
+    lib, torch, hip = env
+    from oracle import cpu_ref as O
+    from seggroup_amd import weights
+    N, K = 3000, 20
+    rng = np.random.default_rng(7)
+    x9 = (rng.uniform(-1, 1, (N, 9)) * spread).astype(np.float32)
+    x9[:, :3] += np.float32(offset)
+    x9[:, 6:9] = x9[:, :3] - x9[:, :3].mean(0)                       # centred copy, like the layout kernel writes it
+    x9[1, 3] += np.float32(spread * 1e-6)                            # a tiny difference beside the large ones
+    knn = rng.integers(0, N, (N, K)).astype(np.int32)
+    W = weights.make_weights(1, 2.0, affine_jitter=0.3)
+    x12 = np.zeros((N, 12), np.float32)
+    x12[:, :9] = x9
+    d_x, d_k = _up(torch, x12), _up(torch, knn)
+    t = {k: _up(torch, W[k]) for k in W}
+    ws = _ws(torch, lib.sg_edgeconv_ws_bytes(N))
+    out = torch.zeros(N, 64, device="cuda:0")
+    rng_bits = torch.zeros(256, dtype=torch.int32, device="cuda:0")
+    hip.check(lib.sg_edge_range(d_x.data_ptr(), N, rng_bits.data_ptr(), None))
+    hip.check(lib.sg_edgeconv_forward_r(d_x.data_ptr(), d_k.data_ptr(), N, K, 1, t["mlp_2.conv1.0.weight"].data_ptr(), t["mlp_2.bn1.weight"].data_ptr(),
+                                        t["mlp_2.bn1.bias"].data_ptr(), None, None, None, out.data_ptr(), ws.data_ptr(), ws.numel(), rng_bits.data_ptr(), None))
+    ref = O.edgeconv_forward(x9, knn.astype(np.int64), W, "mlp_2")
+    assert np.isfinite(out.cpu().numpy()).all()
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-5
 
 
 @pytest.mark.gpu
@@ -534,7 +575,7 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         hip.check(lib.sg_layer_layout(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S,
                                       d["order"].data_ptr(), d["dst"].data_ptr(), d_cls.data_ptr(), d_mean.data_ptr(), lay["members"].data_ptr(),
                                       lay["pop"].data_ptr(), lay["cop"].data_ptr(), lay["sop"].data_ptr(), lay["x9m"].data_ptr(),
-                                      lay["sx"].data_ptr(), lay["sm"].data_ptr(), lay["rec"].data_ptr(), None, None))
+                                      lay["sx"].data_ptr(), lay["sm"].data_ptr(), lay["rec"].data_ptr(), None, None, None))
         assert np.array_equal(lay["members"].cpu().numpy(), members) and np.array_equal(lay["pop"].cpu().numpy(), pos_of_point)
         rec = lay["rec"].cpu().numpy()                          # by point id: xyz + the bits of the point's member position
         assert np.array_equal(rec[:, :3], d_data.cpu().numpy()[:, :3]) and np.array_equal(rec[:, 3].copy().view(np.int32), pos_of_point.astype(np.int32))
@@ -542,10 +583,15 @@ def test_pruned_knn_equals_bruteforce_and_oracle(env, golden_index):
         # the records are indexed by it
         sid = torch.full((N,), -1, dtype=torch.int32, device="cuda:0")
         rec2 = torch.zeros(N, 4, device="cuda:0")
+        rng_bits = torch.zeros(256, dtype=torch.int32, device="cuda:0")
         hip.check(lib.sg_layer_layout(d_data.data_ptr(), N, d["segpts"].data_ptr(), d["segoff"].data_ptr(), sperm.data_ptr(), S,
                                       d["order"].data_ptr(), d["dst"].data_ptr(), d_cls.data_ptr(), d_mean.data_ptr(), lay["members"].data_ptr(),
                                       lay["pop"].data_ptr(), lay["cop"].data_ptr(), lay["sop"].data_ptr(), lay["x9m"].data_ptr(),
-                                      lay["sx"].data_ptr(), lay["sm"].data_ptr(), rec2.data_ptr(), sid.data_ptr(), None))
+                                      lay["sx"].data_ptr(), lay["sm"].data_ptr(), rec2.data_ptr(), sid.data_ptr(), rng_bits.data_ptr(), None))
+        # ... and the layer's range word: bits of the largest |centred xyz| / |feature|
+        xc = lay["x9m"].cpu().numpy()
+        want_range = np.float32(max(np.abs(xc[:, 6:9]).max(), np.abs(xc[:, 3:6]).max()))
+        assert rng_bits.cpu().numpy().view(np.float32).max() == want_range
         sid_np, rec2_np = sid.cpu().numpy(), rec2.cpu().numpy()
         sorted_pts = segorder[sperm.cpu().numpy()]                # seed id -> point id
         assert sorted(sid_np.tolist()) == list(range(N)) and np.array_equal(sorted_pts[sid_np], members)
