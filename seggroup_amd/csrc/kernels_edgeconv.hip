@@ -129,12 +129,12 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     using sg::gptr;
     __shared__ Lds lds;
     constexpr bool kTwo = MODE == S2X;
-    static_assert(!kF16 || MODE == S1X, "the fp16 conv1 is built for MLP2");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     // the two scales of the fp16 conv1
     float Sd = 1.f, Sw = 1.f;
-    if (kF16) {
+    if (kF16 && kTwo) Sd = scales[3];                           // MLP3: k_bn_fold_moments chose it and wrote the image (w2img + 1024)
+    if (kF16 && !kTwo) {
         __shared__ float wred[kWaves], rred[kWaves];
         static_assert(sg::kRangeWords == 64 * kWaves, "one range word per thread");
         float rm = __uint_as_float(range_bits[tid]);              // non-negative floats: the largest word is the range
@@ -157,10 +157,12 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         const int ch = 32 * t + (l & 31), k = 2 * s + (l >> 5);
         float v = (s < 5 && k < 9) ? w1[ch * 18 + 9 + k] : 0.f;
         if (MODE == S1X && gamma_last[ch] < 0.f) v = -v;
-        if (kF16) v *= Sw * Sd;                                     // the x_i half joins an accumulator that runs at Sw Sd
+        if (kF16 && !kTwo) v *= Sw * Sd;                            // MLP2: the x_i half joins an accumulator that runs at Sw Sd
         (&lds.a1x[t][s >> 2][l].x)[s & 3] = v;
     }
-    if (kF16) {
+    if (kF16 && kTwo) {
+        for (int i = tid; i < 2 * 2 * 64; i += 64 * kWaves) (&lds.a1p[0][0][0])[i] = w2img[1024 + 1 + i];      // behind conv2's image and the four scales
+    } else if (kF16) {
         // fp16 image, two MFMAs per output tile: m = 0: (w_hi | w_hi) meeting B = (d_hi | d_lo) of the lane's four values;
         // m = 1: (w_lo | d8's products) meeting B = (d_hi | d8_hi, d8_lo): lanes 0-31 w_hi[8], w_hi[8]; lanes 32-63 w_lo[8], 0
         for (int i = tid; i < 2 * 2 * 64; i += 64 * kWaves) {
@@ -232,6 +234,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     const float vmask = valid ? 1.f : 0.f;
     // S2X runs on scaled operands (conv1' x T, W2 x S, both powers of two: see k_bn_fold_moments); y2 comes out x S T
     const float unscale = kTwo ? scales[0] : kF16 ? 1.f / (Sw * Sd) : 1.f;
+    constexpr bool kFrag = kF16 && !kTwo;                       // MLP2 keeps conv1's four A fragments in registers, MLP3 re-reads them from LDS
     const int ptc = valid ? pt : 0;
 
     if (tile * 32 < N) {
@@ -290,7 +293,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         const gptr<const int32_t> krow = knn + (size_t)ptc * K;
         // the fp16 conv1's four A fragments stay in registers for the whole tile (MLP2 has the room: no conv2 accumulators)
         u32x4 fr16[4] = {};
-        if (kF16) { fr16[0] = lds.a1p[0][0][lane]; fr16[1] = lds.a1p[0][1][lane]; fr16[2] = lds.a1p[1][0][lane]; fr16[3] = lds.a1p[1][1][lane]; }
+        if (kFrag) { fr16[0] = lds.a1p[0][0][lane]; fr16[1] = lds.a1p[0][1][lane]; fr16[2] = lds.a1p[1][0][lane]; fr16[3] = lds.a1p[1][1][lane]; }
         // one neighbour slot, given the neighbour's row
         auto slot_body = [&](const float4& n0, const float4& n1, const float4& n2) {
             // S2X holds 64 statistics + 32 maxima + 48 accumulator registers: do not let the compiler also park the 82
@@ -320,8 +323,8 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                 }
                 const f16x8 x0 = __builtin_bit_cast(f16x8, u32x4{ph[0], ph[1], pl_[0], pl_[1]});      // (d_hi | d_lo) of the lane's four values
                 const f16x8 x1 = __builtin_bit_cast(f16x8, u32x4{ph[0], ph[1], ph[2], pl_[2]});       // (d_hi | d8_hi, d8_lo)
-                const f16x8 wa0 = __builtin_bit_cast(f16x8, fr16[0]), wb0 = __builtin_bit_cast(f16x8, fr16[1]);
-                const f16x8 wa1 = __builtin_bit_cast(f16x8, fr16[2]), wb1 = __builtin_bit_cast(f16x8, fr16[3]);
+                const f16x8 wa0 = __builtin_bit_cast(f16x8, kFrag ? fr16[0] : lds.a1p[0][0][lane]), wb0 = __builtin_bit_cast(f16x8, kFrag ? fr16[1] : lds.a1p[0][1][lane]);
+                const f16x8 wa1 = __builtin_bit_cast(f16x8, kFrag ? fr16[2] : lds.a1p[1][0][lane]), wb1 = __builtin_bit_cast(f16x8, kFrag ? fr16[3] : lds.a1p[1][1][lane]);
                 acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, x1, base[0], 0, 0, 0);           // the smaller terms first
                 acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb1, x1, base[1], 0, 0, 0);
                 acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, x0, acc1[0], 0, 0, 0);
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv_b(const sg
     if constexpr (MODE == S1X) edgeconv_body<MODE, REREAD_A, true, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global(c.ec_w1), nullptr, nullptr, nullptr,
                                                                as_global(c.ec_g1), as_global(c.cat + c.gm_D), as_global(c.ec_partial), blockIdx.x,
                                                                as_global(c.cluster_of_pos), c.Dcat, stagger, as_global((const unsigned int*)c.ec_range));
-    else edgeconv_body<MODE, REREAD_A, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global((const float*)c.ec_w1f),
+    else edgeconv_body<MODE, REREAD_A, true, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global((const float*)c.ec_w1f),
                                              as_global((const float*)c.ec_sh1), as_global(reinterpret_cast<const u32x4*>(c.ec_w2img)),
                                              as_global((const float*)c.ec_scale), as_global(c.ec_g2), as_global(c.cat + c.gm_D),
                                              as_global(c.ec_partial), blockIdx.x, as_global(c.cluster_of_pos), c.Dcat, stagger);
@@ -734,7 +737,8 @@ __device__ __forceinline__ void bn_fold_moments_body(const double* __restrict__ 
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift,
                                                      const float* __restrict__ w2, const float* __restrict__ gamma2,
-                                                     u32x4* __restrict__ w2img, float* __restrict__ scales) {
+                                                     u32x4* __restrict__ w2img, float* __restrict__ scales,
+                                                     const unsigned int* __restrict__ range_bits = nullptr, u32x4* __restrict__ c1img = nullptr) {
     __shared__ double part[4][256];
     __shared__ float sbound[64], swmax[16], sT, sS;
     __shared__ double tot[kMom];
@@ -817,6 +821,56 @@ __device__ __forceinline__ void bn_fold_moments_body(const double* __restrict__ 
             w2img[512 + threadIdx.x] = u32x4{lo[0], lo[1], lo[2], lo[3]};
         }
     }
+    if (c1img) {
+        // Round 3: conv1' d-columns as an fp16 image too (S2X's conv1 on two fp16 pieces like MLP2's: 4 instead of 8 MFMAs per slot).  The
+        // operand d is scaled by Sd (2 Sd range <= 2^12, range = the layer's range words), the folded weights a w T by 1 / Sd -- so the
+        // accumulator stays T x conv1' -- and if a weight would leave fp16 that way (|a w T / Sd| > 2^14: a degenerate variance), T gives:
+        // a smaller T only costs conv2's low pieces precision in that degenerate case.
+        __shared__ double sa[64];
+        __shared__ float samax[64], sSd;
+        if (threadIdx.x < 64) {
+            sa[ch] = a;
+            float m = 0.f;
+            for (int k = 0; k < 9; ++k) m = fmaxf(m, fabsf((float)(a * (double)w[ch * 18 + k])));
+            samax[ch] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float am = 0.f, rm = 0.f;
+            for (int c = 0; c < 64; ++c) am = fmaxf(am, samax[c]);
+            for (int i = 0; i < sg::kRangeWords; ++i) rm = fmaxf(rm, __uint_as_float(range_bits[i]));
+            float Sd = pow2_scale(2.f * rm, 4096.f);
+            const float lim = pow2_scale(am * sT / Sd, 16384.f);
+            if (lim < 1.f) { sT *= lim; scales[0] = 1.f / (sT * sS); scales[1] = sT; }
+            // the product only sees (weight / Sd) (d Sd): move up to 2^7 of the scale from d to the weights while the largest weight stays
+            // below 2^12, so that the weights' low pieces are not cut off at fp16's smallest subnormal (2^-24); d keeps an absolute
+            // resolution of 2^-25 2^7 / Sd <= 2^-30 of the layer's range, finer than the fp32 coordinates it is the difference of
+            const float room = pow2_scale(am * sT / Sd, 4095.f);
+            if (room > 1.f) Sd /= fminf(room, 128.f);
+            sSd = Sd;
+            scales[3] = Sd;
+        }
+        __syncthreads();
+        T = sT;
+        if (threadIdx.x < 2 * 2 * 64) {                            // one (m, t, lane) fragment per thread, the layout of edgeconv_body's fp16 image
+            const int l = threadIdx.x & 63, t = (threadIdx.x >> 6) & 1, m = threadIdx.x >> 7;
+            const int oc = 32 * t + (l & 31), hf = l >> 5, c0 = 4 * hf;
+            const float inv = 1.f / sSd;
+            auto piece = [&](int k, int p) -> unsigned int {
+                if (p == 0) return 0u;
+                const float v = (float)(sa[oc] * (double)w[oc * 18 + k]) * T * inv;       // w_folded's value / Sd: exact (a power of two)
+                const _Float16 h = (_Float16)v;
+                const _Float16 lo_ = (_Float16)(v - (float)h);
+                return (unsigned int)__builtin_bit_cast(unsigned short, p == 1 ? h : lo_);
+            };
+            unsigned int u[4];
+            const int pa = m == 0 ? 1 : 2;
+            u[0] = piece(c0, pa) | (piece(c0 + 1, pa) << 16); u[1] = piece(c0 + 2, pa) | (piece(c0 + 3, pa) << 16);
+            if (m == 0) { u[2] = u[0]; u[3] = u[1]; }
+            else { u[2] = piece(8, hf ? 2 : 1); u[3] = piece(8, hf ? 0 : 1); }
+            c1img[threadIdx.x] = u32x4{u[0], u[1], u[2], u[3]};
+        }
+    }
     for (int k = threadIdx.x >> 6; k < 18; k += 16) w_folded[ch * 18 + k] = (float)(a * (double)w[ch * 18 + k]) * T;
     if (threadIdx.x < 64) shift[ch] = (float)((double)beta[ch] - a * mean) * T;
 }
@@ -824,13 +878,14 @@ __global__ __launch_bounds__(1024) void k_bn_fold_moments(const double* __restri
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ w, float* __restrict__ w_folded, float* __restrict__ shift,
                                                           const float* __restrict__ w2, const float* __restrict__ gamma2,
-                                                          u32x4* __restrict__ w2img, float* __restrict__ scales) {
-    bn_fold_moments_body(partial, nblocks, rows, gamma, beta, w, w_folded, shift, w2, gamma2, w2img, scales);
+                                                          u32x4* __restrict__ w2img, float* __restrict__ scales,
+                                                          const unsigned int* __restrict__ range_bits, u32x4* __restrict__ c1img) {
+    bn_fold_moments_body(partial, nblocks, rows, gamma, beta, w, w_folded, shift, w2, gamma2, w2img, scales, range_bits, c1img);
 }
 __global__ __launch_bounds__(1024) void k_bn_fold_moments_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     bn_fold_moments_body(c.ec_partial, c.ec_mblocks, (double)c.N * 20.0, c.ec_g1, c.ec_b1, c.ec_w1, c.ec_w1f, c.ec_sh1, c.ec_w2, c.ec_g2,
-                         reinterpret_cast<u32x4*>(c.ec_w2img), c.ec_scale);
+                         reinterpret_cast<u32x4*>(c.ec_w2img), c.ec_scale, c.ec_range, reinterpret_cast<u32x4*>(c.ec_scale + 4));
 }
 
 // last layer of an MLP: fixed-order reduction of the per-block partials -> |a| = |gamma| / sqrt(var + eps) and the shift.
@@ -971,9 +1026,11 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     } else {
         const int mblocks = sg::cdiv(N, 256);
         k_edge_moments<<<mblocks, 256, 0, st>>>(d_x9m, d_knn, N, k, partial);
-        k_bn_fold_moments<<<1, 1024, 0, st>>>(partial, mblocks, rows, d_g1, d_b1, d_w1, w1f, sh1, d_w2, d_g2, w2img, scales);
+        k_bn_fold_moments<<<1, 1024, 0, st>>>(partial, mblocks, rows, d_g1, d_b1, d_w1, w1f, sh1, d_w2, d_g2, w2img, scales, d_range_bits,
+                                              d_range_bits ? reinterpret_cast<u32x4*>(scales + 4) : nullptr);
         if (mark) mark(0);
-        k_edgeconv<S2X, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2img, scales, d_g2, d_out, partial);
+        if (d_range_bits) k_edgeconv<S2X, true, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2img, scales, d_g2, d_out, partial, d_range_bits);
+        else k_edgeconv<S2X, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2img, scales, d_g2, d_out, partial);
         k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, w2f, sh2, stats_last, d_range_bits);
         if (mark) mark(1);
         if (d_affine) { d_affine[0] = w2f; d_affine[1] = sh2; d_affine[2] = stats_last; }

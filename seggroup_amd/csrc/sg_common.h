@@ -87,7 +87,7 @@ int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, 
 
 // EdgeConv's fold buffer: w1f [64*18] | sh1 [64] | w2f [64*64] | sh2 [64] | S2X's fp16 weight image [4096] | its scales [4]
 constexpr int kRangeWords = 256;          // EdgeConv's range: the maximum of this many words (k_layer_layout spreads its atomics over them)
-constexpr int kEdgeFoldFloats = 64 * 18 + 64 + 64 * 64 + 64 + 4096 + 4;
+constexpr int kEdgeFoldFloats = 64 * 18 + 64 + 64 * 64 + 64 + 4096 + 4 + 1024;    // ... | conv2' image | scales | conv1' fp16 image
 int edge_moments_partials(const float* d_x9m, const int32_t* d_knn, int N, int K, double* d_partial, hipStream_t st);   // kernels_edgeconv.hip, [cdiv(N,256)][189]
 int reduce_partials(const double* d_partial, int nblocks, int stride, int count, double* d_out, hipStream_t st);   // kernels_train_edge.hip
 int transpose_square(const float* d_src, float* d_dst, int D, hipStream_t st);      // kernels_train.hip

@@ -386,6 +386,14 @@ def test_edgeconv_fp16_conv1_ranges(env, spread, offset):
     ref = O.edgeconv_forward(x9, knn.astype(np.int64), W, "mlp_2")
     assert np.isfinite(out.cpu().numpy()).all()
     assert np.abs(out.cpu().numpy() - ref).max() < 2e-5
+    # MLP3's conv1' the same way (the fp16 image and its scale come out of k_bn_fold_moments)
+    hip.check(lib.sg_edge_range(d_x.data_ptr(), N, rng_bits.data_ptr(), None))
+    hip.check(lib.sg_edgeconv_forward_r(d_x.data_ptr(), d_k.data_ptr(), N, K, 2, t["mlp_3.conv1.0.weight"].data_ptr(), t["mlp_3.bn1.weight"].data_ptr(),
+                                        t["mlp_3.bn1.bias"].data_ptr(), t["mlp_3.conv2.0.weight"].data_ptr(), t["mlp_3.bn2.weight"].data_ptr(),
+                                        t["mlp_3.bn2.bias"].data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), rng_bits.data_ptr(), None))
+    ref = O.edgeconv_forward(x9, knn.astype(np.int64), W, "mlp_3")
+    assert np.isfinite(out.cpu().numpy()).all()
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-5
 
 
 @pytest.mark.gpu
@@ -415,6 +423,17 @@ def test_edgeconv_fp16_operand_scaling(env, g1_scale, w2_scale):
                                       t["mlp_3.bn1.weight"].data_ptr(), t["mlp_3.bn1.bias"].data_ptr(), t["mlp_3.conv2.0.weight"].data_ptr(),
                                       t["mlp_3.bn2.weight"].data_ptr(), t["mlp_3.bn2.bias"].data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), None))
     ref = O.edgeconv_forward(x9, knn.astype(np.int64), W, "mlp_3")
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, float(np.abs(ref).max()))
+    # ... and with conv1' on fp16 pieces too (the ranged entry: its weights a w T / Sd have to stay inside fp16 for every one of these scales)
+    rng_bits = torch.zeros(256, dtype=torch.int32, device="cuda:0")
+    hip.check(lib.sg_edge_range(d_x.data_ptr(), N, rng_bits.data_ptr(), None))
+    out.zero_()
+    hip.check(lib.sg_edgeconv_forward_r(d_x.data_ptr(), d_k.data_ptr(), N, K, 2, t["mlp_3.conv1.0.weight"].data_ptr(),
+                                        t["mlp_3.bn1.weight"].data_ptr(), t["mlp_3.bn1.bias"].data_ptr(), t["mlp_3.conv2.0.weight"].data_ptr(),
+                                        t["mlp_3.bn2.weight"].data_ptr(), t["mlp_3.bn2.bias"].data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        rng_bits.data_ptr(), None))
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() < 2e-5 * max(1.0, float(np.abs(ref).max()))
