@@ -55,8 +55,9 @@ MFMA_BF16_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MIC
 # what the EdgeConv launches EXECUTE per edge row (one of the 20 neighbour slots of a point): fp32 operands split into 16-bit
 # pieces that meet on v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation.  An MFMA of 32x32x16 is
 # 2 * 32 * 32 * 16 flop for 32 rows; CONV1_MFMAS = MFMAs per neighbour slot and 32-row tile for the 9-deep conv1 (two 32-channel
-# output tiles; the six products of the bf16 x 3 split packed along K: round 3, 12 before), conv2 = three fp16 products of 64x64 per row (hi*hi + hi*lo + lo*hi).
-CONV1_MFMAS_PER_SLOT = 8
+# output tiles; the three products of the fp16 x 2 split packed along K into two MFMAs per tile: round 3 -- 12 with bf16 x 3 in round 2),
+# conv2 = three fp16 products of 64x64 per row (hi*hi + hi*lo + lo*hi).
+CONV1_MFMAS_PER_SLOT = 4
 CONV1_EXEC_FLOP_PER_ROW = CONV1_MFMAS_PER_SLOT * 2 * 32 * 32 * 16 // 32
 S1X_EXECUTED_FLOP_PER_ROW = CONV1_EXEC_FLOP_PER_ROW
 S2X_EXECUTED_FLOP_PER_ROW = 3 * 2 * 64 * 64 + CONV1_EXEC_FLOP_PER_ROW
@@ -66,7 +67,7 @@ S2X_EXECUTED_FLOP_PER_ROW = 3 * 2 * 64 * 64 + CONV1_EXEC_FLOP_PER_ROW
 VALU_ISSUE_NS = 2.0
 VALU_PEAK_GINST = 1024 / VALU_ISSUE_NS
 PROFILE_TAG = "r03"
-DTYPE = "f32 (fp32 accumulate; operands split 3 x bf16 / 2 x fp16 on v_mfma_f32_32x32x16; kNN / FPS scores in exact fp32 order)"
+DTYPE = "f32 (fp32 accumulate; operands split into 2 x fp16 pieces on v_mfma_f32_32x32x16_f16; kNN / FPS scores in exact fp32 order)"
 
 
 def kernel_model(n_points: int, k: int = 20):

@@ -456,7 +456,8 @@ __global__ void k_knn_operands(const float* __restrict__ data, const int32_t* __
 }
 
 // profiling aid (SG_KNN_DEBUG & 16): [0] blocks, [1] cycles phase A, [2] merge A, [3] phase B, [4] final merge+write,
-// [5] chunks scanned (wave level), [6] chunks tested, [7] segments tested, [8] lane appends, [9] drain iterations
+// [5] chunks scanned (wave level), [6] chunks tested, [7] segments tested, [8] lane appends, [9] drain iterations,
+// [10] drains, [11] drains with nothing buffered, [12] drains merged twelve at a time
 __device__ unsigned long long g_knn5_stats[16];
 
 // kSlices = waves per 64-query tile (1, 2 or 4): the cluster's candidate chunks are dealt round-robin to them.  More
@@ -561,14 +562,39 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             unsigned long long tot = cnt;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-            if (lane == 0) { atomicAdd(&g_knn5_stats[8], tot); atomicAdd(&g_knn5_stats[9], (unsigned long long)mxc); }
+            if (lane == 0) {
+                atomicAdd(&g_knn5_stats[8], tot); atomicAdd(&g_knn5_stats[9], (unsigned long long)mxc);
+                atomicAdd(&g_knn5_stats[10], 1ull);                                           // drains, of them: empty, merged twelve at a time
+                if (mxc == 0) atomicAdd(&g_knn5_stats[11], 1ull);
+                if (kBufS == 12 && K == 20 && mxc > 0) atomicAdd(&g_knn5_stats[12], 1ull);
+            }
         }
-        // the next buffered key is read while the current one is inserted (an insertion is ~100 VALU, an LDS read ~100 cycles)
-        unsigned long long nxt = buf[0][tid];
-        for (int u = 0; u < mxc; ++u) {
-            const unsigned long long cur = u < cnt ? nxt : 0ull;
-            nxt = buf[min(u + 1, kBufS - 1)][tid];
-            list_insert<K>(kv, cur);
+        if constexpr (kBufS == 12 && K == 20) {
+            // One wave per tile: all twelve buffer entries at once (knn_device.h, list_merge12: ~280 instructions whatever the count, against
+            // ~50 per key one at a time; 14 of a tile's 15.5 drains have 9-12 keys in the busiest lane, tools/knn_counters.py).  Written as
+            // a loop of at most one trip whose count the compiler cannot see, and with no one-at-a-time alternative beside it: the network
+            // leaves the list in other registers than it found it in, and as straight-line code (or with a second way to update the list)
+            // the register allocator paid for that with 20 64-bit moves on the path that does NOT drain -- once per four candidates, more
+            // than the merge saves.  A loop carries the list in place and keeps the moves on its own back edge.
+            int trips = __builtin_amdgcn_readfirstlane(mxc > 0 ? 1 : 0);
+            asm volatile("" : "+s"(trips));
+            for (; trips > 0; --trips) {
+                double b[12];
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const unsigned long long k = buf[u][tid];
+                    b[u] = to_list(u < cnt ? k : 0ull);                // key 0 <-> list_empty()
+                }
+                list_merge12(kv, b);
+            }
+        } else {
+            // the next buffered key is read while the current one is inserted (an insertion is ~50 VALU, an LDS read ~100 cycles)
+            unsigned long long nxt = buf[0][tid];
+            for (int u = 0; u < mxc; ++u) {
+                const unsigned long long cur = u < cnt ? nxt : 0ull;
+                nxt = buf[min(u + 1, kBufS - 1)][tid];
+                list_insert<K>(kv, cur);
+            }
         }
         cnt = 0;
         if (active) {
@@ -805,7 +831,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     }
 }
 template <int K, int kSlices, bool kSeeded = false>
-__global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
+__global__ __launch_bounds__(64 * kSlices, kSlices == 1 ? 4 : 1) void k_cluster_knn_sorted(
     const float4* __restrict__ sxyzw, const int32_t* __restrict__ smpos, const int32_t* __restrict__ cl_off,
     const int32_t* __restrict__ tile_cl, const int32_t* __restrict__ tile_lo, const int32_t* __restrict__ tile_hi,
     const int32_t* __restrict__ cl_seg_off, const int32_t* __restrict__ order, const int32_t* __restrict__ dst,
@@ -824,7 +850,7 @@ __global__ __launch_bounds__(64 * kSlices) void k_cluster_knn_sorted(
 // fourth resident wave per SIMD by capping it at 128 VGPRs (129 -> 118, no spill: 952 -> 848 us per launch of 8 scenes); a
 // fifth wave for the unseeded one (104 -> 96 VGPRs) costs 10 spilled registers and is slower (973 -> 991 us).
 template <int K, int kSlices, bool kSeeded>
-__global__ __launch_bounds__(64 * kSlices, kSlices == 1 && kSeeded ? 4 : 1) void k_cluster_knn_sorted_b(const sg::SlotCtx* __restrict__ cx, int write_seed) {
+__global__ __launch_bounds__(64 * kSlices, kSlices == 1 ? 4 : 1) void k_cluster_knn_sorted_b(const sg::SlotCtx* __restrict__ cx, int write_seed) {
     const sg::SlotCtx& c = cx[blockIdx.x];                    // grid = (scenes, tiles): one scene per XCD (kernels_edgeconv.hip, k_edgeconv_b)
     if ((int)blockIdx.y >= c.T) return;
     // pointers read out of a SlotCtx are generic to the compiler (flat_load: vmcnt AND lgkmcnt); sg_common.h, gptr

@@ -53,17 +53,18 @@ __global__ __launch_bounds__(64) void k_selftest_wave_ops(int* __restrict__ mism
 }
 
 // The top-K list in double form (knn_device.h: list_insert with v_min_f64 / v_max_f64) against the integer form it replaced
-// (key_insert: one 64-bit compare and four selects per slot): 64 lanes x 512 blocks, 300 keys each -- scores drawn from a handful of
+// (key_insert: one 64-bit compare and four selects per slot) and against list_merge12 (twelve keys at once): 64 lanes x 512 blocks, 300 keys each -- scores drawn from a handful of
 // values (many exact ties, decided by the index), negative / zero / tiny positive scores, the empty key.
 __global__ __launch_bounds__(64) void k_selftest_list_insert(int* __restrict__ mismatches) {
     using namespace sgknn;
     constexpr int K = 20;
     unsigned long long ki[K];
-    double kd[K];
+    double kd[K], km[K], b[12];
 #pragma unroll
-    for (int j = 0; j < K; ++j) { ki[j] = 0ull; kd[j] = list_empty(); }
+    for (int j = 0; j < K; ++j) { ki[j] = 0ull; kd[j] = list_empty(); km[j] = list_empty(); }
     int bad = 0;
     unsigned int r = mix(blockIdx.x * 64u + threadIdx.x + 12345u);
+    int fill = (int)(r % 13u);                                          // keys of the coming batch of twelve that are real (per lane)
     for (int i = 0; i < 300; ++i) {
         r = mix(r + i);
         float sc;
@@ -74,9 +75,19 @@ __global__ __launch_bounds__(64) void k_selftest_list_insert(int* __restrict__ m
             default: sc = -__uint_as_float(0x3a000000u + ((r >> 5) & 0x03ffffffu)); break;
         }
         const int idx = (int)((r >> 11) % (unsigned)kListMaxPoints);
-        const unsigned long long key = (r & 0x700u) == 0x700u ? 0ull : make_key(sc, idx);
+        const unsigned long long key = ((r & 0x700u) == 0x700u || i % 12 >= fill) ? 0ull : make_key(sc, idx);
         key_insert<K>(ki, key);
         list_insert<K>(kd, key);
+        // ... and twelve at a time (list_merge12: the drain of the kNN kernels' append buffers), partly filled batches included
+#pragma unroll
+        for (int u = 0; u < 12; ++u)
+            if (i % 12 == u) b[u] = to_list(key);
+        if (i % 12 == 11) {
+            list_merge12(km, b);
+            fill = (int)(mix(r ^ 0x9e3779b9u) % 13u);
+#pragma unroll
+            for (int j = 0; j < K; ++j) bad += __double_as_longlong(km[j]) != __double_as_longlong(kd[j]);
+        }
         if ((i & 15) == 15) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {

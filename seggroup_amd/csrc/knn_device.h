@@ -76,6 +76,48 @@ __device__ __forceinline__ void list_insert(double (&kv)[K], unsigned long long 
     kv[0] = list_max(kv[0], x);
 }
 
+// compare-exchange of two list-form keys: a <- the larger, b <- the smaller
+__device__ __forceinline__ void list_cx(double& a, double& b) {
+    const double hi = list_max(a, b), lo = list_min(a, b);
+    a = hi; b = lo;
+}
+// TWELVE keys into a descending list of 20 at once (round 3): one insertion is 39 instructions whatever it changes, and a drain of the
+// append buffers inserts for the busiest lane (2.6x the average lane).  Instead: sort the twelve with the 39-exchange
+// network (depth 9; checked with the 0-1 principle in tests/test_knn_networks.py), think of them behind the list in ascending order --
+// 20 descending + 12 ascending is a bitonic sequence of 32 -- and run the bitonic merge pruned to what the first 20 outputs need: the
+// first stage pairs list slot i with slot i + 16 (slots 0-3 meet the list's own tail: already in order), the upper 16 are sorted by four
+// full stages, of the lower 16 only the maxima of two halving steps and a 4-sorter survive.  78 + 108 instructions for up to twelve keys
+// against 39 each; the result is the top 20 of the union, the same list sequential insertion leaves (keys are distinct: they carry
+// the index).  Unused entries of `b` = list_empty().
+__device__ __forceinline__ void list_merge12(double (&kv)[20], double (&b)[12]) {
+    list_cx(b[0], b[8]); list_cx(b[1], b[7]); list_cx(b[2], b[6]); list_cx(b[3], b[11]); list_cx(b[4], b[10]); list_cx(b[5], b[9]);
+    list_cx(b[0], b[1]); list_cx(b[2], b[5]); list_cx(b[3], b[4]); list_cx(b[6], b[9]); list_cx(b[7], b[8]); list_cx(b[10], b[11]);
+    list_cx(b[0], b[2]); list_cx(b[1], b[6]); list_cx(b[5], b[10]); list_cx(b[9], b[11]);
+    list_cx(b[0], b[3]); list_cx(b[1], b[2]); list_cx(b[4], b[6]); list_cx(b[5], b[7]); list_cx(b[8], b[11]); list_cx(b[9], b[10]);
+    list_cx(b[1], b[4]); list_cx(b[3], b[5]); list_cx(b[6], b[8]); list_cx(b[7], b[10]);
+    list_cx(b[1], b[3]); list_cx(b[2], b[5]); list_cx(b[6], b[9]); list_cx(b[8], b[10]);
+    list_cx(b[2], b[3]); list_cx(b[4], b[5]); list_cx(b[6], b[7]); list_cx(b[8], b[9]);
+    list_cx(b[4], b[6]); list_cx(b[5], b[7]);
+    list_cx(b[3], b[4]); list_cx(b[5], b[6]); list_cx(b[7], b[8]);
+    // stage 1 (distance 16): kv[4 + i] meets b[11 - i]; the smaller ones fall into the lower half lo[0..15] = {kv[16..19], b'...}
+#pragma unroll
+    for (int i = 0; i < 12; ++i) list_cx(kv[4 + i], b[11 - i]);
+    // lower half, positions 16..31 = kv[16..19], b[11], b[10], ..., b[0]: its four largest, sorted, are the list's slots 16..19
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kv[16 + i] = list_max(kv[16 + i], b[7 - i]);           // positions 16+i vs 24+i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[11 - i] = list_max(b[11 - i], b[3 - i]);              // positions 20+i vs 28+i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kv[16 + i] = list_max(kv[16 + i], b[11 - i]);           // positions 16+i vs 20+i
+    list_cx(kv[16], kv[18]); list_cx(kv[17], kv[19]); list_cx(kv[16], kv[17]); list_cx(kv[18], kv[19]);
+    // upper half: bitonic, four full stages
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if ((i & d) == 0) list_cx(kv[i], kv[i + d]);
+}
+
 // upper bound of the score of ANY point inside an axis-aligned box {min xyz, max xyz, max |p|^2}:
 // -dmin^2 (shrunk by 1e-6) + 16 eps (|q|^2 + max |p|^2) -- the margin covers the fp32 rounding of score4()
 __device__ inline float box_score_bound(const float4& me, const float* bx) {

@@ -30,4 +30,4 @@ for variant, what in ((1, "both layers unseeded"), (8, "layer 2 unseeded + layer
     v = list(buf)
     t = max(v[0], 1)
     print(f"{what}: tiles {v[0]} | per tile: chunk tests {v[6] / t:.1f}, chunks scanned {v[5] / t:.1f} (= {32 * v[5] / t:.0f} candidates), segment tests {v[7] / t:.1f}, "
-          f"keys appended per lane {v[8] / t / 64:.1f}, drain steps {v[9] / t:.1f} | cycles per tile: phase A {v[1] / t:.0f}, B {v[3] / t:.0f}, out {v[4] / t:.0f}; trace {res.trace}")
+          f"keys appended per lane {v[8] / t / 64:.1f}, drain steps {v[9] / t:.1f} in {v[10] / t:.1f} drains ({v[11] / t:.1f} empty, {v[12] / t:.1f} merged by twelve) | cycles per tile: phase A {v[1] / t:.0f}, B {v[3] / t:.0f}, out {v[4] / t:.0f}; trace {res.trace}")
