@@ -128,6 +128,8 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                                               sg::gptr<const unsigned int> range_bits = nullptr) {
     using sg::gptr;
     __shared__ Lds lds;
+    // the fused epilogue's stage (32 rows x 64 maxima per wave); during the slot loop of the fp16 variants: the lanes' neighbour ids [K][64]
+    __shared__ float stage_or_ids[(kFused || kF16) ? kWaves : 1][(kFused || kF16) ? 32 * 65 : 1];
     constexpr bool kTwo = MODE == S2X;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
@@ -452,40 +454,47 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
             r0 = xq[0]; r1 = xq[1]; r2 = xq[2];
         };
         if constexpr (kF16) {
-            // two row buffers that take turns: with one buffer handed over at the loop edge the register allocator copied freshly loaded
-            // registers right behind their load (a memory round trip per slot); requests beyond the last slot re-read it
-            // A lane needs the four values of its half (d0..d3 | d4..d7) and d8 of the neighbour's row: one 16-byte and one 4-byte load, plus
-            // the id of the neighbour after next.  The three requests of a slot are written as instructions: left to the compiler they are
-            // SUNK to their first use (register pressure), which turns the one-slot lookahead into a memory round trip per slot.  `arrive`
-            // waits for everything requested a slot ago and ties the registers to the wait.
+            // kNB row buffers that take turns, kNB - 1 neighbour rows in flight (MLP2: three; its waves sat in s_waitcnt 37 % of their cycles with one
+            // -- a gather of 64 x 2 scattered lines misses L2 more often than not once eight scenes share it; MLP3 has no registers left for more
+            // than one).  A lane needs the four values of its half (d0..d3 | d4..d7) and d8 of the neighbour's row: one 16-byte and one 4-byte load.
+            // The requests of a slot are written as instructions: left to the compiler they are SUNK to their first use (register pressure), which
+            // turns the lookahead into a memory round trip per slot; with the buffers handed over at the loop edge the register allocator copied
+            // freshly loaded registers right behind their load.  `arrive` waits until only the younger requests are outstanding (loads return in
+            // order) and ties the registers to the wait.  The K neighbour ids of the lane's row are parked in the wave's strip of the epilogue's
+            // stage area (unused until the tile's maxima are written there): a request must not depend on a load that is itself in flight.
             using f32x4 = __attribute__((ext_vector_type(4))) float;
+            constexpr int kNB = kTwo ? 2 : 4;
+            int* idl = reinterpret_cast<int*>(&stage_or_ids[wave][0]);
+            for (int j = 0; j < K; ++j) idl[j * 64 + lane] = krow[j];
             // (`cur` = the row the coming slot works on: re-defined by the request so that the slot's code cannot be scheduled in front of
             // it; `done` = a statistic the finished slot wrote: re-defined by the wait so that the wait cannot be scheduled in front of it)
-            auto request = [&](int nb, f32x4& r0, float& e8, int& id_next, int j_next, f32x4& cur) {
+            auto request = [&](int nb, f32x4& r0, float& e8, f32x4& cur) {
                 const gptr<const float> row = x9m + (size_t)nb * 12;
                 const gptr<const float> p16 = row + 4 * half, p4 = row + 8;
-                const gptr<const int32_t> pid = krow + j_next;
                 asm volatile("global_load_dwordx4 %0, %2, off" : "=v"(r0), "+v"(cur) : "v"(p16));
                 asm volatile("global_load_dword %0, %1, off" : "=v"(e8) : "v"(p4));
-                asm volatile("global_load_dword %0, %1, off" : "=v"(id_next) : "v"(pid));
             };
-            auto arrive = [&](f32x4& r0, float& e8, int& id_next, float& done) {
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(e8), "+v"(id_next), "+v"(done));
+            auto arrive = [&](f32x4& r0, float& e8, float& done) {
+                asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r0), "+v"(e8), "+v"(done) : "n"(2 * (kNB - 2)));
             };
-            f32x4 ra, rb;
-            float ea, eb;
-            int ida, idb;
+            f32x4 rb[kNB];
+            float eb[kNB];
             f32x4 none = {0.f, 0.f, 0.f, 0.f};
-            request(krow[0], ra, ea, ida, min(1, K - 1), none);    // slot 0's row, slot 1's id
-            for (int j = 0; j < K; j += 2) {
-                arrive(ra, ea, ida, stat_q[31]);
-                request(ida, rb, eb, idb, min(j + 2, K - 1), ra);   // slot j + 1's row, slot j + 2's id (requests beyond the last slot re-read it)
-                slot_body(make_float4(ra.x, ra.y, ra.z, ra.w), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(ea, 0.f, 0.f, 0.f));
-                arrive(rb, eb, idb, stat_q[31]);
-                request(idb, ra, ea, ida, min(j + 3, K - 1), rb);
-                if (j + 1 < K) slot_body(make_float4(rb.x, rb.y, rb.z, rb.w), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(eb, 0.f, 0.f, 0.f));
+#pragma unroll
+            for (int u = 0; u < kNB - 1; ++u) request(idl[min(u, K - 1) * 64 + lane], rb[u], eb[u], none);
+            int idn = idl[min(kNB - 1, K - 1) * 64 + lane];          // the id of the next request, read a slot ahead of it
+            for (int j = 0; j < K; j += kNB) {
+#pragma unroll
+                for (int u = 0; u < kNB; ++u) {
+                    arrive(rb[u], eb[u], stat_q[31]);
+                    request(idn, rb[(u + kNB - 1) % kNB], eb[(u + kNB - 1) % kNB], rb[u]);      // slot j + u + kNB - 1 (beyond the last slot: re-reads it)
+                    idn = idl[min(j + u + kNB, K - 1) * 64 + lane];
+                    if (u == 0 || j + u < K) slot_body(make_float4(rb[u].x, rb[u].y, rb[u].z, rb[u].w), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(eb[u], 0.f, 0.f, 0.f));
+                }
             }
-            arrive(ra, ea, ida, stat_q[31]);                        // nothing may still be in flight into registers the code below reuses
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(eb[0]), "+v"(eb[1]), "+v"(stat_q[31]));       // nothing may still be in flight into registers the code below reuses
+            if constexpr (kNB > 2) asm volatile("" : "+v"(rb[kNB - 2]), "+v"(rb[kNB - 1]), "+v"(eb[kNB - 2]), "+v"(eb[kNB - 1]));
+            __builtin_amdgcn_wave_barrier();                      // the ids are dead: the strip is the epilogue's now
         } else {
             int nb_next = krow[0];
             float4 p0, p1, p2;
@@ -538,8 +547,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
             // one cluster, sometimes two or three): the wave parks its 32 x 64 maxima in LDS, then lane = channel walks the rows
             // and leaves ONE atomic max per (cluster, channel) -- into the columns of the layer's feature matrix that the fill
             // kernel set to -inf (`ext` = cat + gm_D, stride Dcat); k_cluster_affine applies the activation once the fold is known.
-            __shared__ float stage[kWaves][32 * 65];
-            float* st = &stage[wave][0];
+            float* st = &stage_or_ids[wave][0];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -996,6 +1004,7 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
                             size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine,
                             unsigned int* d_range_bits) {
     SG_REQUIRE(N >= 0 && k > 0 && (layers == 1 || layers == 2) && d_ws, "sg_edgeconv_forward: bad arguments");
+    SG_REQUIRE(!d_range_bits || k <= 32, "sg_edgeconv_forward_r: at most 32 neighbours per point (their ids are parked in a 32 x 65-word LDS strip)");
     if (d_affine) { d_affine[0] = nullptr; d_affine[1] = nullptr; d_affine[2] = nullptr; }
     if (N == 0) return SG_OK;
     const int nblocks = sg::cdiv(sg::cdiv(N, 32), kWaves);

@@ -21,7 +21,8 @@ def main():
     ap.add_argument("--scenes", type=int, default=16)
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--segments", type=int, default=1000)
-    ap.add_argument("--out-format", default="txt,npy")
+    ap.add_argument("--out-format", default="txt,npy", help="label file formats; several sets separated by ';' share one tree (e.g. 'npy;txt,npy')")
+    ap.add_argument("--base", default="/tmp", help="where the input tree and the results live (/dev/shm = tmpfs)")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--inflight", type=int, default=64)
     ap.add_argument("--workers", type=int, default=16)
@@ -32,7 +33,7 @@ def main():
     import torch
     from seggroup_amd import infer, synthetic, weights
 
-    root = tempfile.mkdtemp(prefix="sg_driver_", dir="/tmp")
+    root = tempfile.mkdtemp(prefix="sg_driver_", dir=a.base)
     try:
         t0 = time.time()
         base = [synthetic.make_scene(a.points, a.segments, 20004 + i, name=f"scene{i:04d}_00") for i in range(min(a.scenes, 4))]
@@ -45,35 +46,37 @@ def main():
         os.makedirs(ck)
         torch.save({"state_dict": weights.to_full_state_dict(weights.make_weights(1, bn1_gamma=2.0))}, os.path.join(ck, "last.t7"))
         gen_s = time.time() - t0
-        common = ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--out-format", a.out_format, "-j", str(a.workers)]
+        out = {"scenes": a.scenes, "points": a.points, "base": a.base, "tree_build_s": round(gen_s, 1)}
+        for fmt in a.out_format.split(";"):
+            common = ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--out-format", fmt, "-j", str(a.workers)]
 
-        def run(extra):
-            shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
-            args = infer.build_parser().parse_args(common + extra)
-            t = time.time()
-            r = infer.run_worker(0, 1, args)
-            return time.time() - t, r
+            def run(extra):
+                shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
+                args = infer.build_parser().parse_args(common + extra)
+                t = time.time()
+                r = infer.run_worker(0, 1, args)
+                return time.time() - t, r
 
-        out = {"scenes": a.scenes, "points": a.points, "out_format": a.out_format, "tree_build_s": round(gen_s, 1)}
-        r0 = None
-        if not a.skip_loop:
-            run(["--batch", "0"])                              # warm-up: HIP context, page cache
-            t, r0 = run(["--batch", "0"])
-            out["per_scene_loop"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
-        fast = ["--batch", str(a.batch), "--inflight", str(a.inflight)]
-        run(fast + ["--no-cache"])                             # warm-up of this leg (engine creation, page cache)
-        t, rn = run(fast + ["--no-cache"])
-        out["reference_files_no_pack"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
-        t, r1 = run(fast)
-        out["packed_cold"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
-        t, r2 = run(fast)
-        out["packed_warm"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
-        t, r3 = run(fast)
-        out["packed_warm_2"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
-        ref = r0 if r0 is not None else r1
-        out["summaries_equal"] = all(repr(ref[k]) == repr(r2[k]) for k in ref if k != "elapsed_s")
-        nfiles = sum(len(f) for _, _, f in os.walk(os.path.join(root, "results")))
-        out["files_written"] = nfiles
+            o = {}
+            r0 = None
+            if not a.skip_loop:
+                run(["--batch", "0"])                              # warm-up: HIP context, page cache
+                t, r0 = run(["--batch", "0"])
+                o["per_scene_loop"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
+            fast = ["--batch", str(a.batch), "--inflight", str(a.inflight)]
+            run(fast + ["--no-cache"])                             # warm-up of this leg (engine creation, page cache)
+            t, rn = run(fast + ["--no-cache"])
+            o["reference_files_no_pack"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
+            t, r1 = run(fast)
+            o["packed_cold"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
+            t, r2 = run(fast)
+            o["packed_warm"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2), "driver_elapsed_s": r2.get("elapsed_s")}
+            t, r3 = run(fast)
+            o["packed_warm_2"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2), "driver_elapsed_s": r3.get("elapsed_s")}
+            ref = r0 if r0 is not None else r1
+            o["summaries_equal"] = all(repr(ref[k]) == repr(r2[k]) for k in ref if k != "elapsed_s")
+            o["files_written"] = sum(len(f) for _, _, f in os.walk(os.path.join(root, "results")))
+            out[fmt] = o
         print(json.dumps(out))
         if a.out:
             os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
