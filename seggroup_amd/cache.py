@@ -166,7 +166,7 @@ def _pinned(nbytes: int):
     import torch
     buf = getattr(_tls, "pinned", None)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 24), dtype=torch.uint8).pin_memory()
+        buf = torch.empty(max(nbytes, 1 << 24), dtype=torch.uint8, pin_memory=True)
         _tls.pinned = buf
     return buf
 

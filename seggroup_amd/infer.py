@@ -210,6 +210,8 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         total.v = vec.numpy().copy()
         result = total.summary()
         result['elapsed_s'] = time.time() - t0
+        if getattr(acc, 'startup_s', None) is not None:
+            result['startup_s'], result['first_batch'] = acc.startup_s, acc.first_batch
         final_report(result, io)
         io.close()
     if world > 1 and init_dist:
@@ -255,6 +257,7 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
             if rank == 0:
                 io.cprint(progress_line(min(done * world, len(scene_list)), len(scene_list), acc.summary()))
 
+    t_start, startup = time.time(), None
     for bi, batch in enumerate(batches):
         scenes = [f.result() for f in pending]
         pending = [pool.submit(stage, n) for n in batches[bi + 1]] if bi + 1 < len(batches) else []
@@ -267,6 +270,11 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
             runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps, timing=0)
         # one batch is queued behind the one in flight: the engine's groups never drain between batches
         tickets.append(runner.submit(scenes, mode, writer=writer, out_dirs=[model.output_root(s_.name) for s_ in scenes], formats=formats))
+        if startup is None:
+            # one-off: the first batch staged with nothing to overlap it, the engine's slots (124 MB of device memory each) and the pinned
+            # label ring created -- about a second that a short run cannot amortise
+            startup = time.time() - t_start
+            acc.startup_s, acc.first_batch = startup, len(scenes)
         if len(tickets) > 1:
             consume(tickets.pop(0))
     while tickets:

@@ -128,7 +128,7 @@ class Pipeline:
             self.handle = self.lib.sg_pipeline_create(max_points, max_segments, max_edges, max_vertices, C.byref(cw), sp)
         if not self.handle:
             raise hip.SgError(hip.SG_EHIP, self.lib.sg_last_error().decode())
-        self.labels = torch.empty((hip.NUM_LABEL_VECTORS, max_vertices), dtype=torch.int32).pin_memory()
+        self.labels = torch.empty((hip.NUM_LABEL_VECTORS, max_vertices), dtype=torch.int32, pin_memory=True)
 
     def fits(self, sc: DeviceScene) -> bool:
         return sc.N <= self.caps[0] and sc.S <= self.caps[1] and sc.E0 <= self.caps[2] and sc.V <= self.caps[3]
@@ -241,7 +241,7 @@ class Engine:
             for k in range(self.ring):
                 if self._labels[k] is None or self._labels[k].shape[0] < n:
                     self._release_slot(k)
-                    self._labels[k] = torch.empty((max(n, 1), hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32).pin_memory()
+                    self._labels[k] = torch.empty((max(n, 1), hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32, pin_memory=True)
         buf = self._labels[slot]
         c_scenes = (hip.Scene * n)(*[s.c_struct for s in scenes])
         c_res = (hip.Result * n)()

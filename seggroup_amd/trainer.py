@@ -104,7 +104,7 @@ class Trainer:
             self.buffers[name + ".num_batches_tracked"] = torch.tensor(int(np.asarray(nb)) if nb is not None else 0, dtype=torch.int64)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed))
-        self.labels = torch.empty((hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32).pin_memory()
+        self.labels = torch.empty((hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32, pin_memory=True)
         with torch.cuda.device(self.device):
             self.handle = self.lib.sg_trainer_create(*self.caps, self.params.data_ptr(), self.grads.data_ptr(), None)
         if not self.handle:

@@ -81,7 +81,7 @@ def test_two_ranks_on_one_gpu_write_the_same_files_as_one_rank(tmp_path, golden_
     # 2. the reduced metric vector: the all-reduce of two shards == the one-process accumulation (integer counts in float64: exact)
     assert two["n"] == one["n"] == n_scenes
     for k in one:
-        if k != "elapsed_s":
+        if k not in ("elapsed_s", "startup_s", "first_batch"):
             assert np.array_equal(np.asarray(one[k]), np.asarray(two[k]), equal_nan=True), k
     log = open(os.path.join(root, "checkpoints", "w2", "run_infer.log")).read()
     assert "==> Infer           Instance mIoU:" in log

@@ -395,7 +395,7 @@ def test_packed_scene_and_fast_driver_match_reference_capture(tmp_path, golden_i
     slow = infer.run_worker(0, 1, infer.build_parser().parse_args(
         ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--batch", "0"]))
     for k in fast:
-        if k != "elapsed_s":
+        if k not in ("elapsed_s", "startup_s", "first_batch"):
             assert np.array_equal(np.asarray(fast[k]), np.asarray(slow[k]), equal_nan=True), k   # classes absent from a scene set are NaN
 
 
