@@ -53,9 +53,6 @@ inline hipError_t timed_sync(hipStream_t st) {
     tl_ns_sync += now_ns() - t0;
     return e;
 }
-const char* const kLabelNames[SG_NUM_LABEL_VECTORS] = {"layer_1.seg", "layer_1.ins", "layer_1.sem", "layer_2.seg", "layer_2.ins",
-                                                       "layer_2.sem", "layer_3.seg", "layer_3.ins", "layer_3.sem", "layer_4.seg",
-                                                       "layer_4.ins", "layer_4.sem", "final.ins", "final.sem"};
 
 // bump allocator over a pinned buffer whose device twin has the same layout
 struct Arena {

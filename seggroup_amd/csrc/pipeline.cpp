@@ -187,14 +187,13 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     out->stalled = 0; out->used_fallback = 0;
     for (int i = 0; i < 5; ++i) out->trace[i] = 0;
 
-    sg_partition* part = sg_partition_create(S, sc->h_seg_first, sc->h_seg_size, sc->h_seg_ins, sc->h_seg_sem);
-    if (!part) return SG_EINVAL;
+    // (the partition itself -- S member lists -- is built further down, behind the first launches: the GPU is idle until those are queued,
+    // and one scene alone pays for every microsecond the host spends in front of them)
+    sg_partition* part = nullptr;
     int max_ins = 1;
     for (int s = 0; s < S; ++s) max_ins = std::max(max_ins, sc->h_seg_ins[s] + 2);
-    if (sg_eval_ws_bytes(max_ins) > pl->ws_eval.n) {
-        sg_partition_destroy(part);
+    if (sg_eval_ws_bytes(max_ins) > pl->ws_eval.n)
         return sg::fail(SG_EUNSUP, "weak instance ids up to %d exceed the pipeline's metric workspace (max_segments + 2)", max_ins - 2);
-    }
 
     int32_t* tab = pl->h_tables.p;                       // [14,S]
     auto tables_for = [&](int first_row, bool with_seg) {
@@ -228,6 +227,8 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     PL_CHECK(sg_mlp1_forward(pl->samples.p, S, W + pl->o_m1w, W + pl->o_m1g, W + pl->o_m1b, pl->feat1.p, 128, pl->ws_mlp1.p,
                              pl->ws_mlp1.n, stv));
     pl->mark(2);
+    part = sg_partition_create(S, sc->h_seg_first, sc->h_seg_size, sc->h_seg_ins, sc->h_seg_sem);
+    if (!part) return SG_EINVAL;
     lap(0);
     PL_HIP(timed_sync(st));
     lap(-1);

@@ -40,3 +40,13 @@ for it in range(iters):
     print(f"iter {it}: wall {walls[-1]:.2f} ms  gpu-stage-sum {sum(v for k, v in st.items() if k.count('.') <= 1):.2f} ms trace {res.trace} fallback {res.used_fallback}")
 print(json.dumps({"points": n, "segments": s, "E0": int(sc.adj.shape[0]), "V": int(sc.unmap.shape[0]), "wall_ms_median": round(float(np.median(walls[2:])), 3),
                   "wall_ms_min": round(min(walls[2:]), 3), "trace": list(res.trace), "stage_ms": {k: round(v, 4) for k, v in st.items() if v > 0}}))
+if os.environ.get("SG_HOST_PROFILE"):
+    # where the host's share of the wall time goes (pipeline.cpp prints the split to stderr at the end of an sg_batch_forward call)
+    import ctypes as C
+    cnt = 16
+    pipes = (C.c_void_p * 1)(pipe.handle)
+    c_scenes = (hip.Scene * cnt)(*[ds.c_struct for _ in range(cnt)])
+    c_res = (hip.Result * cnt)()
+    for i in range(cnt):
+        c_res[i].h_labels = pipe.labels.data_ptr()
+    hip.check(hip.lib().sg_batch_forward(pipes, 1, c_scenes, cnt, hip.MODE_INS_INFER, c_res, None, None, None, 0))
