@@ -420,10 +420,10 @@ def main(argv=None):
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
                     "traffic": (pmc.get("hbm_bytes_per_scene_launch", {}) or {}).get(dom), "traffic_source": pmc.get("configuration"),
-                    "basis": "EXECUTED 16-bit MFMA flop of one scene's share of the batched launch (fp32 operands split into bf16 x 3 / fp16 x 2 pieces, "
+                    "basis": "EXECUTED 16-bit MFMA flop of one scene's share of the batched launch (fp32 operands split into two fp16 pieces each, three products, "
                              "fp32 accumulate: DESIGN.md section 4) / the launch's duration with one engine group alone on the GPU (HIP events on the "
                              "group's stream, after the timed region; profiles/%s_solo_batched_kernel_stats.csv is rocprofv3's view of the same "
-                             "configuration) / the dense bf16 / fp16 MFMA peak" % PROFILE_TAG,
+                             "configuration) / the dense fp16 MFMA peak" % PROFILE_TAG,
                     "executed_flop_per_scene_launch": m_dom[5], "algorithmic_flop_per_scene_launch": m_dom[3],
                     "ms_per_scene_launch": round(t_dom * 1e3, 4), "launches_per_scene": 1,
                     "algorithmic_fp32_tflops": round(m_dom[3] / t_dom / 1e12, 1) if t_dom > 0 else None,

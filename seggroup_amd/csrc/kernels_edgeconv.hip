@@ -661,20 +661,22 @@ __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m,
 #pragma unroll
         for (int u = 0; u < kG; ++u) ids[u] = u < K ? krow[u] : 0;
         for (int j0 = 0; j0 < K; j0 += kG) {
-            float4 r0[kG], r1[kG], r2[kG];
+            float4 r0[kG], r1[kG];
+            float r2[kG];                                            // channel 8 alone: the row's last 12 bytes are padding (same time, 12 fewer registers)
 #pragma unroll
             for (int u = 0; u < kG; ++u) {
-                const float4* xq = reinterpret_cast<const float4*>(x9m + (size_t)ids[u] * 12);
-                r0[u] = xq[0]; r1[u] = xq[1]; r2[u] = xq[2];
+                const float* xrow = x9m + (size_t)ids[u] * 12;
+                const float4* xq = reinterpret_cast<const float4*>(xrow);
+                r0[u] = xq[0]; r1[u] = xq[1]; r2[u] = xrow[8];
             }
 #pragma unroll
             for (int u = 0; u < kG; ++u) ids[u] = j0 + kG + u < K ? krow[j0 + kG + u] : 0;
 #pragma unroll
             for (int u = 0; u < kG; ++u) {
                 if (j0 + u >= K) break;
-                const float4 n0 = r0[u], n1 = r1[u], n2 = r2[u];
+                const float4 n0 = r0[u], n1 = r1[u];
                 const float d[9] = {n0.x - xi[0], n0.y - xi[1], n0.z - xi[2], n0.w - xi[3], n1.x - xi[4],
-                                    n1.y - xi[5], n1.z - xi[6], n1.w - xi[7], n2.x - xi[8]};
+                                    n1.y - xi[5], n1.z - xi[6], n1.w - xi[7], r2[u] - xi[8]};
                 int t = 0;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
@@ -835,18 +837,22 @@ __device__ __forceinline__ void bn_fold_moments_body(const double* __restrict__ 
         // accumulator stays T x conv1' -- and if a weight would leave fp16 that way (|a w T / Sd| > 2^14: a degenerate variance), T gives:
         // a smaller T only costs conv2's low pieces precision in that degenerate case.
         __shared__ double sa[64];
-        __shared__ float samax[64], sSd;
+        __shared__ float samax[64], srange[sg::kRangeWords / 64], sSd;
         if (threadIdx.x < 64) {
             sa[ch] = a;
             float m = 0.f;
             for (int k = 0; k < 9; ++k) m = fmaxf(m, fabsf((float)(a * (double)w[ch * 18 + k])));
             samax[ch] = m;
         }
+        if (threadIdx.x < sg::kRangeWords) {                     // one range word per thread (one thread walking all 256: 17 us of dependent loads)
+            const float rw = sgw::wave_max(__uint_as_float(range_bits[threadIdx.x]));
+            if ((threadIdx.x & 63) == 0) srange[threadIdx.x >> 6] = rw;
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             float am = 0.f, rm = 0.f;
             for (int c = 0; c < 64; ++c) am = fmaxf(am, samax[c]);
-            for (int i = 0; i < sg::kRangeWords; ++i) rm = fmaxf(rm, __uint_as_float(range_bits[i]));
+            for (int i = 0; i < sg::kRangeWords / 64; ++i) rm = fmaxf(rm, srange[i]);
             float Sd = pow2_scale(2.f * rm, 4096.f);
             const float lim = pow2_scale(am * sT / Sd, 16384.f);
             if (lim < 1.f) { sT *= lim; scales[0] = 1.f / (sT * sS); scales[1] = sT; }
