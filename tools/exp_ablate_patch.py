@@ -2,7 +2,11 @@
 """Development only: patches seggroup_amd/csrc/kernels_edgeconv.hip IN PLACE so that the high bits of SG_EC_STAGGER2 (value = flags << 8)
 leave parts of the S2X slot out -- 1 conv2's MFMAs, 2 the fp16 cut, 4 the statistics, 8 conv1's MFMAs, 16 LeakyReLU, 32 the neighbour gathers
 (results are garbage; the launch time is what is measured: tools/exp_ablate.sh).  The branches disturb the instruction schedule (the patched
-kernel is ~40 % slower with no flag set), so only differences between flag sets mean something.  Undo: git checkout seggroup_amd/csrc/kernels_edgeconv.hip."""
+kernel is ~40 % slower with no flag set), so only differences between flag sets mean something.  Undo: git checkout seggroup_amd/csrc/kernels_edgeconv.hip.
+
+Written against the slot loop of commit 55849f3 (MLP3's conv1 still on three bf16 pieces, full-row loads): the attribution quoted in DESIGN.md
+section 5 was measured there.  Against a later kernel the script stops with "anchor not found" and changes nothing -- check that commit out to
+repeat the measurement."""
 import os
 import sys
 p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seggroup_amd", "csrc", "kernels_edgeconv.hip")
