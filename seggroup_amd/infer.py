@@ -56,7 +56,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL on ROCm)')
     p.add_argument('--port', type=int, default=2344, help='rendezvous port on 127.0.0.1 (reference: 2344)')
     p.add_argument('--batch', type=int, default=64, help='scenes per batch in the packed fast path (0 = the per-scene SegModel.forward loop)')
-    p.add_argument('--inflight', type=int, default=64, help='scenes in flight per GPU in the packed fast path (engine groups of 8)')
+    p.add_argument('--inflight', type=int, default=80, help='scenes in flight per GPU in the packed fast path (engine groups of 8; two groups more than a batch fills)')
     p.add_argument('--no-cache', action='store_true', help='do not build / use packed scene files (dataset/scannet/cache/...)')
     return p
 

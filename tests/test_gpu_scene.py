@@ -520,8 +520,8 @@ def test_batch_of_64_full_size_scenes_through_the_concurrent_path(golden_index, 
     want = [_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
     solo.close()
     assert len(set(want)) == 64                                    # the scenes really are distinct
-    runner = BatchRunner(W, scenes, inflight=64, device="cuda:0", timing=1)        # the engine in bench.py's shape: 8 groups x 8 scenes in lock-step
-    assert (runner.groups, runner.per_group) == (8, 8)
+    runner = BatchRunner(W, scenes, inflight=80, device="cuda:0", timing=1)        # the engine in bench.py's shape: 10 groups x 8 scenes in lock-step, batches of 64
+    assert (runner.groups, runner.per_group) == (10, 8)
     for rep in range(2):
         order = list(range(64)) if rep == 0 else list(range(63, -1, -1))      # second pass: other scene -> slot assignment
         res = runner.run([scenes[i] for i in order], hip.MODE_INS_INFER)

@@ -10,7 +10,7 @@ cd $R
 # scenes of the profiled runs, generated once by an unprofiled process pool: a profiled process must not spawn (the profiler's preload
 # has initialised the GPU before python starts)
 timeout 600 python3 bench.py --generate-only --no-extras --scene-cache $SG_SCENE_CACHE
-timeout 500 bash tools/prof_engine.sh bench 8 8 | head -12
+timeout 500 bash tools/prof_engine.sh bench 10 8 | head -12
 timeout 500 bash tools/prof_engine.sh solo8 1 8 | head -30
 timeout 900 bash tools/pmc_engine.sh $TAG 1 8 > gpurun_out/${TAG}_pmc.log 2>&1
 (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -- python3 $R/tools/time_train.py --steps 6 > $R/gpurun_out/prof_train.log 2>&1)
