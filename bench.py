@@ -612,6 +612,21 @@ def main(argv=None):
                                     "ms": {k_: round(v / args.extra_train * 1e3, 3) for k_, v in tt.items()},
                                     "note": "one scene per step on one stream (train.py's batch size 1), SGD; off the headline metric"}
             trn.close()
+            # ... and eight scenes per optimizer step (BatchTrainer: eight lanes on their own streams, gradients averaged like DDP ranks')
+            lanes = min(8, len(scenes))
+            if lanes > 1:
+                btr = _trainer.BatchTrainer(st, caps_t, lanes=lanes, device=dev)
+                tb, nb_ = 0.0, max(2, args.extra_train // 2)
+                for it in range(-1, nb_):
+                    grp = [scenes[(it * lanes + k_) % len(scenes)] for k_ in range(lanes)]
+                    torch.cuda.synchronize(); a0 = time.perf_counter()
+                    btr.step(grp)
+                    torch.cuda.synchronize()
+                    if it >= 0:
+                        tb += time.perf_counter() - a0
+                extras["train_step"]["batched"] = {"scenes_per_step": lanes, "ms_per_step": round(tb / nb_ * 1e3, 3),
+                                                   "ms_per_scene": round(tb / nb_ / lanes * 1e3, 3), "steps": nb_}
+                btr.close()
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -48,6 +48,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL on ROCm)')
     p.add_argument('--port', type=int, default=23456, help='rendezvous port on 127.0.0.1 (reference: 23456)')
     p.add_argument('--max-steps', type=int, default=0, help='stop every epoch after this many steps per rank (0 = the whole scene list)')
+    p.add_argument('--scenes-per-step', type=int, default=1, dest='scenes_per_step',
+                   help='scenes per optimizer step and GPU: > 1 runs that many forward / backward passes side by side (BatchTrainer) and averages their '
+                        'gradients, as the reference does over ranks (not in the reference: its batch size per rank is 1)')
     p.add_argument('--no-cache', action='store_true', help='do not build / use packed scene files (dataset/scannet/cache/...)')
     p.add_argument('--param-digests', action='store_true', help='every rank writes sha256 of its final parameter vector to '
                    'checkpoints/<exp>/models/rank<r>.sha256 (the ranks must agree: same averaged gradient, same optimizer)')
@@ -197,6 +200,10 @@ def run_worker(rank: int, world: int, args, make_trainer: Optional[Callable] = N
         def make_trainer(state):   # noqa: F811
             first = stage(names[0])
             caps = (max(first.N, 150000), max(first.S, 4096), max(first.E0, 1 << 20), max(first.V, 400000))
+            if args.scenes_per_step > 1:
+                from .trainer import BatchTrainer
+                return BatchTrainer(state, caps, lanes=args.scenes_per_step, device=dev, use_sgd=args.use_sgd, lr=args.lr, momentum=args.momentum,
+                                    seed=args.seed + rank)
             return Trainer(state, caps, device=dev, use_sgd=args.use_sgd, lr=args.lr, momentum=args.momentum, seed=args.seed + rank)
 
     state = initial_state(args.seed)
@@ -232,6 +239,34 @@ def run_worker(rank: int, world: int, args, make_trainer: Optional[Callable] = N
         if args.max_steps:
             mine = mine[:args.max_steps]
         log = EpochLog()
+        if getattr(args, 'scenes_per_step', 1) > 1:
+            # B scenes per optimizer step (BatchTrainer): the next group is staged while this one trains
+            B = args.scenes_per_step
+            groups = [mine[k:k + B] for k in range(0, len(mine), B)]
+            nxt = [pool.submit(stage, names[si]) for si in groups[0]] if groups else []
+            seen = 0
+            for gi, grp in enumerate(groups):
+                scs = [f.result() for f in nxt]
+                nxt = [pool.submit(stage, names[si]) for si in groups[gi + 1]] if gi + 1 < len(groups) else []
+                if any(not tr.fits(sc) for sc in scs):
+                    bigger = tuple(max(a, *b) for a, b in zip(tr.caps, zip(*[(sc.N, sc.S, sc.E0, sc.V) for sc in scs])))
+                    state_now, opt_now = tr.state_dict(), tr.optimizer_state()
+                    tr.close()
+                    from .trainer import BatchTrainer
+                    tr = BatchTrainer(state_now, bigger, lanes=B, device=dev, use_sgd=args.use_sgd, lr=args.lr, momentum=args.momentum, seed=args.seed + rank)
+                    tr.load_optimizer_state(opt_now)
+                try:
+                    _, ress, summed = tr.step(scs)
+                except Exception as e:
+                    raise RuntimeError('%s: %s' % (' '.join(names[si] for si in grp), e)) from e
+                if writer is not None:
+                    for si, res in zip(grp, ress):
+                        writer.submit(os.path.join(args.root, 'results', args.exp_name, names[si], 'epoch_' + tag), res, formats)
+                seen += len(grp)
+                if rank == 0:
+                    log.add(summed)
+                    io.cprint(log.line('Epoch[%d/%d](%04d/%04d)' % (epoch + 1, args.epochs, min(seen * world, len(names)), len(names))))
+            mine = []
         nxt = pool.submit(stage, names[mine[0]]) if mine else None
         for i, si in enumerate(mine):
             sc = nxt.result()

@@ -10,8 +10,9 @@ Mirrors the loop body of the reference's train.py:160-170 --
 all-reduce of 0.59 MB over RCCL and the optimizer is one kernel.  `state_dict()` / `load_state_dict()` speak the reference's
 checkpoint keys, including the running BatchNorm statistics the reference updates in training mode.
 """
+import contextlib
 import ctypes as C
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -80,12 +81,15 @@ class Trainer:
     use_sgd / lr / momentum follow train.py:95-99: SGD(lr * 100, momentum, weight_decay 1e-4) or Adam(lr, weight_decay 1e-4)."""
 
     def __init__(self, state: Dict[str, np.ndarray], caps, device=None, use_sgd: bool = True, lr: float = 0.001, momentum: float = 0.9,
-                 weight_decay: float = 1e-4, seed: int = 1):
+                 weight_decay: float = 1e-4, seed: int = 1, params: Optional[torch.Tensor] = None, own_stream: bool = False):
+        """`params`: a flat device vector to train IN PLACE of a private copy of `state` (the lanes of a BatchTrainer share one);
+        `own_stream`: forward / loss / backward on a stream of this trainer's own instead of the default stream (lanes run side by side)."""
         hip.require_device()
         self.lib = hip.lib()
         self.device = torch.device(device if device is not None else "cuda")
         self.caps = tuple(int(c) for c in caps)
-        self.params = torch.from_numpy(flatten_state(state)).to(self.device)
+        self.params = params if params is not None else torch.from_numpy(flatten_state(state)).to(self.device)
+        self.stream = torch.cuda.Stream(device=self.device) if own_stream else None
         # gradient vector + the per-step log quantities of train.py:170-173 behind it: ONE collective per step
         self.grads_full = torch.zeros(NUM_PARAMS + NUM_EXTRAS, dtype=torch.float32, device=self.device)
         self.grads = self.grads_full[:NUM_PARAMS]
@@ -106,7 +110,8 @@ class Trainer:
         self.gen.manual_seed(int(seed))
         self.labels = torch.empty((hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32, pin_memory=True)
         with torch.cuda.device(self.device):
-            self.handle = self.lib.sg_trainer_create(*self.caps, self.params.data_ptr(), self.grads.data_ptr(), None)
+            self.handle = self.lib.sg_trainer_create(*self.caps, self.params.data_ptr(), self.grads.data_ptr(),
+                                                     C.c_void_p(self.stream.cuda_stream) if self.stream is not None else None)
         if not self.handle:
             raise hip.SgError(hip.SG_EHIP, self.lib.sg_last_error().decode())
         self.K = self.C5 = 0
@@ -132,11 +137,13 @@ class Trainer:
         if keep is None:
             return None
         if isinstance(keep, str) and keep == "random":
-            return (torch.rand((self.K, 128), device=self.device, generator=self.gen) >= 0.5).float() * 2.0
+            with torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext():
+                return (torch.rand((self.K, 128), device=self.device, generator=self.gen) >= 0.5).float() * 2.0
         if isinstance(keep, str) and keep == "pinned":
             from .synthetic import uniform01
             keep = np.where(uniform01(97, self.K, self.K * 128).reshape(self.K, 128) < 0.5, 2.0, 0.0).astype(np.float32)
-        return torch.as_tensor(np.asarray(keep, np.float32) if not isinstance(keep, torch.Tensor) else keep).to(self.device).float().contiguous()
+        with torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext():
+            return torch.as_tensor(np.asarray(keep, np.float32) if not isinstance(keep, torch.Tensor) else keep).to(self.device).float().contiguous()
 
     def loss(self, mask: Optional[torch.Tensor], want_logits: bool = False):
         """-> loss [1,2] = [[loss_sum, K]] (model.py:928-930)"""
@@ -239,3 +246,65 @@ class Trainer:
             self.close()
         except Exception:
             pass
+
+
+class BatchTrainer(Trainer):
+    """B scenes per optimizer step on ONE GPU: B lanes (an `sg_trainer` each, on its own stream, driven by its own host thread) run forward +
+    loss + backward side by side on the SAME parameter vector, their gradients are averaged and one optimizer step follows -- what the reference
+    does with B ranks (DistributedDataParallel averages the ranks' gradients, train.py:88; every rank sees its own scene and its own BatchNorm
+    batch statistics), without B processes.  One scene's step is a chain of latency-bound launches and host round trips (6.6 ms for 5 ms of
+    kernels); B of them overlap.  The running BatchNorm statistics follow lane 0, as DDP's buffer broadcast from rank 0 does.
+
+    `step(scenes)` takes up to B scenes; the ranks' all-reduce (one per step, as before) averages the lane-averaged gradients."""
+
+    def __init__(self, state: Dict[str, np.ndarray], caps, lanes: int = 4, device=None, use_sgd: bool = True, lr: float = 0.001,
+                 momentum: float = 0.9, weight_decay: float = 1e-4, seed: int = 1):
+        super().__init__(state, caps, device=device, use_sgd=use_sgd, lr=lr, momentum=momentum, weight_decay=weight_decay, seed=seed, own_stream=True)
+        from concurrent.futures import ThreadPoolExecutor
+        self.lanes: List[Trainer] = [self] + [Trainer(state, caps, device=self.device, seed=seed + 7919 * k, params=self.params, own_stream=True)
+                                              for k in range(1, max(1, int(lanes)))]
+        self.pool = ThreadPoolExecutor(max_workers=len(self.lanes))
+
+    @staticmethod
+    def _lane_pass(lane: Trainer, sc: DeviceScene, keep):
+        res = lane.forward(sc)
+        mask = lane.dropout_mask(keep)
+        loss = lane.loss(mask)
+        lane.backward(mask)
+        lane.stream.synchronize()
+        return loss, res
+
+    def forward_backward(self, scenes, keep="random"):
+        """The lanes' passes side by side; afterwards `self.grads` holds the MEAN of the scenes' gradients.  -> [(loss [1,2], SceneResult)]"""
+        if isinstance(scenes, DeviceScene):
+            scenes = [scenes]
+        if not 1 <= len(scenes) <= len(self.lanes):
+            raise ValueError(f"{len(scenes)} scenes for {len(self.lanes)} lanes")
+        torch.cuda.current_stream(self.device).synchronize()          # the optimizer step of the last call wrote the parameters on the default stream
+        done = list(self.pool.map(lambda a: self._lane_pass(*a), [(self.lanes[i], sc, keep) for i, sc in enumerate(scenes)]))
+        n = len(scenes)
+        if n > 1:                                                     # lane 0's vector doubles as the step's gradient: mean over the lanes, in lane order
+            for lane in self.lanes[1:n]:
+                self.grads.add_(lane.grads)
+            self.grads.div_(n)
+        return done
+
+    def step(self, scenes, keep="random"):
+        """-> ([loss [1,2] per scene], [SceneResult per scene], log terms summed over scenes and ranks)"""
+        done = self.forward_backward(scenes, keep)
+        n = len(done)
+        extras = np.zeros(NUM_EXTRAS - 3, np.float32)                 # [loss / K, IoU_sem (80), IoU_ins (80), acc (4)] summed over the scenes
+        for loss, res in done:
+            extras += np.concatenate([[loss[0, 0] / loss[0, 1]], res.iou_sem.reshape(-1), res.iou_ins.reshape(-1), res.acc.reshape(-1)]).astype(np.float32)
+        summed = self.average_gradients(np.concatenate([extras, [float(n)]]).astype(np.float32))
+        self.optimizer_step()
+        self.update_running_stats()
+        return [d[0] for d in done], [d[1] for d in done], summed
+
+    def close(self):
+        for lane in getattr(self, "lanes", [])[1:]:
+            lane.close()
+        if getattr(self, "pool", None) is not None:
+            self.pool.shutdown(wait=True)
+            self.pool = None
+        super().close()

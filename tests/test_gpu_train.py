@@ -529,3 +529,76 @@ def test_two_ranks_share_one_gpu_and_stay_in_step(golden_index, tmp_path):
     assert a == b and len(a.strip()) == 64
     log = open(os.path.join(root, "checkpoints", "ddp", "run.log")).read()
     assert "Epoch[1/1](0004/0004)" in log
+
+
+def test_batch_trainer_equals_the_mean_of_single_scene_steps(golden_index):
+    """BatchTrainer: three scenes per optimizer step, each on its own lane / stream / host thread.  The step's
+    gradient must be the MEAN of the three gradients single-scene Trainers compute for the same parameters (bit for bit: the lanes run the same
+    kernels, the mean is taken in lane order), the losses and label vectors per scene the same, and the parameters after the optimizer step the
+    ones that mean gives -- what DistributedDataParallel does with three ranks (train.py:88)."""
+    import torch
+    from seggroup_amd import synthetic, train, trainer as T, weights as Wm
+    from seggroup_amd.scene import DeviceScene
+    st = train.initial_state(1)
+    st.update({k: (v.numpy() if hasattr(v, "numpy") else np.asarray(v)) for k, v in Wm.to_state_dict(Wm.load_npz(os.path.join(GOLDEN, "weights_g2.npz")), prefix="").items()})
+    scenes = []
+    for i, name in enumerate(("small_20k", "tiny_4k", "tiny_dup_4k")):
+        e = golden_index[name]
+        scenes.append(DeviceScene.from_synthetic(synthetic.make_scene(e["n"], e["s"], e["seed"], name=f"scene{i:04d}_00", **e["kw"]), device="cuda:0"))
+    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+    singles, losses, labels = [], [], []
+    for sc in scenes:
+        tr = T.Trainer(st, caps, device="cuda:0")
+        res = tr.forward(sc)
+        mask = tr.dropout_mask("pinned")
+        losses.append(tr.loss(mask))
+        singles.append(tr.backward(mask).clone())
+        labels.append(res.labels.copy())
+        tr.close()
+    want = (singles[0] + singles[1] + singles[2]) / 3
+    bt = T.BatchTrainer(st, caps, lanes=3, device="cuda:0")
+    p0 = bt.params.clone()
+    for rep in range(2):                                              # twice: the lanes' buffers and streams are reused
+        bt.params.copy_(p0)
+        done = bt.forward_backward(scenes, keep="pinned")
+        torch.cuda.synchronize()
+        assert torch.equal(bt.grads, want)
+        for (loss, res), l1, lab in zip(done, losses, labels):
+            assert np.array_equal(loss, l1) and np.array_equal(res.labels, lab)
+    # a whole step: parameters move by the SGD update of that mean gradient, the log terms are sums over the scenes
+    ref = T.Trainer(st, caps, device="cuda:0")
+    ref.grads.copy_(want)
+    ref.optimizer_step()
+    bt.params.copy_(p0)
+    ls, rs, summed = bt.step(scenes, keep="pinned")
+    torch.cuda.synchronize()
+    assert torch.equal(bt.params, ref.params)
+    assert summed[-1] == 3.0 and abs(summed[0] - sum(float(l[0, 0] / l[0, 1]) for l in losses)) < 1e-4
+    with pytest.raises(ValueError):
+        bt.step(scenes + scenes)                                      # more scenes than lanes
+    ref.close()
+    bt.close()
+
+
+def test_train_driver_with_several_scenes_per_step(golden_index, tmp_path):
+    """`python -m seggroup_amd.train --scenes-per-step 2` on a three-scene tree: groups of two scenes (the last group has one) through the
+    BatchTrainer, the reference's log lines with the running scene count, label files for every scene, a checkpoint `infer` reads back."""
+    import torch
+    from seggroup_amd import synthetic, train
+    root = str(tmp_path)
+    scenes = []
+    for i, name in enumerate(("tiny_4k", "tiny_dup_4k", "small_20k")):
+        e = golden_index[name]
+        scenes.append(synthetic.make_scene(e["n"], e["s"], e["seed"], name=f"scene{i:04d}_00", **e["kw"]))
+    synthetic.write_reference_tree(root, scenes)
+    args = train.build_parser().parse_args(["-n", "b2", "--root", root, "--epochs", "1", "--out-format", "npy", "--lr", "0.0002", "--scenes-per-step", "2"])
+    for d in ("checkpoints/b2/models", "results/b2"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    r = train.run_worker(0, 1, args)
+    assert r["epoch"] == 1 and r["scenes"] == 3 and np.isfinite(r["loss"])
+    log = open(os.path.join(root, "checkpoints", "b2", "run.log")).read()
+    assert "Epoch[1/1](0002/0003)    Loss:" in log and "Epoch[1/1](0003/0003)    Loss:" in log and "==> Epoch[1/1]" in log
+    for sc in scenes:
+        assert os.path.exists(os.path.join(root, "results", "b2", sc.name, "epoch_last", "final.ins.npy")), sc.name
+    ck = torch.load(os.path.join(root, "checkpoints", "b2", "models", "last.t7"), map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 1 and all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.dtype.is_floating_point)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--scenes", type=int, default=4)
     ap.add_argument("--profile", default="uniform")
+    ap.add_argument("--lanes", type=int, default=1, help="> 1: BatchTrainer with this many scenes per optimizer step (each on its own stream)")
     a = ap.parse_args()
     import torch
     from seggroup_amd import synthetic, train, trainer as T, weights as W
@@ -31,6 +32,27 @@ def main():
     scenes = [DeviceScene.from_synthetic(synthetic.make_scene(a.points, a.segments, 20000 + i, name=f"scene{i:04d}_00", **kw), device="cuda:0")
               for i in range(a.scenes)]
     caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+    if a.lanes > 1:
+        a.scenes = max(a.scenes, a.lanes)
+        while len(scenes) < a.scenes:
+            i = len(scenes)
+            scenes.append(DeviceScene.from_synthetic(synthetic.make_scene(a.points, a.segments, 20000 + i, name=f"scene{i:04d}_00", **kw), device="cuda:0"))
+        caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+        bt = T.BatchTrainer(state, caps, lanes=a.lanes, device="cuda:0")
+        losses, t_all = [], 0.0
+        for step in range(-2, a.steps):
+            group = [scenes[(step * a.lanes + k) % len(scenes)] for k in range(a.lanes)]
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ls, _, _ = bt.step(group)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            if step >= 0:
+                t_all += t1 - t0
+                losses.append(float(np.mean([l[0, 0] / l[0, 1] for l in ls])))
+        print(json.dumps({"lanes": a.lanes, "step_ms": round(t_all / a.steps * 1e3, 3), "ms_per_scene": round(t_all / a.steps / a.lanes * 1e3, 3),
+                          "points": a.points, "segments": a.segments, "steps": a.steps, "first_loss": round(losses[0], 4), "last_loss": round(losses[-1], 4),
+                          "device_mb": round(sum(l.device_bytes() for l in bt.lanes) / 2 ** 20, 1)}))
+        bt.close()
+        return
     tr = T.Trainer(state, caps, device="cuda:0")
     t = dict(forward=0.0, loss=0.0, backward=0.0, optimizer=0.0)
     losses = []
