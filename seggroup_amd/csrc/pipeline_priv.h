@@ -64,6 +64,7 @@ struct sg_pipeline {
     sgp::PinBuf<double> h_seg_sums;
 
     hipEvent_t ev[sgp::kNumEvents];
+    hipEvent_t ev_count = nullptr;      // behind the D2H of the contracted edge count: the host waits for THAT, not for the whole structural layer
     int ev_stage[sgp::kNumEvents];
     int n_ev = 0;
     float stage_ms[sgp::kNumStages];
