@@ -35,8 +35,7 @@ struct sg_partition {
         }
         if (moved) {                                             // 191-192
             segs[b].insert(segs[b].end(), segs[a].begin(), segs[a].end());
-            segs[a].clear();
-            segs[a].shrink_to_fit();
+            segs[a].clear();                                     // (capacity kept: a free() per union was a tenth of a layer's host time)
         }
         return moved;
     }
@@ -142,16 +141,29 @@ int sg_partition_group_nearby(sg_partition* p, const int32_t* h_root, int C, con
         p->unite(p->owner[h_root[h_adj[2 * e]]], p->owner[h_root[h_adj[2 * e + 1]]]);
     }
     // pass 2 (model.py:228-239): absorb clusters with < 5 points until a sweep sees none
+    // A cluster's point count only grows (union adds, and find() leads from a dead root to the grown one), so an edge that finds both of its
+    // clusters at >= 5 points never fires again: after the first full sweep only the edges that fired are walked, in their original order --
+    // the same unions in the same order as the reference's full sweeps (a 10k-edge sweep per round was most of this function).
     int rc = SG_OK;
+    thread_local std::vector<int32_t> live;
+    live.clear();
+    bool first = true;
     for (;;) {
         bool small = false, moved = false;
-        for (int e = 0; e < E; ++e) {
+        size_t kept = 0;
+        const size_t n = first ? (size_t)E : live.size();
+        for (size_t i = 0; i < n; ++i) {
+            const int e = first ? (int)i : live[i];
             const int a = p->owner[h_root[h_adj[2 * e]]], b = p->owner[h_root[h_adj[2 * e + 1]]];
             if (p->npts[a] < 5 || p->npts[b] < 5) {
                 moved |= p->unite(a, b);
                 small = true;
+                if (first) live.push_back(e); else live[kept] = e;
+                ++kept;
             }
         }
+        if (!first) live.resize(kept);
+        first = false;
         if (!small) break;
         if (!moved) { rc = SG_ESTALL; break; }   // the reference never terminates here
     }
