@@ -68,16 +68,44 @@ class _StubTrainer:
         self.steps, self.opt_a, self.opt_b = int(st["steps"]), st["a"].clone(), st["b"].clone()
 
 
-def _worker(rank, world, root, port, q, resume):
+class _StubBatchTrainer(_StubTrainer):
+    """seggroup_amd.trainer.BatchTrainer's surface: a step takes a LIST of scenes, its gradient is the mean of theirs, the log terms their sum"""
+
+    def fits(self, sc):
+        return True
+
+    def step(self, scs, keep="random"):
+        from types import SimpleNamespace
+        T = self.T
+        self.grads_full[:T.NUM_PARAMS] = float(np.mean([sc.index + 1 for sc in scs]))
+        extras = np.zeros(165, np.float32)
+        ress, losses = [], []
+        for sc in scs:
+            rng = np.random.default_rng(sc.index)
+            res = SimpleNamespace(iou_sem=rng.integers(1, 9, (1, 2, 40)).astype(np.float32), iou_ins=rng.integers(1, 9, (1, 2, 40)).astype(np.float32),
+                                  acc=rng.uniform(size=4).astype(np.float32))
+            loss = np.array([[2.0 * (sc.index + 1), 2.0]], np.float32)
+            extras += np.concatenate([[loss[0, 0] / loss[0, 1]], res.iou_sem.reshape(-1), res.iou_ins.reshape(-1), res.acc]).astype(np.float32)
+            ress.append(res); losses.append(loss)
+            self.seen.append(sc.index)
+        summed = T.allreduce_step(self.grads_full, np.concatenate([extras, [float(len(scs))]]).astype(np.float32))
+        self.params -= self.grads_full[:T.NUM_PARAMS]
+        self.steps += 1
+        return losses, ress, summed
+
+
+def _worker(rank, world, root, port, q, resume, per_step=1):
     sys.path.insert(0, ROOT)
     import torch
     from seggroup_amd import train, trainer as T
     argv = ["-n", "exp", "--root", root, "--backend", "gloo", "--port", str(port), "--epochs", "2", "--out-format", ""] + (["-r"] if resume else [])
+    if per_step > 1:
+        argv += ["--scenes-per-step", str(per_step)]
     args = train.build_parser().parse_args(argv)
     made = []
 
     def make(state):
-        tr = _StubTrainer(state)
+        tr = (_StubBatchTrainer if per_step > 1 else _StubTrainer)(state)
         for name, _, n in T.BN_LAYERS:
             tr.buffers[name + ".running_mean"] = torch.zeros(n)
             tr.buffers[name + ".running_var"] = torch.ones(n)
@@ -88,12 +116,12 @@ def _worker(rank, world, root, port, q, resume):
     q.put((rank, made[0].seen, float(made[0].params[0]), float(made[0].params[-1]), r))
 
 
-def _run(root, resume=False, world=2):
+def _run(root, resume=False, world=2, per_step=1):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, root, port, q, resume)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, root, port, q, resume, per_step)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=180) for _ in range(world))
@@ -163,3 +191,29 @@ def test_allreduce_step_single_rank_is_identity():
     assert out.tolist() == [1.0, 2.0] and float(g[5]) == 5.0
     with pytest.raises(ValueError):
         T.allreduce_step(g, np.zeros(T.NUM_EXTRAS + 1, np.float32))
+
+
+def test_two_ranks_with_two_scenes_per_step(tmp_path):
+    """--scenes-per-step 2 (BatchTrainer's driver loop) on two gloo ranks: every rank walks its DistributedSampler share in groups of two
+    (the last group of an epoch has one scene), one all-reduce per group, the log counts scenes, both ranks end with the same parameters."""
+    from seggroup_amd import train, trainer as T
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "dataset", "scannet"))
+    n = 6
+    with open(os.path.join(root, "dataset", "scannet", "scannetv2_train.txt"), "w") as f:
+        f.write("".join(f"scene{i:04d}_00\n" for i in range(n)))
+    got = _run(root, per_step=2)
+    for rank, seen, _, _, _ in got:
+        assert seen == train.epoch_indices(n, rank, 2, 0) + train.epoch_indices(n, rank, 2, 1)
+    init = T.flatten_state(train.initial_state(1))
+    moved = 0.0
+    for e in (0, 1):
+        shares = [train.epoch_indices(n, r, 2, e) for r in (0, 1)]
+        for k in range(0, 3, 2):                                   # groups [0:2], [2:3] of each rank's three scenes
+            moved += np.mean([np.mean([i + 1 for i in sh[k:k + 2]]) for sh in shares])      # DDP mean over ranks of the lanes' mean
+    for _, _, p0, p1, _ in got:
+        assert abs(p0 - (init[0] - moved)) < 1e-3 and abs(p1 - (init[-1] - moved)) < 1e-3
+    res = got[0][4]
+    assert res["epoch"] == 2 and res["scenes"] == n
+    log = open(os.path.join(root, "checkpoints", "exp", "run.log")).read()
+    assert "Epoch[1/2](0004/0006)    Loss:" in log and "Epoch[1/2](0006/0006)    Loss:" in log and "==> Epoch[2/2]" in log
