@@ -261,15 +261,25 @@ int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, 
                         const float* d_w1, const float* d_g1, const float* d_b1,
                         const float* d_w2, const float* d_g2, const float* d_b2,
                         float* d_out, void* d_ws, size_t ws_bytes, void* stream);
-/* The same with conv1's operand on fp16 pieces scaled by the layer's range (MLP2: 4 instead of 8 MFMAs per neighbour slot, same
- * accuracy: the pieces keep 22 bits and the scale is a power of two).  d_range_bits: SG_RANGE_WORDS (256) words whose maximum is the bits
- * of a float R with |x_j - x_i| <= 2 R for every edge and channel -- sg_layer_layout raises them while it writes d_x9m, sg_edge_range
- * computes one from d_x9m alone (max |x9m[p][c] - x9m[0][c]|; the words must be 0 or smaller bounds before).  The op clears the words when it is done.
- * NULL = sg_edgeconv_forward.  (MLP3 ignores the range so far and only clears it.) */
+#define SG_RANGE_WORDS 256
+/* The same with conv1's operand on fp16 pieces scaled by the layer's range (4 instead of 8 MFMAs per neighbour slot, same accuracy: the
+ * pieces keep 22 bits and the scale is a power of two).  d_range_bits: a ZERO-INITIALISED buffer of SG_RANGE_WORDS (256) words whose
+ * maximum is the bits of a float R with |x_j - x_i| <= 2 R for every edge and channel -- sg_layer_layout raises them while it writes
+ * d_x9m, sg_edge_range computes one from d_x9m alone (max |x9m[p][c] - x9m[0][c]|; the words must be 0 or smaller bounds before).
+ * BOTH layer counts use the range: MLP2 scales conv1's operand with it, MLP3's fold kernel reads it to choose the scale of conv1' and
+ * writes the fp16 weight image accordingly.  Every kernel involved reads or clears all SG_RANGE_WORDS words (a smaller buffer is read
+ * and written out of bounds); the op clears them when it is done.  NULL = sg_edgeconv_forward (bf16 pieces, no range needed).
+ * With k == 20 the neighbour-slot loop runs as a hand-scheduled gfx950 instruction stream (csrc/edgeconv_slots_gen.h); other k take
+ * the compiler-scheduled loop.  Both compute the same bits. */
 int sg_edgeconv_forward_r(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
                           const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
                           size_t ws_bytes, unsigned int* d_range_bits, void* stream);
-#define SG_RANGE_WORDS 256
+/* sg_edgeconv_forward_r with flags: SG_EDGECONV_COMPILER_LOOP forces the compiler-scheduled slot loop also for k == 20 (the
+ * cross-check of the hand-scheduled one: tests compare the two bit for bit). */
+#define SG_EDGECONV_COMPILER_LOOP 1u
+int sg_edgeconv_forward_x(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
+                          const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
+                          size_t ws_bytes, unsigned int* d_range_bits, unsigned int flags, void* stream);
 int sg_edge_range(const float* d_x9m, int N, unsigned int* d_range_bits, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

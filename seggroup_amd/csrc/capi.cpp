@@ -181,9 +181,11 @@ int npy_header(char* hdr, int V) {                              // NumPy .npy v1
 
 // one label vector as <dir>/<name>.txt and / or .npy; dfd = the directory's descriptor (or AT_FDCWD with a full path in `name`)
 int write_vector_files(int dfd, const char* name, const int32_t* vec, int V, int formats, TlBuf& tl) {
-    char fname[512];
+    std::string fname_s;                                        // no fixed-size buffer: a long path must not lose its extension
+    const char* fname = nullptr;
     if (formats & 2) {
-        snprintf(fname, sizeof fname, "%s.npy", name);
+        fname_s.assign(name).append(".npy");
+        fname = fname_s.c_str();
         const int fd = openat(dfd, fname, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
         if (fd < 0) return sg::fail(SG_EINVAL, "label writer: cannot open %s: %s", fname, strerror(errno));
         char hdr[256];
@@ -202,7 +204,8 @@ int write_vector_files(int dfd, const char* name, const int32_t* vec, int V, int
             else o = put_u32(o, (uint32_t)v);
             *o++ = '\n';
         }
-        snprintf(fname, sizeof fname, "%s.txt", name);
+        fname_s.assign(name).append(".txt");
+        fname = fname_s.c_str();
         const int fd = openat(dfd, fname, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
         if (fd < 0) return sg::fail(SG_EINVAL, "label writer: cannot open %s: %s", fname, strerror(errno));
         const struct iovec iov[1] = {{buf, (size_t)(o - buf)}};

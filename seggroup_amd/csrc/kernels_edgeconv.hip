@@ -68,6 +68,7 @@
 #include "engine_ctx.h"
 #include "sg_common.h"
 #include "wave_ops.h"
+#include "edgeconv_slots_gen.h"
 
 namespace {
 
@@ -118,7 +119,12 @@ __device__ __forceinline__ float pow2_scale(float bound, float target) {      //
 // the layout kernel) <= 2^12 -- every difference inside a cluster is bounded by twice that value, so no piece can overflow; small
 // differences land on fp16 subnormals, which the matrix pipe keeps (absolute error 2^-25 / Sd: 1e-11 of the range) -- and the weights by
 // Sw with max |Sw w| in [2^11, 2^12); 1 / (Sw Sd) is divided out of the statistics and the maxima like S2X's scales.
-template <int MODE, bool REREAD_A, bool kFused = false, bool kF16 = false>
+// kAsm (round 4): the K = 20 slot loop of the fp16 variants as ONE hand-scheduled asm statement (edgeconv_slots_gen.h, written by
+// tools/gen_edgeconv_asm.py: every MFMA followed by up to six instructions of other slots' VALU stages, software-pipelined over the 20
+// slots).  Same instructions on the same values in the same order per accumulator as the C++ loop below it -- bit-identical results;
+// the C++ loop stays for K != 20 and as the cross-check (sg_edgeconv_forward_x, flag 1).  MLP3's version keeps the 20 A fragments in
+// AGPRs and the point's base accumulator in LDS: 256 VGPRs + 80 AGPRs, ONE wave per SIMD.
+template <int MODE, bool REREAD_A, bool kFused = false, bool kF16 = false, bool kAsm = false>
 __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gptr<const int32_t> knn, int N, int K,
                                               sg::gptr<const float> w1, sg::gptr<const float> shift1,
                                               sg::gptr<const u32x4> w2img, sg::gptr<const float> scales,
@@ -131,6 +137,8 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     // the fused epilogue's stage (32 rows x 64 maxima per wave); during the slot loop of the fp16 variants: the lanes' neighbour ids [K][64]
     __shared__ float stage_or_ids[(kFused || kF16) ? kWaves : 1][(kFused || kF16) ? 32 * 65 : 1];
     constexpr bool kTwo = MODE == S2X;
+    // kAsm, MLP3: the stage strip holds the point's base accumulator during the slot loop ([8][64] float4), the ids get a strip of their own
+    __shared__ int ids_strip[(kAsm && kTwo) ? kWaves : 1][(kAsm && kTwo) ? 20 * 64 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     // the two scales of the fp16 conv1
@@ -464,36 +472,82 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
             // stage area (unused until the tile's maxima are written there): a request must not depend on a load that is itself in flight.
             using f32x4 = __attribute__((ext_vector_type(4))) float;
             constexpr int kNB = kTwo ? 2 : 4;
-            int* idl = reinterpret_cast<int*>(&stage_or_ids[wave][0]);
+            int* idl = (kAsm && kTwo) ? &ids_strip[wave][0] : reinterpret_cast<int*>(&stage_or_ids[wave][0]);
             for (int j = 0; j < K; ++j) idl[j * 64 + lane] = krow[j];
-            // (`cur` = the row the coming slot works on: re-defined by the request so that the slot's code cannot be scheduled in front of
-            // it; `done` = a statistic the finished slot wrote: re-defined by the wait so that the wait cannot be scheduled in front of it)
-            auto request = [&](int nb, f32x4& r0, float& e8, f32x4& cur) {
-                const gptr<const float> row = x9m + (size_t)nb * 12;
-                const gptr<const float> p16 = row + 4 * half, p4 = row + 8;
-                asm volatile("global_load_dwordx4 %0, %2, off" : "=v"(r0), "+v"(cur) : "v"(p16));
-                asm volatile("global_load_dword %0, %1, off" : "=v"(e8) : "v"(p4));
-            };
-            auto arrive = [&](f32x4& r0, float& e8, float& done) {
-                asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r0), "+v"(e8), "+v"(done) : "n"(2 * (kNB - 2)));
-            };
-            f32x4 rb[kNB];
-            float eb[kNB];
-            f32x4 none = {0.f, 0.f, 0.f, 0.f};
+            bool slots_done = false;
+            if constexpr (kAsm) {
+                if (K == 20) {
+                    slots_done = true;
+                    f32x16 ss0, ss1, sq0, sq1, bb0, bb1;
+                    const unsigned a_ids = (unsigned)(size_t)(SG_LDS const int*)(idl + lane);
+                    const float sd_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Sd)));
+                    const unsigned l16 = 16u * (unsigned)half;
+                    if constexpr (!kTwo) {
+                        asm volatile(SG_EC_S1X_SLOTS
+                                     : "=&" SG_EC_S1X_STAT_S0(ss0), "=&" SG_EC_S1X_STAT_S1(ss1), "=&" SG_EC_S1X_STAT_Q0(sq0), "=&" SG_EC_S1X_STAT_Q1(sq1),
+                                       "=&" SG_EC_S1X_BEST0(bb0), "=&" SG_EC_S1X_BEST1(bb1)
+                                     : SG_EC_S1X_BASE0(base[0]), SG_EC_S1X_BASE1(base[1]), SG_EC_S1X_FRAG0(fr16[0]), SG_EC_S1X_FRAG1(fr16[1]),
+                                       SG_EC_S1X_FRAG2(fr16[2]), SG_EC_S1X_FRAG3(fr16[3]),
+                                       [x9m] "s"(x9m), [sd] "s"(sd_u), [ids] "v"(a_ids), [l16] "v"(l16),
+                                       [xs0] "v"(xs_s[0]), [xs1] "v"(xs_s[1]), [xs2] "v"(xs_s[2]), [xs3] "v"(xs_s[3]), [xs4] "v"(xs_s[4])
+                                     : "memory", SG_EC_S1X_SLOTS_CLOBBERS);
+                    } else {
+                        // base -> the wave's stage strip, [t * 4 + g][lane] float4 = base[t][4 g .. 4 g + 3]: conv1's C operand, re-read every slot
+                        float4* bl = reinterpret_cast<float4*>(&stage_or_ids[wave][0]);
 #pragma unroll
-            for (int u = 0; u < kNB - 1; ++u) request(idl[min(u, K - 1) * 64 + lane], rb[u], eb[u], none);
-            int idn = idl[min(kNB - 1, K - 1) * 64 + lane];          // the id of the next request, read a slot ahead of it
-            for (int j = 0; j < K; j += kNB) {
+                        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int u = 0; u < kNB; ++u) {
-                    arrive(rb[u], eb[u], stat_q[31]);
-                    request(idn, rb[(u + kNB - 1) % kNB], eb[(u + kNB - 1) % kNB], rb[u]);      // slot j + u + kNB - 1 (beyond the last slot: re-reads it)
-                    idn = idl[min(j + u + kNB, K - 1) * 64 + lane];
-                    if (u == 0 || j + u < K) slot_body(make_float4(rb[u].x, rb[u].y, rb[u].z, rb[u].w), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(eb[u], 0.f, 0.f, 0.f));
+                            for (int g = 0; g < 4; ++g)
+                                bl[(t * 4 + g) * 64 + lane] = make_float4(base[t][4 * g], base[t][4 * g + 1], base[t][4 * g + 2], base[t][4 * g + 3]);
+                        const unsigned a_base = (unsigned)(size_t)(SG_LDS const float4*)(bl + lane);
+                        const unsigned a_frag = (unsigned)(size_t)(SG_LDS const u32x4*)(&lds.a2h[0][0][0][lane]);
+                        const unsigned a_frag1 = (unsigned)(size_t)(SG_LDS const u32x4*)(&lds.a1p[0][0][lane]);
+                        asm volatile(SG_EC_S2X_SLOTS
+                                     : "=&" SG_EC_S2X_STAT_S0(ss0), "=&" SG_EC_S2X_STAT_S1(ss1), "=&" SG_EC_S2X_STAT_Q0(sq0), "=&" SG_EC_S2X_STAT_Q1(sq1),
+                                       "=&" SG_EC_S2X_BEST0(bb0), "=&" SG_EC_S2X_BEST1(bb1)
+                                     : [x9m] "s"(x9m), [sd] "s"(sd_u), [ids] "v"(a_ids), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
+                                       [frag1] "v"(a_frag1),
+                                       [xs0] "v"(xs_s[0]), [xs1] "v"(xs_s[1]), [xs2] "v"(xs_s[2]), [xs3] "v"(xs_s[3]), [xs4] "v"(xs_s[4])
+                                     : "memory", SG_EC_S2X_SLOTS_CLOBBERS);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        stat_s[q] = ss0[q]; stat_s[16 + q] = ss1[q];
+                        stat_q[q] = sq0[q]; stat_q[16 + q] = sq1[q];
+                    }
+                    best[0] = bb0; best[1] = bb1;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(eb[0]), "+v"(eb[1]), "+v"(stat_q[31]));       // nothing may still be in flight into registers the code below reuses
-            if constexpr (kNB > 2) asm volatile("" : "+v"(rb[kNB - 2]), "+v"(rb[kNB - 1]), "+v"(eb[kNB - 2]), "+v"(eb[kNB - 1]));
+            if (!slots_done) {
+                // (`cur` = the row the coming slot works on: re-defined by the request so that the slot's code cannot be scheduled in front of
+                // it; `done` = a statistic the finished slot wrote: re-defined by the wait so that the wait cannot be scheduled in front of it)
+                auto request = [&](int nb, f32x4& r0, float& e8, f32x4& cur) {
+                    const gptr<const float> row = x9m + (size_t)nb * 12;
+                    const gptr<const float> p16 = row + 4 * half, p4 = row + 8;
+                    asm volatile("global_load_dwordx4 %0, %2, off" : "=v"(r0), "+v"(cur) : "v"(p16));
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(e8) : "v"(p4));
+                };
+                auto arrive = [&](f32x4& r0, float& e8, float& done) {
+                    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r0), "+v"(e8), "+v"(done) : "n"(2 * (kNB - 2)));
+                };
+                f32x4 rb[kNB];
+                float eb[kNB];
+                f32x4 none = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < kNB - 1; ++u) request(idl[min(u, K - 1) * 64 + lane], rb[u], eb[u], none);
+                int idn = idl[min(kNB - 1, K - 1) * 64 + lane];          // the id of the next request, read a slot ahead of it
+                for (int j = 0; j < K; j += kNB) {
+#pragma unroll
+                    for (int u = 0; u < kNB; ++u) {
+                        arrive(rb[u], eb[u], stat_q[31]);
+                        request(idn, rb[(u + kNB - 1) % kNB], eb[(u + kNB - 1) % kNB], rb[u]);      // slot j + u + kNB - 1 (beyond the last slot: re-reads it)
+                        idn = idl[min(j + u + kNB, K - 1) * 64 + lane];
+                        if (u == 0 || j + u < K) slot_body(make_float4(rb[u].x, rb[u].y, rb[u].z, rb[u].w), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(eb[u], 0.f, 0.f, 0.f));
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(eb[0]), "+v"(eb[1]), "+v"(stat_q[31]));       // nothing may still be in flight into registers the code below reuses
+                if constexpr (kNB > 2) asm volatile("" : "+v"(rb[kNB - 2]), "+v"(rb[kNB - 1]), "+v"(eb[kNB - 2]), "+v"(eb[kNB - 1]));
+            }
             __builtin_amdgcn_wave_barrier();                      // the ids are dead: the strip is the epilogue's now
         } else {
             int nb_next = krow[0];
@@ -595,6 +649,32 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv(const floa
 }
 // S1X: the scene's MLP2 weights as they are; S2X: its folded conv1 (ec_w1f, ec_sh1) + the raw conv2
 // the engine's launches: E goes straight into the clusters' maxima (kFused above), c.pf is not written
+// the hand-scheduled slot loops (kAsm): MLP2 at two waves per SIMD like the kernels above, MLP3 at ONE (256 VGPRs + 80 AGPRs)
+template <int MODE>
+__global__ __launch_bounds__(64 * kWaves, MODE == S2X ? 1 : 2) void k_edgeconv_h(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
+                                                          const float* __restrict__ w1, const float* __restrict__ shift1,
+                                                          const u32x4* __restrict__ w2img, const float* __restrict__ scales,
+                                                          const float* __restrict__ gamma_last,
+                                                          float* __restrict__ ext, double* __restrict__ partial,
+                                                          const unsigned int* __restrict__ range_bits) {
+    using sg::as_global;
+    edgeconv_body<MODE, MODE == S2X, false, true, true>(as_global(x9m), as_global(knn), N, K, as_global(w1), as_global(shift1), as_global(w2img),
+                                                        as_global(scales), as_global(gamma_last), as_global(ext), as_global(partial), blockIdx.x, nullptr, 64,
+                                                        0, as_global(range_bits));
+}
+template <int MODE>
+__global__ __launch_bounds__(64 * kWaves, MODE == S2X ? 1 : 2) void k_edgeconv_hb(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x >= c.ec_blocks) return;
+    using sg::as_global;
+    if constexpr (MODE == S1X) edgeconv_body<MODE, false, true, true, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global(c.ec_w1), nullptr, nullptr, nullptr,
+                                                               as_global(c.ec_g1), as_global(c.cat + c.gm_D), as_global(c.ec_partial), blockIdx.x,
+                                                               as_global(c.cluster_of_pos), c.Dcat, 0, as_global((const unsigned int*)c.ec_range));
+    else edgeconv_body<MODE, true, true, true, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global((const float*)c.ec_w1f),
+                                             as_global((const float*)c.ec_sh1), as_global(reinterpret_cast<const u32x4*>(c.ec_w2img)),
+                                             as_global((const float*)c.ec_scale), as_global(c.ec_g2), as_global(c.cat + c.gm_D),
+                                             as_global(c.ec_partial), blockIdx.x, as_global(c.cluster_of_pos), c.Dcat, 0);
+}
 template <int MODE, bool REREAD_A>
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx, int stagger) {
     const sg::SlotCtx& c = cx[blockIdx.y];
@@ -994,6 +1074,9 @@ __global__ __launch_bounds__(256) void k_bn_lrelu_apply(float* __restrict__ e, s
 
 namespace sg {
 
+// SG_EC_COMPILER_LOOP=1 (development / A-B timing): every EdgeConv launch of the process takes the compiler-scheduled slot loop
+static const bool g_compiler_loop = getenv("SG_EC_COMPILER_LOOP") ? atoi(getenv("SG_EC_COMPILER_LOOP")) != 0 : false;
+
 // the epilogue alone: d_dst = LReLU(|a| * d_e + b') (debug taps of the pipeline, which otherwise fuses it into the segment max)
 int edgeconv_apply(const float* d_e, int N, const float* d_a, const float* d_shift, float* d_dst, void* stream) {
     if (N == 0) return SG_OK;
@@ -1008,7 +1091,7 @@ int edgeconv_apply(const float* d_e, int N, const float* d_a, const float* d_shi
 int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
                             const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
                             size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine,
-                            unsigned int* d_range_bits) {
+                            unsigned int* d_range_bits, unsigned flags) {
     SG_REQUIRE(N >= 0 && k > 0 && (layers == 1 || layers == 2) && d_ws, "sg_edgeconv_forward: bad arguments");
     SG_REQUIRE(!d_range_bits || k <= 32, "sg_edgeconv_forward_r: at most 32 neighbours per point (their ids are parked in a 32 x 65-word LDS strip)");
     if (d_affine) { d_affine[0] = nullptr; d_affine[1] = nullptr; d_affine[2] = nullptr; }
@@ -1028,10 +1111,12 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     hipStream_t st = sg::as_stream(stream);
     const double rows = (double)N * (double)k;
     const dim3 grid(nblocks), block(64 * kWaves);
+    const bool hand = k == 20 && !(flags & SG_EDGECONV_COMPILER_LOOP) && !g_compiler_loop;       // the hand-scheduled slot loop is written for K = 20
     const size_t n4 = (size_t)N * 16;
     const int egrid = (int)std::min<size_t>((n4 + 255) / 256, 2048);
     if (layers == 1) {
-        if (d_range_bits) k_edgeconv<S1X, false, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, d_g1, d_out, partial, d_range_bits);
+        if (d_range_bits && hand) k_edgeconv_h<S1X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, d_g1, d_out, partial, d_range_bits);
+        else if (d_range_bits) k_edgeconv<S1X, false, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, d_g1, d_out, partial, d_range_bits);
         else k_edgeconv<S1X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, d_w1, nullptr, nullptr, nullptr, d_g1, d_out, partial);
         k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g1, d_b1, w1f, sh1, stats_last, d_range_bits);
         if (mark) mark(0);
@@ -1044,7 +1129,8 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
         k_bn_fold_moments<<<1, 1024, 0, st>>>(partial, mblocks, rows, d_g1, d_b1, d_w1, w1f, sh1, d_w2, d_g2, w2img, scales, d_range_bits,
                                               d_range_bits ? reinterpret_cast<u32x4*>(scales + 4) : nullptr);
         if (mark) mark(0);
-        if (d_range_bits) k_edgeconv<S2X, true, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2img, scales, d_g2, d_out, partial, d_range_bits);
+        if (d_range_bits && hand) k_edgeconv_h<S2X><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2img, scales, d_g2, d_out, partial, d_range_bits);
+        else if (d_range_bits) k_edgeconv<S2X, true, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2img, scales, d_g2, d_out, partial, d_range_bits);
         else k_edgeconv<S2X, true><<<grid, block, 0, st>>>(d_x9m, d_knn, N, k, w1f, sh1, w2img, scales, d_g2, d_out, partial);
         k_bn_fold<<<1, 1024, 0, st>>>(partial, nblocks, rows, d_g2, d_b2, w2f, sh2, stats_last, d_range_bits);
         if (mark) mark(1);
@@ -1072,9 +1158,11 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
     // development knobs: SG_EC_STAGGER1 / SG_EC_STAGGER2 = start offset of the odd wave slot in units of 64 cycles
     static const int stagger1 = getenv("SG_EC_STAGGER1") ? atoi(getenv("SG_EC_STAGGER1")) : kStagger1;
     static const int stagger2 = getenv("SG_EC_STAGGER2") ? atoi(getenv("SG_EC_STAGGER2")) : kStagger2;
+    const bool hand = !g_compiler_loop;                           // the engine's layers all run K = 20 (SlotCtx::K; the kernel checks it)
     if (layers == 1) {
         if (mark) mark(mark_arg, 2);                                  // 2 / 3: in front of / behind the EdgeConv launch itself
-        k_edgeconv_b<S1X, false><<<grid, 64 * kWaves, 0, st>>>(d_ctx, stagger1);
+        if (hand) k_edgeconv_hb<S1X><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
+        else k_edgeconv_b<S1X, false><<<grid, 64 * kWaves, 0, st>>>(d_ctx, stagger1);
         if (mark) mark(mark_arg, 3);
         k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 1);
         k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 1);
@@ -1083,7 +1171,8 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
         k_edge_moments_b<<<dim3(sg::cdiv(bd.max_N, 256), bd.nslots), 256, 0, st>>>(d_ctx);
         k_bn_fold_moments_b<<<one, 1024, 0, st>>>(d_ctx);
         if (mark) mark(mark_arg, 0);
-        k_edgeconv_b<S2X, true><<<grid, 64 * kWaves, 0, st>>>(d_ctx, stagger2);
+        if (hand) k_edgeconv_hb<S2X><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
+        else k_edgeconv_b<S2X, true><<<grid, 64 * kWaves, 0, st>>>(d_ctx, stagger2);
         if (mark) mark(mark_arg, 3);
         k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 2);
         k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 2);
@@ -1107,14 +1196,21 @@ int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, 
                         const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
                         size_t ws_bytes, void* stream) {
     return sg::edgeconv_forward_marked(d_x9m, d_knn, N, k, layers, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, d_out, d_ws, ws_bytes, stream,
-                                       nullptr, nullptr);
+                                       nullptr, nullptr, nullptr, 0u);
 }
 
 int sg_edgeconv_forward_r(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
                           const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
                           size_t ws_bytes, unsigned int* d_range_bits, void* stream) {
     return sg::edgeconv_forward_marked(d_x9m, d_knn, N, k, layers, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, d_out, d_ws, ws_bytes, stream,
-                                       nullptr, nullptr, d_range_bits);
+                                       nullptr, nullptr, d_range_bits, 0u);
+}
+
+int sg_edgeconv_forward_x(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
+                          const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
+                          size_t ws_bytes, unsigned int* d_range_bits, unsigned int flags, void* stream) {
+    return sg::edgeconv_forward_marked(d_x9m, d_knn, N, k, layers, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, d_out, d_ws, ws_bytes, stream,
+                                       nullptr, nullptr, d_range_bits, flags);
 }
 
 int sg_edge_range(const float* d_x9m, int N, unsigned int* d_range_bits, void* stream) {

@@ -68,7 +68,7 @@ int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_memb
 int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int k, int layers, const float* d_w1, const float* d_g1,
                             const float* d_b1, const float* d_w2, const float* d_g2, const float* d_b2, float* d_out, void* d_ws,
                             size_t ws_bytes, void* stream, const std::function<void(int)>& mark, const float** d_affine,
-                            unsigned int* d_range_bits = nullptr);
+                            unsigned int* d_range_bits = nullptr, unsigned flags = 0u);
 // d_range_bits != nullptr (sg_layer_layout's range word, or sg_edge_range's): MLP2's conv1 runs on fp16 pieces scaled by that range
 // (4 instead of 8 MFMAs per neighbour slot); the word is cleared when the op is done with it.
 // d_affine != nullptr: the last BatchNorm + LeakyReLU is NOT applied; d_out holds E = max_k sgn(gamma) y_k and

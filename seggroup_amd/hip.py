@@ -134,6 +134,7 @@ SIGNATURES = {
     "sg_edgeconv_ws_bytes": (_Z, [_I]),
     "sg_edgeconv_forward": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_edgeconv_forward_r": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp, vp]),
+    "sg_edgeconv_forward_x": (_I, [vp, vp, _I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp, _Z, vp, C.c_uint, vp]),
     "sg_edge_range": (_I, [vp, _I, vp, vp]),
     "sg_gcn_ws_bytes": (_Z, [_I, _I, _I]),
     "sg_gcn_forward": (_I, [vp, _I, _I, vp, _I, vp, vp, vp, vp, C.c_float, vp, vp, _Z, vp]),

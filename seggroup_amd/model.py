@@ -222,6 +222,8 @@ class Engine:
         self.ring = 3
         self._labels = [None] * self.ring
         self._slot_writer = [None] * self.ring            # (writer, ticket id) of the files still being written out of a ring slot
+        self._retired = []                                # (writer, ticket id, buffer): label buffers replaced while their ticket was unconsumed
+        self._waited = set()                              # ticket ids whose sg_engine_wait has returned (their writer jobs are all queued)
         self._turn = 0
         self._names = [self.lib.sg_pipeline_stage_name(i).decode() for i in range(32) if self.lib.sg_pipeline_stage_name(i)]
 
@@ -236,11 +238,20 @@ class Engine:
         slot = self._turn
         self._turn = (self._turn + 1) % self.ring
         self._release_slot(slot)                          # the writer pool reads the label vectors in place (sg_writer_submit_scene)
+        self._drain_retired()
         if self._labels[slot] is None or self._labels[slot].shape[0] < n:
             # pinning hundreds of MB takes ~0.1 s: every ring slot is (re)sized at once, not one per submit
             for k in range(self.ring):
                 if self._labels[k] is None or self._labels[k].shape[0] < n:
-                    self._release_slot(k)
+                    # A slot other than `slot` may belong to a ticket that is still in flight in the engine: its writer jobs do not exist
+                    # yet, so sg_writer_wait_tag would return at once and the pool would later format files out of freed pinned memory
+                    # (ADVICE round 3).  Such a buffer is retired, not released: it lives until its ticket was waited for AND its tag drained.
+                    pending = self._slot_writer[k]
+                    if pending is not None and pending[1] not in self._waited:
+                        self._retired.append((pending[0], pending[1], self._labels[k]))
+                        self._slot_writer[k] = None
+                    else:
+                        self._release_slot(k)
                     self._labels[k] = torch.empty((max(n, 1), hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32, pin_memory=True)
         buf = self._labels[slot]
         c_scenes = (hip.Scene * n)(*[s.c_struct for s in scenes])
@@ -269,9 +280,25 @@ class Engine:
             if getattr(w, "handle", None):
                 hip.check(self.lib.sg_writer_wait_tag(w.handle, tid))
             self._slot_writer[slot] = None
+            self._waited.discard(tid)
+
+    def _drain_retired(self, everything: bool = False) -> None:
+        """Drop retired label buffers whose files are written.  A tag can only be drained once the engine has queued all of the
+        ticket's writer jobs, i.e. after `wait()` on it returned (or, with `everything`, after the engine's threads are gone)."""
+        keep = []
+        for w, tid, buf in self._retired:
+            if everything or tid in self._waited:
+                if getattr(w, "handle", None):
+                    hip.check(self.lib.sg_writer_wait_tag(w.handle, tid))
+                self._waited.discard(tid)
+            else:
+                keep.append((w, tid, buf))
+        self._retired = keep
 
     def wait(self, t: Ticket) -> List[SceneResult]:
         hip.check(self.lib.sg_engine_wait(self.handle, t.id))
+        if any(p is not None and p[1] == t.id for p in self._slot_writer) or any(r[1] == t.id for r in self._retired):
+            self._waited.add(t.id)
         nvec = 14 if t.mode == hip.MODE_INS_INFER else 6
         lab = t.labels.numpy()
         nv = hip.NUM_LABEL_VECTORS                  # scene i's vectors are packed at stride V_i inside its slot
@@ -309,10 +336,13 @@ class Engine:
 
     def close(self):
         if getattr(self, "handle", None):
-            for k in range(self.ring):                    # the label buffers die with this object: the writers must be done with them
-                self._release_slot(k)
+            # the label buffers die with this object: the writers must be done with them.  Destroy first (the group threads finish
+            # their super-step and queue its writer jobs), then drain every tag, retired buffers included
             self.lib.sg_engine_destroy(self.handle)
             self.handle = None
+            for k in range(self.ring):
+                self._release_slot(k)
+            self._drain_retired(everything=True)
 
     def __del__(self):
         try:

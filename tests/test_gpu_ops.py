@@ -397,6 +397,47 @@ def test_edgeconv_fp16_conv1_ranges(env, spread, offset):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [31, 4096 + 17, 50_000])
+def test_edgeconv_hand_scheduled_slot_loop_equals_compiler_loop(env, N):
+    """The K = 20 neighbour-slot loop runs as a hand-scheduled instruction stream (csrc/edgeconv_slots_gen.h, tools/gen_edgeconv_asm.py);
+    the compiler-scheduled C++ loop it replaces stays in the library (other K, SG_EDGECONV_COMPILER_LOOP).  Both issue the same
+    operations on the same values in the same order per accumulator: outputs and therefore every label must be BIT-identical, for
+    MLP2 and MLP3, tail tiles, duplicate neighbours and a far-away cloud included."""
+    lib, torch, hip = env
+    from seggroup_amd import weights
+    rng = np.random.default_rng(1000 + N)
+    K = 20
+    x9 = rng.uniform(-1, 1, (N, 9)).astype(np.float32)
+    x9[:, :3] = x9[:, :3] * 4 + np.float32(37.5)
+    x9[:, 6:9] = x9[:, :3] - x9[:, :3].mean(0)
+    knn = rng.integers(0, N, (N, K)).astype(np.int32)
+    knn[::3, 5:] = knn[::3, 4:5]                              # short clusters: repeated neighbours
+    W = weights.make_weights(1, 2.0, affine_jitter=0.3)
+    W["mlp_3.bn2.weight"][::7] *= -1.0
+    W["mlp_2.bn1.weight"][::5] *= -1.0
+    x12 = np.zeros((N, 12), np.float32)
+    x12[:, :9] = x9
+    d_x, d_k = _up(torch, x12), _up(torch, knn)
+    t = {k: _up(torch, W[k]) for k in W}
+    ws = _ws(torch, lib.sg_edgeconv_ws_bytes(N))
+    for layers, which in ((1, "mlp_2"), (2, "mlp_3")):
+        p2 = (t["mlp_3.conv2.0.weight"].data_ptr(), t["mlp_3.bn2.weight"].data_ptr(), t["mlp_3.bn2.bias"].data_ptr()) if layers == 2 \
+            else (None, None, None)
+        outs = []
+        for flags in (0, 1, 0):
+            rng_bits = torch.zeros(256, dtype=torch.int32, device="cuda:0")
+            hip.check(lib.sg_edge_range(d_x.data_ptr(), N, rng_bits.data_ptr(), None))
+            out = torch.full((N, 64), float("nan"), device="cuda:0")
+            hip.check(lib.sg_edgeconv_forward_x(d_x.data_ptr(), d_k.data_ptr(), N, K, layers, t[f"{which}.conv1.0.weight"].data_ptr(),
+                                                t[f"{which}.bn1.weight"].data_ptr(), t[f"{which}.bn1.bias"].data_ptr(), *p2, out.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), rng_bits.data_ptr(), flags, None))
+            outs.append(out.cpu().numpy())
+        assert np.isfinite(outs[0]).all(), which
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (which, float(np.abs(outs[0] - outs[1]).max()))
+        assert np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32)), which      # and the same bits run to run
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("g1_scale,w2_scale", [(1e3, 1e-3), (1e-3, 1e3), (3e4, 1e-4), (1.0, 1e-6)])
 def test_edgeconv_fp16_operand_scaling(env, g1_scale, w2_scale):
     """MLP3's conv2 runs on fp16 pieces; the kernel moves both operands into fp16's exponent range by powers of two derived from
