@@ -65,6 +65,7 @@
 // near the cloud): the statistics (sum y, sum y^2 and the edge-feature moments) are then sums of values of the cloud's
 // extent, not of its distance from the origin, and var = E[y^2] - mean^2 does not cancel for a scan that sits 100 m away
 // from the origin.  The differences d = x_j - x_i are formed from the raw coordinates exactly as the reference does.
+#include <cstddef>
 #include "engine_ctx.h"
 #include "sg_common.h"
 #include "wave_ops.h"
@@ -78,6 +79,27 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+// Profiling builds (make PROFILE=1): where a workgroup's time goes -- 100 MHz stamps (s_memrealtime) at the phase edges of edgeconv_body, summed
+// per wave into g_ec_phase[mode][phase]; sg_debug_ec_phases() copies and clears them.  Release builds compile all of it out.
+#ifdef SG_KNN_PROFILE
+constexpr bool kEcProfile = true;
+__device__ unsigned long long g_ec_phase[3][8];
+#else
+constexpr bool kEcProfile = false;
+#endif
+struct EcStamp {
+    unsigned long long t;
+    int mode;
+    __device__ __forceinline__ void start(int m) { mode = m; if (kEcProfile) t = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void mark(int phase) {
+#ifdef SG_KNN_PROFILE
+        const unsigned long long n = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_ec_phase[mode][phase], n - t);
+        t = n;
+#endif
+    }
+};
 
 enum { S1X = 1, S2X = 2 };     // conv1 statistics + extremum (MLP2) | conv1' -> conv2 statistics + extremum (MLP3)
 
@@ -131,16 +153,19 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                                               sg::gptr<const float> gamma_last,
                                               sg::gptr<float> ext, sg::gptr<double> partial, int bid,
                                               sg::gptr<const int32_t> cluster_of_pos = nullptr, int ext_stride = 64, int stagger = 0,
-                                              sg::gptr<const unsigned int> range_bits = nullptr) {
+                                              sg::gptr<const unsigned int> range_bits = nullptr, int nblk = 1 << 28) {
     using sg::gptr;
     __shared__ Lds lds;
     // the fused epilogue's stage (32 rows x 64 maxima per wave); during the slot loop of the fp16 variants: the lanes' neighbour ids [K][64]
     __shared__ float stage_or_ids[(kFused || kF16) ? kWaves : 1][(kFused || kF16) ? 32 * 65 : 1];
+    __shared__ float flush_sums[kWaves][128];                     // a tile's 64 sums + 64 sums of squares on their way into lds.acc
     constexpr bool kTwo = MODE == S2X;
-    // kAsm, MLP3: the stage strip holds the point's base accumulator during the slot loop ([8][64] float4), the ids get a strip of their own
-    __shared__ int ids_strip[(kAsm && kTwo) ? kWaves : 1][(kAsm && kTwo) ? 20 * 64 : 1];
+    // kAsm, MLP3: the stage strip holds the point's base accumulator during the slot loop ([8][64] float4); the asm reads the neighbour ids
+    // straight from the kNN table (one global load per slot, a slot ahead): no LDS is left for an id strip at two workgroups per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
+    EcStamp stamp;
+    stamp.start(kAsm ? MODE : 0);
     // the two scales of the fp16 conv1
     float Sd = 1.f, Sw = 1.f;
     if (kF16 && kTwo) Sd = scales[3];                           // MLP3: k_bn_fold_moments chose it and wrote the image (w2img + 1024)
@@ -230,6 +255,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     }
     for (int i = tid; i < kWaves * 128; i += 64 * kWaves) (&lds.acc[0][0])[i] = 0.0;
     __syncthreads();
+    stamp.mark(0);                                            // weights staged
 
     // Two waves share a SIMD (different workgroups, started together, running the same loop): they fall into lockstep -- both in
     // their MFMA phase, then both in their VALU phase -- and the matrix pipe idles while both cut operands and add statistics.  The
@@ -238,19 +264,31 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     if (stagger > 0 && (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1)) {
         for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
     }
-    const int tile = bid * kWaves + wave;
-    const int pt = tile * 32 + r;
-    const bool valid = pt < N;
-    const float vmask = valid ? 1.f : 0.f;
     // S2X runs on scaled operands (conv1' x T, W2 x S, both powers of two: see k_bn_fold_moments); y2 comes out x S T
     const float unscale = kTwo ? scales[0] : kF16 ? 1.f / (Sw * Sd) : 1.f;
     constexpr bool kFrag = kF16 && !kTwo;                       // MLP2 keeps conv1's four A fragments in registers, MLP3 re-reads them from LDS
+    // A workgroup walks the tile groups bid, bid + nblk, ... of its scene (round 4: the weights are staged once per workgroup, not once per
+    // four tiles -- staging was 18 % / 10 % of a wave's time in MLP2 / MLP3, tools/ec_phases.py); its waves run their tiles independently
+    // (no barrier inside the walk).  The next tile's own row is requested before this tile's statistics flush, which hides the round trip.
+    const int ngroups = (N + 32 * kWaves - 1) / (32 * kWaves);
+    // row 0's XYZ (the conditioning shift): read once -- the slot-loop statement clobbers "memory", so inside the walk the compiler would
+    // re-read them (three scalar round trips) for every tile
+    const float cx0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)x9m[0])));
+    const float cx1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)x9m[1])));
+    const float cx2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)x9m[2])));
+    auto own_row = [&](int grp) { const int p_ = (grp * kWaves + wave) * 32 + r; return (gptr<const float4>)(x9m + (size_t)(p_ < N ? p_ : 0) * 12); };
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    if (bid < ngroups) { const gptr<const float4> xr = own_row(bid); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
+    for (int grp = bid; grp < ngroups; grp += nblk) {
+    const int tile = grp * kWaves + wave;
+    const int pt = tile * 32 + r;
+    const bool valid = pt < N;
+    const float vmask = valid ? 1.f : 0.f;
     const int ptc = valid ? pt : 0;
+    float4 nq0, nq1, nq2;                                       // the next tile's own row (requested behind the slot loop)
 
     if (tile * 32 < N) {
         // x_i (9 of the 12 floats of the padded row)
-        const gptr<const float4> xr = (gptr<const float4>)(x9m + (size_t)ptc * 12);
-        const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
         const float xi[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
         // B operands, k = 2s + half: the x_i half of the edge feature is the same for all K neighbours of a point, so its
         // contribution W1[:, 9:18] x_i (+ the folded BN1 shift) is evaluated ONCE into `base` and every slot's accumulator
@@ -260,7 +298,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         const float xs[5] = {half ? xi[4] : xi[0], half ? xi[5] : xi[1], half ? xi[6] : xi[2], half ? xi[7] : xi[3], xi[8]};
         const float xs_s[5] = {xs[0] * Sd, xs[1] * Sd, xs[2] * Sd, xs[3] * Sd, xs[4] * Sd};        // kF16 only
         // the x_i half sees coordinates relative to row 0 (see "Conditioning" in the header); d below uses the raw ones
-        const float xcen[5] = {half ? xi[1] - x9m[1] : xi[0] - x9m[0], half ? xi[3] : xi[2] - x9m[2], xsel[2], xsel[3], xsel[4]};
+        const float xcen[5] = {half ? xi[1] - cx1 : xi[0] - cx0, half ? xi[3] : xi[2] - cx2, xsel[2], xsel[3], xsel[4]};
         f32x16 base[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -291,6 +329,8 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
             }
         }
 
+        asm volatile("" :: "v"(base[0]), "v"(base[1]));
+        stamp.mark(1);                                        // own row, base accumulator
         float stat_s[32], stat_q[32];
         f32x16 best[2];
 #pragma unroll
@@ -303,7 +343,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         const gptr<const int32_t> krow = knn + (size_t)ptc * K;
         // the fp16 conv1's four A fragments stay in registers for the whole tile (MLP2 has the room: no conv2 accumulators)
         u32x4 fr16[4] = {};
-        if (kFrag) { fr16[0] = lds.a1p[0][0][lane]; fr16[1] = lds.a1p[0][1][lane]; fr16[2] = lds.a1p[1][0][lane]; fr16[3] = lds.a1p[1][1][lane]; }
+        if (kFrag && !(kAsm && K == 20)) { fr16[0] = lds.a1p[0][0][lane]; fr16[1] = lds.a1p[0][1][lane]; fr16[2] = lds.a1p[1][0][lane]; fr16[3] = lds.a1p[1][1][lane]; }
         // one neighbour slot, given the neighbour's row
         auto slot_body = [&](const float4& n0, const float4& n1, const float4& n2) {
             // S2X holds 64 statistics + 32 maxima + 48 accumulator registers: do not let the compiler also park the 82
@@ -472,41 +512,42 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
             // stage area (unused until the tile's maxima are written there): a request must not depend on a load that is itself in flight.
             using f32x4 = __attribute__((ext_vector_type(4))) float;
             constexpr int kNB = kTwo ? 2 : 4;
-            int* idl = (kAsm && kTwo) ? &ids_strip[wave][0] : reinterpret_cast<int*>(&stage_or_ids[wave][0]);
-            for (int j = 0; j < K; ++j) idl[j * 64 + lane] = krow[j];
+            int* idl = reinterpret_cast<int*>(&stage_or_ids[wave][0]);
+            if (!(kAsm && K == 20))                               // the hand-scheduled loops read the ids from the kNN table themselves
+                for (int j = 0; j < K; ++j) idl[j * 64 + lane] = krow[j];
             bool slots_done = false;
             if constexpr (kAsm) {
                 if (K == 20) {
                     slots_done = true;
                     f32x16 ss0, ss1, sq0, sq1, bb0, bb1;
-                    const unsigned a_ids = (unsigned)(size_t)(SG_LDS const int*)(idl + lane);
+                    const unsigned koff = (unsigned)ptc * 80u;                      // the lane's row of the kNN table (K = 20 ids)
                     const float sd_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Sd)));
                     const unsigned l16 = 16u * (unsigned)half;
+                    // base -> the wave's stage strip, [t * 4 + g][lane] float4 = base[t][4 g .. 4 g + 3]: conv1's C operand.  MLP3 re-reads it every
+                    // slot; MLP2 reads it (and its four A fragments) ONCE, at the head of the statement -- handing 48 registers over as operands
+                    // made the compiler copy every one of them into place (~300 v_mov per tile)
+                    float4* bl = reinterpret_cast<float4*>(&stage_or_ids[wave][0]);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            bl[(t * 4 + g) * 64 + lane] = make_float4(base[t][4 * g], base[t][4 * g + 1], base[t][4 * g + 2], base[t][4 * g + 3]);
+                    const unsigned a_base = (unsigned)(size_t)(SG_LDS const float4*)(bl + lane);
+                    // the A fragments stay in LDS (MLP3: they pass through a ring of four register tuples); a2h sits 12288 B behind a1p (struct Lds)
+                    static_assert(offsetof(Lds, a2h) - offsetof(Lds, a1p) == 12288, "edgeconv_slots_gen.h addresses conv2's fragments relative to conv1's");
+                    const unsigned a_frag = (unsigned)(size_t)(SG_LDS const u32x4*)(&lds.a1p[0][0][lane]);
                     if constexpr (!kTwo) {
-                        asm volatile(SG_EC_S1X_SLOTS
+                        asm volatile(SG_EC_S1X_SLOTS_PK
                                      : "=&" SG_EC_S1X_STAT_S0(ss0), "=&" SG_EC_S1X_STAT_S1(ss1), "=&" SG_EC_S1X_STAT_Q0(sq0), "=&" SG_EC_S1X_STAT_Q1(sq1),
                                        "=&" SG_EC_S1X_BEST0(bb0), "=&" SG_EC_S1X_BEST1(bb1)
-                                     : SG_EC_S1X_BASE0(base[0]), SG_EC_S1X_BASE1(base[1]), SG_EC_S1X_FRAG0(fr16[0]), SG_EC_S1X_FRAG1(fr16[1]),
-                                       SG_EC_S1X_FRAG2(fr16[2]), SG_EC_S1X_FRAG3(fr16[3]),
-                                       [x9m] "s"(x9m), [sd] "s"(sd_u), [ids] "v"(a_ids), [l16] "v"(l16),
+                                     : [x9m] "s"(x9m), [knn] "s"(knn), [sd] "s"(sd_u), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
                                        [xs0] "v"(xs_s[0]), [xs1] "v"(xs_s[1]), [xs2] "v"(xs_s[2]), [xs3] "v"(xs_s[3]), [xs4] "v"(xs_s[4])
-                                     : "memory", SG_EC_S1X_SLOTS_CLOBBERS);
+                                     : "memory", SG_EC_S1X_SLOTS_PK_CLOBBERS);
                     } else {
-                        // base -> the wave's stage strip, [t * 4 + g][lane] float4 = base[t][4 g .. 4 g + 3]: conv1's C operand, re-read every slot
-                        float4* bl = reinterpret_cast<float4*>(&stage_or_ids[wave][0]);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g)
-                                bl[(t * 4 + g) * 64 + lane] = make_float4(base[t][4 * g], base[t][4 * g + 1], base[t][4 * g + 2], base[t][4 * g + 3]);
-                        const unsigned a_base = (unsigned)(size_t)(SG_LDS const float4*)(bl + lane);
-                        const unsigned a_frag = (unsigned)(size_t)(SG_LDS const u32x4*)(&lds.a2h[0][0][0][lane]);
-                        const unsigned a_frag1 = (unsigned)(size_t)(SG_LDS const u32x4*)(&lds.a1p[0][0][lane]);
                         asm volatile(SG_EC_S2X_SLOTS
                                      : "=&" SG_EC_S2X_STAT_S0(ss0), "=&" SG_EC_S2X_STAT_S1(ss1), "=&" SG_EC_S2X_STAT_Q0(sq0), "=&" SG_EC_S2X_STAT_Q1(sq1),
                                        "=&" SG_EC_S2X_BEST0(bb0), "=&" SG_EC_S2X_BEST1(bb1)
-                                     : [x9m] "s"(x9m), [sd] "s"(sd_u), [ids] "v"(a_ids), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
-                                       [frag1] "v"(a_frag1),
+                                     : [x9m] "s"(x9m), [knn] "s"(knn), [sd] "s"(sd_u), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
                                        [xs0] "v"(xs_s[0]), [xs1] "v"(xs_s[1]), [xs2] "v"(xs_s[2]), [xs3] "v"(xs_s[3]), [xs4] "v"(xs_s[4])
                                      : "memory", SG_EC_S2X_SLOTS_CLOBBERS);
                     }
@@ -564,23 +605,45 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
             }
         }
 
+        asm volatile("" :: "v"(stat_q[31]), "v"(best[0]));
+        stamp.mark(2);                                        // the slot loop
+        if (grp + nblk < ngroups) { const gptr<const float4> xn = own_row(grp + nblk); nq0 = xn[0]; nq1 = xn[1]; nq2 = xn[2]; }
+        int myc = 0;
+        if constexpr (kFused) myc = cluster_of_pos[ptc];      // asked for here, needed behind the statistics flush
         // sum over the 32 rows of each half on the DPP path (wave_ops.h; `__shfl_xor` is an LDS round trip per step on gfx950): quads,
-        // 16-lane rows, then row_bcast15 folds row 0 into row 1 and row 2 into row 3 -- lanes 31 and 63 hold their half's sum and
-        // add it into the wave's fp64 LDS accumulators
+        // 16-lane rows, then row_bcast15 folds row 0 into row 1 and row 2 into row 3 -- lanes 31 and 63 hold their half's sums.  They park
+        // them in LDS and lane = channel adds them into the wave's fp64 accumulators: two parallel read-modify-writes per lane instead of
+        // 64 serial ones by two lanes (each an LDS round trip: the flush was 12 % of a wave's time in MLP2; same values, same order)
+        float* fs = &flush_sums[wave][0];
+        if (tile * 32 + 32 > N) {                              // rows past N (the scene's last tile only) do not count
+#pragma unroll
+            for (int q = 0; q < 32; ++q) { stat_s[q] *= vmask; stat_q[q] *= vmask; }
+        }
+        // the 64 reductions are independent chains: written without a branch in between, the compiler interleaves them and the two wait
+        // states a DPP read needs behind the write of its source cost nothing (one exec-mask region per value left 99 s_nop per tile)
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
-            float s = stat_s[q] * vmask, v = stat_q[q] * vmask;
+            float s = stat_s[q], v = stat_q[q];
             s += sgw::dpp_f<sgw::kQuadXor1>(s, s); v += sgw::dpp_f<sgw::kQuadXor1>(v, v);
             s += sgw::dpp_f<sgw::kQuadXor2>(s, s); v += sgw::dpp_f<sgw::kQuadXor2>(v, v);
             s += sgw::dpp_f<sgw::kRowRor4>(s, s);  v += sgw::dpp_f<sgw::kRowRor4>(v, v);
             s += sgw::dpp_f<sgw::kRowRor8>(s, s);  v += sgw::dpp_f<sgw::kRowRor8>(v, v);
             s += sgw::dpp_f<sgw::kRowBcast15, 0xA>(0.f, s); v += sgw::dpp_f<sgw::kRowBcast15, 0xA>(0.f, v);
-            if (r == 31) {
+            stat_s[q] = s; stat_q[q] = v;
+        }
+        if (r == 31) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
                 const int ch = acc_channel(q >> 4, q & 15, half);
-                lds.acc[wave][ch] += (double)s * (double)unscale;                                  // power of two: exact
-                lds.acc[wave][64 + ch] += (double)v * ((double)unscale * (double)unscale);
+                fs[ch] = stat_s[q];
+                fs[64 + ch] = stat_q[q];
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        lds.acc[wave][lane] += (double)fs[lane] * (double)unscale;                                  // power of two: exact
+        lds.acc[wave][64 + lane] += (double)fs[64 + lane] * ((double)unscale * (double)unscale);
+        __builtin_amdgcn_wave_barrier();
+        stamp.mark(3);                                        // statistics flush
         if constexpr (!kFused) {
             if (valid) {
                 // E = max_j y'_j : 4 consecutive channels per float4 store
@@ -606,7 +669,6 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) st[r * 65 + acc_channel(t, q, half)] = best[t][q] * unscale;
-            const int myc = cluster_of_pos[ptc];
             __builtin_amdgcn_wave_barrier();
             const int rows_here = min(32, N - tile * 32);
             int cprev = __builtin_amdgcn_readfirstlane(myc);
@@ -617,15 +679,32 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                 if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
                 else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
             };
-            for (int rr = 0; rr < rows_here; ++rr) {
-                const int cr = __builtin_amdgcn_readlane(myc, rr);
-                const float v = st[rr * 65 + lane];
-                if (cr != cprev) { flush(cprev, m); m = v; cprev = cr; }
-                else m = fmaxf(m, v);
+            if (rows_here == 32 && __builtin_amdgcn_ballot_w64(myc != cprev) == 0) {
+                // the usual case -- all 32 rows in one cluster: the channel's 32 values are requested together and folded by a tree
+                // (the walk below is a chain of 32 dependent LDS round trips)
+                float col[32];
+#pragma unroll
+                for (int rr = 0; rr < 32; ++rr) col[rr] = st[rr * 65 + lane];
+#pragma unroll
+                for (int w_ = 16; w_ >= 1; w_ >>= 1)
+#pragma unroll
+                    for (int rr = 0; rr < w_; ++rr) col[rr] = fmaxf(col[rr], col[rr + w_]);
+                flush(cprev, col[0]);
+            } else {
+                for (int rr = 0; rr < rows_here; ++rr) {
+                    const int cr = __builtin_amdgcn_readlane(myc, rr);
+                    const float v = st[rr * 65 + lane];
+                    if (cr != cprev) { flush(cprev, m); m = v; cprev = cr; }
+                    else m = fmaxf(m, v);
+                }
+                flush(cprev, m);
             }
-            flush(cprev, m);
+            __builtin_amdgcn_wave_barrier();                    // the strip is the next tile's
         }
     }
+    stamp.mark(4);                                            // maxima out (store / cluster maxima)
+    q0 = nq0; q1 = nq1; q2 = nq2;
+    }   // tile groups
 
     __syncthreads();
     if (tid < 128) {
@@ -634,6 +713,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         for (int w = 0; w < kWaves; ++w) s += lds.acc[w][tid];
         partial[(size_t)bid * 128 + tid] = s;
     }
+    stamp.mark(5);                                            // barrier + partial sums
 }
 template <int MODE, bool REREAD_A = false, bool kF16 = false>
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
@@ -649,9 +729,9 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv(const floa
 }
 // S1X: the scene's MLP2 weights as they are; S2X: its folded conv1 (ec_w1f, ec_sh1) + the raw conv2
 // the engine's launches: E goes straight into the clusters' maxima (kFused above), c.pf is not written
-// the hand-scheduled slot loops (kAsm): MLP2 at two waves per SIMD like the kernels above, MLP3 at ONE (256 VGPRs + 80 AGPRs)
+// the hand-scheduled slot loops (kAsm), two waves per SIMD like the kernels above
 template <int MODE>
-__global__ __launch_bounds__(64 * kWaves, MODE == S2X ? 1 : 2) void k_edgeconv_h(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
+__global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_h(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                                           const float* __restrict__ w1, const float* __restrict__ shift1,
                                                           const u32x4* __restrict__ w2img, const float* __restrict__ scales,
                                                           const float* __restrict__ gamma_last,
@@ -660,20 +740,23 @@ __global__ __launch_bounds__(64 * kWaves, MODE == S2X ? 1 : 2) void k_edgeconv_h
     using sg::as_global;
     edgeconv_body<MODE, MODE == S2X, false, true, true>(as_global(x9m), as_global(knn), N, K, as_global(w1), as_global(shift1), as_global(w2img),
                                                         as_global(scales), as_global(gamma_last), as_global(ext), as_global(partial), blockIdx.x, nullptr, 64,
-                                                        0, as_global(range_bits));
+                                                        0, as_global(range_bits), gridDim.x);
 }
 template <int MODE>
-__global__ __launch_bounds__(64 * kWaves, MODE == S2X ? 1 : 2) void k_edgeconv_hb(const sg::SlotCtx* __restrict__ cx) {
+__global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_hb(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
-    if ((int)blockIdx.x >= c.ec_blocks) return;
+    // gridDim.x workgroups walk the scene's ec_blocks tile groups (b_edgeconv sizes the grid by what is resident at once); a scene with
+    // fewer groups than that uses one workgroup per group.  The workgroups that run are the ones that leave a row of partial sums.
+    const int nblk = min((int)gridDim.x, c.ec_blocks);
+    if ((int)blockIdx.x >= nblk) return;
     using sg::as_global;
     if constexpr (MODE == S1X) edgeconv_body<MODE, false, true, true, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global(c.ec_w1), nullptr, nullptr, nullptr,
                                                                as_global(c.ec_g1), as_global(c.cat + c.gm_D), as_global(c.ec_partial), blockIdx.x,
-                                                               as_global(c.cluster_of_pos), c.Dcat, 0, as_global((const unsigned int*)c.ec_range));
+                                                               as_global(c.cluster_of_pos), c.Dcat, 0, as_global((const unsigned int*)c.ec_range), nblk);
     else edgeconv_body<MODE, true, true, true, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global((const float*)c.ec_w1f),
                                              as_global((const float*)c.ec_sh1), as_global(reinterpret_cast<const u32x4*>(c.ec_w2img)),
                                              as_global((const float*)c.ec_scale), as_global(c.ec_g2), as_global(c.cat + c.gm_D),
-                                             as_global(c.ec_partial), blockIdx.x, as_global(c.cluster_of_pos), c.Dcat, 0);
+                                             as_global(c.ec_partial), blockIdx.x, as_global(c.cluster_of_pos), c.Dcat, 0, nullptr, nblk);
 }
 template <int MODE, bool REREAD_A>
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx, int stagger) {
@@ -1033,10 +1116,11 @@ __global__ __launch_bounds__(1024) void k_bn_fold(const double* __restrict__ par
     if (range_bits && threadIdx.x < sg::kRangeWords) range_bits[threadIdx.x] = 0u;      // the layer is done with its range words: the next layout starts from zero
 }
 // layers == 1: MLP2's only BN (-> ec_w1f = |a|, ec_sh1); layers == 2: MLP3's last BN (-> ec_w2f, ec_sh2)
-__global__ __launch_bounds__(1024) void k_bn_fold_b(const sg::SlotCtx* __restrict__ cx, int layers) {
+__global__ __launch_bounds__(1024) void k_bn_fold_b(const sg::SlotCtx* __restrict__ cx, int layers, int max_rows) {
     const sg::SlotCtx& c = cx[blockIdx.y];
-    if (layers == 1) bn_fold_body(c.ec_partial, c.ec_blocks, (double)c.N * 20.0, c.ec_g1, c.ec_b1, c.ec_w1f, c.ec_sh1);
-    else bn_fold_body(c.ec_partial, c.ec_blocks, (double)c.N * 20.0, c.ec_g2, c.ec_b2, c.ec_w2f, c.ec_sh2);
+    const int rows = min(c.ec_blocks, max_rows);             // the workgroups of the EdgeConv launch that walked this scene
+    if (layers == 1) bn_fold_body(c.ec_partial, rows, (double)c.N * 20.0, c.ec_g1, c.ec_b1, c.ec_w1f, c.ec_sh1);
+    else bn_fold_body(c.ec_partial, rows, (double)c.N * 20.0, c.ec_g2, c.ec_b2, c.ec_w2f, c.ec_sh2);
     if (threadIdx.x < sg::kRangeWords) c.ec_range[threadIdx.x] = 0u;      // the layer is done with its range words (k_layer_layout raises them again)
 }
 
@@ -1074,6 +1158,19 @@ __global__ __launch_bounds__(256) void k_bn_lrelu_apply(float* __restrict__ e, s
 
 namespace sg {
 
+// workgroups of 64 * kWaves threads resident at once at two per CU (what the hand-scheduled kernels are built for): the grid of a launch
+// whose workgroups walk their scene's tile groups.  SG_EC_WALK (development) overrides the factor: 0 = one group per workgroup.
+static int resident_workgroups() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* e = getenv("SG_EC_WALK");
+        const double f = e ? atof(e) : 2.0;
+        return f <= 0.0 ? (1 << 28) : std::max(1, (int)(cus * f));
+    }();
+    return n;
+}
+
 // SG_EC_COMPILER_LOOP=1 (development / A-B timing): every EdgeConv launch of the process takes the compiler-scheduled slot loop
 static const bool g_compiler_loop = getenv("SG_EC_COMPILER_LOOP") ? atoi(getenv("SG_EC_COMPILER_LOOP")) != 0 : false;
 
@@ -1096,7 +1193,9 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     SG_REQUIRE(!d_range_bits || k <= 32, "sg_edgeconv_forward_r: at most 32 neighbours per point (their ids are parked in a 32 x 65-word LDS strip)");
     if (d_affine) { d_affine[0] = nullptr; d_affine[1] = nullptr; d_affine[2] = nullptr; }
     if (N == 0) return SG_OK;
-    const int nblocks = sg::cdiv(sg::cdiv(N, 32), kWaves);
+    const int ngroups = sg::cdiv(sg::cdiv(N, 32), kWaves);
+    const bool hand = k == 20 && d_range_bits && !(flags & SG_EDGECONV_COMPILER_LOOP) && !g_compiler_loop;    // the hand-scheduled slot loop is written for K = 20
+    const int nblocks = hand ? std::min(ngroups, resident_workgroups()) : ngroups;       // = rows of partial sums
     sg::Carver cv(d_ws, ws_bytes);
     double* partial = cv.take<double>(std::max((size_t)nblocks * 128, (size_t)sg::cdiv(N, 256) * kMom));
     float* fold = cv.take<float>(sg::kEdgeFoldFloats + 128);
@@ -1111,7 +1210,6 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     hipStream_t st = sg::as_stream(stream);
     const double rows = (double)N * (double)k;
     const dim3 grid(nblocks), block(64 * kWaves);
-    const bool hand = k == 20 && !(flags & SG_EDGECONV_COMPILER_LOOP) && !g_compiler_loop;       // the hand-scheduled slot loop is written for K = 20
     const size_t n4 = (size_t)N * 16;
     const int egrid = (int)std::min<size_t>((n4 + 255) / 256, 2048);
     if (layers == 1) {
@@ -1153,18 +1251,19 @@ int edge_moments_partials(const float* d_x9m, const int32_t* d_knn, int N, int K
 
 int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mark)(void*, int), void* mark_arg, hipStream_t st) {
     if (bd.nslots == 0 || bd.max_N == 0) return SG_OK;
-    const int nblocks = sg::cdiv(sg::cdiv(bd.max_N, 32), kWaves);
+    const int ngroups = sg::cdiv(sg::cdiv(bd.max_N, 32), kWaves);
+    const bool hand = !g_compiler_loop;                           // the engine's layers all run K = 20 (SlotCtx::K; the kernel checks it)
+    const int nblocks = hand ? std::min(ngroups, std::max(1, resident_workgroups() / bd.nslots)) : ngroups;
     const dim3 grid(nblocks, bd.nslots), one(1, bd.nslots);
     // development knobs: SG_EC_STAGGER1 / SG_EC_STAGGER2 = start offset of the odd wave slot in units of 64 cycles
     static const int stagger1 = getenv("SG_EC_STAGGER1") ? atoi(getenv("SG_EC_STAGGER1")) : kStagger1;
     static const int stagger2 = getenv("SG_EC_STAGGER2") ? atoi(getenv("SG_EC_STAGGER2")) : kStagger2;
-    const bool hand = !g_compiler_loop;                           // the engine's layers all run K = 20 (SlotCtx::K; the kernel checks it)
     if (layers == 1) {
         if (mark) mark(mark_arg, 2);                                  // 2 / 3: in front of / behind the EdgeConv launch itself
         if (hand) k_edgeconv_hb<S1X><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
         else k_edgeconv_b<S1X, false><<<grid, 64 * kWaves, 0, st>>>(d_ctx, stagger1);
         if (mark) mark(mark_arg, 3);
-        k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 1);
+        k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 1, nblocks);
         k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 1);
         if (mark) mark(mark_arg, 0);
     } else {
@@ -1174,7 +1273,7 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
         if (hand) k_edgeconv_hb<S2X><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
         else k_edgeconv_b<S2X, true><<<grid, 64 * kWaves, 0, st>>>(d_ctx, stagger2);
         if (mark) mark(mark_arg, 3);
-        k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 2);
+        k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 2, nblocks);
         k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 2);
         if (mark) mark(mark_arg, 1);
     }
@@ -1212,6 +1311,16 @@ int sg_edgeconv_forward_x(const float* d_x9m, const int32_t* d_knn, int N, int k
     return sg::edgeconv_forward_marked(d_x9m, d_knn, N, k, layers, d_w1, d_g1, d_b1, d_w2, d_g2, d_b2, d_out, d_ws, ws_bytes, stream,
                                        nullptr, nullptr, d_range_bits, flags);
 }
+
+#ifdef SG_KNN_PROFILE
+// profiling builds only: [3][8] sums of 10 ns ticks per (0 = compiler loop, 1 = MLP2 hand, 2 = MLP3 hand) x phase; cleared by the call
+int sg_debug_ec_phases(unsigned long long* h_out) {
+    SG_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_ec_phase), sizeof(unsigned long long) * 24));
+    unsigned long long z[24] = {0};
+    SG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ec_phase), z, sizeof z));
+    return SG_OK;
+}
+#endif
 
 int sg_edge_range(const float* d_x9m, int N, unsigned int* d_range_bits, void* stream) {
     SG_REQUIRE(N >= 0 && d_x9m && d_range_bits, "sg_edge_range: bad arguments");

@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseggroup_hip.so")
+# SEGGROUP_HIP_LIB: another build of the same library (a profiling build: `make PROFILE=1`, tools/ec_phases.py)
+LIB_PATH = os.environ.get("SEGGROUP_HIP_LIB") or os.path.join(_HERE, "libseggroup_hip.so")
 # SEGGROUP_HIP_HOST_LIB: a HOST-ONLY build of the library (`make -C seggroup_amd/csrc asan`: grouping engine, writers,
 # parsers under ASan/UBSan).  It has no kernels, so only the host entry points bind; everything else raises on use.
 HOST_LIB_OVERRIDE = os.environ.get("SEGGROUP_HIP_HOST_LIB")

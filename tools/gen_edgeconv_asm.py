@@ -29,11 +29,12 @@ OUT = os.path.join(HERE, "..", "seggroup_amd", "csrc", "edgeconv_slots_gen.h")
 
 MFMA_TO_READ = 14      # instructions between an MFMA and a non-MFMA reader / overwriter of its D (hipcc: s_nop 11 = 12 states; + margin)
 VALU_TO_MFMA = 3       # instructions between a VALU write and the MFMA reading it (hipcc: s_nop 1 = 2 states)
-MFMA_SRC_WAR = 12      # instructions between an MFMA and an overwrite of one of its sources
+MFMA_SRC_WAR = 12      # instructions between an MFMA and an overwrite of its C operand (read pass by pass)
+MFMA_AB_WAR = 2        # ... of its A / B operand (read when the MFMA issues: hipcc pads nothing here)
 
 
 class Op:
-    __slots__ = ("kind", "text", "reads", "writes", "cls", "tag", "idx", "deps", "fill")
+    __slots__ = ("kind", "text", "reads", "writes", "cls", "tag", "idx", "deps", "fill", "frag", "cregs")
 
     def __init__(self, kind, text, reads=(), writes=(), cls=None, tag="", fill=True):
         self.kind = kind            # mfma | valu | lds | vmem | salu
@@ -43,6 +44,8 @@ class Op:
         self.cls = cls              # 'vm' | 'lgkm' for loads (asynchronous register writes)
         self.tag = tag
         self.fill = fill
+        self.frag = None
+        self.cregs = frozenset()
 
 
 def vr(n, cnt=1):
@@ -85,6 +88,57 @@ class Prog:
         ctxt = "0" if c is None else vt(c, 16)
         reads = list(a_regs) + vr(b, 4) + ([] if c is None else vr(c, 16))
         self.add("mfma", "v_mfma_f32_32x32x16_f16 %s, %s, %s, %s" % (vt(d, 16), a_txt, vt(b, 4), ctxt), reads, vr(d, 16), tag=tag)
+        self.ops[-1].cregs = frozenset([] if c is None else vr(c, 16))
+
+    def mfma_frag(self, d, off, b, c, tag=""):
+        """the same with the A fragment at LDS offset `off` taken from the ring (assign_frag_ring fills in the registers)"""
+        self.mfma(d, "@A@", [], b, c, tag)
+        self.ops[-1].frag = FragUse(off)
+
+
+class FragUse:
+    """placeholder in an MFMA's A operand: the fragment at LDS byte offset `off` (from %[frag]), to be found in a ring slot"""
+    def __init__(self, off):
+        self.off = off
+
+
+def assign_frag_ring(ops, ring):
+    """A fragments live in LDS and pass through `ring` (VGPR tuples of 4): every MFMA built with a FragUse gets the slot its fragment
+    sits in; a fragment that is not resident is loaded into the slot that was read longest ago, and the load is listed right behind
+    that read -- as early as the registers allow, so the scheduler can issue it that many MFMAs ahead (the 20 fragments of a slot come
+    round every 28 MFMAs: whatever is evicted misses next time anyway, so the oldest slot gives the longest run-up)."""
+    uses = [(i, o.frag.off) for i, o in enumerate(ops) if getattr(o, "frag", None) is not None]
+    nxt = {}                                             # position in `uses` -> position of the next use of the same fragment
+    last = {}
+    for k in range(len(uses) - 1, -1, -1):
+        nxt[k] = last.get(uses[k][1], 1 << 30)
+        last[uses[k][1]] = k
+    slot_frag = [None] * len(ring)
+    slot_next = [(-1)] * len(ring)                       # next use (position in `uses`) of the slot's content; -1 = empty
+    slot_last_op = [-1] * len(ring)                      # op index of the last MFMA that read the slot
+    inserts = []                                         # (after op index, Op)
+    for k, (i, off) in enumerate(uses):
+        op = ops[i]
+        if off in slot_frag:
+            sl = slot_frag.index(off)
+        else:
+            sl = min(range(len(ring)), key=lambda q: slot_last_op[q])
+            ld = Op("lds", "ds_read_b128 %s, %%[frag] offset:%d" % (vt(ring[sl], 4), off), ["%[frag]"], vr(ring[sl], 4), cls="lgkm", tag="F")
+            inserts.append((slot_last_op[sl], ld))
+            slot_frag[sl] = off
+        slot_next[sl] = nxt[k]
+        slot_last_op[sl] = i
+        op.text = op.text.replace("@A@", vt(ring[sl], 4))
+        op.reads = tuple(list(op.reads) + vr(ring[sl], 4))
+    out = []
+    by_pos = defaultdict(list)
+    for pos, ld in inserts:
+        by_pos[pos].append(ld)
+    out.extend(by_pos.get(-1, []))
+    for i, o in enumerate(ops):
+        out.append(o)
+        out.extend(by_pos.get(i, []))
+    return out
 
 
 def operand(x):
@@ -122,7 +176,7 @@ def build_deps(ops):
 
 
 DEP_DIST = int(os.environ.get("SG_EC_DEP_DIST", "2"))     # keep a VALU this many instructions away from the VALU whose result it reads
-LAT = {"lgkm": 48, "vm": 400}          # instructions after which a load of the class is taken to have landed (placement only; the s_waitcnt is exact)
+LAT = {"lgkm": 32, "vm": 250}          # instructions after which a load of the class is taken to have landed (placement only; the s_waitcnt is exact)
 
 
 def schedule(ops, fill, window=96):
@@ -152,8 +206,10 @@ def schedule(ops, fill, window=96):
                 w = set(p.writes)
                 if w & orr or w & ow:
                     need = max(need, at_ + MFMA_TO_READ)
-                elif set(p.reads) & ow:
+                elif p.cregs & ow:
                     need = max(need, at_ + MFMA_SRC_WAR)
+                elif set(p.reads) & ow:
+                    need = max(need, at_ + MFMA_AB_WAR)
             elif p.kind == "mfma" and op.kind == "mfma":
                 w = set(p.writes)
                 # the accumulate chain (C = the producer's whole D, same D) issues back to back; any other read of a result waits
@@ -181,7 +237,7 @@ def schedule(ops, fill, window=96):
         op = ops[i]
         c = max(0, min_pos(op) - pos)
         for cls, k in waits_for(op).items():
-            c = max(c, emitted_at[mem_issued[cls][k]] + LAT[cls] - pos, 1)
+            c = max(c, emitted_at[mem_issued[cls][k]] + LAT[cls] - pos)
         if c == 0 and op.kind == "valu" and DEP_DIST:
             for back, d in enumerate(reversed(recent[-DEP_DIST:])):
                 if d in op.deps and emitted_at[d] >= pos - DEP_DIST:
@@ -241,7 +297,7 @@ def schedule(ops, fill, window=96):
             continue
         pick, best = None, None
         for want_mem in (True, False):               # loads first: their latency is what the instructions behind them hide
-            for j, i in enumerate(pend[:window]):
+            for j, i in enumerate(pend[:8 * window if want_mem else window]):
                 if not_before[i] > im:
                     break
                 if (ops[i].cls is not None) != want_mem or not ready(i):
@@ -307,23 +363,27 @@ def verify(ops, out_order_idx):
 # S1X (MLP2): conv1 on two fp16 pieces + statistics + maxima.  Two waves per SIMD (<= 256 VGPRs), base and the four A fragments in VGPRs.
 # ------------------------------------------------------------------------------------------------------------------------------
 class MapS1X:
-    FREE = 12                     # v0..v11 stay with the compiler (inputs, values live across the statement)
+    # Two waves per SIMD; base and the four A fragments in VGPRs; ONE conv1 accumulator (the partner wave's MFMAs cover the statistics
+    # phase; a second accumulator left the compiler 13 registers around the statement and ~90 spilled values per tile)
+    FREE = 12                     # v0..v11 stay with the compiler (inputs, values live across the statement), and everything from END on
     STAT_S = 12                   # 32: stat_s[16 t + q]
     STAT_Q = 44
     BEST = 76
-    ACC = (108, 140)              # two conv1 accumulators that take turns (32 each)
-    BASE = 172                    # 32: the x_i half of conv1 (C operand of every slot's first MFMAs)
-    FRAG = 204                    # 16: fr16[0..3]
-    ROW = 220                     # 3 x 6: the neighbour rows in flight (16 B on an even register + channel 8 + one unused)
+    ACC = (108, 108)              # conv1's accumulator (32)
+    BASE = 140                    # 32: the x_i half of conv1 (C operand of every slot's first MFMAs)
+    FRAG = 172                    # 16: fr16[0..3]
+    ROW = 188                     # 3 x 6: the neighbour rows in flight (16 B on an even register + channel 8 + one unused)
     NROW = 3
     RSTRIDE = 6
-    X0 = 238                      # (d_hi | d_lo)
-    X1 = 242                      # (d_hi | d8_hi, d8_lo)
-    DS = 246                      # 5
-    IDV = 251                     # 2 ids (alternating)
-    T48 = 253
-    OFF = 254
-    END = 255
+    X0 = 206                      # (d_hi | d_lo)
+    X1 = 210                      # (d_hi | d8_hi, d8_lo)
+    DS = 214                      # 5
+    IDV = 219                     # 2 ids (alternating)
+    IDSTRIDE = 1
+    GLOBAL_IDS = True             # ids straight from the kNN table, a slot ahead (staging them in LDS cost 20 loads + 20 stores + their round trip per tile)
+    T48 = 221
+    OFF = 222
+    END = 223
 
 
 def d_cut(p, m, j, row, sd, xs):
@@ -359,10 +419,17 @@ def init_outputs(p, m):
         p.valu("v_mov_b32 v%d, 0xff800000" % (m.BEST + q), [], vr(m.BEST + q))
 
 
+def id_reg(m, j):
+    return m.IDV + m.IDSTRIDE * (j & 1)
+
+
 def id_read(p, m, j):
     if "G" in OMIT:
         return
-    p.add("lds", "ds_read_b32 v%d, %%[ids] offset:%d" % (m.IDV + (j & 1), j * 256), ["%[ids]"], vr(m.IDV + (j & 1)), cls="lgkm", tag="ID%d" % j)
+    if getattr(m, "GLOBAL_IDS", False):                  # straight from the kNN table (MLP3: no LDS left for an id strip at two workgroups per CU)
+        p.add("vmem", "global_load_dword v%d, %%[koff], %%[knn] offset:%d" % (id_reg(m, j), 4 * j), ["%[koff]"], vr(id_reg(m, j)), cls="vm", tag="ID%d" % j)
+    else:
+        p.add("lds", "ds_read_b32 v%d, %%[ids] offset:%d" % (id_reg(m, j), j * 256), ["%[ids]"], vr(id_reg(m, j)), cls="lgkm", tag="ID%d" % j)
 
 
 def gather(p, m, j):
@@ -373,7 +440,7 @@ def gather(p, m, j):
 
 def _gather(p, m, j):
     row = m.ROW + m.RSTRIDE * (j % m.NROW)
-    idv = m.IDV + (j & 1)
+    idv = id_reg(m, j)
     p.valu("v_mul_u32_u24 v%d, 48, v%d" % (m.T48, idv), vr(idv), vr(m.T48), tag="G%d" % j)
     p.valu("v_add_u32 v%d, v%d, %%[l16]" % (m.OFF, m.T48), vr(m.T48), vr(m.OFF))
     p.add("vmem", "global_load_dwordx4 %s, v%d, %%[x9m]" % (vt(row, 4), m.OFF), vr(m.OFF), vr(row, 4), cls="vm")
@@ -384,7 +451,12 @@ def program_s1x(pk_stats):
     m = MapS1X
     p = Prog()
     xs = ["%%[xs%d]" % q for q in range(5)]
-    # prologue: the first rows (an id is read one request ahead of its own: two id registers take turns)
+    # prologue: base and the four A fragments from LDS (once per tile), the first rows (an id is read one request ahead of its own: two
+    # id registers take turns)
+    for g in range(8):
+        p.add("lds", "ds_read_b128 %s, %%[base] offset:%d" % (vt(m.BASE + 4 * g, 4), g * 1024), ["%[base]"], vr(m.BASE + 4 * g, 4), cls="lgkm", tag="B")
+    for i in range(4):
+        p.add("lds", "ds_read_b128 %s, %%[frag] offset:%d" % (vt(m.FRAG + 4 * i, 4), i * 1024), ["%[frag]"], vr(m.FRAG + 4 * i, 4), cls="lgkm", tag="F")
     init_outputs(p, m)
     id_read(p, m, 0)
     for j in range(min(K, m.NROW)):
@@ -399,15 +471,18 @@ def program_s1x(pk_stats):
         if j + m.NROW < K:
             gather(p, m, j + m.NROW)                     # re-uses the row registers d_cut has just read
         acc = m.ACC[j & 1]
-        # statistics + maxima of the slot before (its accumulator is the other one): listed in front of conv1, i.e. offered to its shadows
-        if j >= 1:
+        # statistics + maxima of the slot before, if it has an accumulator of its own: listed in front of conv1, i.e. offered to its shadows
+        if j >= 1 and m.ACC[0] != m.ACC[1]:
             stats_s1x(p, m, j - 1, pk_stats)
         # conv1: the smaller terms first, like the C++ loop
         for t in range(2):
             p.mfma(acc + 16 * t, vt(m.FRAG + 4 * (2 + t), 4), vr(m.FRAG + 4 * (2 + t), 4), m.X1, m.BASE + 16 * t, tag="C1 %d" % j)
         for t in range(2):
             p.mfma(acc + 16 * t, vt(m.FRAG + 4 * t, 4), vr(m.FRAG + 4 * t, 4), m.X0, acc + 16 * t)
-    stats_s1x(p, m, K - 1, pk_stats)
+        if m.ACC[0] == m.ACC[1]:
+            stats_s1x(p, m, j, pk_stats)
+    if m.ACC[0] != m.ACC[1]:
+        stats_s1x(p, m, K - 1, pk_stats)
     return p
 
 
@@ -431,27 +506,35 @@ def stats_s1x(p, m, j, pk):
 # S2X (MLP3): conv1' -> LeakyReLU -> cut -> conv2 -> statistics + maxima.  One wave per SIMD: 256 VGPRs + the 20 A fragments in AGPRs.
 # ------------------------------------------------------------------------------------------------------------------------------
 class MapS2X:
-    FREE = 12
-    STAT_S = 12
-    STAT_Q = 44
-    BEST = 76
-    ACC2 = 108                    # 32: tile 0 | tile 1
-    BUF = (140, 176)              # conv1 accumulator -> conv2's operand pieces, in place (32) + 4 extra for the first high block
-    EXT = (172, 208)
-    ROW = 212                     # 3 x 6
-    NROW = 3
+    # Two waves per SIMD, VGPRs only.  (First version: one wave per SIMD with the 20 A fragments in AGPRs.  MFMAs that read an operand
+    # from an AGPR run the chip at ~1.65 instead of ~1.97 GHz -- same cycle count per slot, 19 % more time; tools/micro/ec_slots_bench.hip,
+    # DESIGN.md section 5 -- and one wave per SIMD leaves a tile's prologue and statistics flush uncovered.)  The A fragments stay in LDS
+    # and pass through a ring of four register tuples, each requested as soon as the tuple's last reader has issued.
+    FREE = 10                     # v0..v9 stay with the compiler (nine inputs)
+    STAT_S = 10
+    STAT_Q = 42
+    BEST = 74
+    ACC2 = 106                    # 32: tile 0 | tile 1
+    BUF = (138, 174)              # conv1 accumulator -> conv2's operand pieces, in place (32) + 4 extra for the first high block
+    EXT = (170, 206)
+    ROW = 210                     # 2 x 6: 16 B on an even register + channel 8; the sixth register of each row holds an id
+    NROW = 2
     RSTRIDE = 6
-    X0 = 230
-    X1 = 234
-    DS = 238                      # 5
-    TMP = 243                     # 4: 0.2 x
-    IDV = 247                     # 2
-    T48 = 249
-    OFF = 250
-    END = 251
-    # AGPRs: a2h[piece][ot][kb] at 4 * ((piece * 2 + ot) * 4 + kb), then a1p[m][t] at 64 + 4 * (2 m + t)
-    A2 = 0
-    A1 = 64
+    IDV = 215                     # + 6 * (j & 1)
+    IDSTRIDE = 6
+    X0 = 222
+    X1 = 226
+    DS = 230                      # 5
+    T48 = 235
+    TMP = 236                     # 2: 0.2 x
+    NTMP = 2
+    OFF = 238
+    RING = (240, 244, 248, 252)   # A fragments in flight
+    GLOBAL_IDS = True
+    END = 256
+    # LDS byte offsets from %[frag] = &lds.a1p[0][0][lane]: a1p[m][t] at 1024 (2 m + t); a2h[piece][ot][kb] behind a1p and a1x
+    A1 = 0
+    A2 = 8192 + 4096
 
 
 def base_load(p, m, j):
@@ -474,8 +557,7 @@ def conv1_s2x(p, m, j, fillers=()):
     k = 0
     for x, base_a in ((m.X1, 2), (m.X0, 0)):
         for t in range(2):
-            a = m.A1 + 4 * (base_a + t)
-            p.mfma(buf + 16 * t, at(a, 4), ar(a, 4), x, buf + 16 * t, tag="C1 %d" % j if (x == m.X1 and t == 0) else "")
+            p.mfma_frag(buf + 16 * t, m.A1 + 1024 * (base_a + t), x, buf + 16 * t, tag="C1 %d" % j if (x == m.X1 and t == 0) else "")
             k += 1
             take = fillers[:6] if k < 4 else fillers
             fillers = fillers[len(take):]
@@ -496,7 +578,7 @@ def _lrelu_cut(p, m, j):
         r = buf + 8 * kb
         hi = ext if kb == 0 else buf + 8 * (kb - 1) + 4
         for u in range(8):
-            t = m.TMP + (u & 3)
+            t = m.TMP + (u % m.NTMP)
             p.valu("v_mul_f32 v%d, 0x3e4ccccd, v%d" % (t, r + u), vr(r + u), vr(t), tag="L%d.%d" % (j, kb))
             p.valu("v_max_f32 v%d, v%d, v%d" % (r + u, r + u, t), vr(r + u) + vr(t), vr(r + u))
         for u in range(4):
@@ -518,9 +600,8 @@ def conv2(p, m, j):
         xh = ext if kb == 0 else buf + 8 * (kb - 1) + 4
         for (piece, x) in ((1, xh), (0, xl), (0, xh)):                # w_lo x_hi, w_hi x_lo, w_hi x_hi: smallest terms first
             for ot in range(2):
-                w = m.A2 + 4 * ((piece * 2 + ot) * 4 + kb)
                 d = m.ACC2 + 16 * ot
-                p.mfma(d, at(w, 4), ar(w, 4), x, None if first else d, tag="C2 %d" % j if (first and ot == 0) else "")
+                p.mfma_frag(d, m.A2 + 1024 * ((piece * 2 + ot) * 4 + kb), x, None if first else d, tag="C2 %d" % j if (first and ot == 0) else "")
             first = False
 
 
@@ -540,22 +621,8 @@ OMIT = set(x for x in os.environ.get("SG_EC_OMIT", "").split(",") if x)       # 
 
 def program_s2x():
     m = MapS2X
-    if os.environ.get("SG_EC_COMPACT"):                  # timing experiment (MFMA-only stream): everything below v128, the AGPRs right behind
-        class M2(MapS2X):
-            STAT_S, STAT_Q, BEST = 12, 12, 12
-            ACC2 = 12
-            BUF = (44, 80)
-            EXT = (76, 112)
-            X0, X1 = 116, 120
-            END = 124
-        m = M2
     p = Prog()
     xs = ["%%[xs%d]" % q for q in range(5)]
-    # the 20 A fragments: LDS -> AGPRs, once per tile
-    for i in range(16):
-        p.add("lds", "ds_read_b128 %s, %%[frag] offset:%d" % (at(m.A2 + 4 * i, 4), 1024 * i), ["%[frag]"], ar(m.A2 + 4 * i, 4), cls="lgkm", tag="A2")
-    for i in range(4):
-        p.add("lds", "ds_read_b128 %s, %%[frag1] offset:%d" % (at(m.A1 + 4 * i, 4), 1024 * i), ["%[frag1]"], ar(m.A1 + 4 * i, 4), cls="lgkm", tag="A1")
     init_outputs(p, m)
     id_read(p, m, 0)
     for j in range(min(K, m.NROW)):
@@ -590,6 +657,7 @@ def program_s2x():
         stats_s2x(q, m, j, 0)
         stats_s2x(q, m, j, 1)
         front(j + 2, q.ops)                              # the slot's statistics: in the shadows of conv1's four MFMAs and while its base rows load
+    p.ops = assign_frag_ring(p.ops, m.RING)
     return p
 
 
@@ -627,7 +695,7 @@ def main():
         nm = "SG_EC_S1X_SLOTS_PK" if pk else "SG_EC_S1X_SLOTS"
         m = MapS1X
         outs = list(range(m.STAT_S, m.BEST + 32))
-        clob = [i for i in range(m.FREE, m.END) if i not in outs and not (m.BASE <= i < m.BASE + 32) and not (m.FRAG <= i < m.FRAG + 16)]
+        clob = [i for i in range(m.FREE, m.END) if i not in outs]
         out.append(render(nm, sched, clob, [], "MLP2, K = %d slots, %s statistics: %d instructions (%d MFMA, %d s_nop states, %d s_waitcnt)"
                           % (K, "packed" if pk else "plain", len(sched), c["v_mfma_f32_32x32x16_f16"], st["nops"], st["waits"])))
         report.append((nm, len(sched), dict(c), st))
@@ -636,13 +704,8 @@ def main():
     c = count(sched)
     m = MapS2X
     outs = list(range(m.STAT_S, m.BEST + 32))
-    if os.environ.get("SG_EC_COMPACT"):
-        class m(MapS2X):
-            END = 124
-            STAT_S, STAT_Q, BEST = 124, 156, 188       # outputs somewhere (never written in this experiment)
-        outs = []
     clob = [i for i in range(m.FREE, m.END) if i not in outs]
-    out.append(render("SG_EC_S2X_SLOTS", sched, clob, list(range(0, 80)), "MLP3, K = %d slots: %d instructions (%d MFMA, %d s_nop states, %d s_waitcnt)"
+    out.append(render("SG_EC_S2X_SLOTS", sched, clob, [], "MLP3, K = %d slots: %d instructions (%d MFMA, %d s_nop states, %d s_waitcnt)"
                       % (K, len(sched), c["v_mfma_f32_32x32x16_f16"], st["nops"], st["waits"])))
     report.append(("SG_EC_S2X_SLOTS", len(sched), dict(c), st))
     for cls, mm in (("S1X", MapS1X), ("S2X", MapS2X)):
