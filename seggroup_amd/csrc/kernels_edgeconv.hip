@@ -279,7 +279,13 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     auto own_row = [&](int grp) { const int p_ = (grp * kWaves + wave) * 32 + r; return (gptr<const float4>)(x9m + (size_t)(p_ < N ? p_ : 0) * 12); };
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
     if (bid < ngroups) { const gptr<const float4> xr = own_row(bid); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
+    const int tid_outer = tid;
     for (int grp = bid; grp < ngroups; grp += nblk) {
+    // Everything a lane knows about itself is re-derived from the thread id here and again behind the slot loop: the statement of the
+    // hand-scheduled loop leaves the compiler ten registers, and what is live across it goes to scratch and back (45 values per tile before)
+    int tid = tid_outer;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     const int tile = grp * kWaves + wave;
     const int pt = tile * 32 + r;
     const bool valid = pt < N;
@@ -343,7 +349,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         const gptr<const int32_t> krow = knn + (size_t)ptc * K;
         // the fp16 conv1's four A fragments stay in registers for the whole tile (MLP2 has the room: no conv2 accumulators)
         u32x4 fr16[4] = {};
-        if (kFrag && !(kAsm && K == 20)) { fr16[0] = lds.a1p[0][0][lane]; fr16[1] = lds.a1p[0][1][lane]; fr16[2] = lds.a1p[1][0][lane]; fr16[3] = lds.a1p[1][1][lane]; }
+        if (kFrag && !kAsm) { fr16[0] = lds.a1p[0][0][lane]; fr16[1] = lds.a1p[0][1][lane]; fr16[2] = lds.a1p[1][0][lane]; fr16[3] = lds.a1p[1][1][lane]; }
         // one neighbour slot, given the neighbour's row
         auto slot_body = [&](const float4& n0, const float4& n1, const float4& n2) {
             // S2X holds 64 statistics + 32 maxima + 48 accumulator registers: do not let the compiler also park the 82
@@ -513,16 +519,13 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
             using f32x4 = __attribute__((ext_vector_type(4))) float;
             constexpr int kNB = kTwo ? 2 : 4;
             int* idl = reinterpret_cast<int*>(&stage_or_ids[wave][0]);
-            if (!(kAsm && K == 20))                               // the hand-scheduled loops read the ids from the kNN table themselves
+            if constexpr (!kAsm)                                  // the hand-scheduled loops read the ids from the kNN table themselves
                 for (int j = 0; j < K; ++j) idl[j * 64 + lane] = krow[j];
-            bool slots_done = false;
+            constexpr bool slots_done = kAsm;                       // the kAsm kernels are only launched with K == 20 (the host checks)
             if constexpr (kAsm) {
-                if (K == 20) {
-                    slots_done = true;
+                {
                     f32x16 ss0, ss1, sq0, sq1, bb0, bb1;
-                    const unsigned koff = (unsigned)ptc * 80u;                      // the lane's row of the kNN table (K = 20 ids)
                     const float sd_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Sd)));
-                    const unsigned l16 = 16u * (unsigned)half;
                     // base -> the wave's stage strip, [t * 4 + g][lane] float4 = base[t][4 g .. 4 g + 3]: conv1's C operand.  MLP3 re-reads it every
                     // slot; MLP2 reads it (and its four A fragments) ONCE, at the head of the statement -- handing 48 registers over as operands
                     // made the compiler copy every one of them into place (~300 v_mov per tile)
@@ -532,23 +535,37 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
                             bl[(t * 4 + g) * 64 + lane] = make_float4(base[t][4 * g], base[t][4 * g + 1], base[t][4 * g + 2], base[t][4 * g + 3]);
-                    const unsigned a_base = (unsigned)(size_t)(SG_LDS const float4*)(bl + lane);
+                    // The statement's operands are derived HERE, behind the base stores, from laundered copies of the thread id and the own row:
+                    // computed earlier they sit in the registers base is built in, and the compiler parks them in scratch and fetches them back
+                    // (7 scratch round trips in front of every tile's slot loop)
+                    int tid_c = tid_outer;
+                    using f32x4 = __attribute__((ext_vector_type(4))) float;
+                    f32x4 c0 = {q0.x, q0.y, q0.z, q0.w}, c1 = {q1.x, q1.y, q1.z, q1.w};
+                    float c2x = q2.x;
+                    asm volatile("" : "+v"(tid_c), "+v"(c0), "+v"(c1), "+v"(c2x));
+                    const int lane_c = tid_c & 63, half_c = lane_c >> 5, r_c = lane_c & 31, wave_c = tid_c >> 6;
+                    const int pt_c = (grp * kWaves + wave_c) * 32 + r_c;
+                    const unsigned koff = (unsigned)(pt_c < N ? pt_c : 0) * 80u;    // the lane's row of the kNN table (K = 20 ids)
+                    const unsigned l16 = 16u * (unsigned)half_c;
+                    const float xs_c[5] = {(half_c ? c1.x : c0.x) * Sd, (half_c ? c1.y : c0.y) * Sd, (half_c ? c1.z : c0.z) * Sd, (half_c ? c1.w : c0.w) * Sd,
+                                           c2x * Sd};
+                    const unsigned a_base = (unsigned)(size_t)(SG_LDS const float4*)(reinterpret_cast<float4*>(&stage_or_ids[wave_c][0]) + lane_c);
                     // the A fragments stay in LDS (MLP3: they pass through a ring of four register tuples); a2h sits 12288 B behind a1p (struct Lds)
                     static_assert(offsetof(Lds, a2h) - offsetof(Lds, a1p) == 12288, "edgeconv_slots_gen.h addresses conv2's fragments relative to conv1's");
-                    const unsigned a_frag = (unsigned)(size_t)(SG_LDS const u32x4*)(&lds.a1p[0][0][lane]);
+                    const unsigned a_frag = (unsigned)(size_t)(SG_LDS const u32x4*)(&lds.a1p[0][0][lane_c]);
                     if constexpr (!kTwo) {
                         asm volatile(SG_EC_S1X_SLOTS_PK
                                      : "=&" SG_EC_S1X_STAT_S0(ss0), "=&" SG_EC_S1X_STAT_S1(ss1), "=&" SG_EC_S1X_STAT_Q0(sq0), "=&" SG_EC_S1X_STAT_Q1(sq1),
                                        "=&" SG_EC_S1X_BEST0(bb0), "=&" SG_EC_S1X_BEST1(bb1)
                                      : [x9m] "s"(x9m), [knn] "s"(knn), [sd] "s"(sd_u), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
-                                       [xs0] "v"(xs_s[0]), [xs1] "v"(xs_s[1]), [xs2] "v"(xs_s[2]), [xs3] "v"(xs_s[3]), [xs4] "v"(xs_s[4])
+                                       [xs0] "v"(xs_c[0]), [xs1] "v"(xs_c[1]), [xs2] "v"(xs_c[2]), [xs3] "v"(xs_c[3]), [xs4] "v"(xs_c[4])
                                      : "memory", SG_EC_S1X_SLOTS_PK_CLOBBERS);
                     } else {
                         asm volatile(SG_EC_S2X_SLOTS
                                      : "=&" SG_EC_S2X_STAT_S0(ss0), "=&" SG_EC_S2X_STAT_S1(ss1), "=&" SG_EC_S2X_STAT_Q0(sq0), "=&" SG_EC_S2X_STAT_Q1(sq1),
                                        "=&" SG_EC_S2X_BEST0(bb0), "=&" SG_EC_S2X_BEST1(bb1)
                                      : [x9m] "s"(x9m), [knn] "s"(knn), [sd] "s"(sd_u), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
-                                       [xs0] "v"(xs_s[0]), [xs1] "v"(xs_s[1]), [xs2] "v"(xs_s[2]), [xs3] "v"(xs_s[3]), [xs4] "v"(xs_s[4])
+                                       [xs0] "v"(xs_c[0]), [xs1] "v"(xs_c[1]), [xs2] "v"(xs_c[2]), [xs3] "v"(xs_c[3]), [xs4] "v"(xs_c[4])
                                      : "memory", SG_EC_S2X_SLOTS_CLOBBERS);
                     }
 #pragma unroll
@@ -559,7 +576,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                     best[0] = bb0; best[1] = bb1;
                 }
             }
-            if (!slots_done) {
+            if constexpr (!slots_done) {
                 // (`cur` = the row the coming slot works on: re-defined by the request so that the slot's code cannot be scheduled in front of
                 // it; `done` = a statistic the finished slot wrote: re-defined by the wait so that the wait cannot be scheduled in front of it)
                 auto request = [&](int nb, f32x4& r0, float& e8, f32x4& cur) {
@@ -607,6 +624,14 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
 
         asm volatile("" :: "v"(stat_q[31]), "v"(best[0]));
         stamp.mark(2);                                        // the slot loop
+        int tid = tid_outer;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+        const int tile = grp * kWaves + wave;
+        const int pt = tile * 32 + r;
+        const bool valid = pt < N;
+        const float vmask = valid ? 1.f : 0.f;
+        const int ptc = valid ? pt : 0;
         if (grp + nblk < ngroups) { const gptr<const float4> xn = own_row(grp + nblk); nq0 = xn[0]; nq1 = xn[1]; nq2 = xn[2]; }
         int myc = 0;
         if constexpr (kFused) myc = cluster_of_pos[ptc];      // asked for here, needed behind the statistics flush

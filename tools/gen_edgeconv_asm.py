@@ -509,26 +509,27 @@ class MapS2X:
     # Two waves per SIMD, VGPRs only.  (First version: one wave per SIMD with the 20 A fragments in AGPRs.  MFMAs that read an operand
     # from an AGPR run the chip at ~1.65 instead of ~1.97 GHz -- same cycle count per slot, 19 % more time; tools/micro/ec_slots_bench.hip,
     # DESIGN.md section 5 -- and one wave per SIMD leaves a tile's prologue and statistics flush uncovered.)  The A fragments stay in LDS
-    # and pass through a ring of four register tuples, each requested as soon as the tuple's last reader has issued.
-    FREE = 10                     # v0..v9 stay with the compiler (nine inputs)
-    STAT_S = 10
-    STAT_Q = 42
-    BEST = 74
-    ACC2 = 106                    # 32: tile 0 | tile 1
-    BUF = (138, 174)              # conv1 accumulator -> conv2's operand pieces, in place (32) + 4 extra for the first high block
-    EXT = (170, 206)
-    ROW = 210                     # 2 x 6: 16 B on an even register + channel 8; the sixth register of each row holds an id
-    NROW = 2
+    # and pass through a ring of four register tuples, each requested as soon as the tuple's last reader has issued.  ONE neighbour row
+    # in flight: a slot lasts ~1.4 us per wave here, several memory round trips.
+    FREE = 16                     # v0..v15 stay with the compiler (nine inputs + what lives across the statement)
+    STAT_S = 16
+    STAT_Q = 48
+    BEST = 80
+    ACC2 = 112                    # 32: tile 0 | tile 1
+    BUF = (144, 180)              # conv1 accumulator -> conv2's operand pieces, in place (32) + 4 extra for the first high block
+    EXT = (176, 212)
+    ROW = 216                     # 16 B on an even register + channel 8; the sixth register holds an id
+    NROW = 1
     RSTRIDE = 6
-    IDV = 215                     # + 6 * (j & 1)
-    IDSTRIDE = 6
-    X0 = 222
-    X1 = 226
-    DS = 230                      # 5
-    T48 = 235
-    TMP = 236                     # 2: 0.2 x
+    IDV = 221                     # 221, 222
+    IDSTRIDE = 1
+    T48 = 223
+    X0 = 224
+    X1 = 228
+    DS = 232                      # 5
+    OFF = 237
+    TMP = 238                     # 2: 0.2 x
     NTMP = 2
-    OFF = 238
     RING = (240, 244, 248, 252)   # A fragments in flight
     GLOBAL_IDS = True
     END = 256
