@@ -8,13 +8,15 @@
 //   sg_mesh_adjacency       get_adj_from_mesh 771-792: per-row sorted, lexicographically unique edge lists, raw and resampled
 //   sg_segment_lists        generate_seg_labels_and_ds_set 174-220: compacted segment ids + member lists
 //
+// Sorting (round 4): csrc/sort_device.h -- a stable LSD radix sort over exactly the bits that carry an id (an edge key lo << 32 | hi of
+// ids below 2^b is sorted by its two b + 1-bit fields: four 11-bit passes at b <= 20, where the library sort this file used before ran
+// eight over all 64 bits), exclusive scans and an adjacent-unique compaction.
 // All of it is index / byte work (HBM- and sort-bound) except the nearest-point search, a brute-force scan in the
 // reference's exact fp32 formula  s_ij = ((-xx_i) - (-2 x_i.y_j)) - yy_j  (argmax, lowest j on ties): at ScanNet's worst
 // case (380k unsampled vertices x 150k samples = 5.7e10 pairs) that is ~4.6e11 VALU lane-ops, ~15 ms on MI355X, so a
 // spatial index is not worth its exactness proof.
-#include <hipcub/hipcub.hpp>
-
 #include "sg_common.h"
+#include "sort_device.h"
 
 namespace {
 
@@ -144,7 +146,7 @@ __global__ void k_unmap_finish(const int32_t* __restrict__ last, int V, int64_t*
 // edges (0,1), (0,2), (1,2) of every face; zero-length edges (util.py:783) and, for the resampled list, the same rows
 // mapped through `unmap` -- packed as lo << 32 | hi; dropped rows become ~0 and sort to the end
 __global__ void k_face_edges(const int32_t* __restrict__ faces, int F, const int64_t* __restrict__ unmap,
-                             unsigned long long* __restrict__ raw, unsigned long long* __restrict__ res) {
+                             unsigned long long* __restrict__ raw, unsigned long long* __restrict__ res, long long id_limit, int* __restrict__ too_large) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const int v[3] = {faces[(size_t)f * 3], faces[(size_t)f * 3 + 1], faces[(size_t)f * 3 + 2]};
@@ -156,6 +158,7 @@ __global__ void k_face_edges(const int32_t* __restrict__ faces, int F, const int
         raw[(size_t)f * 3 + e] = keep ? ((unsigned long long)(unsigned)min(a, b) << 32) | (unsigned)max(a, b) : ~0ull;
         if (res) {
             const long long ua = keep ? unmap[a] : 0, ub = keep ? unmap[b] : 0;
+            if (ua >= id_limit || ub >= id_limit || ua < 0 || ub < 0) *too_large = 1;           // outside the bit range the sort covers
             res[(size_t)f * 3 + e] = keep ? ((unsigned long long)(unsigned)min(ua, ub) << 32) | (unsigned)max(ua, ub) : ~0ull;
         }
     }
@@ -190,31 +193,30 @@ __global__ void k_sampled_labels(const int32_t* __restrict__ raw_label, const in
     val[i] = i;
 }
 
-// heads[i] = 1 where a new group starts in the label-sorted order
-__global__ void k_group_heads(const int32_t* __restrict__ key, int Np, int32_t* __restrict__ head_pos, int32_t* __restrict__ n_groups) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Np) return;
-    if (i == 0 || key[i] != key[i - 1]) head_pos[atomicAdd(n_groups, 1)] = i;          // sorted afterwards (G is small)
-}
-
 int bits_for(long long n) {
     int b = 1;
     while ((1ll << b) < n) ++b;
     return b;
 }
 
-size_t sort_keys_temp(int n) {
-    size_t t = 0;
-    hipcub::DoubleBuffer<unsigned long long> d(nullptr, nullptr);
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t, d, std::max(n, 1), 0, 64, (hipStream_t)0);
-    return t;
-}
+using EdgeLists = sgsort::Lists<unsigned long long, int>;
 
-size_t unique_temp(int n) {
-    size_t t = 0;
-    (void)hipcub::DeviceSelect::Unique(nullptr, t, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, std::max(n, 1),
-                                       (hipStream_t)0);
-    return t;
+// sorts `nl` lists of n pair keys (lo << 32 | hi, ids < 2^idbits; dropped rows = ~0, which must come out last: one bit more than the
+// ids carry is sorted per field) and leaves each list's distinct keys in out[l], their number in d_count[l].  a / b: the keys and a
+// second buffer of the same size per list; hist: sgsort::hist_ints(n) ints per list; scratch: sgsort::unique_ints(n) ints.
+int sort_unique_edges(unsigned long long* const* a, unsigned long long* const* b, unsigned long long* const* out, int nl, int n, int idbits,
+                      int* const* hist, int* scratch, int* d_count, hipStream_t st) {
+    EdgeLists L{};
+    for (int l = 0; l < nl; ++l) { L.kin[l] = a[l]; L.kout[l] = b[l]; L.vin[l] = nullptr; L.vout[l] = nullptr; L.hist[l] = hist[l]; L.n[l] = n; }
+    const int field = std::min(32, idbits + 1);
+    // LSD: the hi field (bits 0 ..), then the lo field (bits 32 ..)
+    sgsort::radix_sort<unsigned long long, int, false>(L, nl, 0, field, st);
+    sgsort::radix_sort<unsigned long long, int, false>(L, nl, 32, field, st);
+    for (int l = 0; l < nl; ++l) {
+        if (out[l] == L.kin[l]) return sg::fail(SG_EINVAL, "sort_unique_edges: the output aliases the sorted keys");
+        sgsort::unique_sorted<unsigned long long>(L.kin[l], n, out[l], nullptr, d_count + l, scratch, st);
+    }
+    return SG_OK;
 }
 
 }  // namespace
@@ -268,7 +270,7 @@ int sg_prep_sample_points(const float* d_xyz, const uint8_t* d_rgb, int V, const
 
 size_t sg_mesh_adjacency_ws_bytes(int F) {
     const size_t n = (size_t)std::max(F, 1) * 3;
-    return sg::align_up(std::max(sort_keys_temp((int)n), unique_temp((int)n))) + 4 * sg::align_up(n * 8) + 256;
+    return 6 * sg::align_up(n * 8) + 2 * sg::align_up(sgsort::hist_ints((long long)n) * 4) + sg::align_up(sgsort::unique_ints((long long)n) * 4) + 512;
 }
 
 // d_adj_raw / d_adj_res: room for [3F,2] int64 each; the row counts come back through h_n_raw / h_n_res
@@ -279,44 +281,43 @@ int sg_mesh_adjacency(const int32_t* d_faces, int F, const int64_t* d_unmap, int
     if (h_n_res) *h_n_res = 0;
     if (F == 0) return SG_OK;
     const int n = 3 * F;
-    const size_t temp = std::max(sort_keys_temp(n), unique_temp(n));
+    const bool res = d_adj_res != nullptr;
     sg::Carver cv(d_ws, ws_bytes);
-    char* tmp = cv.take<char>(temp);
     unsigned long long* k0 = cv.take<unsigned long long>(n);
     unsigned long long* k1 = cv.take<unsigned long long>(n);
+    unsigned long long* k2 = cv.take<unsigned long long>(n);
     unsigned long long* r0 = cv.take<unsigned long long>(n);
     unsigned long long* r1 = cv.take<unsigned long long>(n);
-    int* d_count = cv.take<int>(2);
+    unsigned long long* r2 = cv.take<unsigned long long>(n);
+    int* h0 = cv.take<int>(sgsort::hist_ints(n));
+    int* h1 = cv.take<int>(sgsort::hist_ints(n));
+    int* scratch = cv.take<int>(sgsort::unique_ints(n));
+    int* d_count = cv.take<int>(4);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_mesh_adjacency: workspace too small (%zu < %zu)", ws_bytes, sg_mesh_adjacency_ws_bytes(F));
     hipStream_t st = sg::as_stream(stream);
-    const bool res = d_adj_res != nullptr;
-    k_face_edges<<<sg::cdiv(F, 256), 256, 0, st>>>(d_faces, F, d_unmap, k0, res ? r0 : nullptr);
-    auto sort_unique = [&](unsigned long long* a, unsigned long long* b, int* cnt) -> int {
-        size_t t = temp;
-        hipcub::DoubleBuffer<unsigned long long> d(a, b);
-        SG_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, t, d, n, 0, 64, st));
-        unsigned long long* sorted = d.Current();
-        unsigned long long* other = sorted == a ? b : a;
-        t = temp;
-        SG_HIP(hipcub::DeviceSelect::Unique(tmp, t, sorted, other, cnt, n, st));
-        if (other != b) SG_HIP(hipMemcpyAsync(b, other, (size_t)n * 8, hipMemcpyDeviceToDevice, st));     // result always in b
-        return SG_OK;
-    };
-    int rc = sort_unique(k0, k1, d_count);
+    // ids below 2^idbits: the raw vertex ids by V; the resampled ids are checked by the kernel (sampled clouds stay below 2^20 points)
+    const int idbits = std::max(bits_for((long long)V + 1), 20);
+    SG_HIP(hipMemsetAsync(d_count, 0, 16, st));
+    k_face_edges<<<sg::cdiv(F, 256), 256, 0, st>>>(d_faces, F, d_unmap, k0, res ? r0 : nullptr, 1ll << idbits, d_count + 2);
+    unsigned long long* a[2] = {k0, r0};
+    unsigned long long* b[2] = {k1, r1};
+    unsigned long long* o[2] = {k2, r2};
+    int* hh[2] = {h0, h1};
+    const int rc = sort_unique_edges(a, b, o, res ? 2 : 1, n, idbits, hh, scratch, d_count, st);
     if (rc < 0) return rc;
-    if (res && (rc = sort_unique(r0, r1, d_count + 1)) < 0) return rc;
-    int cnt[2] = {0, 0};
-    unsigned long long tail[2] = {0, 0};
-    SG_HIP(hipMemcpyAsync(cnt, d_count, res ? 8 : 4, hipMemcpyDeviceToHost, st));
+    int cnt[3] = {0, 0, 0};
+    unsigned long long tail_[2] = {0, 0};
+    SG_HIP(hipMemcpyAsync(cnt, d_count, 12, hipMemcpyDeviceToHost, st));
     SG_HIP(hipStreamSynchronize(st));
+    if (cnt[2]) return sg::fail(SG_EUNSUP, "sg_mesh_adjacency: a resampled vertex id does not fit %d bits", idbits);
     // the dropped rows, if any, collapsed into one trailing ~0 key
-    SG_HIP(hipMemcpyAsync(&tail[0], k1 + cnt[0] - 1, 8, hipMemcpyDeviceToHost, st));
-    if (res) SG_HIP(hipMemcpyAsync(&tail[1], r1 + cnt[1] - 1, 8, hipMemcpyDeviceToHost, st));
+    SG_HIP(hipMemcpyAsync(&tail_[0], k2 + cnt[0] - 1, 8, hipMemcpyDeviceToHost, st));
+    if (res) SG_HIP(hipMemcpyAsync(&tail_[1], r2 + cnt[1] - 1, 8, hipMemcpyDeviceToHost, st));
     SG_HIP(hipStreamSynchronize(st));
-    if (tail[0] == ~0ull) --cnt[0];
-    if (res && tail[1] == ~0ull) --cnt[1];
-    if (cnt[0] > 0) k_unpack_edges<<<sg::cdiv(cnt[0], 256), 256, 0, st>>>(k1, cnt[0], d_adj_raw);
-    if (res && cnt[1] > 0) k_unpack_edges<<<sg::cdiv(cnt[1], 256), 256, 0, st>>>(r1, cnt[1], d_adj_res);
+    if (tail_[0] == ~0ull) --cnt[0];
+    if (res && tail_[1] == ~0ull) --cnt[1];
+    if (cnt[0] > 0) k_unpack_edges<<<sg::cdiv(cnt[0], 256), 256, 0, st>>>(k2, cnt[0], d_adj_raw);
+    if (res && cnt[1] > 0) k_unpack_edges<<<sg::cdiv(cnt[1], 256), 256, 0, st>>>(r2, cnt[1], d_adj_res);
     *h_n_raw = cnt[0];
     if (res) *h_n_res = cnt[1];
     SG_LAUNCH_CHECK();
@@ -325,7 +326,8 @@ int sg_mesh_adjacency(const int32_t* d_faces, int F, const int64_t* d_unmap, int
 
 size_t sg_pointcloud_adjacency_ws_bytes(int N, int k) {
     const size_t n = (size_t)std::max(N, 1) * std::max(k, 1);
-    return sg::align_up(std::max(sort_keys_temp((int)n), unique_temp((int)n))) + 2 * sg::align_up(n * 8) + sg::align_up((size_t)std::max(N, 1) * 16) + 256;
+    return 3 * sg::align_up(n * 8) + sg::align_up(sgsort::hist_ints((long long)n) * 4) + sg::align_up(sgsort::unique_ints((long long)n) * 4) +
+           sg::align_up((size_t)std::max(N, 1) * 16) + 512;
 }
 
 // get_adj_from_pointcloud (util.py:814-834): d_points rows of `stride` floats (xyz first), k in {5, 10, 20}; d_adj: room for [N*k,2]
@@ -336,30 +338,30 @@ int sg_pointcloud_adjacency(const float* d_points, int stride, int N, int k, int
     if (N <= k) return sg::fail(SG_EINVAL, "sg_pointcloud_adjacency: %d points for k = %d (topk(k + 1) raises in the reference)", N, k);
     *h_n = 0;
     const int n = N * k;
-    const size_t temp = std::max(sort_keys_temp(n), unique_temp(n));
     sg::Carver cv(d_ws, ws_bytes);
-    char* tmp = cv.take<char>(temp);
     unsigned long long* k0 = cv.take<unsigned long long>(n);
     unsigned long long* k1 = cv.take<unsigned long long>(n);
+    unsigned long long* k2 = cv.take<unsigned long long>(n);
+    int* h0 = cv.take<int>(sgsort::hist_ints(n));
+    int* scratch = cv.take<int>(sgsort::unique_ints(n));
     float4* cand = cv.take<float4>(N);
-    int* d_count = cv.take<int>(1);
+    int* d_count = cv.take<int>(2);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_pointcloud_adjacency: workspace too small (%zu < %zu)", ws_bytes, sg_pointcloud_adjacency_ws_bytes(N, k));
     hipStream_t st = sg::as_stream(stream);
     k_pack_xyzw<<<sg::cdiv(N, 256), 256, 0, st>>>(d_points, stride, N, cand);
     if (k == 5) k_nearest_k<6><<<sg::cdiv(N, kTile), kTile, 0, st>>>(cand, N, k0);
     else if (k == 10) k_nearest_k<11><<<sg::cdiv(N, kTile), kTile, 0, st>>>(cand, N, k0);
     else k_nearest_k<21><<<sg::cdiv(N, kTile), kTile, 0, st>>>(cand, N, k0);
-    size_t t = temp;
-    hipcub::DoubleBuffer<unsigned long long> d(k0, k1);
-    SG_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, t, d, n, 0, 64, st));
-    unsigned long long* sorted = d.Current();
-    unsigned long long* other = sorted == k0 ? k1 : k0;
-    t = temp;
-    SG_HIP(hipcub::DeviceSelect::Unique(tmp, t, sorted, other, d_count, n, st));
+    unsigned long long* a[1] = {k0};
+    unsigned long long* b[1] = {k1};
+    unsigned long long* o[1] = {k2};
+    int* hh[1] = {h0};
+    const int rc = sort_unique_edges(a, b, o, 1, n, bits_for((long long)N + 1), hh, scratch, d_count, st);
+    if (rc < 0) return rc;
     int cnt = 0;
     SG_HIP(hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, st));
     SG_HIP(hipStreamSynchronize(st));
-    if (cnt > 0) k_unpack_edges<<<sg::cdiv(cnt, 256), 256, 0, st>>>(other, cnt, d_adj);
+    if (cnt > 0) k_unpack_edges<<<sg::cdiv(cnt, 256), 256, 0, st>>>(k2, cnt, d_adj);
     *h_n = cnt;
     SG_LAUNCH_CHECK();
     return SG_OK;
@@ -367,12 +369,7 @@ int sg_pointcloud_adjacency(const float* d_points, int stride, int N, int k, int
 
 size_t sg_segment_lists_ws_bytes(int V, int Np) {
     const size_t n = (size_t)std::max(std::max(V, Np), 1);
-    size_t t1 = 0, t2 = 0, t3 = 0;
-    hipcub::DoubleBuffer<int32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t1, dk, (int)n, 0, 32, (hipStream_t)0);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, dk, dv, (int)n, 0, 32, (hipStream_t)0);
-    (void)hipcub::DeviceSelect::Unique(nullptr, t3, (int32_t*)nullptr, (int32_t*)nullptr, (int*)nullptr, (int)n, (hipStream_t)0);
-    return sg::align_up(std::max(t1, std::max(t2, t3))) + 5 * sg::align_up(n * 4) + 256;
+    return 6 * sg::align_up(n * 4) + sg::align_up(sgsort::hist_ints((long long)n) * 4) + sg::align_up(sgsort::unique_ints((long long)n) * 4) + 512;
 }
 
 // d_raw_label [V]: compacted ids (the `.seg.txt` column).  d_seg_points [Np] / d_seg_off [G+1]: sampled points grouped
@@ -383,51 +380,43 @@ int sg_segment_lists(const int32_t* d_seg_indices, int V, const int64_t* d_mappe
     SG_REQUIRE(V > 0 && Np > 0 && d_seg_indices && d_mapper && d_raw_label && d_seg_points && d_seg_off && h_counts && d_ws,
                "sg_segment_lists: bad arguments");
     const size_t n = (size_t)std::max(V, Np);
-    size_t t1 = 0, t2 = 0, t3 = 0;
-    {
-        hipcub::DoubleBuffer<int32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
-        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t1, dk, (int)n, 0, 32, (hipStream_t)0);
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, dk, dv, (int)n, 0, 32, (hipStream_t)0);
-        (void)hipcub::DeviceSelect::Unique(nullptr, t3, (int32_t*)nullptr, (int32_t*)nullptr, (int*)nullptr, (int)n, (hipStream_t)0);
-    }
-    const size_t temp = std::max(t1, std::max(t2, t3));
     sg::Carver cv(d_ws, ws_bytes);
-    char* tmp = cv.take<char>(temp);
     int32_t* a = cv.take<int32_t>(n);
     int32_t* b = cv.take<int32_t>(n);
     int32_t* c = cv.take<int32_t>(n);
     int32_t* d = cv.take<int32_t>(n);
     int32_t* e = cv.take<int32_t>(n);
+    int32_t* f = cv.take<int32_t>(n);
+    int* hist = cv.take<int>(sgsort::hist_ints((long long)n));
+    int* scratch = cv.take<int>(sgsort::unique_ints((long long)n));
     int* d_cnt = cv.take<int>(2);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_segment_lists: workspace too small (%zu < %zu)", ws_bytes, sg_segment_lists_ws_bytes(V, Np));
     hipStream_t st = sg::as_stream(stream);
-    // 1. sorted unique raw ids (ids are non-negative in ScanNet; the sort is on the signed value's bits)
+    using L32 = sgsort::Lists<unsigned int, int>;
+    // 1. sorted unique raw ids (ids are non-negative in ScanNet: the sort is on the value's 32 bits)
     SG_HIP(hipMemcpyAsync(a, d_seg_indices, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
-    size_t t = temp;
-    hipcub::DoubleBuffer<int32_t> ids(a, b);
-    SG_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, t, ids, V, 0, 32, st));
-    int32_t* uniq = ids.Current() == a ? b : a;
-    t = temp;
-    SG_HIP(hipcub::DeviceSelect::Unique(tmp, t, ids.Current(), uniq, d_cnt, V, st));
+    L32 L{};
+    L.kin[0] = (const unsigned int*)a; L.kout[0] = (unsigned int*)b; L.hist[0] = hist; L.n[0] = V;
+    sgsort::radix_sort<unsigned int, int, false>(L, 1, 0, 32, st);
+    const unsigned int* sorted = L.kin[0];
+    int32_t* uniq = (int32_t*)L.kout[0];
+    sgsort::unique_sorted<unsigned int>(sorted, V, (unsigned int*)uniq, nullptr, d_cnt, scratch, st);
     k_rank_labels<<<sg::cdiv(V, 256), 256, 0, st>>>(d_seg_indices, V, uniq, d_cnt, d_raw_label);
-    // 2. stable sort of (sampled label, point index): groups in ascending label order, ascending index inside
+    // 2. stable sort of (sampled label, point index): groups in ascending label order, ascending index inside (a label is below V: the
+    // number of raw segments is not on the host yet, so the sort covers the bits a label can have)
     k_sampled_labels<<<sg::cdiv(Np, 256), 256, 0, st>>>(d_raw_label, d_mapper, Np, c, d);
-    hipcub::DoubleBuffer<int32_t> keys(c, ids.Current()), vals(d, e);      // ids.Current() is free again
-    t = temp;
-    SG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, t, keys, vals, Np, 0, 32, st));
-    SG_HIP(hipMemcpyAsync(d_seg_points, vals.Current(), (size_t)Np * 4, hipMemcpyDeviceToDevice, st));
-    // 3. group starts
-    SG_HIP(hipMemsetAsync(d_cnt + 1, 0, 4, st));
-    int32_t* heads = vals.Alternate();
-    k_group_heads<<<sg::cdiv(Np, 256), 256, 0, st>>>(keys.Current(), Np, heads, d_cnt + 1);
+    L32 P{};
+    P.kin[0] = (const unsigned int*)c; P.kout[0] = (unsigned int*)e; P.vin[0] = d; P.vout[0] = f; P.hist[0] = hist; P.n[0] = Np;
+    sgsort::radix_sort<unsigned int, int, true>(P, 1, 0, bits_for((long long)V + 1), st);
+    const unsigned int* skeys = P.kin[0];
+    const int32_t* svals = P.vin[0];
+    SG_HIP(hipMemcpyAsync(d_seg_points, svals, (size_t)Np * 4, hipMemcpyDeviceToDevice, st));
+    // 3. group starts: where the sorted label changes, already in ascending order (the compaction keeps the order)
+    sgsort::unique_sorted<unsigned int>(skeys, Np, nullptr, d_seg_off, d_cnt + 1, scratch, st);
     int cnt[2] = {0, 0};
     SG_HIP(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
     SG_HIP(hipStreamSynchronize(st));
     const int G = cnt[1];
-    hipcub::DoubleBuffer<int32_t> hs(heads, keys.Alternate());
-    t = temp;
-    SG_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, t, hs, G, 0, 32, st));
-    SG_HIP(hipMemcpyAsync(d_seg_off, hs.Current(), (size_t)G * 4, hipMemcpyDeviceToDevice, st));
     SG_HIP(hipMemcpyAsync(d_seg_off + G, &Np, 4, hipMemcpyHostToDevice, st));
     SG_HIP(hipStreamSynchronize(st));
     h_counts[0] = cnt[0];
