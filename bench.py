@@ -202,10 +202,10 @@ def label_digest(res) -> str:
 def reduce_accumulators(vec: np.ndarray, world: int, backend: str, dev=None) -> np.ndarray:
     """The path's only collective: one all-reduce of the float64 metric accumulators
     [I_sem 40 | U_sem 40 | I_ins 40 | U_ins 40 | acc 4 | scenes 1]."""
-    if world == 1:
-        return vec
     import torch
     import torch.distributed as dist
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return vec
     t = torch.from_numpy(vec.copy())
     if backend == "nccl":
         t = t.to(dev)

@@ -199,7 +199,9 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
     if forward_fn is not None and hasattr(forward_fn, "flush"):
         forward_fn.flush()               # label files are written asynchronously: wait for them before reporting
     vec = torch.from_numpy(acc.v.copy())
-    if world > 1:
+    # a process group that exists is used, also at world size 1 (the RCCL communicator of a one-GPU run is built and exercised: the
+    # `-m gpu` tests drive exactly this on a one-GPU box)
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         if dev is not None and args.backend == 'nccl':
             vec = vec.to(dev)
         dist.all_reduce(vec)           # the ONLY collective: 165 float64 over RCCL/xGMI (1.3 KB, latency-bound)

@@ -85,3 +85,85 @@ def test_two_ranks_on_one_gpu_write_the_same_files_as_one_rank(tmp_path, golden_
             assert np.array_equal(np.asarray(one[k]), np.asarray(two[k]), equal_nan=True), k
     log = open(os.path.join(root, "checkpoints", "w2", "run_infer.log")).read()
     assert "==> Infer           Instance mIoU:" in log
+
+
+def _rccl_worker(root, port, q):
+    """world size 1 over RCCL: the process group exists, so the driver's and the bench's reductions go through an RCCL communicator"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from seggroup_amd import infer
+    import bench
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+    args = infer.build_parser().parse_args(["-n", "rccl", "--ins_infer", "--root", root, "--backend", "nccl", "--batch", "4", "--inflight", "4", "-j", "2"])
+    r = infer.run_worker(0, 1, args, init_dist=False)
+    vec = np.arange(165, dtype=np.float64) * 0.5
+    red = bench.reduce_accumulators(vec, 1, "nccl", dev)
+    # a MAX reduction like the bench's timing line, and a barrier: the other two collectives the GPU paths issue
+    t = torch.tensor([3.25], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    maps = open("/proc/self/maps").read()
+    dist.destroy_process_group()
+    q.put({"summary": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in r.items()}, "reduced_equal": bool(np.array_equal(red, vec)),
+           "max": float(t.item()), "rccl_mapped": ("librccl" in maps) or ("libnccl" in maps)})
+
+
+def test_rccl_communicator_at_world_size_one(tmp_path, golden_index, weight_sets):
+    """The reference runs one process per GPU over NCCL (infer.py:84-85,234-237).  A test box has one GPU: a world-size-1 `nccl` process
+    group still loads RCCL, builds a communicator and runs the path's collectives on the device -- the driver's end-of-run all-reduce
+    of the 165 float64 accumulators (infer.run_worker), the bench's reduction, a MAX all-reduce and a barrier -- and must change nothing."""
+    import torch
+    import torch.multiprocessing as mp
+    from seggroup_amd import infer, synthetic, weights
+    root = str(tmp_path)
+    scenes = [synthetic.make_scene(4000 + 500 * i, 40 + 5 * i, 83000 + i, name=f"scene{i:04d}_00") for i in range(6)]
+    synthetic.write_reference_tree(root, scenes)
+    for exp in ("plain", "rccl"):
+        ck = os.path.join(root, "checkpoints", exp, "models")
+        os.makedirs(ck)
+        torch.save({"state_dict": weights.to_full_state_dict(weight_sets["ins_infer"])}, os.path.join(ck, "last.t7"))
+    one = infer.run_worker(0, 1, infer.build_parser().parse_args(["-n", "plain", "--ins_infer", "--root", root, "--world-size", "1", "--batch", "4",
+                                                                  "--inflight", "4", "-j", "2"]))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(root, port, q))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert got["rccl_mapped"], "the nccl backend did not load RCCL"
+    assert got["reduced_equal"] and got["max"] == 3.25
+    for k in ("iou_sem", "iou_ins", "acc_sem", "acc_ins", "acc_sem_sel", "acc_ins_sel", "n"):
+        assert np.array_equal(np.asarray(one[k], dtype=np.float64), np.asarray(got["summary"][k], dtype=np.float64), equal_nan=True), k
+    names = [s_.name for s_ in scenes]
+    assert _tree_digest(root, "plain", names) == _tree_digest(root, "rccl", names)
+
+
+def test_bench_strong_scaling_two_ranks_on_one_gpu():
+    """BASELINE configs[3] through bench.py itself: `--scenes-total 1201` shards ONE set of 1,201 scenes i mod W.  Two ranks (gloo rendezvous,
+    both on cuda:0, small scenes) must report the same all-reduced pseudo-label mIoU over the same 1,201 scenes as one rank, with their
+    own parity checks green -- the bench's rank logic on the hardware a test box has."""
+    import json
+    import subprocess
+    common = ["--scenes-total", "1201", "--points", "3000", "--segments", "30", "--steps", "2", "--warmup", "1", "--repeats", "1",
+              "--no-cpu-baseline", "--no-files", "--no-extras", "--batch", "64", "--parity-scenes", "8", "--backend", "gloo", "--groups", "4"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900,
+                         env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1 and j2["scaling"] == "strong" and j1["scaling"] == "strong"
+    assert j2["parity_check"]["ranks_equal"] and j1["parity_check"]["ranks_equal"]
+    assert j2["pseudo_label_mIoU"]["scenes"] == j1["pseudo_label_mIoU"]["scenes"] == 1201 * 2               # the timed steps' scenes, all-reduced
+    assert j2["pseudo_label_mIoU"]["semantic"] == j1["pseudo_label_mIoU"]["semantic"]
+    assert j2["pseudo_label_mIoU"]["instance"] == j1["pseudo_label_mIoU"]["instance"]
