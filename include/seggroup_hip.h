@@ -398,6 +398,10 @@ typedef struct sg_scene {         /* one scene, DEVICE-resident inputs (staged b
     const int32_t* h_seg_size;      /* [S]                                                             */
     const int32_t* h_seg_ins;       /* [S] weak instance label of the first point (weak_label[:,1])   */
     const int32_t* h_seg_sem;       /* [S] weak semantic label of the first point (weak_label[:,0])   */
+    /* HOST, optional (NULL = not given): the over-segment of every raw vertex, seg_of_point[unmap[v]] (-1 where unmap[v] is not a
+     * point).  Needed by the engine's compact label transfer (sg_engine_set_label_transfer): a label vector is a table look-up
+     * through this array, so the look-up can run on the host and only the [14,S] tables have to cross PCIe. */
+    const int32_t* h_seg_of_vertex; /* [V]                                                             */
 } sg_scene;
 
 typedef struct sg_result {        /* HOST outputs                                                       */
@@ -410,6 +414,8 @@ typedef struct sg_result {        /* HOST outputs                               
     int32_t trace[5];               /* cluster counts of layers 1..5                                     */
     int32_t stalled;                /* 1 if a pass-2 sweep was cut short (SG_ESTALL condition)           */
     int32_t used_fallback;          /* 1 if the FPS-1024 fallback of model.py:479-494 ran                */
+    int32_t* h_tables;              /* optional [14,S] int32 (NULL = not wanted): the label tables the vectors are looked up in,
+                                       h_labels[t][v] = s >= 0 ? h_tables[t][s] : -1 with s = h_seg_of_vertex[v] (sg_expand_labels) */
 } sg_result;
 
 typedef struct sg_debug {         /* optional taps for stage-level parity tests (every pointer may be NULL) */
@@ -475,6 +481,11 @@ int sg_engine_submit(sg_engine* e, const sg_scene* scenes, int count, int mode, 
 int sg_engine_wait(sg_engine* e, int ticket);
 /* 0 = no stage timing (default), 1 | 2 = HIP events around the stages of every batched launch.  Returns the previous level. */
 int sg_engine_set_timing(sg_engine* e, int level);
+/* 0 (default): every scene's 14 label vectors are copied to results[i].h_labels (8.4 MB per 150k-vertex scene).  1 = compact: the
+ * vectors stay on the device; results[i].h_tables (if given) receives the [14,S] tables, the writer pool is handed tables + the scene's
+ * h_seg_of_vertex and expands while it writes, results[i].h_labels is left untouched (may be NULL).  Scenes without h_seg_of_vertex
+ * fall back to the full copy.  Returns the previous setting.  (Round 4: at the headline rate the full copy is 24 GB/s of D2H per GPU.) */
+int sg_engine_set_label_transfer(sg_engine* e, int compact);
 /* sg_pipeline_set_knn_variant for every slot (the two-pass kernel, 0, has no batched twin: the seeded kernel runs instead) */
 int sg_engine_set_knn_variant(sg_engine* e, int variant);
 /* accumulated device time per stage (ms; a batched launch counts once, whatever the number of scenes in it) since the
@@ -521,6 +532,13 @@ int  sg_writer_submit(sg_writer* w, const char* path_without_ext, const int32_t*
  * copied: the buffer must stay untouched until sg_writer_wait_tag(w, tag) or sg_writer_flush returned.  tag >= 0, ascending over time
  * (the engine passes its ticket number); sg_writer_wait_tag blocks until every scene with a tag <= `tag` is on disk. */
 int  sg_writer_submit_scene(sg_writer* w, const char* out_dir, const int32_t* h_labels, int V, int nvec, int formats, long long tag);
+/* The same scene given as label TABLES [nvec,S] + the over-segment of every vertex [V] (both copied: ~0.7 MB instead of a reference
+ * to 8.4 MB of vectors that had to cross PCIe first); the worker expands vector by vector while it formats.  Files byte-identical to
+ * sg_writer_submit_scene's. */
+int  sg_writer_submit_scene_tables(sg_writer* w, const char* out_dir, const int32_t* h_tables, int S, const int32_t* h_seg_of_vertex, int V,
+                                   int nvec, int formats, long long tag);
+/* h_out[t][v] = (s >= 0 && s < S) ? h_tables[t][s] : -1, s = h_seg_of_vertex[v]: what k_export computes on the device (model.py:525-605) */
+int  sg_expand_labels(const int32_t* h_tables, int nvec, int S, const int32_t* h_seg_of_vertex, int V, int32_t* h_out);
 int  sg_writer_wait_tag(sg_writer* w, long long tag);
 int  sg_writer_flush(sg_writer* w);
 void sg_writer_destroy(sg_writer* w);

@@ -202,6 +202,12 @@ def load_pack(path: str, device="cuda"):
             dt, shape, off = hdr["arrays"][k]
             n = int(np.prod(shape)) * np.dtype(dt).itemsize
             host[k] = view[off:off + n].view(np.dtype(dt)).reshape(shape).copy()
+        from .scene import seg_of_vertex
+
+        def hv(k):
+            dt, shape, off = hdr["arrays"][k]
+            return view[off:off + int(np.prod(shape)) * np.dtype(dt).itemsize].view(np.dtype(dt)).reshape(shape)
+        sov = seg_of_vertex(hv("seg_of_point"), hv("unmap"))          # host-side look-up table of the compact label transfer
         stream.synchronize()                                  # the pinned buffer is free again, the blob is complete
     tdt = {"<f4": torch.float32, "<i4": torch.int32, "<i8": torch.int64}
     arrays = {}
@@ -212,4 +218,5 @@ def load_pack(path: str, device="cuda"):
         else:
             n = int(np.prod(shape)) * np.dtype(dt).itemsize
             arrays[k] = blob[off:off + n].view(tdt[dt]).view(*shape)
+    arrays["seg_of_vertex"] = sov
     return DeviceScene.from_staged(arrays, name=hdr["name"], device=dev)

@@ -218,7 +218,8 @@ int write_vector_files(int dfd, const char* name, const int32_t* vec, int V, int
 
 struct sg_writer {
     // a scene (dir + nvec vectors of V values at `base`, stride V; not owned) or one owned vector (`own`, full path without extension in dir)
-    struct Job { std::string dir; const int32_t* base = nullptr; int V = 0, nvec = 0, formats = 0; long long tag = 0; std::vector<int32_t> own; };
+    // ... or a scene as tables: `own` = [nvec * S] tables followed by [V] seg_of_vertex, S > 0
+    struct Job { std::string dir; const int32_t* base = nullptr; int V = 0, nvec = 0, formats = 0, S = 0; long long tag = 0; std::vector<int32_t> own; };
     std::mutex mu;
     std::condition_variable cv_job, cv_idle;
     std::deque<Job> q;
@@ -232,6 +233,7 @@ struct sg_writer {
 
     void run() {
         TlBuf tl;
+        std::vector<int32_t> expand;
         for (;;) {
             Job j;
             {
@@ -244,7 +246,20 @@ struct sg_writer {
             }
             cv_idle.notify_all();
             int rc = 0;
-            if (j.base) {
+            if (j.S > 0) {
+                // tables + seg_of_vertex: expand one vector at a time into this thread's buffer, then format / write it like any other
+                const int dfd = open(j.dir.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
+                if (dfd < 0) rc = sg::fail(SG_EINVAL, "label writer: cannot open directory %s: %s", j.dir.c_str(), strerror(errno));
+                const int32_t* tab = j.own.data();
+                const int32_t* sov = tab + (size_t)j.nvec * j.S;
+                expand.resize((size_t)std::max(j.V, 1));
+                for (int v = 0; v < j.nvec && rc == 0; ++v) {
+                    const int32_t* t = tab + (size_t)v * j.S;
+                    for (int i = 0; i < j.V; ++i) { const int s_ = sov[i]; expand[i] = (s_ >= 0 && s_ < j.S) ? t[s_] : -1; }
+                    rc = write_vector_files(dfd, kWriterNames[v], expand.data(), j.V, j.formats, tl);
+                }
+                if (dfd >= 0) close(dfd);
+            } else if (j.base) {
                 const int dfd = open(j.dir.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
                 if (dfd < 0) rc = sg::fail(SG_EINVAL, "label writer: cannot open directory %s: %s", j.dir.c_str(), strerror(errno));
                 for (int v = 0; v < j.nvec && rc == 0; ++v) rc = write_vector_files(dfd, kWriterNames[v], j.base + (size_t)v * j.V, j.V, j.formats, tl);
@@ -297,6 +312,30 @@ int sg_writer_submit_scene(sg_writer* w, const char* out_dir, const int32_t* h_l
     sg_writer::Job j;
     j.dir = out_dir; j.base = h_labels; j.V = V; j.nvec = nvec; j.formats = formats; j.tag = tag;
     return w->push(std::move(j));
+}
+
+int sg_writer_submit_scene_tables(sg_writer* w, const char* out_dir, const int32_t* h_tables, int S, const int32_t* h_seg_of_vertex, int V, int nvec,
+                                  int formats, long long tag) {
+    if (!w || !out_dir || !h_tables || S <= 0 || (V > 0 && !h_seg_of_vertex) || V < 0 || nvec < 0 || nvec > SG_NUM_LABEL_VECTORS || !(formats & 3))
+        return sg::fail(SG_EINVAL, "sg_writer_submit_scene_tables: bad arguments");
+    sg_writer::Job j;
+    j.dir = out_dir; j.V = V; j.nvec = nvec; j.formats = formats; j.S = S;
+    j.tag = -1;                                                  // owns its data: nothing of the caller's to wait for
+    (void)tag;
+    j.own.resize((size_t)nvec * S + (size_t)V);
+    std::memcpy(j.own.data(), h_tables, (size_t)nvec * S * 4);
+    if (V > 0) std::memcpy(j.own.data() + (size_t)nvec * S, h_seg_of_vertex, (size_t)V * 4);
+    return w->push(std::move(j));
+}
+
+int sg_expand_labels(const int32_t* h_tables, int nvec, int S, const int32_t* h_seg_of_vertex, int V, int32_t* h_out) {
+    if (!h_tables || !h_out || nvec < 0 || S <= 0 || V < 0 || (V > 0 && !h_seg_of_vertex)) return sg::fail(SG_EINVAL, "sg_expand_labels: bad arguments");
+    for (int t = 0; t < nvec; ++t) {
+        const int32_t* tab = h_tables + (size_t)t * S;
+        int32_t* o = h_out + (size_t)t * V;
+        for (int i = 0; i < V; ++i) { const int s_ = h_seg_of_vertex[i]; o[i] = (s_ >= 0 && s_ < S) ? tab[s_] : -1; }
+    }
+    return SG_OK;
 }
 
 int sg_writer_wait_tag(sg_writer* w, long long tag) {

@@ -131,6 +131,7 @@ struct sg_engine {
     int G = 0, B = 0, device = 0;
     int maxN = 0, maxS = 0, maxE = 0, maxV = 0;
     int timing = 0;
+    int label_compact = 0;                      // sg_engine_set_label_transfer
     size_t dev_bytes = 0;
 
     struct Group {
@@ -599,7 +600,13 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
     EG_CHECK(sg::b_export_eval(d_ctx, bd, stream));
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
-        EG_HIP(hipMemcpyAsync(r.out->h_labels, r.pl->labels.p, (size_t)r.n_tables * r.sc->V * 4, hipMemcpyDeviceToHost, stream));
+        // compact transfer: the vectors stay on the device (the evaluate kernels read two of them there); the host has the tables already
+        const bool compact = eng->label_compact && r.sc->h_seg_of_vertex;
+        if (!compact) {
+            if (!r.out->h_labels) return sg::fail(SG_EINVAL, "sg_engine: results[].h_labels is null (and the compact label transfer is off, or the scene has no h_seg_of_vertex)");
+            EG_HIP(hipMemcpyAsync(r.out->h_labels, r.pl->labels.p, (size_t)r.n_tables * r.sc->V * 4, hipMemcpyDeviceToHost, stream));
+        }
+        if (r.out->h_tables) std::memcpy(r.out->h_tables, r.tab.data(), (size_t)r.n_tables * r.sc->S * 4);
     }
     EG_HIP(hipMemcpyAsync(box.h, box.d, box.used, hipMemcpyDeviceToHost, stream));
     mark(18);
@@ -644,8 +651,10 @@ int sg_engine::Group::superstep(Run* r, int n, int mode, sg_writer* writer, int 
         const int nvec = mode == SG_MODE_INS_INFER ? SG_NUM_LABEL_VECTORS : 6;
         for (int i = 0; i < n && rc >= 0; ++i) {
             if (!r[i].out_dir) continue;
-            // by reference: the vectors stay in the caller's buffer, which the caller reuses only behind sg_writer_wait_tag(ticket)
-            rc = sg_writer_submit_scene(writer, r[i].out_dir, r[i].out->h_labels, r[i].sc->V, nvec, formats, tag);
+            if (eng->label_compact && r[i].sc->h_seg_of_vertex)     // tables + seg_of_vertex, copied: the worker expands while it formats
+                rc = sg_writer_submit_scene_tables(writer, r[i].out_dir, r[i].tab.data(), r[i].sc->S, r[i].sc->h_seg_of_vertex, r[i].sc->V, nvec, formats, tag);
+            else   // by reference: the vectors stay in the caller's buffer, which the caller reuses only behind sg_writer_wait_tag(ticket)
+                rc = sg_writer_submit_scene(writer, r[i].out_dir, r[i].out->h_labels, r[i].sc->V, nvec, formats, tag);
         }
     }
     for (int i = 0; i < n; ++i) {
@@ -704,7 +713,8 @@ void sg_engine::Group::loop() {
             else if (sc->N > eng->maxN || sc->S > eng->maxS || sc->E0 > eng->maxE || sc->V > eng->maxV)
                 rc = sg::fail(SG_EINVAL, "sg_engine: scene (N=%d S=%d E0=%d V=%d) exceeds the engine capacity (N=%d S=%d E0=%d V=%d)", sc->N, sc->S,
                               sc->E0, sc->V, eng->maxN, eng->maxS, eng->maxE, eng->maxV);
-            else if (!runs[i].out->h_labels) rc = sg::fail(SG_EINVAL, "sg_engine: results[%d].h_labels is null", first + i);
+            else if (!runs[i].out->h_labels && !(eng->label_compact && sc->h_seg_of_vertex))
+                rc = sg::fail(SG_EINVAL, "sg_engine: results[%d].h_labels is null", first + i);
         }
         if (rc >= 0) rc = superstep(runs.data(), take, job->mode, job->writer, job->formats, job->id);
         if (g_profile) { eng->ns_step += now_ns() - t_step; eng->ns_sync += tl_ns_sync; ++eng->n_steps; eng->n_step_scenes += take; }
@@ -850,6 +860,13 @@ int sg_engine_wait(sg_engine* e, int ticket) {
     }
     if (job->err != 0) return sg::fail(job->err, "sg_engine: %s", job->msg.c_str());
     return SG_OK;
+}
+
+int sg_engine_set_label_transfer(sg_engine* e, int compact) {
+    if (!e || (compact != 0 && compact != 1)) return sg::fail(SG_EINVAL, "sg_engine_set_label_transfer: bad arguments");
+    const int prev = e->label_compact;
+    e->label_compact = compact;
+    return prev;
 }
 
 int sg_engine_set_timing(sg_engine* e, int level) {

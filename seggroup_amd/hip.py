@@ -43,12 +43,12 @@ class Scene(C.Structure):
     _fields_ = [("N", C.c_int), ("S", C.c_int), ("E0", C.c_int), ("V", C.c_int),
                 ("d_data", vp), ("d_adj", vp), ("d_seg_of_point", vp), ("d_seg_points", vp), ("d_seg_off", vp),
                 ("d_unmap", vp), ("d_gt", vp),
-                ("h_seg_first", vp), ("h_seg_size", vp), ("h_seg_ins", vp), ("h_seg_sem", vp)]
+                ("h_seg_first", vp), ("h_seg_size", vp), ("h_seg_ins", vp), ("h_seg_sem", vp), ("h_seg_of_vertex", vp)]
 
 
 class Result(C.Structure):
     _fields_ = [("h_labels", vp), ("iou_sem", C.c_float * 80), ("iou_ins", C.c_float * 80), ("acc", C.c_float * 4),
-                ("trace", C.c_int32 * 5), ("stalled", C.c_int32), ("used_fallback", C.c_int32)]
+                ("trace", C.c_int32 * 5), ("stalled", C.c_int32), ("used_fallback", C.c_int32), ("h_tables", vp)]
 
 
 class Classifier(C.Structure):
@@ -164,6 +164,7 @@ SIGNATURES = {
     "sg_engine_submit": (_I, [vp, vp, _I, _I, vp, vp, vp, _I]),
     "sg_engine_wait": (_I, [vp, _I]),
     "sg_engine_set_timing": (_I, [vp, _I]),
+    "sg_engine_set_label_transfer": (_I, [vp, _I]),
     "sg_engine_set_knn_variant": (_I, [vp, _I]),
     "sg_engine_stage_times": (C.c_longlong, [vp, vp, _I, _I]),
     "sg_engine_device_bytes": (_Z, [vp]),
@@ -177,6 +178,8 @@ SIGNATURES = {
     "sg_writer_create": (vp, [_I, _I]),
     "sg_writer_submit": (_I, [vp, C.c_char_p, vp, _I, _I]),
     "sg_writer_submit_scene": (_I, [vp, C.c_char_p, vp, _I, _I, _I, C.c_longlong]),
+    "sg_writer_submit_scene_tables": (_I, [vp, C.c_char_p, vp, _I, vp, _I, _I, _I, C.c_longlong]),
+    "sg_expand_labels": (_I, [vp, _I, _I, vp, _I, vp]),
     "sg_writer_wait_tag": (_I, [vp, C.c_longlong]),
     "sg_writer_flush": (_I, [vp]),
     "sg_writer_destroy": (None, [vp]),

@@ -54,6 +54,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--out-format', type=str, default='txt,npy', help='comma list of txt,npy')
     p.add_argument('--world-size', type=int, default=0, help='processes to spawn (default: one per visible GPU)')
     p.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL on ROCm)')
+    p.add_argument('--label-transfer', type=str, default='tables', choices=['full', 'tables'],
+                   help="fast path: 'tables' = only the [14,S] label tables cross PCIe and the writer workers look the 14 vectors up "
+                        "(same files, byte for byte); 'full' = the vectors themselves are copied (8.4 MB per 150k-vertex scene)")
     p.add_argument('--port', type=int, default=2344, help='rendezvous port on 127.0.0.1 (reference: 2344)')
     p.add_argument('--batch', type=int, default=64, help='scenes per batch in the packed fast path (0 = the per-scene SegModel.forward loop)')
     p.add_argument('--inflight', type=int, default=80, help='scenes in flight per GPU in the packed fast path (engine groups of 8; two groups more than a batch fills)')
@@ -269,7 +272,7 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
             caps = runner.caps if runner is not None else None
             if runner is not None:
                 runner.close()
-            runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps, timing=0)
+            runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps, timing=0, label_transfer=args.label_transfer)
         # one batch is queued behind the one in flight: the engine's groups never drain between batches
         tickets.append(runner.submit(scenes, mode, writer=writer, out_dirs=[model.output_root(s_.name) for s_ in scenes], formats=formats))
         if startup is None:

@@ -97,8 +97,11 @@ class Classifier(nn.Module):
 class SceneResult:
     """Outputs of one forward: 14 (ins mode) or 6 (sem mode) int32 label vectors + metric tensors."""
 
-    def __init__(self, labels: np.ndarray, n_vectors: int, res: hip.Result):
-        self.labels = labels                      # [14, V] int32 (pinned)
+    def __init__(self, labels: Optional[np.ndarray], n_vectors: int, res: hip.Result, tables: Optional[np.ndarray] = None,
+                 seg_of_vertex: Optional[np.ndarray] = None):
+        self._labels = labels                     # [14, V] int32 (pinned) -- or None: compact transfer, expanded on first use
+        self.tables = tables                      # [14, S] int32 (compact transfer only)
+        self._sov = seg_of_vertex
         self.n_vectors = n_vectors
         self.iou_sem = np.ctypeslib.as_array(res.iou_sem).reshape(1, 2, 40).copy()
         self.iou_ins = np.ctypeslib.as_array(res.iou_ins).reshape(1, 2, 40).copy()
@@ -107,6 +110,19 @@ class SceneResult:
         self.stalled = bool(res.stalled)
         self.used_fallback = bool(res.used_fallback)
         self.feat5 = self.ins5 = self.sem5 = None        # train mode only: Feat_5 [C5,256] + weak labels of the final clusters
+
+    @property
+    def labels(self) -> np.ndarray:
+        if self._labels is None:                  # compact transfer: labels[t][v] = tables[t][seg_of_vertex[v]] (-1 outside), on the host
+            nv, S = self.tables.shape
+            out = np.empty((nv, self._sov.shape[0]), dtype=np.int32)
+            hip.check(hip.lib().sg_expand_labels(self.tables.ctypes.data, nv, S, self._sov.ctypes.data, self._sov.shape[0], out.ctypes.data))
+            self._labels = out
+        return self._labels
+
+    @labels.setter
+    def labels(self, v):
+        self._labels = v
 
     def label_dict(self) -> Dict[str, np.ndarray]:
         return {hip.LABEL_NAMES[i]: self.labels[i] for i in range(self.n_vectors)}
@@ -207,7 +223,10 @@ class Engine:
     Label vectors of a waited ticket are VIEWS into one of `ring` pinned buffers used in turn: they stay valid until the
     `ring`-th `submit()` after theirs (ring = 3: two tickets can be queued behind the one being consumed)."""
 
-    def __init__(self, w: Dict[str, np.ndarray], caps, groups: int = 4, per_group: int = 8, device=None, timing: int = 0):
+    def __init__(self, w: Dict[str, np.ndarray], caps, groups: int = 4, per_group: int = 8, device=None, timing: int = 0,
+                 label_transfer: str = "full"):
+        """label_transfer: "full" = the 14 label vectors of every scene cross PCIe (8.4 MB per 150k-vertex scene); "tables" = only the
+        [14,S] tables do, the vectors are looked up on the host (in the writer pool's workers, or on first access of SceneResult.labels)."""
         hip.require_device()
         self.lib = hip.lib()
         self.device = torch.device(device if device is not None else "cuda")
@@ -219,6 +238,10 @@ class Engine:
         if not self.handle:
             raise hip.SgError(hip.SG_EHIP, self.lib.sg_last_error().decode())
         self.lib.sg_engine_set_timing(self.handle, int(timing))
+        if label_transfer not in ("full", "tables"):
+            raise ValueError("label_transfer: 'full' or 'tables'")
+        self.compact = label_transfer == "tables"
+        hip.check(self.lib.sg_engine_set_label_transfer(self.handle, 1 if self.compact else 0))
         self.ring = 3
         self._labels = [None] * self.ring
         self._slot_writer = [None] * self.ring            # (writer, ticket id) of the files still being written out of a ring slot
@@ -239,7 +262,9 @@ class Engine:
         self._turn = (self._turn + 1) % self.ring
         self._release_slot(slot)                          # the writer pool reads the label vectors in place (sg_writer_submit_scene)
         self._drain_retired()
-        if self._labels[slot] is None or self._labels[slot].shape[0] < n:
+        # compact transfer: no label vectors cross PCIe, so no pinned label ring either (1.6 GB at 3 x 64 scenes of 150k vertices)
+        need_labels = not (self.compact and all(s.h_seg_of_vertex is not None for s in scenes))
+        if need_labels and (self._labels[slot] is None or self._labels[slot].shape[0] < n):
             # pinning hundreds of MB takes ~0.1 s: every ring slot is (re)sized at once, not one per submit
             for k in range(self.ring):
                 if self._labels[k] is None or self._labels[k].shape[0] < n:
@@ -253,11 +278,16 @@ class Engine:
                     else:
                         self._release_slot(k)
                     self._labels[k] = torch.empty((max(n, 1), hip.NUM_LABEL_VECTORS, self.caps[3]), dtype=torch.int32, pin_memory=True)
-        buf = self._labels[slot]
+        buf = self._labels[slot] if need_labels else None
         c_scenes = (hip.Scene * n)(*[s.c_struct for s in scenes])
         c_res = (hip.Result * n)()
+        tabs = None
+        if self.compact:
+            tabs = [np.empty((hip.NUM_LABEL_VECTORS, s.S), dtype=np.int32) for s in scenes]
         for i in range(n):
-            c_res[i].h_labels = buf[i].data_ptr()
+            c_res[i].h_labels = buf[i].data_ptr() if buf is not None else None
+            if tabs is not None:
+                c_res[i].h_tables = tabs[i].ctypes.data
         c_dirs, wh, fm = None, None, 0
         if writer is not None and out_dirs is not None:
             for d_ in out_dirs:
@@ -270,7 +300,9 @@ class Engine:
         hip.check(tid)
         if wh is not None:
             self._slot_writer[slot] = (writer, tid)
-        return Ticket(tid, list(scenes), c_scenes, c_res, c_dirs, buf, mode)
+        t = Ticket(tid, list(scenes), c_scenes, c_res, c_dirs, buf, mode)
+        t.tables = tabs
+        return t
 
     def _release_slot(self, slot: int) -> None:
         """Block until the writer pool has written the files whose label vectors still sit in ring slot `slot`."""
@@ -300,9 +332,15 @@ class Engine:
         if any(p is not None and p[1] == t.id for p in self._slot_writer) or any(r[1] == t.id for r in self._retired):
             self._waited.add(t.id)
         nvec = 14 if t.mode == hip.MODE_INS_INFER else 6
-        lab = t.labels.numpy()
+        lab = t.labels.numpy() if t.labels is not None else None
         nv = hip.NUM_LABEL_VECTORS                  # scene i's vectors are packed at stride V_i inside its slot
-        return [SceneResult(lab[i].reshape(-1)[:nv * s.V].reshape(nv, s.V), nvec, t.c_res[i]) for i, s in enumerate(t.scenes)]
+        out = []
+        for i, s in enumerate(t.scenes):
+            if getattr(t, "tables", None) is not None and s.h_seg_of_vertex is not None:
+                out.append(SceneResult(None, nvec, t.c_res[i], tables=t.tables[i][:nvec], seg_of_vertex=s.h_seg_of_vertex))
+            else:
+                out.append(SceneResult(lab[i].reshape(-1)[:nv * s.V].reshape(nv, s.V), nvec, t.c_res[i]))
+        return out
 
     def run(self, scenes: List[DeviceScene], mode: int = hip.MODE_INS_INFER, writer: "Optional[AsyncLabelWriter]" = None,
             out_dirs: Optional[List[str]] = None, formats=("txt", "npy")) -> List[SceneResult]:
@@ -356,14 +394,15 @@ class BatchRunner(Engine):
     the tests' entry point).  inflight >= 16 runs inflight // 8 groups of 8 scenes."""
 
     def __init__(self, w: Dict[str, np.ndarray], scenes: List[DeviceScene], inflight: int = 4, device=None, min_caps=None,
-                 timing: int = 0, per_group: Optional[int] = None):
+                 timing: int = 0, per_group: Optional[int] = None, label_transfer: str = "full"):
         dev = torch.device(device if device is not None else scenes[0].device)
         caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
         if min_caps is not None:                    # regrowing: never shrink below the previous capacities
             caps = tuple(max(a, b) for a, b in zip(caps, min_caps))
         if per_group is None:
             per_group = min(8, max(1, inflight // 2))
-        super().__init__(w, caps, groups=max(1, inflight // per_group), per_group=per_group, device=dev, timing=timing)
+        super().__init__(w, caps, groups=max(1, inflight // per_group), per_group=per_group, device=dev, timing=timing,
+                         label_transfer=label_transfer)
 
 
 class AsyncLabelWriter:

@@ -42,6 +42,17 @@ def seg_from_file(path: str, num_points: int) -> np.ndarray:
     return seg
 
 
+def seg_of_vertex(seg_of_point: np.ndarray, unmap: np.ndarray) -> np.ndarray:
+    """The over-segment of every raw vertex, seg_of_point[unmap[v]] (-1 where unmap[v] is not a point): what a label vector is looked
+    up through (model.py:525-605); the engine's compact label transfer does that look-up on the host."""
+    seg_of_point = np.asarray(seg_of_point)
+    p_ = np.asarray(unmap).astype(np.int64, copy=False)
+    ok = (p_ >= 0) & (p_ < seg_of_point.shape[0])
+    out = np.full(p_.shape[0], -1, dtype=np.int32)
+    out[ok] = seg_of_point[p_[ok]]
+    return out
+
+
 class DeviceScene:
     """One scene resident on a HIP device (torch tensors) + the segment-level host arrays."""
 
@@ -67,6 +78,10 @@ class DeviceScene:
         self.h_seg_size = np.ascontiguousarray(a["seg_size"], dtype=np.int32)
         self.h_seg_ins = np.ascontiguousarray(a["seg_ins"], dtype=np.int32)
         self.h_seg_sem = np.ascontiguousarray(a["seg_sem"], dtype=np.int32)
+        sov = a.get("seg_of_vertex")
+        if sov is None and not isinstance(a["seg_of_point"], torch.Tensor) and not isinstance(a["unmap"], torch.Tensor):
+            sov = seg_of_vertex(a["seg_of_point"], a["unmap"])
+        self.h_seg_of_vertex = None if sov is None else np.ascontiguousarray(sov, dtype=np.int32)
         dev = torch.device(device)
         self.device = dev
         # device tensors pass through (views into a scene pack's blob); host arrays are uploaded
@@ -84,7 +99,8 @@ class DeviceScene:
                             d_seg_of_point=self.d_seg_of_point.data_ptr(), d_seg_points=self.d_seg_points.data_ptr(),
                             d_seg_off=self.d_seg_off.data_ptr(), d_unmap=self.d_unmap.data_ptr(), d_gt=self.d_gt.data_ptr(),
                             h_seg_first=self.h_seg_first.ctypes.data, h_seg_size=self.h_seg_size.ctypes.data,
-                            h_seg_ins=self.h_seg_ins.ctypes.data, h_seg_sem=self.h_seg_sem.ctypes.data)
+                            h_seg_ins=self.h_seg_ins.ctypes.data, h_seg_sem=self.h_seg_sem.ctypes.data,
+                            h_seg_of_vertex=None if self.h_seg_of_vertex is None else self.h_seg_of_vertex.ctypes.data)
 
     @property
     def c_struct(self) -> hip.Scene:

@@ -3,6 +3,8 @@ vectors captured from the real reference and vs the NumPy oracle.  Integer label
 counts must be bit-exact; float stage taps within 1e-4 (north_star tolerance)."""
 import hashlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -359,6 +361,58 @@ def test_engine_pipelined_tickets_odd_scenes_and_errors(weight_sets):
         eng2.submit([big], hip.MODE_INS_INFER)
     assert [_digest(r) for r in eng2.run(scenes[:2], hip.MODE_INS_INFER)] == want[:2]
     eng.close(); eng2.close()
+
+
+def test_compact_label_transfer_and_growing_batches_write_the_same_files(tmp_path, weight_sets):
+    """(1) sg_engine_set_label_transfer: with only the [14,S] tables crossing PCIe -- the 14 vectors looked up on the host, in the writer
+    pool's workers and on first access of SceneResult.labels -- labels, metrics and every label file are identical to the full copy,
+    dup / V != N scenes and sem_infer included.  (2) Ragged, GROWING batches with the writer: a submit that re-allocates
+    the pinned label ring while an earlier ticket is unconsumed must not free the buffer the pool still formats files from."""
+    import hashlib
+    from seggroup_amd import hip, synthetic
+    from seggroup_amd.model import AsyncLabelWriter, BatchRunner
+    from seggroup_amd.scene import DeviceScene
+    W = weight_sets["ins_infer"]
+    host = [synthetic.make_scene(3000 + 700 * i, 30 + 6 * i, 86000 + i, **({"dup_frac": 0.05} if i % 3 == 0 else {})) for i in range(7)]
+    scenes = [DeviceScene.from_synthetic(h, device="cuda:0") for h in host]
+    assert all(s.h_seg_of_vertex is not None for s in scenes)
+
+    def tree(root):
+        out = {}
+        for d in sorted(os.listdir(root)):
+            for f in sorted(os.listdir(os.path.join(root, d))):
+                out[d + "/" + f] = hashlib.sha256(open(os.path.join(root, d, f), "rb").read()).hexdigest()
+        return out
+
+    results = {}
+    for transfer in ("full", "tables"):
+        for mode, tag in ((hip.MODE_INS_INFER, "ins"), (hip.MODE_SEM_INFER, "sem")):
+            root = str(tmp_path / f"{transfer}_{tag}")
+            os.makedirs(root)
+            eng = BatchRunner(W, scenes, inflight=4, per_group=2, device="cuda:0", label_transfer=transfer)
+            wr = AsyncLabelWriter(threads=4)
+            # growing batches, the second queued before the first is waited for
+            t1 = eng.submit(scenes[:1], mode, writer=wr, out_dirs=[os.path.join(root, "s0")])
+            t2 = eng.submit(scenes[1:4], mode, writer=wr, out_dirs=[os.path.join(root, f"s{i}") for i in (1, 2, 3)])
+            r1 = eng.wait(t1)
+            t3 = eng.submit(scenes[4:], mode, writer=wr, out_dirs=[os.path.join(root, f"s{i}") for i in (4, 5, 6)])
+            res = r1 + eng.wait(t2) + eng.wait(t3)
+            dig = [_digest(r) for r in res]
+            del r1, res, t1, t2, t3                                           # nothing but the engine keeps the old label buffers alive now
+            wr.flush(); wr.close(); eng.close()
+            results[(transfer, tag)] = (dig, tree(root))
+            assert len(results[(transfer, tag)][1]) == 7 * (28 if tag == "ins" else 12)
+    for tag in ("ins", "sem"):
+        assert results[("full", tag)][0] == results[("tables", tag)][0], tag
+        assert results[("full", tag)][1] == results[("tables", tag)][1], tag
+    # the files of the ragged run equal those of one scene at a time through a fresh engine
+    eng = BatchRunner(W, scenes, inflight=2, per_group=1, device="cuda:0")
+    wr = AsyncLabelWriter(threads=2)
+    root = str(tmp_path / "one_by_one")
+    for i, s_ in enumerate(scenes):
+        eng.run([s_], hip.MODE_INS_INFER, writer=wr, out_dirs=[os.path.join(root, f"s{i}")])
+    wr.flush(); wr.close(); eng.close()
+    assert tree(root) == results[("full", "ins")][1]
 
 
 def test_packed_scene_and_fast_driver_match_reference_capture(tmp_path, golden_index, weight_sets):
