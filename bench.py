@@ -108,6 +108,7 @@ def parse_args(argv=None):
     ap.add_argument("--extra-scannet", type=int, default=48, help="scenes of the ScanNet-shaped profile in the extra leg (rank 0, N = 1)")
     ap.add_argument("--writer-threads", type=int, default=32, help="native writer threads for the with-files leg")
     ap.add_argument("--gen-workers", type=int, default=0, help="scene generator processes (0 = min(16, cores))")
+    ap.add_argument("--numa", default="auto", choices=["auto", "off"], help="auto = bind every rank's process (engine groups, writer pool) to the CPUs of its GPU's NUMA node")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU rehearsals of the reduction)")
     ap.add_argument("--parity-scenes", type=int, default=64, help="scenes of the last batch re-run on a single pipeline and compared (default: all 64)")
     ap.add_argument("--extra-strong", type=int, default=1201, help="extra leg (rank 0, N = 1): ONE pass over this many distinct scenes = BASELINE configs[3] "
@@ -271,6 +272,8 @@ def main(argv=None):
     local = local % max(n_dev, 1)                       # several ranks on one GPU only in gloo rehearsals
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from seggroup_amd.numa import bind_to_gpu_node
+    numa_info = bind_to_gpu_node(local, args.numa)          # before the engine's group threads and the writer pool exist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -678,7 +681,7 @@ def main(argv=None):
             "with_label_files_scenes_per_s": with_files or None,
             "pseudo_label_mIoU": {"semantic": round(miou_sem, 4), "instance": round(miou_ins, 4), "scenes": int(vec[164])},
             "extra": extras or None,
-            "engine_profile": engine_profile,
+            "engine_profile": engine_profile, "numa": numa_info,
             "cluster_trace_scene0": batch_trace0, "scene_generation_s": round(gen_s, 1),
         }
         print(json.dumps(out), flush=True)

@@ -54,6 +54,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--out-format', type=str, default='txt,npy', help='comma list of txt,npy')
     p.add_argument('--world-size', type=int, default=0, help='processes to spawn (default: one per visible GPU)')
     p.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL on ROCm)')
+    p.add_argument('--numa', type=str, default='auto', choices=['auto', 'off'],
+                   help="'auto' = bind this rank's process (engine, writer and loader threads) to the CPUs of its GPU's NUMA node")
     p.add_argument('--label-transfer', type=str, default='tables', choices=['full', 'tables'],
                    help="fast path: 'tables' = only the [14,S] label tables cross PCIe and the writer workers look the 14 vectors up "
                         "(same files, byte for byte); 'full' = the vectors themselves are copied (8.4 MB per 150k-vertex scene)")
@@ -163,6 +165,10 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         from .model import SegModel
         torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))
         dev = torch.device('cuda', torch.cuda.current_device())
+        from .numa import bind_to_gpu_node
+        numa = bind_to_gpu_node(dev.index, getattr(args, 'numa', 'auto'))      # before any thread of this rank exists
+        if numa['bound']:
+            print('[rank %d] GPU %s on NUMA node %d: bound to %d of %d CPUs' % (rank, numa['pci'], numa['numa_node'], numa['cpus_after'], numa['cpus_before']), flush=True)
         model = SegModel(exp_name=args.exp_name, cuda=True, visualize=False, sem_infer=args.sem_infer, ins_infer=args.ins_infer,
                          data_root=args.root, out_formats=tuple(args.out_format.split(',')), label_style=args.label_style).to(dev)
         if rank == 0:
