@@ -66,7 +66,7 @@ S2X_EXECUTED_FLOP_PER_ROW = 3 * 2 * 64 * 64 + CONV1_EXEC_FLOP_PER_ROW
 # sustains, not the two of the SIMD-32 data path (round 2 priced the kNN against 1,229 G instructions/s).  1024 SIMDs / 2.0 ns:
 VALU_ISSUE_NS = 2.0
 VALU_PEAK_GINST = 1024 / VALU_ISSUE_NS
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 DTYPE = "f32 (fp32 accumulate; operands split into 2 x fp16 pieces on v_mfma_f32_32x32x16_f16; kNN / FPS scores in exact fp32 order)"
 
 
@@ -408,7 +408,8 @@ def main(argv=None):
         alg_all = sum(m[3] for m in model.values() if m[2] == "mfma")
         t_dom = solo_b.get(dom, 0.0) * 1e-3
         m_dom = model[dom]
-        ach = m_dom[5] / t_dom / 1e12 if t_dom > 0 else 0.0
+        ach = m_dom[3] / t_dom / 1e12 if t_dom > 0 else 0.0       # ALGORITHMIC: 2 x 20 x N x (18 x 64 + 64 x 64) flop per scene-launch
+        ach_exec = m_dom[5] / t_dom / 1e12 if t_dom > 0 else 0.0
         kernels = {}
         for kn, m in model.items():
             t = solo_b.get(kn, 0.0) * 1e-3
@@ -417,23 +418,25 @@ def main(argv=None):
             e = {"ms_per_scene_launch_solo_batched": round(t * 1e3, 4), "ms_per_scene_launch_in_timed_region": round(in_region.get(kn, 0.0), 4),
                  "launches_per_scene": m[1]}
             if m[2] == "mfma":
-                e.update({"executed_tflops": round(m[5] / t / 1e12, 1), "frac_of_16bit_mfma_peak": round(m[5] / t / 1e12 / MFMA_BF16_PEAK_TF, 4),
-                          "algorithmic_fp32_tflops": round(m[3] / t / 1e12, 1)})
+                e.update({"algorithmic_tflops": round(m[3] / t / 1e12, 1), "frac_of_16bit_mfma_peak": round(m[3] / t / 1e12 / MFMA_BF16_PEAK_TF, 4),
+                          "executed_tflops": round(m[5] / t / 1e12, 1), "executed_frac_of_16bit_mfma_peak": round(m[5] / t / 1e12 / MFMA_BF16_PEAK_TF, 4)})
             kernels[kn] = e
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_PEAK_TF, 4),
                     "traffic": (pmc.get("hbm_bytes_per_scene_launch", {}) or {}).get(dom), "traffic_source": pmc.get("configuration"),
-                    "basis": "EXECUTED 16-bit MFMA flop of one scene's share of the batched launch (fp32 operands split into two fp16 pieces each, three products, "
-                             "fp32 accumulate: DESIGN.md section 4) / the launch's duration with one engine group alone on the GPU (HIP events on the "
-                             "group's stream, after the timed region; profiles/%s_solo_batched_kernel_stats.csv is rocprofv3's view of the same "
-                             "configuration) / the dense fp16 MFMA peak" % PROFILE_TAG,
+                    "basis": "ALGORITHMIC flop of one scene's share of the batched launch -- 2 x 20 x N x (18 x 64 + 64 x 64), the fp32 contraction of "
+                             "MLP3 (SURVEY.md 8d) -- / the launch's duration with one engine group alone on the GPU (HIP events on the group's stream, after "
+                             "the timed region; profiles/%s_solo_batched_kernel_stats.csv is rocprofv3's view of the same configuration) / the dense "
+                             "16-bit MFMA peak.  The kernel EXECUTES 2.73x that (fp32 operands cut into two fp16 pieces, three products, fp32 accumulate: "
+                             "fp32-emulated, DESIGN.md section 5): `executed` below" % PROFILE_TAG,
+                    "executed": {"tflops": round(ach_exec, 1), "frac_of_16bit_mfma_peak": round(ach_exec / MFMA_BF16_PEAK_TF, 4),
+                                 "flop_per_scene_launch": m_dom[5], "over_algorithmic": round(m_dom[5] / m_dom[3], 3)},
                     "executed_flop_per_scene_launch": m_dom[5], "algorithmic_flop_per_scene_launch": m_dom[3],
                     "ms_per_scene_launch": round(t_dom * 1e3, 4), "launches_per_scene": 1,
-                    "algorithmic_fp32_tflops": round(m_dom[3] / t_dom / 1e12, 1) if t_dom > 0 else None,
                     "algorithmic_vs_fp32_mfma_peak_157tf": round(m_dom[3] / t_dom / 1e12 / MFMA_F32_PEAK_TF, 3) if t_dom > 0 else None,
-                    "whole_gpu": {"executed_mfma_tflops": round(ex_all * value / world / 1e12, 1),
-                                  "frac_of_16bit_mfma_peak": round(ex_all * value / world / 1e12 / MFMA_BF16_PEAK_TF, 4),
-                                  "algorithmic_fp32_tflops": round(alg_all * value / world / 1e12, 1),
+                    "whole_gpu": {"algorithmic_tflops": round(alg_all * value / world / 1e12, 1),
+                                  "frac_of_16bit_mfma_peak": round(alg_all * value / world / 1e12 / MFMA_BF16_PEAK_TF, 4),
+                                  "executed_mfma_tflops": round(ex_all * value / world / 1e12, 1),
                                   "executed_flop_per_scene": ex_all, "algorithmic_flop_per_scene": alg_all},
                     "kernels": kernels,
                     # consistency: the kernels' own time for a step's scenes must fit inside the step (overlapped in-region durations did not)
@@ -636,21 +639,42 @@ def main(argv=None):
             from oracle import cpu_ref
             from threadpoolctl import threadpool_limits
             # bounded thread count: the oracle is many small NumPy/torch ops, oversubscribing a 256-core host
-            # makes it ~10x slower than 16 threads
+            # makes it ~10x slower than 16 threads -- the curve below is measured here, on this box, and travels in the line
             used = min(cores, args.cpu_threads)
-            torch.set_num_threads(used)
             times, same = [], True
-            with threadpool_limits(limits=used):
-                while len(times) < 3 and sum(times) < 40.0:             # bounded: ~20-50 s of CPU work in total
+
+            def one_run(nthreads):
+                torch.set_num_threads(nthreads)
+                with threadpool_limits(limits=nthreads):
                     t1 = time.perf_counter()
-                    ref = cpu_ref.forward_scene(host_scene0, W, "ins_infer", faithful=True)
-                    times.append(time.perf_counter() - t1)
-                    same = same and ref["trace"] == batch_trace0 if args.scenes_total == 0 else same
+                    ref_ = cpu_ref.forward_scene(host_scene0, W, "ins_infer", faithful=True)
+                    return time.perf_counter() - t1, ref_
+            while len(times) < 3 and sum(times) < 40.0:                 # bounded: ~20-50 s of CPU work in total
+                dt, ref = one_run(used)
+                times.append(dt)
+                same = same and ref["trace"] == batch_trace0 if args.scenes_total == 0 else same
             best, med = min(times), float(np.median(times))
+            # one run each at other thread counts, ALL host cores included (bounded: a run that takes longer than 60 s ends the sweep)
+            curve = {str(used): round(best, 2)}
+            for nt in sorted({8, 32, 64, cores} - {used}):
+                if nt > cores:
+                    continue
+                dt, _ = one_run(nt)
+                curve[str(nt)] = round(dt, 2)
+                if dt > 60.0:
+                    break
+            torch.set_num_threads(used)
+            anchor = None
+            apath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_cpu_anchor_check.json")
+            if os.path.exists(apath):
+                anchor = json.load(open(apath))
             cpu = {"value": round(1.0 / best, 5), "unit": "scenes/s", "cores": used, "host_cores": cores, "kind": "port",
                    "runs": len(times), "seconds_min_median": [round(best, 2), round(med, 2)],
+                   "seconds_per_scene_by_threads": curve,
                    "sample": f"1 scene of the same workload ({args.points} pts / {args.segments} segs), oracle/cpu_ref.py faithful mode, "
-                             f"{len(times)} runs on {used} of {cores} host cores (value = best run); cluster trace equals the HIP path: {same}"}
+                             f"{len(times)} runs on {used} of {cores} host cores (value = best run; `seconds_per_scene_by_threads` = one run each at other "
+                             f"thread counts, all {cores} cores included: {used} is the fastest or close to it); cluster trace equals the HIP path: {same}",
+                   "anchor_check": anchor}
 
         I_s, U_s = vec[:40], vec[40:80]
         I_i, U_i = vec[80:120], vec[120:160]

@@ -524,6 +524,22 @@ int sg_write_label_npy(const char* path, const int32_t* h_vec, int V);
 /* Asynchronous writer pool: submit() copies h_vec and returns; `formats` = 1 txt | 2 npy | 3 both, written to
  * <path_without_ext>.txt / .npy by one of `threads` native threads.  At most `max_queue` vectors are pending
  * (submit blocks beyond that).  flush() waits for everything submitted so far and reports the first error. */
+/* ---------------------------------------------------------------------------------------------
+ * Native scene-pack loader (csrc/loader.cpp; reference data.py:28-38 + the per-forward file reads of model.py:696-724).
+ * `threads` workers, each with a pinned staging buffer and a copy stream; `slots` device blobs of `slot_bytes` allocated at creation
+ * (nothing allocates per scene).  sg_loader_submit queues a `.sgpack` (seggroup_amd/cache.py) and returns a ticket at once;
+ * sg_loader_wait blocks until that pack is resident and fills *out (device arrays inside the slot's blob, the four per-segment host
+ * arrays and h_seg_of_vertex owned by the slot), *slot and the scene's name.  The slot belongs to the caller until
+ * sg_loader_release(slot): release it when the engine has finished the scene.  A worker takes a job only when a slot is free.
+ * Call on the thread / device context the engine uses (the device current at creation is the loader's).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sg_loader sg_loader;
+sg_loader* sg_loader_create(int threads, int slots, size_t slot_bytes);
+int  sg_loader_submit(sg_loader* l, const char* pack_path);
+int  sg_loader_wait(sg_loader* l, int ticket, sg_scene* out, int* slot, char* name, int name_capacity);
+int  sg_loader_release(sg_loader* l, int slot);
+void sg_loader_destroy(sg_loader* l);
+
 typedef struct sg_writer sg_writer;
 sg_writer* sg_writer_create(int threads, int max_queue);
 int  sg_writer_submit(sg_writer* w, const char* path_without_ext, const int32_t* h_vec, int V, int formats);

@@ -220,3 +220,71 @@ def load_pack(path: str, device="cuda"):
             arrays[k] = blob[off:off + n].view(tdt[dt]).view(*shape)
     arrays["seg_of_vertex"] = sov
     return DeviceScene.from_staged(arrays, name=hdr["name"], device=dev)
+
+
+class LoadedScene:
+    """A scene resident in a loader slot: what the engine needs of a DeviceScene (`c_struct`, the dimensions, the name, the host-side
+    seg_of_vertex), with the memory owned by the native loader until `release()`."""
+
+    def __init__(self, loader: "PackLoader", c_scene, slot: int, name: str):
+        import ctypes as C
+        self._loader, self._c, self.slot, self.name = loader, c_scene, slot, name
+        self.device = loader.device
+        self.N, self.S, self.E0, self.V = int(c_scene.N), int(c_scene.S), int(c_scene.E0), int(c_scene.V)
+        self.h_seg_of_vertex = np.ctypeslib.as_array(C.cast(c_scene.h_seg_of_vertex, C.POINTER(C.c_int32)), shape=(self.V,))
+        self.h_seg_size = np.ctypeslib.as_array(C.cast(c_scene.h_seg_size, C.POINTER(C.c_int32)), shape=(self.S,))
+
+    @property
+    def c_struct(self):
+        return self._c
+
+    def release(self) -> None:
+        if self.slot is not None:
+            self._loader.release(self.slot)
+            self.slot = None
+
+
+class PackLoader:
+    """`sg_loader_*` (csrc/loader.cpp): native threads read scene packs into pinned buffers and upload them into pre-allocated device
+    slots.  submit(path) -> ticket at once; wait(ticket) -> LoadedScene; the scene's slot is free again after LoadedScene.release()."""
+
+    def __init__(self, threads: int, slots: int, slot_bytes: int, device=None):
+        import torch
+        from . import hip
+        hip.require_device()
+        self.lib = hip.lib()
+        self.device = torch.device(device if device is not None else "cuda")
+        with torch.cuda.device(self.device):
+            self.handle = self.lib.sg_loader_create(int(threads), int(slots), int(slot_bytes))
+        if not self.handle:
+            raise hip.SgError(hip.SG_ENOMEM, self.lib.sg_last_error().decode())
+
+    def submit(self, path: str) -> int:
+        from . import hip
+        t = self.lib.sg_loader_submit(self.handle, path.encode())
+        hip.check(t)
+        return t
+
+    def wait(self, ticket: int) -> LoadedScene:
+        import ctypes as C
+        from . import hip
+        sc = hip.Scene()
+        slot = C.c_int(-1)
+        name = C.create_string_buffer(256)
+        hip.check(self.lib.sg_loader_wait(self.handle, ticket, C.byref(sc), C.byref(slot), name, 256))
+        return LoadedScene(self, sc, slot.value, name.value.decode())
+
+    def release(self, slot: int) -> None:
+        from . import hip
+        hip.check(self.lib.sg_loader_release(self.handle, slot))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.sg_loader_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

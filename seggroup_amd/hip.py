@@ -177,6 +177,11 @@ SIGNATURES = {
     "sg_write_label_npy": (_I, [C.c_char_p, vp, _I]),
     "sg_writer_create": (vp, [_I, _I]),
     "sg_writer_submit": (_I, [vp, C.c_char_p, vp, _I, _I]),
+    "sg_loader_create": (vp, [_I, _I, _Z]),
+    "sg_loader_submit": (_I, [vp, C.c_char_p]),
+    "sg_loader_wait": (_I, [vp, _I, vp, C.POINTER(C.c_int), C.c_char_p, _I]),
+    "sg_loader_release": (_I, [vp, _I]),
+    "sg_loader_destroy": (None, [vp]),
     "sg_writer_submit_scene": (_I, [vp, C.c_char_p, vp, _I, _I, _I, C.c_longlong]),
     "sg_writer_submit_scene_tables": (_I, [vp, C.c_char_p, vp, _I, vp, _I, _I, _I, C.c_longlong]),
     "sg_expand_labels": (_I, [vp, _I, _I, vp, _I, vp]),

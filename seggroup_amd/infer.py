@@ -241,23 +241,53 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     mode = hip.MODE_SEM_INFER if args.sem_infer else hip.MODE_INS_INFER
     workers = max(1, int(args.workers))
 
+    # Scene packs come through the native loader (csrc/loader.cpp): worker threads read them into pinned buffers and upload them into
+    # device slots allocated here, once.  --no-cache
+    # stages straight from the reference's files in Python threads (no pack written).
+    loader = None
+    if not args.no_cache:
+        paths = {n: cache.pack_scene(args.root, n, args.label_style) for n in dict.fromkeys(names)}
+        slot_bytes = max((os.path.getsize(p) for p in paths.values()), default=1 << 20)
+        # four batches' worth of slots: one in the engine, one queued behind it, two being loaded (two batches of requests are outstanding:
+        # with one, the loop alternated between waiting for the loader and waiting for the engine)
+        # eight loader threads read and upload ~2,800 packs/s (tools/time_loader.py: PCIe-bound at 45 GB/s from 16 on); more only take
+        # cores from the writer pool
+        loader = cache.PackLoader(threads=min(8, workers), slots=4 * max(args.batch, 1), slot_bytes=slot_bytes, device=dev)
+
+        class _Loaded:                                      # a future-like handle on a loader ticket
+            def __init__(self, t):
+                self.t = t
+
+            def result(self):
+                return loader.wait(self.t)
+
     def stage(name):
-        if args.no_cache:
-            from .scene import DeviceScene
-            return DeviceScene.from_reference_tree(name, root=args.root, label_style=args.label_style, device=dev)
-        return cache.load_pack(cache.pack_scene(args.root, name, args.label_style), device=dev)
+        from .scene import DeviceScene
+        return DeviceScene.from_reference_tree(name, root=args.root, label_style=args.label_style, device=dev)
 
     pool = ThreadPoolExecutor(max_workers=workers)
+
+    def request(name):
+        return _Loaded(loader.submit(paths[name])) if loader is not None else pool.submit(stage, name)
+
     batches = [names[k:k + args.batch] for k in range(0, len(names), args.batch)]
-    pending = [pool.submit(stage, n) for n in batches[0]] if batches else []
+    ahead = 2 if loader is not None else 1                 # batches of staging requests outstanding
+    pending_q = [[request(n) for n in batches[k]] for k in range(min(ahead, len(batches)))]
     writer = AsyncLabelWriter(threads=max(2, workers))
     runner, done, stalled = None, 0, []
     w = model.export_weights()
     tickets = []
 
+    prof = {"load_wait": 0.0, "submit": 0.0, "engine_wait": 0.0, "log": 0.0} if os.environ.get("SG_DRIVER_PROFILE") else None
+
     def consume(t):
         nonlocal done
-        for s_, r in zip(t.scenes, runner.wait(t)):
+        t_a = time.time()
+        results = runner.wait(t)
+        if prof is not None:
+            prof["engine_wait"] += time.time() - t_a
+            t_a = time.time()
+        for s_, r in zip(t.scenes, results):
             acc.add(r.iou_sem, r.iou_ins, r.acc)
             done += 1
             if r.stalled:
@@ -267,11 +297,19 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
                 print('[rank %d] %s: a <5-point cluster could not be merged (reference would not terminate); sweep cut short' % (rank, s_.name), flush=True)
             if rank == 0:
                 io.cprint(progress_line(min(done * world, len(scene_list)), len(scene_list), acc.summary()))
+            if hasattr(s_, "release"):
+                s_.release()                                # the loader's slot is free for the batch after next
+        if prof is not None:
+            prof["log"] += time.time() - t_a
 
     t_start, startup = time.time(), None
     for bi, batch in enumerate(batches):
-        scenes = [f.result() for f in pending]
-        pending = [pool.submit(stage, n) for n in batches[bi + 1]] if bi + 1 < len(batches) else []
+        t_a = time.time()
+        scenes = [f.result() for f in pending_q.pop(0)]
+        if prof is not None:
+            prof["load_wait"] += time.time() - t_a
+        if bi + ahead < len(batches):
+            pending_q.append([request(n) for n in batches[bi + ahead]])
         if runner is None or any(not runner.fits(s_) for s_ in scenes):
             while tickets:                                  # the engine is rebuilt with larger capacities: drain it first
                 consume(tickets.pop(0))
@@ -280,7 +318,10 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
                 runner.close()
             runner = BatchRunner(w, scenes, inflight=args.inflight, device=dev, min_caps=caps, timing=0, label_transfer=args.label_transfer)
         # one batch is queued behind the one in flight: the engine's groups never drain between batches
+        t_a = time.time()
         tickets.append(runner.submit(scenes, mode, writer=writer, out_dirs=[model.output_root(s_.name) for s_ in scenes], formats=formats))
+        if prof is not None:
+            prof["submit"] += time.time() - t_a
         if startup is None:
             # one-off: the first batch staged with nothing to overlap it, the engine's slots (124 MB of device memory each) and the pinned
             # label ring created -- about a second that a short run cannot amortise
@@ -290,10 +331,16 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
             consume(tickets.pop(0))
     while tickets:
         consume(tickets.pop(0))
+    t_a = time.time()
     writer.flush()
+    if prof is not None:
+        prof["final_flush"] = time.time() - t_a
+        print("[driver profile] %s total %.3f s" % ({k: round(v, 3) for k, v in prof.items()}, time.time() - t_start), flush=True)
     writer.close()
     if runner is not None:
         runner.close()
+    if loader is not None:
+        loader.close()
     pool.shutdown()
     if stalled and rank == 0:
         io.cprint('%d scene(s) hit the non-terminating pass-2 case of group_nearby_clusters: %s' % (len(stalled), ' '.join(stalled)))

@@ -47,11 +47,28 @@ def pmc(name, counter):
 
 
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+valu = pmc("valu", "SQ_INSTS_VALU")            # wave-instructions per launch (the kNN kernels' roof is VALU issue: 512 G wave-instructions/s)
 # executed MFMA flop per edge row (bench.py: CONV1 12 MFMAs of 32x32x16 per 32 rows, conv2 three fp16 products of 64x64)
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-flop = {"k_edgeconv<2, true>": bench.S2X_EXECUTED_FLOP_PER_ROW * 20.0 * N, "k_edgeconv<1, false>": bench.S1X_EXECUTED_FLOP_PER_ROW * 20.0 * N,
-        "k_edgeconv<2, false>": bench.S2X_EXECUTED_FLOP_PER_ROW * 20.0 * N, "k_edgeconv<1, true>": bench.S1X_EXECUTED_FLOP_PER_ROW * 20.0 * N}
+
+
+def edgeconv_mode(k):
+    """1 (MLP2) / 2 (MLP3) for any EdgeConv launch -- k_edgeconv<MODE, ...>, k_edgeconv_h<MODE>, k_edgeconv_b / _hb -- else 0"""
+    m = re.match(r"k_edgeconv(_h|_b|_hb)?<(\d)", k)
+    return int(m.group(2)) if m else 0
+
+
+def flops_of(k):
+    """(algorithmic fp32-contraction flop, executed 16-bit MFMA flop) of one launch over the N-point scene"""
+    mode = edgeconv_mode(k)
+    if mode == 1:
+        return 2.0 * 20 * N * (18 * 64), bench.S1X_EXECUTED_FLOP_PER_ROW * 20.0 * N
+    if mode == 2:
+        return 2.0 * 20 * N * (18 * 64 + 64 * 64), bench.S2X_EXECUTED_FLOP_PER_ROW * 20.0 * N
+    return None
+
+
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 out = []
 with open(os.path.join(P, f"{tag}_stress_500k_kernel_stats.csv"), "w") as o:
@@ -67,25 +84,29 @@ for r in rows:
     per_fwd = int(r["Calls"]) / iters
     b = (2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0
     gbs = b / (us * 1e-6) / 1e9 if us > 0 and b > 0 else 0.0
-    tf = flop.get(k, 0.0) / (us * 1e-6) / 1e12 if k in flop else None
-    out.append((k, per_fwd, us, us * per_fwd, b, gbs, tf, 100 * float(r["TotalDurationNs"]) / tot))
+    fl = flops_of(k)
+    tf = (fl[0] / (us * 1e-6) / 1e12, fl[1] / (us * 1e-6) / 1e12) if fl and us > 0 else None
+    vfrac = valu[k] / (us * 1e-6) / (bench.VALU_PEAK_GINST * 1e9) if k in valu and us > 0 and k.startswith("k_cluster_knn") else None
+    out.append((k, per_fwd, us, us * per_fwd, b, gbs, tf, 100 * float(r["TotalDurationNs"]) / tot, vfrac))
 with open(os.path.join(P, f"{tag}_stress_500k_report.md"), "w") as o:
     o.write(f"# Stress scene {N} points / {S} segments / 20-NN graph on 1x MI355X (BASELINE.json configs[4])\n\n")
     o.write(f"`tools/stress_500k.sh {tag}`: `rocprofv3 --kernel-trace --stats -- python3 tools/time_scene.py {N} {S}` (one scene at a time through the single-scene "
             "pipeline, default stream) + two separate `--pmc` passes (`FETCH_SIZE`, `WRITE_SIZE`).  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB "
-            "(gfx950 correction of `MI355X_MICROARCH.md`); GB/s against the 8,000 GB/s HBM roof; EdgeConv launches also as EXECUTED 16-bit MFMA TFLOP/s "
-            "against the 2,500 TF dense peak.\n\n")
+            "(gfx950 correction of `MI355X_MICROARCH.md`); GB/s against the 8,000 GB/s HBM roof.  EdgeConv launches: ALGORITHMIC TFLOP/s "
+            "(2 x 20 x N x (18 x 64 [+ 64 x 64]) fp32-contraction flop / time) against the 2,500 TF dense 16-bit MFMA peak, and beside it the flop the "
+            "two-piece fp16 emulation EXECUTES.  kNN launches: `SQ_INSTS_VALU` (a fourth pass) / time against the measured VALU issue roof of "
+            "%.0f G wave-instructions/s.\n\n" % bench.VALU_PEAK_GINST)
     if meta:
         o.write(f"Scene: E0 = {meta.get('E0')} mesh edges, V = {meta.get('V')} raw vertices, cluster trace {meta.get('trace')}.  Wall per forward "
                 f"(kernels + serial host grouping + D2H of the 14 label vectors): median {meta.get('wall_ms_median')} ms, min {meta.get('wall_ms_min')} ms; "
                 f"device time summed over the kernels below: {sum(x[3] for x in out) / 1e3:.2f} ms.\n\n")
-    o.write("| kernel | launches / forward | us / launch | us / forward | % | HBM MB / launch | GB/s | frac of 8 TB/s | MFMA TFLOP/s (frac of 2.5 PF) |\n|---|---|---|---|---|---|---|---|---|\n")
-    for k, n_, us, usf, b, gbs, tf, pct in out:
+    o.write("| kernel | launches / forward | us / launch | us / forward | % | HBM MB / launch | GB/s | frac of 8 TB/s | MFMA TFLOP/s algorithmic (frac of 2.5 PF); executed | VALU issue frac |\n|---|---|---|---|---|---|---|---|---|---|\n")
+    for k, n_, us, usf, b, gbs, tf, pct, vfrac in out:
         if pct < 0.05:
             continue
-        o.write("| `%s` | %.1f | %.1f | %.1f | %.1f | %s | %s | %s | %s |\n" % (
+        o.write("| `%s` | %.1f | %.1f | %.1f | %.1f | %s | %s | %s | %s | %s |\n" % (
             k, n_, us, usf, pct, ("%.2f" % (b / 1e6)) if b else "-", ("%.0f" % gbs) if gbs else "-", ("%.3f" % (gbs / 8000.0)) if gbs else "-",
-            ("%.0f (%.3f)" % (tf, tf / 2500.0)) if tf else "-"))
+            ("%.0f (%.3f); %.0f (%.3f)" % (tf[0], tf[0] / 2500.0, tf[1], tf[1] / 2500.0)) if tf else "-", ("%.2f" % vfrac) if vfrac else "-"))
     if meta.get("stage_ms"):
         o.write("\nPipeline stage times of the last forward (HIP events, ms): `%s`\n" % json.dumps(meta["stage_ms"]))
 print(open(os.path.join(P, f"{tag}_stress_500k_report.md")).read()[:3000])

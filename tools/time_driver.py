@@ -29,6 +29,10 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--skip-nopack", action="store_true", help="skip the legs that stage from the reference's files")
     ap.add_argument("--skip-loop", action="store_true", help="skip the per-scene loop legs (7 scenes/s: slow for many scenes)")
+    ap.add_argument("--numa", default="auto", choices=["auto", "off"])
+    ap.add_argument("--label-transfer", default="tables", choices=["tables", "full"])
+    ap.add_argument("--distinct", type=int, default=0, help="write this many scenes' files for real and symlink the others' to them (0 = write "
+                                                            "every scene: 2,048 scenes take five minutes of torch.save on the GPU box)")
     a = ap.parse_args()
 
     import torch
@@ -42,7 +46,21 @@ def main():
         for i in range(a.scenes):          # distinct names, 4 distinct geometries (generation is the slow part here)
             b = base[i % len(base)]
             scenes.append(synthetic.Scene(f"scene{i:04d}_00", b.data, b.weak_label, b.seg, b.adj, b.unmap, b.gt))
-        synthetic.write_reference_tree(root, scenes)
+        d_ = a.distinct if 0 < a.distinct < len(scenes) else len(scenes)
+        synthetic.write_reference_tree(root, scenes[:d_])
+        if d_ < len(scenes):
+            base_ = os.path.join(root, "dataset", "scannet")
+            kinds = [(("data", "resampled"), (".pcl.pth", ".info.pth", ".unmap.pth")), (("label", "seg", "manual", "resampled"), (".label.pth",)),
+                     (("label", "real", "resampled"), (".seg.json",)), (("label", "real", "raw"), (".label.pth",)), (("adj", "mesh", "resampled"), (".adj.pth",))]
+            for i in range(d_, len(scenes)):
+                src, dst = scenes[i % d_].name, scenes[i].name
+                for sub, exts in kinds:
+                    os.makedirs(os.path.join(base_, *sub, dst), exist_ok=True)
+                    for e in exts:
+                        os.symlink(os.path.join(base_, *sub, src, src + e), os.path.join(base_, *sub, dst, dst + e))
+            with open(os.path.join(base_, "scannetv2_train.txt"), "w") as f:
+                for sc_ in scenes:
+                    f.write(sc_.name + "\n")
         ck = os.path.join(root, "checkpoints", "exp", "models")
         os.makedirs(ck)
         torch.save({"state_dict": weights.to_full_state_dict(weights.make_weights(1, bn1_gamma=2.0))}, os.path.join(ck, "last.t7"))
@@ -51,10 +69,11 @@ def main():
         for fmt_w in a.out_format.split(";"):
             fmt, _, wk = fmt_w.partition("@")                      # 'npy@4' = this leg with -j 4
             a.workers = int(wk) if wk else a.workers
-            common = ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--out-format", fmt, "-j", str(a.workers)]
+            common = ["-n", "exp", "--ins_infer", "--root", root, "--world-size", "1", "--out-format", fmt, "-j", str(a.workers), "--numa", a.numa, "--label-transfer", a.label_transfer]
 
-            def run(extra):
-                shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
+            def run(extra, keep=False):
+                if not keep:
+                    shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
                 args = infer.build_parser().parse_args(common + extra)
                 t = time.time()
                 r = infer.run_worker(0, 1, args)
@@ -73,6 +92,9 @@ def main():
                 o["reference_files_no_pack"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
             t, r1 = run(fast)
             o["packed_cold"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
+            # the same run over the files of the last one (a re-run of infer.py: the label files exist and are overwritten, no pages to allocate)
+            t, rk = run(fast, keep=True)
+            o["packed_warm_overwrite"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2), "driver_elapsed_s": round(rk.get("elapsed_s", 0.0), 3)}
             t, r2 = run(fast)
             def leg(t_, r_):
                 d_ = {"s": round(t_, 3), "scenes_per_s": round(a.scenes / t_, 2), "driver_elapsed_s": round(r_.get("elapsed_s", 0.0), 3)}
