@@ -137,8 +137,9 @@ def test_150k_scene_float_stages_match_reference_capture_and_oracle(golden_index
         ARE the reference's tables;
       * match the reference's point features within 1e-4 on every sampled row that is not a tie row (the split-operand EdgeConv:
         bf16 x 3 / fp16 x 2 pieces on the 16-bit matrix pipe);
-      * match the oracle's GCN outputs and decision distances within 1e-4 EVERYWHERE, and the reference's on > 90 % of the entries
-        (a tie row moves its cluster's maximum and, through the GCN, its neighbours')."""
+      * match the oracle's GCN outputs and decision distances within 1e-4 EVERYWHERE, and the reference's everywhere EXCEPT on the
+        clusters a stored tie row reaches: its own cluster, that cluster's neighbours (one GCN hop) and, in layer 3, the clusters
+        that inherit a moved layer-2 cluster through the carried features."""
     name = "scene_150k"
     e = golden_index[name]
     g = load_golden(name)
@@ -164,12 +165,35 @@ def test_150k_scene_float_stages_match_reference_capture_and_oracle(golden_index
         C, D = res.trace[1 + i], (192, 256)[i]
         gcn = t["gcn"][i].reshape(-1)[:C * D].reshape(C, D)
         assert np.abs(gcn - g[f"ins.oracle.gcn_{nm[-1]}"]).max() < FLOAT_TOL, nm
-        assert (np.abs(gcn - g[f"ins.tap.gcn_{nm[-1]}"]).max(axis=1) < FLOAT_TOL).mean() > 0.9, nm
-    for i in range(3):
-        want, ref = g[f"ins.oracle.dists.{i}"], g[f"ins.tap.dists.{i}"]
-        got = t["dist"][i][:want.shape[0]]
-        assert np.abs(got - want).max() < FLOAT_TOL, f"decision distances {i} vs the oracle"
-        assert (np.abs(got - ref) < FLOAT_TOL).mean() > 0.9, f"decision distances {i} vs the reference"
+        # Against the REFERENCE only rows downstream of a kNN tie may deviate (round 4: the set is derived, not counted).  A tie row moves
+        # its cluster's maximum; the GCN hands that to the cluster's neighbours (one hop); layer 3 also inherits, through the carried
+        # features, every layer-2 cluster that moved.  cluster index = rank of the root id (model.py:759-768), rows of the GCN output.
+        seg_row = 3 * (i + 1)                                             # layer_2.seg / layer_3.seg: root id per vertex (unmap is the identity here)
+        roots = res.labels[seg_row]
+        cl = np.searchsorted(np.unique(roots), roots)
+        assert cl.max() + 1 == C
+        adj = t["adj"][i + 1][:t["n_adj"][i + 1]].astype(np.int64)
+        moved = np.zeros(C, bool)
+        moved[cl[rows]] = True
+        if i == 1:
+            moved[np.unique(cl[touched_prev[cl_prev]])] = True            # layer-3 clusters that contain a layer-2 cluster which moved
+        touched = moved.copy()
+        touched[adj[moved[adj[:, 1]], 0]] = True
+        touched[adj[moved[adj[:, 0]], 1]] = True
+        bad = np.abs(gcn - g[f"ins.tap.gcn_{nm[-1]}"]).max(axis=1) >= FLOAT_TOL
+        assert not np.any(bad & ~touched), (nm, int(np.sum(bad & ~touched)), "GCN rows off the reference that no kNN tie explains")
+        assert bad.sum() < touched.sum()
+        # the layer's decision distances: only edges with an end in a touched cluster may deviate
+        want, ref = g[f"ins.oracle.dists.{i + 1}"], g[f"ins.tap.dists.{i + 1}"]
+        got = t["dist"][i + 1][:want.shape[0]]
+        assert np.abs(got - want).max() < FLOAT_TOL, f"decision distances {i + 1} vs the oracle"
+        off = np.abs(got - ref) >= FLOAT_TOL
+        assert adj.shape[0] == want.shape[0]
+        assert not np.any(off & ~(touched[adj[:, 0]] | touched[adj[:, 1]])), f"decision distances {i + 1}: off the reference away from every tie"
+        touched_prev, cl_prev = touched, cl
+    want, ref = g["ins.oracle.dists.0"], g["ins.tap.dists.0"]                # the structural layer: no kNN-20 upstream, no exceptions
+    got = t["dist"][0][:want.shape[0]]
+    assert np.abs(got - want).max() < FLOAT_TOL and np.abs(got - ref).max() < FLOAT_TOL
 
 
 def test_150k_scene_sem_infer_matches_reference_digests(golden_index, weight_sets):

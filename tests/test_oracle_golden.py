@@ -49,18 +49,15 @@ def test_stage_tensors(golden_index, weight_sets, name):
     r = _oracle(golden_index, weight_sets, name, "ins_infer")
     st = r["stages"]
     sc = make_fixture_scene(golden_index, name)
-    # island_20k moves a blob to x ~ 20..28 m: the reference's fp32 mean in get_cluster_pointcloud (model.py:422)
-    # is then ~7e-6 off in the normalised samples, which flips a handful of near-tied kNN-10 ranks inside MLP1;
-    # through BatchNorm's batch statistics that moves every row by ~1e-4.  The oracle evaluates the mean exactly,
-    # so for this fixture floats are compared in a wide band and a few rows may be outliers; integers stay exact.
+    # island_20k moves a blob to x ~ 20..28 m: the reference's fp32 mean in get_cluster_pointcloud (model.py:422) is ~7e-6 off there,
+    # which flips near-tied kNN-10 ranks inside MLP1.  The oracle reproduces torch's fp32 mean bit for bit since round 2 (four
+    # interleaved accumulators, cpu_ref.sample_clusters), so this fixture pins floats like the others: samples bit-equal, features and
+    # distances within 1e-4 (observed: 2e-6 on MLP1, 1.4e-5 on the GCN outputs).  Round 3 still compared it in a 0.5 band.
     far = name == "island_20k"
-    assert np.abs(g["ins.data_1"] - st["samples"]).max() < (2e-5 if far else 3e-6)      # FPS picks + transform
+    assert np.abs(g["ins.data_1"] - st["samples"]).max() < 3e-6                         # FPS picks + transform
     d = np.abs(g["ins.feat.mlp_1"] - st["feat1"])
-    if far:
-        assert np.median(d) < 1e-4 and np.mean(d.max(axis=1) > 1e-3) < 0.05
-    else:
-        assert d.max() < 1e-5
-    assert np.abs(g["ins.dists.0"] - st["d1"]).max() < (0.5 if far else 1e-4)
+    assert d.max() < 1e-5
+    assert np.abs(g["ins.dists.0"] - st["d1"]).max() < 1e-4
     for i, a in enumerate((st["adj1"], st["adj2"], st["mlp_2"]["adj"], st["mlp_3"]["adj"])):
         assert np.array_equal(g[f"ins.adj.{i}"].reshape(-1, 2), a), f"adj_{i + 1}"
     for i, root in enumerate((st["root2"], st["mlp_2"]["root"], st["mlp_3"]["root"], st["root5"])):
@@ -83,7 +80,7 @@ def test_stage_tensors(golden_index, weight_sets, name):
     band2 = 1e-5 if tie_rows[0] == 0 and "ins.knn.0" in g.files else 5e-4
     band3 = 1e-5 if sum(tie_rows) == 0 and "ins.knn.0" in g.files else 5e-4
     if far:
-        band2 = band3 = 0.5                                   # carried MLP1 features: see above
+        band2 = band3 = 1e-4                                  # no kNN table is stored for this fixture: the float bar of the north star
     assert np.abs(g["ins.feat.gcn_2"] - st["mlp_2"]["gcn"]).max() < band2
     assert np.abs(g["ins.feat.gcn_3"] - st["mlp_3"]["gcn"]).max() < band3
     assert np.abs(g["ins.dists.2"] - st["mlp_2"]["d"]).max() < max(band2, 1e-4)
