@@ -40,6 +40,10 @@ extern "C" {
 #define SG_MODE_SEM_INFER 1   /* infer.py --sem_infer : returns after layer 2 (model.py:781-783)   */
 
 #define SG_NUM_LABEL_VECTORS 14 /* layer_{1..4}.{seg,ins,sem} + final.{ins,sem} (model.py:525-605) */
+#define SG_RANGE_WORDS 256      /* words of every d_range_bits buffer below (zero-initialised by the caller)  */
+#define SG_MAX_POINTS (1 << 20) /* points of one scene: the in-cluster kNN's list keys carry 20 index bits; sg_pipeline_create,
+                                 * sg_engine_create and the trainers return NULL / SG_EUNSUP above it (the reference has no such limit;
+                                 * ScanNet scenes stay below 600k points)                                     */
 
 const char* sg_last_error(void);
 int  sg_version(void);
@@ -261,7 +265,6 @@ int sg_edgeconv_forward(const float* d_x9m, const int32_t* d_knn, int N, int k, 
                         const float* d_w1, const float* d_g1, const float* d_b1,
                         const float* d_w2, const float* d_g2, const float* d_b2,
                         float* d_out, void* d_ws, size_t ws_bytes, void* stream);
-#define SG_RANGE_WORDS 256
 /* The same with conv1's operand on fp16 pieces scaled by the layer's range (4 instead of 8 MFMAs per neighbour slot, same accuracy: the
  * pieces keep 22 bits and the scale is a power of two).  d_range_bits: a ZERO-INITIALISED buffer of SG_RANGE_WORDS (256) words whose
  * maximum is the bits of a float R with |x_j - x_i| <= 2 R for every edge and channel -- sg_layer_layout raises them while it writes

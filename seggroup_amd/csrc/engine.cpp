@@ -764,6 +764,10 @@ sg_engine* sg_engine_create(int maxN, int maxS, int maxE, int maxV, const sg_wei
         sg::fail(SG_EINVAL, "sg_engine_create: bad arguments");
         return nullptr;
     }
+    if (maxN > SG_MAX_POINTS) {
+        sg::fail(SG_EUNSUP, "sg_engine_create: maxN = %d; a scene holds at most %d points (the kNN list keys carry 20 index bits)", maxN, SG_MAX_POINTS);
+        return nullptr;
+    }
     if (sg_device_count() <= 0) {
         sg::fail(SG_EHIP, "sg_engine_create: no HIP device visible -- the SegGroup hot path has no CPU fallback");
         return nullptr;

@@ -54,7 +54,7 @@ __device__ inline void key_insert(unsigned long long (&kv)[K], unsigned long lon
 // identical lists).  All keys share one exponent: no NaN, no denormal, no -0 can appear.  20 index bits: member positions inside one
 // cluster, i.e. N <= 2^20 points per scene (the host entry points check it).  Key 0 ("nothing yet") <-> kListEmpty, the smallest.
 constexpr int kListIndexBits = 20;
-constexpr int kListMaxPoints = 1 << kListIndexBits;
+constexpr int kListMaxPoints = 1 << kListIndexBits;      // == SG_MAX_POINTS (include/seggroup_hip.h), checked in pipeline.cpp
 __device__ __forceinline__ double list_empty() { return __hiloint2double(0x43300000, 0); }
 __device__ __forceinline__ double to_list(unsigned long long key) {
     const unsigned int o = (unsigned int)(key >> 32), lo = (unsigned int)key;

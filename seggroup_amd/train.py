@@ -47,7 +47,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--world-size', type=int, default=0, help='processes to spawn (default: one per visible GPU)')
     p.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL on ROCm)')
     p.add_argument('--port', type=int, default=23456, help='rendezvous port on 127.0.0.1 (reference: 23456)')
-    p.add_argument('--max-steps', type=int, default=0, help='stop every epoch after this many steps per rank (0 = the whole scene list)')
+    p.add_argument('--max-steps', type=int, default=0, help='stop every epoch after this many optimizer steps per rank (0 = the whole scene list)')
     p.add_argument('--scenes-per-step', type=int, default=1, dest='scenes_per_step',
                    help='scenes per optimizer step and GPU: > 1 runs that many forward / backward passes side by side (BatchTrainer) and averages their '
                         'gradients, as the reference does over ranks (not in the reference: its batch size per rank is 1)')
@@ -236,8 +236,9 @@ def run_worker(rank: int, world: int, args, make_trainer: Optional[Callable] = N
     for epoch in range(start_epoch, args.epochs):
         tag = 'last' if epoch == args.epochs - 1 else str(epoch + 1)              # train.py:135-138
         mine = epoch_indices(len(names), rank, world, epoch)
+        B_step = max(int(getattr(args, 'scenes_per_step', 1)), 1)
         if args.max_steps:
-            mine = mine[:args.max_steps]
+            mine = mine[:args.max_steps * B_step]                                   # --max-steps counts OPTIMIZER steps: B scenes each
         log = EpochLog()
         if getattr(args, 'scenes_per_step', 1) > 1:
             # B scenes per optimizer step (BatchTrainer): the next group is staged while this one trains
@@ -248,13 +249,16 @@ def run_worker(rank: int, world: int, args, make_trainer: Optional[Callable] = N
             for gi, grp in enumerate(groups):
                 scs = [f.result() for f in nxt]
                 nxt = [pool.submit(stage, names[si]) for si in groups[gi + 1]] if gi + 1 < len(groups) else []
-                if any(not tr.fits(sc) for sc in scs):
+                if hasattr(tr, "fits") and any(not tr.fits(sc) for sc in scs):
                     bigger = tuple(max(a, *b) for a, b in zip(tr.caps, zip(*[(sc.N, sc.S, sc.E0, sc.V) for sc in scs])))
                     state_now, opt_now = tr.state_dict(), tr.optimizer_state()
+                    gens = tr.generator_states() if hasattr(tr, "generator_states") else None
                     tr.close()
                     from .trainer import BatchTrainer
                     tr = BatchTrainer(state_now, bigger, lanes=B, device=dev, use_sgd=args.use_sgd, lr=args.lr, momentum=args.momentum, seed=args.seed + rank)
                     tr.load_optimizer_state(opt_now)
+                    if gens is not None:
+                        tr.load_generator_states(gens)                               # the dropout streams go on where they were, not from step 0
                 try:
                     _, ress, summed = tr.step(scs)
                 except Exception as e:
@@ -276,9 +280,12 @@ def run_worker(rank: int, world: int, args, make_trainer: Optional[Callable] = N
                 bigger = tuple(max(a, b) for a, b in zip(tr.caps, (sc.N, sc.S, sc.E0, sc.V)))
                 # the old trainer's device buffers go first: two pipelines of the larger size need not fit together
                 state_now, opt_now = tr.state_dict(), tr.optimizer_state()
+                gens = tr.generator_states() if hasattr(tr, "generator_states") else None
                 tr.close()
                 tr = Trainer(state_now, bigger, device=dev, use_sgd=args.use_sgd, lr=args.lr, momentum=args.momentum, seed=args.seed + rank)
                 tr.load_optimizer_state(opt_now)
+                if gens is not None:
+                    tr.load_generator_states(gens)
             try:
                 loss, res, summed = tr.step(sc)
             except Exception as e:                                                   # e.g. a scene with one weak instance: BatchNorm1d raises

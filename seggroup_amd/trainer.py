@@ -233,6 +233,13 @@ class Trainer:
         self.steps = int(st["steps"])
         self.opt_a.copy_(st["a"].to(self.opt_a.device)); self.opt_b.copy_(st["b"].to(self.opt_b.device))
 
+    def generator_states(self) -> List[torch.Tensor]:
+        """the dropout generator's state (one per lane for a BatchTrainer): carried into the trainer that replaces this one on growth"""
+        return [self.gen.get_state()]
+
+    def load_generator_states(self, states) -> None:
+        self.gen.set_state(states[0])
+
     def device_bytes(self) -> int:
         return int(self.lib.sg_trainer_device_bytes(self.handle))
 
@@ -264,6 +271,13 @@ class BatchTrainer(Trainer):
         self.lanes: List[Trainer] = [self] + [Trainer(state, caps, device=self.device, seed=seed + 7919 * k, params=self.params, own_stream=True)
                                               for k in range(1, max(1, int(lanes)))]
         self.pool = ThreadPoolExecutor(max_workers=len(self.lanes))
+
+    def generator_states(self) -> List[torch.Tensor]:
+        return [lane.gen.get_state() for lane in self.lanes]
+
+    def load_generator_states(self, states) -> None:
+        for lane, st in zip(self.lanes, states):
+            lane.gen.set_state(st)
 
     @staticmethod
     def _lane_pass(lane: Trainer, sc: DeviceScene, keep):

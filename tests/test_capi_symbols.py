@@ -52,3 +52,15 @@ def test_missing_device_fails_loudly(sg_lib):
     w = hip.Weights()
     assert not sg_lib.sg_pipeline_create(10, 1, 1, 10, C.byref(w), None)
     assert b"no HIP device" in sg_lib.sg_last_error() or b"null" in sg_lib.sg_last_error()
+
+
+def test_scene_size_limit_is_rejected_at_creation(sg_lib):
+    """SG_MAX_POINTS (the kNN list keys' 20 index bits): a larger capacity fails when the pipeline / engine is CREATED, not at the first forward"""
+    import ctypes as C
+    from seggroup_amd import hip
+    w = hip.Weights()
+    too_many = (1 << 20) + 1
+    assert not sg_lib.sg_pipeline_create(too_many, 1, 1, too_many, C.byref(w), None)
+    assert b"at most 1048576 points" in sg_lib.sg_last_error()
+    assert not sg_lib.sg_engine_create(too_many, 1, 1, too_many, C.byref(w), 1, 1)
+    assert b"at most 1048576 points" in sg_lib.sg_last_error()

@@ -57,6 +57,7 @@ if passes:
     eng = next(iter(passes.values()))["engine"]
     B = int(eng.split(" x ")[1].split()[0])
     alias = {"k_edgeconv_b<2, true>": "k_edgeconv<S2X>", "k_edgeconv_b<1, false>": "k_edgeconv<S1X>",
+             "k_edgeconv_hb<2>": "k_edgeconv<S2X>", "k_edgeconv_hb<1>": "k_edgeconv<S1X>",
              "k_cluster_knn_sorted_b<20, 1, false>": "k_cluster_knn_sorted<unseeded>", "k_cluster_knn_sorted_b<20, 1, true>": "k_cluster_knn_sorted<seeded>"}
     out = {"configuration": f"solo batched: {eng}, python bench.py --steps 2 --warmup 1 under rocprofv3 --pmc (one counter set per pass, --kernel-trace only)",
            "scenes_per_launch": B,
