@@ -561,10 +561,11 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                                        [xs0] "v"(xs_c[0]), [xs1] "v"(xs_c[1]), [xs2] "v"(xs_c[2]), [xs3] "v"(xs_c[3]), [xs4] "v"(xs_c[4])
                                      : "memory", SG_EC_S1X_SLOTS_PK_CLOBBERS);
                     } else {
+                        const unsigned long long c02 = 0x3e4ccccd3e4ccccdull;     // LeakyReLU's 0.2f twice: v_pk_mul_f32 takes no literal
                         asm volatile(SG_EC_S2X_SLOTS
                                      : "=&" SG_EC_S2X_STAT_S0(ss0), "=&" SG_EC_S2X_STAT_S1(ss1), "=&" SG_EC_S2X_STAT_Q0(sq0), "=&" SG_EC_S2X_STAT_Q1(sq1),
                                        "=&" SG_EC_S2X_BEST0(bb0), "=&" SG_EC_S2X_BEST1(bb1)
-                                     : [x9m] "s"(x9m), [knn] "s"(knn), [sd] "s"(sd_u), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
+                                     : [c02] "s"(c02), [x9m] "s"(x9m), [knn] "s"(knn), [sd] "s"(sd_u), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
                                        [xs0] "v"(xs_c[0]), [xs1] "v"(xs_c[1]), [xs2] "v"(xs_c[2]), [xs3] "v"(xs_c[3]), [xs4] "v"(xs_c[4])
                                      : "memory", SG_EC_S2X_SLOTS_CLOBBERS);
                     }

@@ -1128,7 +1128,8 @@ int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
 
 int b_layer_layout(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
     if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
-    k_layer_layout_b<<<dim3(bd.max_S, bd.nslots), 256, 0, st>>>(d_ctx);
+    static const int threads = [] { const char* e = getenv("SG_LAYOUT_BLOCK"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256) ? v : 256; }();
+    k_layer_layout_b<<<dim3(bd.max_S, bd.nslots), threads, 0, st>>>(d_ctx);
     if (bd.max_lay_big > 0) k_layer_layout_big_b<<<dim3(bd.max_lay_big, bd.nslots), 256, 0, st>>>(d_ctx);
     SG_LAUNCH_CHECK();
     return SG_OK;

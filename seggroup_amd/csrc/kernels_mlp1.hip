@@ -168,25 +168,36 @@ __device__ __forceinline__ void mlp1_apply_body(const float* __restrict__ sample
     __shared__ float hs[64 * 65];
     // the folded weights (384 + 64 floats) through LDS once: read per channel from global memory they were seven loads of one
     // address per lane and channel (the pointer comes out of a SlotCtx: flat loads), each waited for inside the channel loop
-    __shared__ float wl[448];
+    __shared__ __attribute__((aligned(8))) float wl[448];
+    // transposed on the way in: wl[k * 64 + ch], so that the weights of a channel PAIR are one 8-byte read and the pair's six FMAs per
+    // neighbour are v_pk_fma_f32 (the neighbour's value feeds both halves): 6 + 2 instead of 12 + 2 instructions per (pair, neighbour),
+    // the same IEEE operations in the same order per channel
 #pragma unroll
-    for (int i = 0; i < 7; ++i) wl[lane + 64 * i] = folded[lane + 64 * i];
+    for (int i = 0; i < 7; ++i) {
+        const int e_ = lane + 64 * i;
+        wl[e_ < 384 ? (e_ % 6) * 64 + e_ / 6 : e_] = folded[e_];
+    }
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-    for (int ch = 0; ch < 64; ++ch) {
-        const float w0 = wl[ch * 6 + 0], w1 = wl[ch * 6 + 1], w2 = wl[ch * 6 + 2], w3 = wl[ch * 6 + 3],
-                    w4 = wl[ch * 6 + 4], w5 = wl[ch * 6 + 5], b = wl[384 + ch];
-        float h = -INFINITY;
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+#pragma unroll 2
+    for (int ch = 0; ch < 64; ch += 2) {
+        f32x2 w[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w[k] = *reinterpret_cast<const f32x2*>(&wl[k * 64 + ch]);
+        const f32x2 b = *reinterpret_cast<const f32x2*>(&wl[384 + ch]);
+        float h0 = -INFINITY, h1 = -INFINITY;
 #pragma unroll
         for (int t = 0; t < K1; ++t) {
-            float y = b;
-            y = __builtin_fmaf(w0, e[t][0], y); y = __builtin_fmaf(w1, e[t][1], y); y = __builtin_fmaf(w2, e[t][2], y);
-            y = __builtin_fmaf(w3, e[t][3], y); y = __builtin_fmaf(w4, e[t][4], y); y = __builtin_fmaf(w5, e[t][5], y);
-            h = fmaxf(h, y);                                     // max over k (model.py:76) ...
+            f32x2 y = b;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) y = __builtin_elementwise_fma(w[k], f32x2{e[t][k], e[t][k]}, y);
+            h0 = fmaxf(h0, y.x);                                 // max over k (model.py:76) ...
+            h1 = fmaxf(h1, y.y);
         }
         // ... BEFORE LeakyReLU(0.2): x -> max(x, 0.2 x) is non-decreasing (also in fp32: rounding is monotone), so the maximum of the
         // activations is the activation of the maximum, bit for bit -- two instructions per channel instead of two per (channel, neighbour)
-        hs[ch * 65 + lane] = fmaxf(h, 0.2f * h);
+        hs[ch * 65 + lane] = fmaxf(h0, 0.2f * h0);
+        hs[(ch + 1) * 65 + lane] = fmaxf(h1, 0.2f * h1);
     }
     __builtin_amdgcn_wave_barrier();
     {

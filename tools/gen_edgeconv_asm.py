@@ -25,7 +25,7 @@ from collections import defaultdict
 
 K = 20
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "..", "seggroup_amd", "csrc", "edgeconv_slots_gen.h")
+OUT = os.environ.get("SG_EC_OUT") or os.path.join(HERE, "..", "seggroup_amd", "csrc", "edgeconv_slots_gen.h")
 
 MFMA_TO_READ = 14      # instructions between an MFMA and a non-MFMA reader / overwriter of its D (hipcc: s_nop 11 = 12 states; + margin)
 VALU_TO_MFMA = 3       # instructions between a VALU write and the MFMA reading it (hipcc: s_nop 1 = 2 states)
@@ -401,6 +401,15 @@ def _d_cut(p, m, j, row, sd, xs):
     p.valu("v_cvt_pk_f16_f32 v%d, v%d, v%d" % (m.X1, ds, ds + 1), vr(ds, 2), vr(m.X1), tag="D%d" % j)
     p.valu("v_cvt_pk_f16_f32 v%d, v%d, v%d" % (m.X1 + 1, ds + 2, ds + 3), vr(ds + 2, 2), vr(m.X1 + 1))
     p.valu("v_cvt_pk_f16_f32 v%d, v%d, 0" % (m.X1 + 2, ds + 4), vr(ds + 4), vr(m.X1 + 2))
+    if MIXLO and m is MapS2X:
+        p.valu("v_mov_b32 v%d, v%d" % (m.X0, m.X1), vr(m.X1), vr(m.X0))
+        p.valu("v_mov_b32 v%d, v%d" % (m.X0 + 1, m.X1 + 1), vr(m.X1 + 1), vr(m.X0 + 1))
+        for q in range(5):                                 # lo = rn16(d - hi) as fp16 halves (see _lrelu_cut); the upper half of x1[3] stays 0 (init_outputs)
+            src = m.X1 + q // 2
+            dst = (m.X0 + 2 + q // 2) if q < 4 else (m.X1 + 3)
+            p.valu("v_fma_mix%s_f16 v%d, v%d, -1.0, v%d op_sel:[%d,0,0] op_sel_hi:[1,0,0]" % ("hi" if q & 1 else "lo", dst, src, ds + q, q & 1),
+                   vr(src) + vr(ds + q) + vr(dst), vr(dst))
+        return
     # lo = d - hi (exact in fp32), in place
     for q in range(5):
         src = m.X1 + q // 2
@@ -417,6 +426,8 @@ def init_outputs(p, m):
         p.valu("v_mov_b32 v%d, 0" % (m.STAT_S + q), [], vr(m.STAT_S + q), tag="init" if q == 0 else "")
         p.valu("v_mov_b32 v%d, 0" % (m.STAT_Q + q), [], vr(m.STAT_Q + q))
         p.valu("v_mov_b32 v%d, 0xff800000" % (m.BEST + q), [], vr(m.BEST + q))
+    if MIXLO and m is MapS2X:
+        p.valu("v_mov_b32 v%d, 0" % (m.X1 + 3), [], vr(m.X1 + 3))
 
 
 def id_reg(m, j):
@@ -578,13 +589,27 @@ def _lrelu_cut(p, m, j):
     for kb in range(4):
         r = buf + 8 * kb
         hi = ext if kb == 0 else buf + 8 * (kb - 1) + 4
-        for u in range(8):
+        if LRELU_PK:
+            # 0.2 x for two channels at once (the constant pair sits in SGPRs: VOP3P takes no literal), one v_max each
+            for u in range(0, 8, 2):
+                t = m.TMP
+                p.valu("v_pk_mul_f32 %s, %s, %%[c02]" % (vt(t, 2), vt(r + u, 2)), vr(r + u, 2), vr(t, 2), tag="L%d.%d" % (j, kb))
+                p.valu("v_max_f32 v%d, v%d, v%d" % (r + u, r + u, t), vr(r + u) + vr(t), vr(r + u))
+                p.valu("v_max_f32 v%d, v%d, v%d" % (r + u + 1, r + u + 1, t + 1), vr(r + u + 1) + vr(t + 1), vr(r + u + 1))
+        for u in range(0 if LRELU_PK else 8):
             t = m.TMP + (u % m.NTMP)
             p.valu("v_mul_f32 v%d, 0x3e4ccccd, v%d" % (t, r + u), vr(r + u), vr(t), tag="L%d.%d" % (j, kb))
             p.valu("v_max_f32 v%d, v%d, v%d" % (r + u, r + u, t), vr(r + u) + vr(t), vr(r + u))
         for u in range(4):
             a, b = r + 2 * u, r + 2 * u + 1
             p.valu("v_cvt_pk_f16_f32 v%d, v%d, v%d" % (hi + u, a, b), vr(a) + vr(b), vr(hi + u))
+            if MIXLO:
+                # lo = rn16(x - hi) written as fp16 halves of the destination by the mixed-precision FMA itself (x - hi is exact in fp32,
+                # so the one rounding is cvt_pk's): two instructions per pair instead of three.  A half write keeps the other half: the
+                # destination counts as read.  Order: u ascending, so r+u (= a for u = 0, an already consumed b / a otherwise) is free.
+                p.valu("v_fma_mixlo_f16 v%d, v%d, -1.0, v%d op_sel:[0,0,0] op_sel_hi:[1,0,0]" % (r + u, hi + u, a), vr(hi + u) + vr(a) + vr(r + u), vr(r + u))
+                p.valu("v_fma_mixhi_f16 v%d, v%d, -1.0, v%d op_sel:[1,0,0] op_sel_hi:[1,0,0]" % (r + u, hi + u, b), vr(hi + u) + vr(b) + vr(r + u), vr(r + u))
+                continue
             p.valu("v_fma_mix_f32 v%d, v%d, -1.0, v%d op_sel:[0,0,0] op_sel_hi:[1,0,0]" % (a, hi + u, a), vr(hi + u) + vr(a), vr(a))
             p.valu("v_fma_mix_f32 v%d, v%d, -1.0, v%d op_sel:[1,0,0] op_sel_hi:[1,0,0]" % (b, hi + u, b), vr(hi + u) + vr(b), vr(b))
             p.valu("v_cvt_pk_f16_f32 v%d, v%d, v%d" % (r + u, a, b), vr(a) + vr(b), vr(r + u))
@@ -609,7 +634,14 @@ def conv2(p, m, j):
 def stats_s2x(p, m, j, ot):
     if "S" in OMIT:
         return
-    for q in range(16):
+    for q in range(0, 16 if S2X_PKSTAT else 0, 2):
+        z = m.ACC2 + 16 * ot + q
+        o = 16 * ot + q
+        p.valu("v_pk_add_f32 %s, %s, %s" % (vt(m.STAT_S + o, 2), vt(m.STAT_S + o, 2), vt(z, 2)), vr(m.STAT_S + o, 2) + vr(z, 2), vr(m.STAT_S + o, 2), tag="S%d.%d" % (j, ot) if q == 0 else "")
+        p.valu("v_pk_fma_f32 %s, %s, %s, %s" % (vt(m.STAT_Q + o, 2), vt(z, 2), vt(z, 2), vt(m.STAT_Q + o, 2)), vr(m.STAT_Q + o, 2) + vr(z, 2), vr(m.STAT_Q + o, 2))
+        p.valu("v_max_f32 v%d, v%d, v%d" % (m.BEST + o, m.BEST + o, z), vr(m.BEST + o) + vr(z), vr(m.BEST + o))
+        p.valu("v_max_f32 v%d, v%d, v%d" % (m.BEST + o + 1, m.BEST + o + 1, z + 1), vr(m.BEST + o + 1) + vr(z + 1), vr(m.BEST + o + 1))
+    for q in range(0 if S2X_PKSTAT else 16):
         z = m.ACC2 + 16 * ot + q
         o = 16 * ot + q
         p.valu("v_add_f32 v%d, v%d, v%d" % (m.STAT_S + o, m.STAT_S + o, z), vr(m.STAT_S + o) + vr(z), vr(m.STAT_S + o), tag="S%d.%d" % (j, ot) if q == 0 else "")
@@ -617,6 +649,9 @@ def stats_s2x(p, m, j, ot):
         p.valu("v_max_f32 v%d, v%d, v%d" % (m.BEST + o, m.BEST + o, z), vr(m.BEST + o) + vr(z), vr(m.BEST + o))
 
 
+MIXLO = bool(int(os.environ.get("SG_EC_MIXLO", "0")))             # S2X: the low fp16 pieces of conv2's operand straight from v_fma_mixlo/hi_f16
+LRELU_PK = bool(int(os.environ.get("SG_EC_LRELU_PK", "0")))       # S2X: LeakyReLU's 0.2 x as v_pk_mul_f32 (asm operand %[c02] = the constant twice, in SGPRs)
+S2X_PKSTAT = bool(int(os.environ.get("SG_EC_S2X_PKSTAT", "0")))   # S2X: packed sums / sums of squares
 OMIT = set(x for x in os.environ.get("SG_EC_OMIT", "").split(",") if x)       # timing experiments: leave stages out (results are garbage)
 
 

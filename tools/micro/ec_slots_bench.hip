@@ -53,10 +53,11 @@ __global__ __launch_bounds__(256, 2) void k_slots(const float* __restrict__ x9m,
             const unsigned a_frag = (unsigned)(size_t)(SG_LDS const u32x4*)(&a1p[0][lane]);
             const auto kp = (__attribute__((address_space(1))) const int*)knn;
             const unsigned koff = (unsigned)pt * 80u;
+            const unsigned long long c02 = 0x3e4ccccd3e4ccccdull;             // 0.2f twice: v_pk_mul_f32's constant pair
             asm volatile(SG_EC_S2X_SLOTS
                          : "=&" SG_EC_S2X_STAT_S0(ss0), "=&" SG_EC_S2X_STAT_S1(ss1), "=&" SG_EC_S2X_STAT_Q0(sq0), "=&" SG_EC_S2X_STAT_Q1(sq1),
                            "=&" SG_EC_S2X_BEST0(bb0), "=&" SG_EC_S2X_BEST1(bb1)
-                         : [x9m] "s"(xp), [knn] "s"(kp), [sd] "s"(sd), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
+                         : [c02] "s"(c02), [x9m] "s"(xp), [knn] "s"(kp), [sd] "s"(sd), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
                            [xs0] "v"(xs0), [xs1] "v"(xs1), [xs2] "v"(xs2), [xs3] "v"(xs3), [xs4] "v"(xs4)
                          : "memory", SG_EC_S2X_SLOTS_CLOBBERS);
         } else {

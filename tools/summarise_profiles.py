@@ -70,7 +70,7 @@ if passes:
     fe, wr = passes.get("fetch", {}).get("kernels", {}), passes.get("write", {}).get("kernels", {})
     lines = []
     for k in sorted(set(sq) | set(mf) | set(fe) | set(wr)):
-        if not k.endswith("_b") and "_b<" not in k:
+        if not k.endswith("_b") and "_b<" not in k and "_hb<" not in k:
             continue                                           # batched kernels only (the single-pipeline parity check runs a few unbatched ones)
         name = alias.get(k, k)
         raw = {}

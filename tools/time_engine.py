@@ -42,7 +42,7 @@ for _ in range(a.rounds):
     eng.run(scenes, hip.MODE_INS_INFER)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 ms = eng.mean_stage_ms()
-keys = ["kernel.l2.edgeconv", "kernel.l3.edgeconv", "l2.knn", "l3.knn", "l3.edgeconv.stats1", "mlp1", "fps64", "l2.gather", "l3.gather", "contract_edges"]
+keys = ["kernel.l2.edgeconv", "evaluate", "l2.gcn+dist", "l3.gcn+dist", "dist1+d2h", "kernel.l3.edgeconv", "l2.knn", "l3.knn", "l3.edgeconv.stats1", "mlp1", "fps64", "l2.gather", "l3.gather", "contract_edges"]
 print(json.dumps({"tag": a.tag, "env": {k: v for k, v in os.environ.items() if k.startswith("SG_")}, "scenes_per_s": round(a.rounds * len(scenes) / dt, 1),
                   "us_per_scene": {k: round(ms.get(k, 0.0) * 1e3, 1) for k in keys},
                   "sum_us_per_scene": round(sum(v for k, v in ms.items() if k.count(".") <= 1) * 1e3, 1)}))
