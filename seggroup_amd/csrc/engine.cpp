@@ -110,7 +110,6 @@ struct Run {
     float* o_feat = nullptr;
     uint32_t* o_cnt = nullptr;
     bool dist_in_outbox = true;
-    std::vector<float> big_dist;               // rare: more edges than the outbox holds
     std::vector<double> seg_sums;              // [S,3] kept for the cluster centroids of both layers
     std::vector<int32_t> chunk_off;            // [S+1] first 32-point chunk of every segment (re-shipped with every phase's parameters)
     // fixed carve of the slot's workspaces
@@ -294,12 +293,13 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
         if (E1 > r.cap1) return sg::fail(SG_ENOMEM, "adjacency capacity exceeded (%d > %d)", E1, r.cap1);
         const float* h_dist = r.o_dist;
         if (E1 > r.out_rows) {                                    // rare: denser than the outbox assumes -- fetch the full arrays
-            r.adj.resize(2 * (size_t)E1);
-            r.big_dist.resize(E1);
-            EG_HIP(hipMemcpyAsync(r.adj.data(), r.pl->adj1.p, (size_t)E1 * 8, hipMemcpyDeviceToHost, stream));
-            EG_HIP(hipMemcpyAsync(r.big_dist.data(), r.pl->dist.p, (size_t)E1 * 4, hipMemcpyDeviceToHost, stream));
+            // into the pipeline's PINNED landing buffers (sized for the adjacency capacity): a pageable destination makes the copy a
+            // staged, synchronous one on the group's stream
+            EG_HIP(hipMemcpyAsync(r.pl->h_adj.p, r.pl->adj1.p, (size_t)E1 * 8, hipMemcpyDeviceToHost, stream));
+            EG_HIP(hipMemcpyAsync(r.pl->h_dist.p, r.pl->dist.p, (size_t)E1 * 4, hipMemcpyDeviceToHost, stream));
             EG_HIP(timed_sync(stream));
-            h_dist = r.big_dist.data();
+            r.adj.assign(r.pl->h_adj.p, r.pl->h_adj.p + 2 * (size_t)E1);
+            h_dist = r.pl->h_dist.p;
         } else {
             r.adj.assign(r.o_adj1, r.o_adj1 + 2 * (size_t)E1);
         }
@@ -500,8 +500,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
         if (!r.dist_in_outbox) {
-            r.big_dist.resize(r.E);
-            EG_HIP(hipMemcpyAsync(r.big_dist.data(), r.pl->dist.p, (size_t)r.E * 4, hipMemcpyDeviceToHost, stream));
+            EG_HIP(hipMemcpyAsync(r.pl->h_dist.p, r.pl->dist.p, (size_t)r.E * 4, hipMemcpyDeviceToHost, stream));     // pinned (see above)
         }
     }
     mark(sb + 5);
@@ -512,7 +511,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
         Run& r = runs_[i];
         const int Dcat = r.feat_prev_dim + 64;
         r.Lcur = r.Lnew;
-        EG_CHECK(regroup(r, r.dist_in_outbox ? r.o_dist : r.big_dist.data(), 2.0f));
+        EG_CHECK(regroup(r, r.dist_in_outbox ? r.o_dist : r.pl->h_dist.p, 2.0f));
         r.out->trace[2 + layer] = r.Lnew.C;
         EG_CHECK(tables_for(r, 6 + 3 * layer, true));             // layer_3.* / layer_4.*
         // next layer: previous features = this GCN output (featB); its concat goes to featA again and its GCN output back

@@ -59,6 +59,8 @@ void sg_pipeline_destroy(sg_pipeline* pl) {
     if (!pl) return;
     for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(pl->ev[i]);
     if (pl->ev_count) (void)hipEventDestroy(pl->ev_count);
+    if (pl->ev_side) (void)hipEventDestroy(pl->ev_side);
+    if (pl->side) (void)hipStreamDestroy(pl->side);
     delete pl;
 }
 
@@ -83,6 +85,11 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     for (int i = 0; i < kNumEvents; ++i)
         if (hipEventCreate(&pl->ev[i]) != hipSuccess) { sg::fail(SG_EHIP, "hipEventCreate failed"); return nullptr; }
     if (hipEventCreateWithFlags(&pl->ev_count, hipEventDisableTiming) != hipSuccess) { sg::fail(SG_EHIP, "hipEventCreate failed"); return nullptr; }
+    if (hipEventCreateWithFlags(&pl->ev_side, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking) != hipSuccess) {
+        sg::fail(SG_EHIP, "sg_pipeline_create: side stream / event creation failed");
+        sg_pipeline_destroy(pl.release());
+        return nullptr;
+    }
     for (float& m : pl->stage_ms) m = 0.f;
 
     int bad = 0;
@@ -210,9 +217,42 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
         return sg::fail(SG_EUNSUP, "weak instance ids up to %d exceed the pipeline's metric workspace (max_segments + 2)", max_ins - 2);
 
     int32_t* tab = pl->h_tables.p;                       // [14,S]
-    auto tables_for = [&](int first_row, bool with_seg) {
+    // The label vectors of a layer leave as soon as its tables exist: table rows H2D, k_export for those rows, vectors D2H -- all on the
+    // pipeline's second stream, beside the next layer's kernels (one scene alone used to wait for 8.4 MB / 28 MB of labels to cross PCIe
+    // behind its last kernel: 0.17 / 0.55 ms at 150k / 500k points).  The rows of h_tables / tables / labels of different layers are disjoint.
+    hipStream_t side = pl->side;
+    struct SideGuard {                                     // an early return must not leave copies into out->h_labels in flight
+        hipStream_t s;
+        ~SideGuard() { (void)hipStreamSynchronize(s); }
+    } side_guard{side};
+    SG_HIP(hipEventRecord(pl->ev_side, st));               // the scene's arrays are ready for `st`: so they are for `side`
+    SG_HIP(hipStreamWaitEvent(side, pl->ev_side, 0));
+    // tables_for() only fills the host rows (the partition changes with the next grouping pass); the second stream's calls -- ~20 API calls per
+    // scene -- are issued by flush_exports() right in front of the NEXT stream sync, i.e. while the layer just launched runs (issued where the
+    // tables are made they cost a scene 0.24 ms of host time with the GPU idle)
+    int pend_row[5], pend_rows[5], npend = 0;
+    auto tables_for = [&](int first_row, bool with_seg) -> int {
         int32_t* a = tab + (size_t)first_row * S;
-        return sg_partition_export_tables(part, with_seg ? a : nullptr, with_seg ? a + S : a, with_seg ? a + 2 * (size_t)S : a + S);
+        const int rc = sg_partition_export_tables(part, with_seg ? a : nullptr, with_seg ? a + S : a, with_seg ? a + 2 * (size_t)S : a + S);
+        if (rc < 0) return rc;
+        pend_row[npend] = first_row; pend_rows[npend] = with_seg ? 3 : 2; ++npend;
+        return SG_OK;
+    };
+    auto flush_exports = [&](bool last) -> int {
+        for (int i = 0; i < npend; ++i) {
+            const int rows = pend_rows[i];
+            const size_t t0 = (size_t)pend_row[i] * S, l0 = (size_t)pend_row[i] * V;
+            if (hipMemcpyAsync(pl->tables.p + t0, tab + t0, (size_t)rows * S * 4, hipMemcpyHostToDevice, side) != hipSuccess)
+                return sg::fail(SG_EHIP, "label tables: H2D failed");
+            const int rc2 = sg_export_labels(sc->d_unmap, V, sc->d_seg_of_point, N, pl->tables.p + t0, rows, S, pl->labels.p + l0, (void*)side);
+            if (rc2 < 0) return rc2;
+            if (last && i == npend - 1 && hipEventRecord(pl->ev_side, side) != hipSuccess)       // behind the LAST export kernel: the metric kernels wait for it
+                return sg::fail(SG_EHIP, "label tables: event record failed");
+            if (hipMemcpyAsync(out->h_labels + l0, pl->labels.p + l0, (size_t)rows * V * 4, hipMemcpyDeviceToHost, side) != hipSuccess)
+                return sg::fail(SG_EHIP, "label vectors: D2H failed");
+        }
+        npend = 0;
+        return SG_OK;
     };
 
     // ---------------- graph initialisation + structural grouping layer (model.py:710-783) ---------------
@@ -264,6 +304,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     freeze_layer(part, S, Lcur);                          // layer 1: every segment its own cluster
     out->trace[0] = Lcur.C;
     PL_CHECK(tables_for(0, true));                        // layer_1.{seg,ins,sem}
+    PL_CHECK(flush_exports(false));
     lap(2);
     PL_HIP(timed_sync(st));
     lap(-1);
@@ -483,6 +524,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
                 PL_HIP(hipMemcpyAsync(TL.bn_last.p, affine[2], 128 * 4, hipMemcpyDeviceToDevice, st));
             }
             pl->mark(sb + 5);
+            PL_CHECK(flush_exports(false));                  // the finished layers' label rows, beside this layer's kernels
             lap(4);
             PL_HIP(timed_sync(st));
             lap(-1);
@@ -590,15 +632,16 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
 
     // ---------------- export + evaluate (model.py:525-655) -------------------------------------------
     pl->mark(-1);
-    PL_HIP(hipMemcpyAsync(pl->tables.p, tab, (size_t)n_tables * S * 4, hipMemcpyHostToDevice, st));
-    PL_CHECK(sg_export_labels(sc->d_unmap, V, sc->d_seg_of_point, N, pl->tables.p, n_tables, S, pl->labels.p, stv));
-    PL_HIP(hipMemcpyAsync(out->h_labels, pl->labels.p, (size_t)n_tables * V * 4, hipMemcpyDeviceToHost, st));
+    (void)n_tables;
+    PL_CHECK(flush_exports(true));                         // whatever is left (at least the final rows)
+    PL_HIP(hipStreamWaitEvent(st, pl->ev_side, 0));        // the metric kernels read the LAST exported rows on the device
     pl->mark(17);
     PL_CHECK(sg_evaluate(sc->d_gt, pl->labels.p + (size_t)sem_row * V, pl->labels.p + (size_t)ins_row * V, V, max_ins, out->iou_sem,
                          out->iou_ins, out->acc, pl->ws_eval.p, pl->ws_eval.n, stv));
     pl->mark(18);
     lap(6);
     PL_HIP(timed_sync(st));
+    PL_HIP(timed_sync(side));                             // the last rows' D2H
     lap(-1);
     sg_partition_destroy(part);
     part = nullptr;

@@ -65,6 +65,10 @@ struct sg_pipeline {
 
     hipEvent_t ev[sgp::kNumEvents];
     hipEvent_t ev_count = nullptr;      // behind the D2H of the contracted edge count: the host waits for THAT, not for the whole structural layer
+    // label rows leave as soon as their tables exist (round 4): H2D of a layer's table rows, the export kernel for them and the D2H of the vectors run
+    // on this second stream while the next layer computes; ev_side orders it behind the scene's start and the metric kernels behind the last export
+    hipStream_t side = nullptr;
+    hipEvent_t ev_side = nullptr;
     int ev_stage[sgp::kNumEvents];
     int n_ev = 0;
     float stage_ms[sgp::kNumStages];

@@ -48,18 +48,22 @@ __global__ __launch_bounds__(256, 2) void k_slots(const float* __restrict__ x9m,
         const unsigned l16 = 16u * (unsigned)half;
         const long long t0 = __builtin_readcyclecounter();
         const long long r0 = __builtin_amdgcn_s_memrealtime();
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 2 || MODE == 4) {
             const unsigned a_base = (unsigned)(size_t)(SG_LDS const float4*)(&bl[wave][0][lane]);
             const unsigned a_frag = (unsigned)(size_t)(SG_LDS const u32x4*)(&a1p[0][lane]);
             const auto kp = (__attribute__((address_space(1))) const int*)knn;
             const unsigned koff = (unsigned)pt * 80u;
             const unsigned long long c02 = 0x3e4ccccd3e4ccccdull;             // 0.2f twice: v_pk_mul_f32's constant pair
-            asm volatile(SG_EC_S2X_SLOTS
-                         : "=&" SG_EC_S2X_STAT_S0(ss0), "=&" SG_EC_S2X_STAT_S1(ss1), "=&" SG_EC_S2X_STAT_Q0(sq0), "=&" SG_EC_S2X_STAT_Q1(sq1),
-                           "=&" SG_EC_S2X_BEST0(bb0), "=&" SG_EC_S2X_BEST1(bb1)
-                         : [c02] "s"(c02), [x9m] "s"(xp), [knn] "s"(kp), [sd] "s"(sd), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
-                           [xs0] "v"(xs0), [xs1] "v"(xs1), [xs2] "v"(xs2), [xs3] "v"(xs3), [xs4] "v"(xs4)
-                         : "memory", SG_EC_S2X_SLOTS_CLOBBERS);
+#define SG_S2X_STATEMENT(prefix) \
+            asm volatile(prefix SG_EC_S2X_SLOTS \
+                         : "=&" SG_EC_S2X_STAT_S0(ss0), "=&" SG_EC_S2X_STAT_S1(ss1), "=&" SG_EC_S2X_STAT_Q0(sq0), "=&" SG_EC_S2X_STAT_Q1(sq1), \
+                           "=&" SG_EC_S2X_BEST0(bb0), "=&" SG_EC_S2X_BEST1(bb1) \
+                         : [c02] "s"(c02), [x9m] "s"(xp), [knn] "s"(kp), [sd] "s"(sd), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag), \
+                           [xs0] "v"(xs0), [xs1] "v"(xs1), [xs2] "v"(xs2), [xs3] "v"(xs3), [xs4] "v"(xs4) \
+                         : "memory", SG_EC_S2X_SLOTS_CLOBBERS)
+            // MODE 4: two textual copies of the statement taken in turn -- twice the code (2 x 52 KB against a 64 KB instruction cache per two CUs)
+            if (MODE == 4 && (trip & 1)) SG_S2X_STATEMENT("; second copy\n\t");
+            else SG_S2X_STATEMENT("");
         } else {
             f32x16 base0, base1;
             for (int q = 0; q < 16; ++q) { base0[q] = 0.01f * q + 0.001f * lane; base1[q] = -0.02f * q; }
@@ -121,6 +125,8 @@ int main() {
     for (int fresh = 0; fresh < 2; ++fresh) {
         run<2>("S2X (MLP3) 2 waves/SIMD", dx, dk, ntiles, dout, dcyc, 512, fresh);
         run<2>("S2X (MLP3) 1 wave/SIMD", dx, dk, ntiles, dout, dcyc, 256, fresh);
+        run<4>("S2X two copies 2 w/SIMD", dx, dk, ntiles, dout, dcyc, 512, fresh);
+        run<4>("S2X two copies 1 w/SIMD", dx, dk, ntiles, dout, dcyc, 256, fresh);
         run<1>("S1X plain  2 waves/SIMD", dx, dk, ntiles, dout, dcyc, 512, fresh);
         run<3>("S1X packed 2 waves/SIMD", dx, dk, ntiles, dout, dcyc, 512, fresh);
         run<1>("S1X plain  1 wave/SIMD", dx, dk, ntiles, dout, dcyc, 256, fresh);
