@@ -257,6 +257,29 @@ def test_determinism_same_scene_twice(golden_index, weight_sets):
     assert np.array_equal(la, b.labels) and np.array_equal(a.iou_ins, b.iou_ins)
 
 
+def test_results_of_consecutive_forwards_on_one_pipeline_do_not_alias(golden_index, weight_sets):
+    """Pipeline.forward hands out the pinned block the library filled (no copy): a held result must survive the pipeline's later forwards, and
+    the rows exported per layer on the second stream must all have landed when forward returns (both modes: 14 and 6 vectors)."""
+    from seggroup_amd import hip
+    from seggroup_amd.scene import DeviceScene
+    small = make_fixture_scene(golden_index, "small_20k")
+    tiny = make_fixture_scene(golden_index, "tiny_4k")
+    first, _, pipe = _run(small, weight_sets["ins_infer"], "ins_infer")
+    want = first.labels.copy()
+    assert want.shape[0] == 14 and (want[12:] >= -1).all()
+    d_small, d_tiny = DeviceScene.from_synthetic(small, device="cuda:0"), DeviceScene.from_synthetic(tiny, device="cuda:0")
+    held = [first]
+    for k in range(6):                                    # smaller scene, other mode, the same scene again
+        held.append(pipe.forward(d_tiny if k % 2 == 0 else d_small, hip.MODE_SEM_INFER if k % 3 == 0 else hip.MODE_INS_INFER))
+    assert np.array_equal(first.labels, want)
+    again = [r for k, r in enumerate(held[1:]) if k % 2 == 1 and k % 3 != 0]
+    assert again and all(np.array_equal(r.labels, want) for r in again)
+    sem = [r for k, r in enumerate(held[1:]) if k % 2 == 0 and k % 3 == 0]
+    ins = [r for k, r in enumerate(held[1:]) if k % 2 == 0 and k % 3 != 0]
+    assert sem and ins and sem[0].n_vectors == 6 and sem[0].labels.shape[1] == d_tiny.V
+    assert all(np.array_equal(r.labels, ins[0].labels) for r in ins)
+
+
 def test_dropin_forward_and_driver_write_reference_files(tmp_path, golden_index, weight_sets, monkeypatch):
     """The reference's entry points: SegModel.forward(data, weak_label, info) reading the reference's
     on-disk tree by scene name, and `infer.py --ins_infer` with a reference-layout checkpoint; the 14

@@ -30,6 +30,8 @@ net.epoch = "ins_infer"
 ds = DeviceScene.from_synthetic(sc, "cuda:0")
 pipe = net.pipeline_for(ds)
 print("pipeline device MB %.1f" % (pipe.device_bytes() / 1e6))
+if os.environ.get("SG_KNN_VARIANT"):                      # 1 / 2 / 4 waves per tile of the one-pass kernel, 0 = two-pass, 8 = one wave + seeded layer 3
+    hip.lib().sg_pipeline_set_knn_variant(pipe.handle, int(os.environ["SG_KNN_VARIANT"]))
 walls, st = [], {}
 for it in range(iters):
     torch.cuda.synchronize()
