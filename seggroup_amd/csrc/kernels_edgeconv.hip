@@ -694,12 +694,13 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) st[r * 65 + acc_channel(t, q, half)] = best[t][q] * unscale;
+                for (int q = 0; q < 16; ++q) st[r * 65 + acc_channel(t, q, half)] = best[t][q];     // x unscale (> 0) behind the maximum: monotone, same bits
             __builtin_amdgcn_wave_barrier();
             const int rows_here = min(32, N - tile * 32);
             int cprev = __builtin_amdgcn_readfirstlane(myc);
             float m = -INFINITY;
             auto flush = [&](int c, float v) {
+                v *= unscale;                                     // one multiply per (cluster, channel) instead of 32 per lane and tile
                 float* addr = (float*)(ext + (size_t)c * ext_stride + lane);
                 // order-preserving integer view: non-negative floats compare as ints, negative floats reversed as uints
                 if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));

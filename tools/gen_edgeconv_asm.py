@@ -422,10 +422,12 @@ def _d_cut(p, m, j, row, sd, xs):
 
 
 def init_outputs(p, m):
-    for q in range(32):
-        p.valu("v_mov_b32 v%d, 0" % (m.STAT_S + q), [], vr(m.STAT_S + q), tag="init" if q == 0 else "")
-        p.valu("v_mov_b32 v%d, 0" % (m.STAT_Q + q), [], vr(m.STAT_Q + q))
-        p.valu("v_mov_b32 v%d, 0xff800000" % (m.BEST + q), [], vr(m.BEST + q))
+    if S2X_PKSTAT and m is MapS2X:                       # (experiment knob: the packed S2X statistics still accumulate from slot 0)
+        for q in range(32):
+            p.valu("v_mov_b32 v%d, 0" % (m.STAT_S + q), [], vr(m.STAT_S + q), tag="init" if q == 0 else "")
+            p.valu("v_mov_b32 v%d, 0" % (m.STAT_Q + q), [], vr(m.STAT_Q + q))
+            p.valu("v_mov_b32 v%d, 0xff800000" % (m.BEST + q), [], vr(m.BEST + q))
+    # otherwise nothing to initialise: slot 0's statistics WRITE the sums, sums of squares and maxima (stats_s1x / stats_s2x)
     if MIXLO and m is MapS2X:
         p.valu("v_mov_b32 v%d, 0" % (m.X1 + 3), [], vr(m.X1 + 3))
 
@@ -498,9 +500,21 @@ def program_s1x(pk_stats):
 
 
 def stats_s1x(p, m, j, pk):
+    """slot j's 32 outputs into the running sums / sums of squares / maxima.  Slot 0 WRITES them (0 + y, y * y, y: the same bits as adding to
+    zeroed registers, without the 96 v_mov of an initialisation per tile)"""
     acc = m.ACC[j & 1]
     for q in range(0, 32, 2):
         y0, y1 = acc + q, acc + q + 1
+        if j == 0:
+            for y in (y0, y1):
+                o = y - acc
+                p.valu("v_add_f32 v%d, 0, v%d" % (m.STAT_S + o, y), vr(y), vr(m.STAT_S + o), tag="S%d" % j)
+                if not pk:
+                    p.valu("v_mul_f32 v%d, v%d, v%d" % (m.STAT_Q + o, y, y), vr(y), vr(m.STAT_Q + o))
+                p.valu("v_mov_b32 v%d, v%d" % (m.BEST + o, y), vr(y), vr(m.BEST + o))
+            if pk:
+                p.valu("v_pk_mul_f32 %s, %s, %s" % (vt(m.STAT_Q + q, 2), vt(y0, 2), vt(y0, 2)), vr(y0, 2), vr(m.STAT_Q + q, 2))
+            continue
         if pk:
             p.valu("v_pk_add_f32 %s, %s, %s" % (vt(m.STAT_S + q, 2), vt(m.STAT_S + q, 2), vt(y0, 2)), vr(m.STAT_S + q, 2) + vr(y0, 2), vr(m.STAT_S + q, 2), tag="S%d" % j)
             p.valu("v_pk_fma_f32 %s, %s, %s, %s" % (vt(m.STAT_Q + q, 2), vt(y0, 2), vt(y0, 2), vt(m.STAT_Q + q, 2)), vr(m.STAT_Q + q, 2) + vr(y0, 2), vr(m.STAT_Q + q, 2))
@@ -641,7 +655,13 @@ def stats_s2x(p, m, j, ot):
         p.valu("v_pk_fma_f32 %s, %s, %s, %s" % (vt(m.STAT_Q + o, 2), vt(z, 2), vt(z, 2), vt(m.STAT_Q + o, 2)), vr(m.STAT_Q + o, 2) + vr(z, 2), vr(m.STAT_Q + o, 2))
         p.valu("v_max_f32 v%d, v%d, v%d" % (m.BEST + o, m.BEST + o, z), vr(m.BEST + o) + vr(z), vr(m.BEST + o))
         p.valu("v_max_f32 v%d, v%d, v%d" % (m.BEST + o + 1, m.BEST + o + 1, z + 1), vr(m.BEST + o + 1) + vr(z + 1), vr(m.BEST + o + 1))
-    for q in range(0 if S2X_PKSTAT else 16):
+    for q in range(16 if (j == 0 and not S2X_PKSTAT) else 0):           # slot 0 writes (see stats_s1x)
+        z = m.ACC2 + 16 * ot + q
+        o = 16 * ot + q
+        p.valu("v_add_f32 v%d, 0, v%d" % (m.STAT_S + o, z), vr(z), vr(m.STAT_S + o), tag="S%d.%d" % (j, ot) if q == 0 else "")
+        p.valu("v_mul_f32 v%d, v%d, v%d" % (m.STAT_Q + o, z, z), vr(z), vr(m.STAT_Q + o))
+        p.valu("v_mov_b32 v%d, v%d" % (m.BEST + o, z), vr(z), vr(m.BEST + o))
+    for q in range(0 if (S2X_PKSTAT or j == 0) else 16):
         z = m.ACC2 + 16 * ot + q
         o = 16 * ot + q
         p.valu("v_add_f32 v%d, v%d, v%d" % (m.STAT_S + o, m.STAT_S + o, z), vr(m.STAT_S + o) + vr(z), vr(m.STAT_S + o), tag="S%d.%d" % (j, ot) if q == 0 else "")
