@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -32,6 +33,12 @@
 namespace {
 
 struct ArrayRef { size_t off = 0, bytes = 0; bool found = false; };
+
+// packs store the [E0,2] adjacency as int32 (half of a pack's bytes were the int64 form: 8.6 of 17 MB at 150k points); the library's
+// kernels take the reference's int64 rows (model.py:724), so the loader widens them on the device, behind the upload on its own stream
+__global__ void k_widen_adj(const int32_t* __restrict__ src, long long* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (long long)src[i];
+}
 
 // the header is written by json.dumps: {"name": "...", "N": n, ..., "arrays": {"data": ["<f4", [N, 6], off], ...}}
 bool find_int(const std::string& h, const char* key, long long* out) {
@@ -104,7 +111,8 @@ struct sg_loader {
     };
     struct Job { int ticket = 0; std::string path; int slot = -1; int rc = 0; std::string err; bool done = false; sg_scene sc{}; };
     int device = 0;
-    size_t slot_bytes = 0;
+    size_t slot_bytes = 0;              // a pack's bytes (pinned read buffer of every worker)
+    size_t blob_bytes = 0;              // a device slot: the pack + its adjacency widened to int64 (at most the pack's size again)
     std::vector<Slot> slots;
     std::deque<int> free_slots;
     std::deque<std::shared_ptr<Job>> queue;
@@ -168,7 +176,8 @@ struct sg_loader {
         ArrayRef a[11];
         for (int i = 0; i < 11; ++i)
             if (!find_array(hdr, kNames[i], &a[i])) return sg::fail(SG_EINVAL, "sg_loader: %s: array %s missing from the header", j.path.c_str(), kNames[i]);
-        const size_t expect[11] = {(size_t)N * 24, (size_t)E0 * 16, (size_t)N * 4, (size_t)N * 4, (size_t)(S + 1) * 4, (size_t)V * 4, (size_t)V * 8,
+        const bool adj32 = a[1].bytes == (size_t)E0 * 8 && E0 > 0;                       // int32 pairs (packs written from round 4 on) | int64 pairs
+        const size_t expect[11] = {(size_t)N * 24, adj32 ? (size_t)E0 * 8 : (size_t)E0 * 16, (size_t)N * 4, (size_t)N * 4, (size_t)(S + 1) * 4, (size_t)V * 4, (size_t)V * 8,
                                    (size_t)S * 4, (size_t)S * 4, (size_t)S * 4, (size_t)S * 4};
         for (int i = 0; i < 11; ++i)
             if (a[i].bytes != expect[i]) return sg::fail(SG_EINVAL, "sg_loader: %s: array %s has %zu bytes, expected %zu", j.path.c_str(), kNames[i], a[i].bytes, expect[i]);
@@ -177,6 +186,9 @@ struct sg_loader {
         const size_t base = 12 + (size_t)hlen;
         const size_t size = (size_t)stt.st_size - base;
         if (size > slot_bytes) return sg::fail(SG_ENOMEM, "sg_loader: %s holds %zu bytes, a slot %zu", j.path.c_str(), size, slot_bytes);
+        const size_t wide_off = (size + 255) / 256 * 256;                                  // the widened adjacency sits behind the file's bytes
+        if (adj32 && wide_off + (size_t)E0 * 16 > blob_bytes)
+            return sg::fail(SG_ENOMEM, "sg_loader: %s: no room for the widened adjacency (%zu + %zu > %zu)", j.path.c_str(), wide_off, (size_t)E0 * 16, blob_bytes);
         for (int i = 0; i < 11; ++i)
             if (a[i].off + a[i].bytes > size) return sg::fail(SG_EINVAL, "sg_loader: %s: array %s runs past the end of the file", j.path.c_str(), kNames[i]);
         size_t got = 0;
@@ -188,6 +200,12 @@ struct sg_loader {
         }
         // one upload; the arrays are typed views into the slot's blob (every array starts on a 64-byte boundary of the file)
         if (hipMemcpyAsync(sl.d_blob, pin, size, hipMemcpyHostToDevice, st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
+        if (adj32) {
+            const size_t n2 = (size_t)E0 * 2;
+            k_widen_adj<<<(unsigned)std::min<size_t>((n2 + 255) / 256, 1024), 256, 0, st>>>(reinterpret_cast<const int32_t*>(sl.d_blob + a[1].off),
+                                                                                         reinterpret_cast<long long*>(sl.d_blob + wide_off), n2);
+            if (hipGetLastError() != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: widening the adjacency of %s failed", j.path.c_str());
+        }
         auto host = [&](int i, std::vector<int32_t>& v) { v.resize((size_t)S); memcpy(v.data(), pin + a[i].off, (size_t)S * 4); };
         host(7, sl.seg_first); host(8, sl.seg_size); host(9, sl.seg_ins); host(10, sl.seg_sem);
         // seg_of_vertex[v] = seg_of_point[unmap[v]] (-1 where unmap[v] is not a point): the host-side look-up of the compact label transfer
@@ -201,7 +219,7 @@ struct sg_loader {
         sg_scene& sc = j.sc;
         sc.N = (int)N; sc.S = (int)S; sc.E0 = (int)E0; sc.V = (int)V;
         sc.d_data = reinterpret_cast<const float*>(sl.d_blob + a[0].off);
-        sc.d_adj = reinterpret_cast<const int64_t*>(sl.d_blob + a[1].off);
+        sc.d_adj = reinterpret_cast<const int64_t*>(sl.d_blob + (adj32 ? wide_off : a[1].off));
         sc.d_seg_of_point = reinterpret_cast<const int32_t*>(sl.d_blob + a[2].off);
         sc.d_seg_points = reinterpret_cast<const int32_t*>(sl.d_blob + a[3].off);
         sc.d_seg_off = reinterpret_cast<const int32_t*>(sl.d_blob + a[4].off);
@@ -220,10 +238,11 @@ sg_loader* sg_loader_create(int threads, int slots, size_t slot_bytes) {
     auto* L = new sg_loader();
     if (hipGetDevice(&L->device) != hipSuccess) { sg::fail(SG_EHIP, "sg_loader_create: no HIP device"); delete L; return nullptr; }
     L->slot_bytes = (slot_bytes + 4095) / 4096 * 4096;
+    L->blob_bytes = 2 * L->slot_bytes + 4096;
     L->slots.resize((size_t)slots);
     for (int i = 0; i < slots; ++i) {
-        if (hipMalloc((void**)&L->slots[i].d_blob, L->slot_bytes) != hipSuccess) {
-            sg::fail(SG_ENOMEM, "sg_loader_create: cannot allocate %d device slots of %zu bytes", slots, L->slot_bytes);
+        if (hipMalloc((void**)&L->slots[i].d_blob, L->blob_bytes) != hipSuccess) {
+            sg::fail(SG_ENOMEM, "sg_loader_create: cannot allocate %d device slots of %zu bytes", slots, L->blob_bytes);
             for (auto& s : L->slots) if (s.d_blob) (void)hipFree(s.d_blob);
             delete L;
             return nullptr;
