@@ -20,22 +20,29 @@ struct sg_partition {
     std::vector<int32_t> owner;               // find(): root segment of every segment
     std::vector<int64_t> ins, sem;            // per root segment (stale on dead roots, like the reference)
     std::vector<double> npts;                 // point_num (float64 in the reference, model.py:176)
-    std::vector<std::vector<int32_t>> segs;   // ordered member segments of each live root
+    // ordered member segments of each live root as singly linked lists over the segment ids (head[r] < 0: dead root).  Round 4: S small
+    // vectors cost a scene 1,500 allocations when the partition is built and as many frees when it goes, plus a copy per union
+    // (0.1 ms of a 1.9 ms single-scene forward, 0.36 ms at 5,000 segments); appending list a to list b is two stores here
+    std::vector<int32_t> head, tail, next;
+
+    bool live(int r) const { return head[r] >= 0; }
 
     bool unite(int a, int b) {                // DisjointSet.union(id1=a, id2=b), model.py:181-192
         if (a == b) return false;
         const int64_t ia = ins[a], ib = ins[b];
         if (ia != -1 && ib != -1 && ia != ib) return false;      // label veto (184-185)
-        const bool moved = !segs[a].empty();
-        for (int32_t s : segs[a]) owner[s] = b;                  // 186
+        const bool moved = head[a] >= 0;
+        for (int32_t s = head[a]; s >= 0; s = next[s]) owner[s] = b;   // 186
         npts[b] += npts[a];                                      // 187 (also for stale dead roots)
         if (ia != ib) {                                          // 188-190
             ins[b] = -ia * ib;
             sem[b] = -sem[a] * sem[b];
         }
-        if (moved) {                                             // 191-192
-            segs[b].insert(segs[b].end(), segs[a].begin(), segs[a].end());
-            segs[a].clear();                                     // (capacity kept: a free() per union was a tenth of a layer's host time)
+        if (moved) {                                             // 191-192: b's members first, then a's, both in their own order
+            if (head[b] < 0) head[b] = head[a];
+            else next[tail[b]] = head[a];
+            tail[b] = tail[a];
+            head[a] = -1;
         }
         return moved;
     }
@@ -45,7 +52,7 @@ struct sg_partition {
         num_of_root.assign(S, -1);
         int c = 0;
         for (int r = 0; r < S; ++r)
-            if (!segs[r].empty()) num_of_root[r] = c++;
+            if (head[r] >= 0) num_of_root[r] = c++;
         return c;
     }
 };
@@ -72,10 +79,10 @@ sg_partition* sg_partition_create(int S, const int32_t* h_seg_first, const int32
     p->ins.assign(h_seg_ins, h_seg_ins + S);
     p->sem.assign(h_seg_sem, h_seg_sem + S);
     p->npts.resize(S);
-    p->segs.resize(S);
+    p->head.resize(S); p->tail.resize(S); p->next.assign(S, -1);
     for (int s = 0; s < S; ++s) {
         p->npts[s] = (double)h_seg_size[s];
-        p->segs[s].assign(1, s);
+        p->head[s] = p->tail[s] = s;
     }
     return p;
 }
@@ -85,7 +92,7 @@ void sg_partition_destroy(sg_partition* p) { delete p; }
 int sg_partition_num_clusters(const sg_partition* p) {
     if (!p) return sg::fail(SG_EINVAL, "null partition");
     int c = 0;
-    for (int r = 0; r < p->S; ++r) c += !p->segs[r].empty();
+    for (int r = 0; r < p->S; ++r) c += p->head[r] >= 0;
     return c;
 }
 
@@ -112,11 +119,11 @@ int sg_partition_layer(const sg_partition* p, int32_t* h_root, int32_t* h_cl_of_
     if (!p) return sg::fail(SG_EINVAL, "null partition");
     int c = 0, so = 0, po = 0;
     for (int r = 0; r < p->S; ++r) {
-        if (p->segs[r].empty()) continue;
+        if (p->head[r] < 0) continue;
         if (h_root) h_root[c] = r;
         if (h_cl_seg_off) h_cl_seg_off[c] = so;
         if (h_cl_pt_off) h_cl_pt_off[c] = po;
-        for (int32_t s : p->segs[r]) {
+        for (int32_t s = p->head[r]; s >= 0; s = p->next[s]) {
             if (h_cl_of_seg) h_cl_of_seg[s] = c;
             if (h_order) h_order[so] = s;
             if (h_dst) h_dst[so] = po;
