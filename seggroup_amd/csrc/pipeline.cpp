@@ -239,6 +239,13 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
         return SG_OK;
     };
     auto flush_exports = [&](bool last) -> int {
+        for (int i = 0; i + 1 < npend;) {                   // consecutive row ranges leave as one (layer_4.* + final.* at the end: five rows, three calls)
+            if (pend_row[i] + pend_rows[i] == pend_row[i + 1]) {
+                pend_rows[i] += pend_rows[i + 1];
+                for (int k = i + 1; k + 1 < npend; ++k) { pend_row[k] = pend_row[k + 1]; pend_rows[k] = pend_rows[k + 1]; }
+                --npend;
+            } else ++i;
+        }
         for (int i = 0; i < npend; ++i) {
             const int rows = pend_rows[i];
             const size_t t0 = (size_t)pend_row[i] * S, l0 = (size_t)pend_row[i] * V;
