@@ -163,7 +163,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     // kAsm, MLP3: the stage strip holds the point's base accumulator during the slot loop ([8][64] float4); the asm reads the neighbour ids
     // straight from the kNN table (one global load per slot, a slot ahead): no LDS is left for an id strip at two workgroups per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, half = lane >> 5;
+    [[maybe_unused]] const int r = lane & 31, half = lane >> 5;      // (shadowed inside the walk: re-derived from the laundered thread id)
     EcStamp stamp;
     stamp.start(kAsm ? MODE : 0);
     // the two scales of the fp16 conv1
@@ -289,7 +289,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     const int tile = grp * kWaves + wave;
     const int pt = tile * 32 + r;
     const bool valid = pt < N;
-    const float vmask = valid ? 1.f : 0.f;
+    [[maybe_unused]] const float vmask = valid ? 1.f : 0.f;
     const int ptc = valid ? pt : 0;
     float4 nq0, nq1, nq2;                                       // the next tile's own row (requested behind the slot loop)
 

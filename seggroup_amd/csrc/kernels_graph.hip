@@ -338,6 +338,10 @@ __global__ void k_export(const int32_t* __restrict__ unmap, int V, const int32_t
                          const int32_t* __restrict__ tables, int T, int S, int32_t* __restrict__ out) {
     export_body(unmap, V, seg_of_point, N, tables, T, S, out, blockIdx.x, gridDim.x);
 }
+__global__ void k_eval_clear(uint32_t* __restrict__ cnt, int n0, int n1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n1) cnt[i] = i < n0 ? 0u : 0xffffffffu;
+}
 // also resets the metric counters the evaluate kernels of the same phase accumulate into (saves two memset launches)
 __global__ void k_export_b(const SlotCtx* __restrict__ cx) {
     const SlotCtx& c = cx[blockIdx.y];
@@ -624,28 +628,43 @@ int sg_export_labels(const int32_t* d_unmap, int V, const int32_t* d_seg_of_poin
     return SG_OK;
 }
 
-size_t sg_eval_ws_bytes(int max_ins) { return sg::align_up((size_t)(128 + 5 * (size_t)std::max(max_ins, 1)) * 4); }
+}  // extern "C"
 
-int sg_evaluate(const int32_t* d_gt, const int32_t* d_sem_pred, const int32_t* d_ins_pred, int V, int max_ins,
-                float* h_iou_sem, float* h_iou_ins, float* h_acc, void* d_ws, size_t ws_bytes, void* stream) {
-    SG_REQUIRE(V >= 0 && max_ins >= 1 && h_iou_sem && h_iou_ins && h_acc, "sg_evaluate: bad arguments");
+namespace sg {
+// sg_evaluate with the counters' host landing buffer handed in (128 + 5 max_ins words): the pipeline passes a PINNED one -- with a pageable
+// destination the copy in the tail of every single-scene forward was a staged, synchronous one
+int evaluate_landing(const int32_t* d_gt, const int32_t* d_sem_pred, const int32_t* d_ins_pred, int V, int max_ins, float* h_iou_sem,
+                     float* h_iou_ins, float* h_acc, void* d_ws, size_t ws_bytes, void* stream, uint32_t* h_landing) {
+    SG_REQUIRE(V >= 0 && max_ins >= 1 && h_iou_sem && h_iou_ins && h_acc && h_landing, "sg_evaluate: bad arguments");
     const size_t n = 128 + 5 * (size_t)max_ins;
     if (ws_bytes < n * 4) return sg::fail(SG_ENOMEM, "sg_evaluate: workspace too small");
     uint32_t* cnt = (uint32_t*)d_ws;
     hipStream_t st = sg::as_stream(stream);
-    SG_HIP(hipMemsetAsync(cnt, 0, (128 + 3 * (size_t)max_ins) * 4, st));
-    SG_HIP(hipMemsetAsync(cnt + 128 + 3 * (size_t)max_ins, 0xff, (size_t)max_ins * 4, st));
+    {   // counters 0, first-occurrence slots all-ones: one launch instead of two memsets
+        const int n0 = 128 + 3 * max_ins, n1 = n0 + max_ins;
+        k_eval_clear<<<sg::cdiv(n1, 256), 256, 0, st>>>(cnt, n0, n1);
+    }
     if (V > 0) {
         const size_t dyn = max_ins <= kInsLds ? (size_t)max_ins * 16 : 0;
         k_eval_counts<<<std::min(sg::cdiv(V, 1024), 256), 256, dyn, st>>>(d_gt, d_sem_pred, d_ins_pred, V, max_ins, cnt);
     }
     k_eval_first_sem<<<sg::cdiv(max_ins, 256), 256, 0, st>>>(d_sem_pred, max_ins, cnt);
     SG_LAUNCH_CHECK();
-    std::vector<uint32_t> h(n);
-    SG_HIP(hipMemcpyAsync(h.data(), cnt, n * 4, hipMemcpyDeviceToHost, st));
+    SG_HIP(hipMemcpyAsync(h_landing, cnt, n * 4, hipMemcpyDeviceToHost, st));
     SG_HIP(hipStreamSynchronize(st));
-    sg::eval_finish(h.data(), max_ins, h_iou_sem, h_iou_ins, h_acc);
+    sg::eval_finish(h_landing, max_ins, h_iou_sem, h_iou_ins, h_acc);
     return SG_OK;
+}
+}  // namespace sg
+
+extern "C" {
+
+size_t sg_eval_ws_bytes(int max_ins) { return sg::align_up((size_t)(128 + 5 * (size_t)std::max(max_ins, 1)) * 4); }
+
+int sg_evaluate(const int32_t* d_gt, const int32_t* d_sem_pred, const int32_t* d_ins_pred, int V, int max_ins,
+                float* h_iou_sem, float* h_iou_ins, float* h_acc, void* d_ws, size_t ws_bytes, void* stream) {
+    std::vector<uint32_t> h(128 + 5 * (size_t)std::max(max_ins, 1));      // a pageable landing buffer: the copy is a staged, synchronous one
+    return sg::evaluate_landing(d_gt, d_sem_pred, d_ins_pred, V, max_ins, h_iou_sem, h_iou_ins, h_acc, d_ws, ws_bytes, stream, h.data());
 }
 
 }  // extern "C"

@@ -143,7 +143,7 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->feat1, S * 128); D(pl->featA, S * 256); D(pl->featB, S * 256);
     D(pl->seg_sums, S * 3); P(pl->h_seg_sums, S * 3); D(pl->segbox, S * 8); D(pl->chunk_box, (N / 32 + S + 1) * 8); D(pl->chunk_table, (N / 32 + S + 1) * 8); D(pl->sperm, N); D(pl->smpos, N); D(pl->seg_chunk_off, S + 1);
     D(pl->ws_sort, sg_segment_sort_ws_bytes(maxN)); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64); D(pl->point_rec, N * 4);
-    P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4); P(pl->h_chunk_off, S + 1);
+    P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4); P(pl->h_chunk_off, S + 1); P(pl->h_eval, pl->ws_eval.n / 4 + 16);
     P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
     if (bad) { sg::fail(SG_ENOMEM, "sg_pipeline_create: device/pinned allocation failed (N=%d S=%d E=%d V=%d)", maxN, maxS, maxE, maxV); return nullptr; }
     if (hipMemset(pl->ec_range.p, 0, sg::kRangeWords * sizeof(unsigned int)) != hipSuccess) { sg::fail(SG_EHIP, "sg_pipeline_create: hipMemset failed"); return nullptr; }
@@ -643,8 +643,8 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     PL_CHECK(flush_exports(true));                         // whatever is left (at least the final rows)
     PL_HIP(hipStreamWaitEvent(st, pl->ev_side, 0));        // the metric kernels read the LAST exported rows on the device
     pl->mark(17);
-    PL_CHECK(sg_evaluate(sc->d_gt, pl->labels.p + (size_t)sem_row * V, pl->labels.p + (size_t)ins_row * V, V, max_ins, out->iou_sem,
-                         out->iou_ins, out->acc, pl->ws_eval.p, pl->ws_eval.n, stv));
+    PL_CHECK(sg::evaluate_landing(sc->d_gt, pl->labels.p + (size_t)sem_row * V, pl->labels.p + (size_t)ins_row * V, V, max_ins, out->iou_sem,
+                                  out->iou_ins, out->acc, pl->ws_eval.p, pl->ws_eval.n, stv, reinterpret_cast<uint32_t*>(pl->h_eval.p)));
     pl->mark(18);
     lap(6);
     PL_HIP(timed_sync(st));

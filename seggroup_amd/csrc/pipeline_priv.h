@@ -58,7 +58,7 @@ struct sg_pipeline {
     sgp::DevBuf<float> samples, samples_big, feat1, featA, featB, dist, x9m, xyzw, pf, segbox, chunk_box, chunk_table, point_rec;
 
     // pinned host staging
-    sgp::PinBuf<int32_t> h_adj, h_desc, h_tables, h_count, h_chunk_off;
+    sgp::PinBuf<int32_t> h_adj, h_desc, h_tables, h_count, h_chunk_off, h_eval;      // h_eval: the metric counters' landing buffer
     sgp::PinBuf<float> h_dist, h_feat, h_samples;
     sgp::DevBuf<double> seg_sums;          // [S,3] coordinate sums of every over-segment (layer-invariant)
     sgp::PinBuf<double> h_seg_sums;

@@ -57,6 +57,8 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
     } while (0)
 
 // internal variant of sg_fps_sample with the largest cluster size known to the host (kernels_fps.hip)
+int evaluate_landing(const int32_t* d_gt, const int32_t* d_sem_pred, const int32_t* d_ins_pred, int V, int max_ins, float* h_iou_sem,
+                     float* h_iou_ins, float* h_acc, void* d_ws, size_t ws_bytes, void* stream, uint32_t* h_landing);   // kernels_graph.hip
 int knn_variant_for(int T, int override);   // kernels_knn_sorted.hip: 0 = two-pass over the chunk table, 1/2/4 = waves per tile of the one-pass kernel, 8 = x1 seeded
 int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_members, const int32_t* d_cl_off, int C, int P,
                     int ch_out, int transform, float* d_samples, int32_t* d_sel, void* d_ws, size_t ws_bytes, void* stream,

@@ -161,9 +161,12 @@ class Pipeline:
             debug = debug if debug is not None else hip.Debug()
             feat5 = np.zeros((sc.S, 256), np.float32); ins5 = np.zeros(sc.S, np.int32); sem5 = np.zeros(sc.S, np.int32)
             debug.h_feat5, debug.h_ins5, debug.h_sem5 = feat5.ctypes.data, ins5.ctypes.data, sem5.ctypes.data
-        with torch.cuda.device(self.device):
-            rc = self.lib.sg_pipeline_forward(self.handle, C.byref(sc.c_struct), mode, C.byref(res),
-                                              C.byref(debug) if debug is not None else None)
+        dbg_ref = C.byref(debug) if debug is not None else None
+        if self.device.index is None or torch.cuda.current_device() == self.device.index:      # (the library sets its device itself)
+            rc = self.lib.sg_pipeline_forward(self.handle, C.byref(sc.c_struct), mode, C.byref(res), dbg_ref)
+        else:
+            with torch.cuda.device(self.device):
+                rc = self.lib.sg_pipeline_forward(self.handle, C.byref(sc.c_struct), mode, C.byref(res), dbg_ref)
         hip.check(rc)
         nvec = 14 if mode == hip.MODE_INS_INFER else 6
         # the C side packs the vectors at stride V of THIS scene (include/seggroup_hip.h, sg_result.h_labels)
