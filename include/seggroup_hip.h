@@ -530,7 +530,7 @@ int sg_write_label_npy(const char* path, const int32_t* h_vec, int V);
 /* ---------------------------------------------------------------------------------------------
  * Native scene-pack loader (csrc/loader.cpp; reference data.py:28-38 + the per-forward file reads of model.py:696-724).
  * `threads` workers, each with a pinned staging buffer of `slot_bytes` (>= the largest pack file) and a copy stream; `slots` device blobs
- * of 2 x `slot_bytes` allocated at creation (nothing allocates per scene): packs written from round 4 on store the [E0,2] adjacency as int32
+ * of 3 x `slot_bytes` (one allocation) made at creation (nothing allocates per scene): packs written from round 4 on store the [E0,2] adjacency as int32
  * (half the bytes of the reference's int64 rows) and the loader widens it to int64 behind the upload, inside the slot -- sg_scene.d_adj is
  * int64 either way; packs with int64 rows still load.  sg_loader_submit queues a `.sgpack` (seggroup_amd/cache.py) and returns a ticket at once;
  * sg_loader_wait blocks until that pack is resident and fills *out (device arrays inside the slot's blob, the four per-segment host

@@ -112,7 +112,8 @@ struct sg_loader {
     struct Job { int ticket = 0; std::string path; int slot = -1; int rc = 0; std::string err; bool done = false; sg_scene sc{}; };
     int device = 0;
     size_t slot_bytes = 0;              // a pack's bytes (pinned read buffer of every worker)
-    size_t blob_bytes = 0;              // a device slot: the pack + its adjacency widened to int64 (at most the pack's size again)
+    size_t blob_bytes = 0;              // a device slot: the pack + its adjacency widened to int64
+    char* arena = nullptr;              // all slots: one allocation
     std::vector<Slot> slots;
     std::deque<int> free_slots;
     std::deque<std::shared_ptr<Job>> queue;
@@ -238,15 +239,17 @@ sg_loader* sg_loader_create(int threads, int slots, size_t slot_bytes) {
     auto* L = new sg_loader();
     if (hipGetDevice(&L->device) != hipSuccess) { sg::fail(SG_EHIP, "sg_loader_create: no HIP device"); delete L; return nullptr; }
     L->slot_bytes = (slot_bytes + 4095) / 4096 * 4096;
-    L->blob_bytes = 2 * L->slot_bytes + 4096;
+    // a slot holds a pack and, behind it, its int32 adjacency widened to int64: at most twice the adjacency's bytes, i.e. three times the
+    // pack at worst.  ONE allocation for all slots (one hipMalloc / hipFree instead of `slots` of them: start-up and tear-down of the driver)
+    L->blob_bytes = 3 * L->slot_bytes + 4096;
     L->slots.resize((size_t)slots);
+    if (hipMalloc((void**)&L->arena, (size_t)slots * L->blob_bytes) != hipSuccess) {
+        sg::fail(SG_ENOMEM, "sg_loader_create: cannot allocate %d device slots of %zu bytes", slots, L->blob_bytes);
+        delete L;
+        return nullptr;
+    }
     for (int i = 0; i < slots; ++i) {
-        if (hipMalloc((void**)&L->slots[i].d_blob, L->blob_bytes) != hipSuccess) {
-            sg::fail(SG_ENOMEM, "sg_loader_create: cannot allocate %d device slots of %zu bytes", slots, L->blob_bytes);
-            for (auto& s : L->slots) if (s.d_blob) (void)hipFree(s.d_blob);
-            delete L;
-            return nullptr;
-        }
+        L->slots[i].d_blob = L->arena + (size_t)i * L->blob_bytes;
         L->free_slots.push_back(i);
     }
     for (int i = 0; i < threads; ++i) L->threads.emplace_back([L] { L->run(); });
@@ -310,7 +313,7 @@ void sg_loader_destroy(sg_loader* L) {
     }
     L->cv_work.notify_all();
     for (auto& t : L->threads) if (t.joinable()) t.join();
-    for (auto& s : L->slots) if (s.d_blob) (void)hipFree(s.d_blob);
+    if (L->arena) (void)hipFree(L->arena);
     delete L;
 }
 

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -94,8 +95,24 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
 
     int bad = 0;
     size_t dev = 0, pin = 0;
-    auto D = [&](auto& buf, size_t count) { bad |= buf.alloc(count); dev += buf.n * sizeof(*buf.p); };
-    auto P = [&](auto& buf, size_t count) { bad |= buf.alloc(count); pin += buf.n * sizeof(*buf.p); };
+    // D / P only RECORD a request (the buffer's element count is known at once: later requests read it); the two arenas are allocated when
+    // all requests are in and every buffer becomes a 256-byte aligned view (sgp::DevBuf::view)
+    struct Req { std::function<void(char*)> set; size_t off; };
+    std::vector<Req> dreq, preq;
+    auto D = [&](auto& buf, size_t count) {
+        count = count ? count : 1;
+        buf.n = count;
+        auto* b = &buf;
+        dreq.push_back({[b, count](char* at) { b->view(at, count); }, dev});
+        dev += (count * sizeof(*buf.p) + 255) / 256 * 256;
+    };
+    auto P = [&](auto& buf, size_t count) {
+        count = count ? count : 1;
+        buf.n = count;
+        auto* b = &buf;
+        preq.push_back({[b, count](char* at) { b->view(at, count); }, pin});
+        pin += (count * sizeof(*buf.p) + 255) / 256 * 256;
+    };
 
     // weights
     size_t off = 0;
@@ -107,7 +124,7 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     pl->o_m3w2 = slot(64 * 64); pl->o_m3g2 = slot(64); pl->o_m3b2 = slot(64);
     pl->o_g3 = slot(256 * 256);
     pl->o_g2t = slot(192 * 192); pl->o_g3t = slot(256 * 256);        // W^T of the two GCN layers (k_gcn_fc reads [k][o])
-    D(pl->w, off);
+    bad |= pl->w.alloc(off);                             // (owned: filled right below)
     if (!bad) {
         std::vector<float> hw(off, 0.f);
         auto put = [&](size_t o, const float* src, size_t n) { if (src) std::copy(src, src + n, hw.begin() + o); else bad = 1; };
@@ -145,7 +162,12 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->ws_sort, sg_segment_sort_ws_bytes(maxN)); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64); D(pl->point_rec, N * 4);
     P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4); P(pl->h_chunk_off, S + 1); P(pl->h_eval, pl->ws_eval.n / 4 + 16);
     P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
+    if (!bad && hipMalloc((void**)&pl->dev_arena, dev) != hipSuccess) bad = 1;
+    if (!bad && hipHostMalloc((void**)&pl->pin_arena, pin, hipHostMallocDefault) != hipSuccess) bad = 1;
     if (bad) { sg::fail(SG_ENOMEM, "sg_pipeline_create: device/pinned allocation failed (N=%d S=%d E=%d V=%d)", maxN, maxS, maxE, maxV); return nullptr; }
+    for (auto& r : dreq) r.set(pl->dev_arena + r.off);
+    for (auto& r : preq) r.set(pl->pin_arena + r.off);
+    dev += pl->w.n * sizeof(float);
     if (hipMemset(pl->ec_range.p, 0, sg::kRangeWords * sizeof(unsigned int)) != hipSuccess) { sg::fail(SG_EHIP, "sg_pipeline_create: hipMemset failed"); return nullptr; }
     pl->dev_bytes = dev; pl->pin_bytes = pin;
     return pl.release();

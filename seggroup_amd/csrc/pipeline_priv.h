@@ -18,25 +18,34 @@ static const char* const kStageNames[] = {"contract_edges", "fps64", "mlp1", "di
                              "kernel.l2.edgeconv", "kernel.l3.edgeconv"};
 constexpr int kNumStages = sizeof(kStageNames) / sizeof(kStageNames[0]);
 
+// A buffer either owns its allocation (alloc) or is a view into its pipeline's arena (view): sg_pipeline_create asks for ~45 device and
+// ~10 pinned buffers per pipeline, the engine creates 80 pipelines -- as individual hipMalloc / hipHostMalloc calls that was most of the
+// driver's start-up and tear-down (round 4: one device arena and one pinned arena per pipeline).
 template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool own = false;
     int alloc(size_t count) {
         n = count ? count : 1;
-        return hipMalloc((void**)&p, n * sizeof(T)) == hipSuccess ? 0 : -1;
+        own = hipMalloc((void**)&p, n * sizeof(T)) == hipSuccess;
+        return own ? 0 : -1;
     }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    void view(void* at, size_t count) { p = static_cast<T*>(at); n = count ? count : 1; own = false; }
+    ~DevBuf() { if (p && own) (void)hipFree(p); }
 };
 template <class T>
 struct PinBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool own = false;
     int alloc(size_t count) {
         n = count ? count : 1;
-        return hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault) == hipSuccess ? 0 : -1;
+        own = hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault) == hipSuccess;
+        return own ? 0 : -1;
     }
-    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    void view(void* at, size_t count) { p = static_cast<T*>(at); n = count ? count : 1; own = false; }
+    ~PinBuf() { if (p && own) (void)hipHostFree(p); }
 };
 
 }  // namespace sgp
@@ -46,6 +55,12 @@ struct sg_pipeline {
     int device = 0;
     hipStream_t stream = nullptr;
     size_t dev_bytes = 0, pin_bytes = 0;
+    char* dev_arena = nullptr;          // every DevBuf / PinBuf below (but the weights) is a view into one of these two allocations
+    char* pin_arena = nullptr;
+    ~sg_pipeline() {
+        if (dev_arena) (void)hipFree(dev_arena);
+        if (pin_arena) (void)hipHostFree(pin_arena);
+    }
 
     // weights (device)
     sgp::DevBuf<float> w;   // all parameters, offsets below
