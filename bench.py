@@ -102,6 +102,7 @@ def parse_args(argv=None):
     ap.add_argument("--seg-profile", default="voronoi", help="synthetic segment-size profile: voronoi (SURVEY 8d recipe) | scannet (heavy-tailed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline leg")
+    ap.add_argument("--cpu-curve-full", action="store_true", help="CPU baseline leg: also time the port on 64 threads and on ALL host cores (minutes on a 256-core host)")
     ap.add_argument("--no-files", action="store_true", help="skip the separate with-files measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra leg (scenes/s on the ScanNet-shaped segment profile)")
     ap.add_argument("--extra-train", type=int, default=8, help="training steps timed in the extra leg (rank 0, N = 1; 0 = skip)")
@@ -649,20 +650,24 @@ def main(argv=None):
                     t1 = time.perf_counter()
                     ref_ = cpu_ref.forward_scene(host_scene0, W, "ins_infer", faithful=True)
                     return time.perf_counter() - t1, ref_
-            while len(times) < 3 and sum(times) < 40.0:                 # bounded: ~20-50 s of CPU work in total
+            while len(times) < 2 and sum(times) < 40.0:                 # bounded: the CPU leg is ~35 s in total (two runs here + the curve below)
                 dt, ref = one_run(used)
                 times.append(dt)
                 same = same and ref["trace"] == batch_trace0 if args.scenes_total == 0 else same
             best, med = min(times), float(np.median(times))
-            # one run each at other thread counts, ALL host cores included (bounded: a run that takes longer than 60 s ends the sweep)
+            # one run each at neighbouring thread counts; --cpu-curve-full adds 64 and ALL host cores (on the 256-core boxes of round 4 that point
+            # alone takes 460-468 s -- oversubscribed BLAS threads -- which the default run cannot afford: it is quoted from those runs instead)
             curve = {str(used): round(best, 2)}
-            for nt in sorted({8, 32, 64, cores} - {used}):
+            for nt in sorted(({8, 32} | ({64, cores} if args.cpu_curve_full else set())) - {used}):
                 if nt > cores:
                     continue
                 dt, _ = one_run(nt)
                 curve[str(nt)] = round(dt, 2)
-                if dt > 60.0:
-                    break
+            measured_before = None
+            if not args.cpu_curve_full:
+                measured_before = {"threads_64_s": [24.85, 27.39, 28.42, 31.74], "threads_256_all_cores_s": [460.21, 464.21, 465.21, 467.96],
+                                   "source": "four `python bench.py` runs of round 4 with the full curve on 256-core boxes (the profiles/r04_bench.json of "
+                                             "commits 2283df8, b2d6c4f and before); re-measure with --cpu-curve-full"}
             torch.set_num_threads(used)
             anchor = None
             apath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_cpu_anchor_check.json")
@@ -670,10 +675,10 @@ def main(argv=None):
                 anchor = json.load(open(apath))
             cpu = {"value": round(1.0 / best, 5), "unit": "scenes/s", "cores": used, "host_cores": cores, "kind": "port",
                    "runs": len(times), "seconds_min_median": [round(best, 2), round(med, 2)],
-                   "seconds_per_scene_by_threads": curve,
+                   "seconds_per_scene_by_threads": curve, "more_threads_measured_in_round_4": measured_before,
                    "sample": f"1 scene of the same workload ({args.points} pts / {args.segments} segs), oracle/cpu_ref.py faithful mode, "
                              f"{len(times)} runs on {used} of {cores} host cores (value = best run; `seconds_per_scene_by_threads` = one run each at other "
-                             f"thread counts, all {cores} cores included: {used} is the fastest or close to it); cluster trace equals the HIP path: {same}",
+                             f"thread counts: {used} is the fastest or close to it; 64 threads and all {cores} cores only with --cpu-curve-full, see `more_threads_measured_in_round_4`); cluster trace equals the HIP path: {same}",
                    "anchor_check": anchor}
 
         I_s, U_s = vec[:40], vec[40:80]
