@@ -252,7 +252,7 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
         # with one, the loop alternated between waiting for the loader and waiting for the engine)
         # eight loader threads read and upload ~2,800 packs/s (tools/time_loader.py: PCIe-bound at 45 GB/s from 16 on); more only take
         # cores from the writer pool
-        loader = cache.PackLoader(threads=min(8, workers), slots=4 * max(args.batch, 1), slot_bytes=slot_bytes, device=dev)
+        loader = cache.PackLoader(threads=min(6 if 'txt' not in formats else 8, workers), slots=4 * max(args.batch, 1), slot_bytes=slot_bytes, device=dev)
 
         class _Loaded:                                      # a future-like handle on a loader ticket
             def __init__(self, t):
@@ -273,7 +273,10 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     batches = [names[k:k + args.batch] for k in range(0, len(names), args.batch)]
     ahead = 2 if loader is not None else 1                 # batches of staging requests outstanding
     pending_q = [[request(n) for n in batches[k]] for k in range(min(ahead, len(batches)))]
-    writer = AsyncLabelWriter(threads=max(2, workers))
+    # Writer threads beyond what the formats need take memory bandwidth from the loader's copies (2,048 scenes on tmpfs, 256-core host,
+    # tools/time_driver.py --out-format "npy@6;npy@16;txt,npy@16;txt,npy@32"): `.npy` only 1,430 scenes/s with 6 threads, 1,230 with 16;
+    # `.txt` + `.npy` (the text formatter is 11 ms of one core per scene) 930 with 16, 760 with 32
+    writer = AsyncLabelWriter(threads=max(2, min(workers, 16 if 'txt' in formats else 6)))
     runner, done, stalled = None, 0, []
     w = model.export_weights()
     tickets = []
