@@ -66,12 +66,12 @@ def stage_arrays(data, weak_label, seg, adj, unmap, gt) -> Dict[str, np.ndarray]
                 seg_sem=np.ascontiguousarray(weak_label[first, 0], dtype=np.int32))
 
 
-def write_pack(path: str, name: str, arrays: Dict[str, np.ndarray]) -> None:
+def write_pack(path: str, name: str, arrays: Dict[str, np.ndarray], adj_int32: bool = True) -> None:
     os.makedirs(os.path.dirname(path), exist_ok=True)
     meta, blobs, off = {}, [], 0
     for k in ARRAYS:
         a = np.ascontiguousarray(arrays[k])
-        if k == "adj" and a.dtype == np.int64 and (a.size == 0 or (0 <= int(a.min()) and int(a.max()) < 2 ** 31)):
+        if adj_int32 and k == "adj" and a.dtype == np.int64 and (a.size == 0 or (0 <= int(a.min()) and int(a.max()) < 2 ** 31)):
             # point indices fit int32: half of a pack's bytes were this array as int64 (8.6 of 17 MB at 150k points / 536k edges).  Readers
             # hand out int64 again: read_pack widens on the host, load_pack / the native loader on the device
             a = a.astype(np.int32)
