@@ -67,6 +67,28 @@ inline char* put_u32(char* o, uint32_t v) {
     return o;
 }
 
+// Round 4: nearly every label is small -- segment numbers below S, instance / semantic ids, -1 -- so the text of every value in [-1, 9999]
+// comes ready-made from a table: "digits + newline" left-aligned in eight bytes and its length.  A value is then one 8-byte store (the
+// bytes behind the newline are overwritten by the next value; the buffer has slack) and an add: ~1.5 ns instead of ~5 per value
+// (14 x 150k values per scene: 11 -> ~3.5 ms of one core).  Larger values take put_u32.
+struct SmallText {
+    uint64_t word[10001];
+    uint8_t len[10001];
+    SmallText() {
+        for (int i = 0; i <= 10000; ++i) {
+            char t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            char* o = t;
+            const int v = i - 1;
+            if (v < 0) { *o++ = '-'; *o++ = '1'; }
+            else o = put_u32(o, (uint32_t)v);
+            *o++ = '\n';
+            memcpy(&word[i], t, 8);
+            len[i] = (uint8_t)(o - t);
+        }
+    }
+};
+const SmallText kSmallText;
+
 struct TlBuf {
     char* p = nullptr;
     size_t cap = 0;
@@ -200,6 +222,12 @@ int write_vector_files(int dfd, const char* name, const int32_t* vec, int V, int
         char* o = buf;
         for (int i = 0; i < V; ++i) {
             const int32_t v = vec[i];
+            const uint32_t idx = (uint32_t)v + 1u;                   // -1 -> 0 ... 9999 -> 10000; anything else wraps beyond the table
+            if (idx <= 10000u) {
+                memcpy(o, &kSmallText.word[idx], 8);
+                o += kSmallText.len[idx];
+                continue;
+            }
             if (v < 0) { *o++ = '-'; o = put_u32(o, (uint32_t)(-(int64_t)v)); }
             else o = put_u32(o, (uint32_t)v);
             *o++ = '\n';

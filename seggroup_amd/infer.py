@@ -274,9 +274,10 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     ahead = 2 if loader is not None else 1                 # batches of staging requests outstanding
     pending_q = [[request(n) for n in batches[k]] for k in range(min(ahead, len(batches)))]
     # Writer threads beyond what the formats need take memory bandwidth from the loader's copies (2,048 scenes on tmpfs, 256-core host,
-    # tools/time_driver.py --out-format "npy@6;npy@16;txt,npy@16;txt,npy@32"): `.npy` only 1,430 scenes/s with 6 threads, 1,230 with 16;
-    # `.txt` + `.npy` (the text formatter is 11 ms of one core per scene) 930 with 16, 760 with 32
-    writer = AsyncLabelWriter(threads=max(2, min(workers, 16 if 'txt' in formats else 6)))
+    # tools/time_driver.py --out-format "npy@6;npy@16;txt,npy@8;txt,npy@16;txt,npy@32"): `.npy` only 1,430-1,500 scenes/s with 6 threads, 1,230
+    # with 16; `.txt` + `.npy` (the text of a scene is ~3 ms of one core since the formatter takes small values from a table) 1,290 with 8,
+    # 1,205 with 16, 1,150 with 32
+    writer = AsyncLabelWriter(threads=max(2, min(workers, 8 if 'txt' in formats else 6)))
     runner, done, stalled = None, 0, []
     w = model.export_weights()
     tickets = []
