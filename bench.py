@@ -107,7 +107,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the extra leg (scenes/s on the ScanNet-shaped segment profile)")
     ap.add_argument("--extra-train", type=int, default=8, help="training steps timed in the extra leg (rank 0, N = 1; 0 = skip)")
     ap.add_argument("--extra-scannet", type=int, default=48, help="scenes of the ScanNet-shaped profile in the extra leg (rank 0, N = 1)")
-    ap.add_argument("--writer-threads", type=int, default=32, help="native writer threads for the with-files leg")
+    ap.add_argument("--writer-threads", type=int, default=12, help="native writer threads for the with-files leg (tmpfs, txt + npy: 8 threads 1,690, 12 2,020, 16 1,830, 32 1,250-1,390 scenes/s once the text comes from a table: more threads only contend for memory bandwidth)")
     ap.add_argument("--gen-workers", type=int, default=0, help="scene generator processes (0 = min(16, cores))")
     ap.add_argument("--numa", default="auto", choices=["auto", "off"], help="auto = bind every rank's process (engine groups, writer pool) to the CPUs of its GPU's NUMA node")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU rehearsals of the reduction)")
