@@ -440,7 +440,7 @@ def id_read(p, m, j):
     if "G" in OMIT:
         return
     if getattr(m, "GLOBAL_IDS", False):                  # straight from the kNN table (MLP3: no LDS left for an id strip at two workgroups per CU)
-        p.add("vmem", "global_load_dword v%d, %%[koff], %%[knn] offset:%d" % (id_reg(m, j), 4 * j), ["%[koff]"], vr(id_reg(m, j)), cls="vm", tag="ID%d" % j)
+        p.add("vmem", "global_load_dword v%d, %%[koff], %%[knn] offset:%d" % (id_reg(m, j), ID_STRIDE * j), ["%[koff]"], vr(id_reg(m, j)), cls="vm", tag="ID%d" % j)
     else:
         p.add("lds", "ds_read_b32 v%d, %%[ids] offset:%d" % (id_reg(m, j), j * 256), ["%[ids]"], vr(id_reg(m, j)), cls="lgkm", tag="ID%d" % j)
 
@@ -669,6 +669,7 @@ def stats_s2x(p, m, j, ot):
         p.valu("v_max_f32 v%d, v%d, v%d" % (m.BEST + o, m.BEST + o, z), vr(m.BEST + o) + vr(z), vr(m.BEST + o))
 
 
+ID_STRIDE = int(os.environ.get("SG_EC_ID_STRIDE", "4"))            # bytes between a lane's consecutive neighbour ids: 4 = row-major [N][20] table; 128 = slot-major per 32-row tile
 MIXLO = bool(int(os.environ.get("SG_EC_MIXLO", "0")))             # S2X: the low fp16 pieces of conv2's operand straight from v_fma_mixlo/hi_f16
 LRELU_PK = bool(int(os.environ.get("SG_EC_LRELU_PK", "0")))       # S2X: LeakyReLU's 0.2 x as v_pk_mul_f32 (asm operand %[c02] = the constant twice, in SGPRs)
 S2X_PKSTAT = bool(int(os.environ.get("SG_EC_S2X_PKSTAT", "0")))   # S2X: packed sums / sums of squares
