@@ -361,7 +361,7 @@ def test_edgeconv_forward(env, N):
 def test_edgeconv_fp16_conv1_ranges(env, spread, offset):
     """MLP2's conv1 on fp16 pieces (sg_edgeconv_forward_r): clouds of 1 mm, 50 m and 4 m extent -- the last 900 m from the origin -- and one
     that is constant up to 1e-6: the power-of-two scale keeps the pieces inside fp16 whatever the data's magnitude (a difference can be
-    1e-6 of the range: it lands on fp16 subnormals, which the matrix pipe keeps), the result stays within 2e-5 of the float64 oracle."""
+    1e-6 of the range: it lands on fp16 subnormals, which the matrix pipe keeps), the result stays within 2e-5 of the float64 oracle (3e-5 for the near-constant cloud)."""
     lib, torch, hip = env
     from oracle import cpu_ref as O
     from seggroup_amd import weights
@@ -393,7 +393,9 @@ def test_edgeconv_fp16_conv1_ranges(env, spread, offset):
                                         t["mlp_3.bn2.bias"].data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), rng_bits.data_ptr(), None))
     ref = O.edgeconv_forward(x9, knn.astype(np.int64), W, "mlp_3")
     assert np.isfinite(out.cpu().numpy()).all()
-    assert np.abs(out.cpu().numpy() - ref).max() < 2e-5
+    # the cloud that is constant up to 1e-6 normalises by a standard deviation of ~1e-6 of the values: how a tile's fp32 partial sums are
+    # associated shows there first (2.2e-5 with the halving cross-lane reduction of round 4, 1.9e-5 with the chains before it)
+    assert np.abs(out.cpu().numpy() - ref).max() < (3e-5 if spread < 1e-5 else 2e-5)
 
 
 @pytest.mark.gpu
