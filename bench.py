@@ -639,46 +639,52 @@ def main(argv=None):
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_ref
             from threadpoolctl import threadpool_limits
-            # bounded thread count: the oracle is many small NumPy/torch ops, oversubscribing a 256-core host
-            # makes it ~10x slower than 16 threads -- the curve below is measured here, on this box, and travels in the line
-            used = min(cores, args.cpu_threads)
-            times, same = [], True
+            from seggroup_amd.numa import unbound
+            # The rank is bound to its GPU's NUMA node (half of a two-socket host); the CPU leg gets the WHOLE host back for its duration
+            # (every thread of the process, BLAS / OpenMP pools included: ADVICE round 4), and `cores` / the curve's "all cores" point are
+            # what sched_getaffinity grants inside that window, not os.cpu_count().
+            with unbound():
+                host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
+                # bounded thread count: the oracle is many small NumPy/torch ops, oversubscribing a 256-core host
+                # makes it ~10x slower than 16 threads -- the curve below is measured here, on this box, and travels in the line
+                used = min(host_cores, args.cpu_threads)
+                times, same = [], True
 
-            def one_run(nthreads):
-                torch.set_num_threads(nthreads)
-                with threadpool_limits(limits=nthreads):
-                    t1 = time.perf_counter()
-                    ref_ = cpu_ref.forward_scene(host_scene0, W, "ins_infer", faithful=True)
-                    return time.perf_counter() - t1, ref_
-            while len(times) < 2 and sum(times) < 40.0:                 # bounded: the CPU leg is ~35 s in total (two runs here + the curve below)
-                dt, ref = one_run(used)
-                times.append(dt)
-                same = same and ref["trace"] == batch_trace0 if args.scenes_total == 0 else same
-            best, med = min(times), float(np.median(times))
-            # one run each at neighbouring thread counts; --cpu-curve-full adds 64 and ALL host cores (on the 256-core boxes of round 4 that point
-            # alone takes 460-468 s -- oversubscribed BLAS threads -- which the default run cannot afford: it is quoted from those runs instead)
-            curve = {str(used): round(best, 2)}
-            for nt in sorted(({8, 32} | ({64, cores} if args.cpu_curve_full else set())) - {used}):
-                if nt > cores:
-                    continue
-                dt, _ = one_run(nt)
-                curve[str(nt)] = round(dt, 2)
-            measured_before = None
-            if not args.cpu_curve_full:
-                measured_before = {"threads_64_s": [24.85, 27.39, 28.42, 31.74], "threads_256_all_cores_s": [460.21, 464.21, 465.21, 467.96],
-                                   "source": "four `python bench.py` runs of round 4 with the full curve on 256-core boxes (the profiles/r04_bench.json of "
-                                             "commits 2283df8, b2d6c4f and before); re-measure with --cpu-curve-full"}
-            torch.set_num_threads(used)
+                def one_run(nthreads):
+                    torch.set_num_threads(nthreads)
+                    with threadpool_limits(limits=nthreads):
+                        t1 = time.perf_counter()
+                        ref_ = cpu_ref.forward_scene(host_scene0, W, "ins_infer", faithful=True)
+                        return time.perf_counter() - t1, ref_
+                while len(times) < 2 and sum(times) < 40.0:                 # bounded: the CPU leg is ~35 s in total (two runs here + the curve below)
+                    dt, ref = one_run(used)
+                    times.append(dt)
+                    same = same and ref["trace"] == batch_trace0 if args.scenes_total == 0 else same
+                best, med = min(times), float(np.median(times))
+                # one run each at neighbouring thread counts; --cpu-curve-full adds 64 threads and ALL granted cores (minutes on a 256-core
+                # host: oversubscribed BLAS threads make that point the slowest by far, which is why the default run does not take it)
+                curve = {str(used): round(best, 2)}
+                for nt in sorted(({8, 32} | ({64, host_cores} if args.cpu_curve_full else set())) - {used}):
+                    if nt > host_cores:
+                        continue
+                    dt, _ = one_run(nt)
+                    curve[str(nt)] = round(dt, 2)
+                torch.set_num_threads(used)
             anchor = None
             apath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_cpu_anchor_check.json")
+            if not os.path.exists(apath):
+                apath = os.path.join(ROOT, "profiles", "r04_cpu_anchor_check.json")
             if os.path.exists(apath):
                 anchor = json.load(open(apath))
-            cpu = {"value": round(1.0 / best, 5), "unit": "scenes/s", "cores": used, "host_cores": cores, "kind": "port",
+            cpu = {"value": round(1.0 / best, 5), "unit": "scenes/s", "cores": used, "host_cores": host_cores, "kind": "port",
                    "runs": len(times), "seconds_min_median": [round(best, 2), round(med, 2)],
-                   "seconds_per_scene_by_threads": curve, "more_threads_measured_in_round_4": measured_before,
+                   "seconds_per_scene_by_threads": curve,
+                   "affinity": f"CPU leg run with the process's pre-bind CPU mask restored ({host_cores} CPUs; the rank itself is bound to "
+                               f"{numa_info.get('cpus_after')} for the GPU legs)",
                    "sample": f"1 scene of the same workload ({args.points} pts / {args.segments} segs), oracle/cpu_ref.py faithful mode, "
-                             f"{len(times)} runs on {used} of {cores} host cores (value = best run; `seconds_per_scene_by_threads` = one run each at other "
-                             f"thread counts: {used} is the fastest or close to it; 64 threads and all {cores} cores only with --cpu-curve-full, see `more_threads_measured_in_round_4`); cluster trace equals the HIP path: {same}",
+                             f"{len(times)} runs on {used} of {host_cores} host cores (value = best run; `seconds_per_scene_by_threads` = one run each at other "
+                             f"thread counts: {used} is the fastest or close to it; 64 threads and all {host_cores} cores only with --cpu-curve-full); "
+                             f"cluster trace equals the HIP path: {same}",
                    "anchor_check": anchor}
 
         I_s, U_s = vec[:40], vec[40:80]

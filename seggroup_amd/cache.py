@@ -246,10 +246,17 @@ class LoadedScene:
     def c_struct(self):
         return self._c
 
+    @property
+    def released(self) -> bool:
+        return self.slot is None
+
     def release(self) -> None:
+        """Hand the slot back.  `h_seg_of_vertex` / `h_seg_size` are views into the slot's host storage, which the next load overwrites:
+        they are withdrawn here, and a SceneResult that still wants to expand from them raises (model.SceneResult.labels)."""
         if self.slot is not None:
             self._loader.release(self.slot)
             self.slot = None
+            self.h_seg_of_vertex = self.h_seg_size = None
 
 
 class PackLoader:

@@ -154,6 +154,7 @@ struct BatchDims {                       // maxima over the slots of a group (gr
     int max_C = 0, max_T = 0, max_E = 0, max_ins = 0;
     int max_prevC = 0;
     int max_lay_big = 0;                 // pieces of segments beyond kLayoutPiece rows (layout kernel)
+    int min_K = 0, max_K = 0;            // range of SlotCtx::K over the slots: the hand-scheduled EdgeConv loops are unrolled for K = 20 only
 };
 
 int b_contract(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);

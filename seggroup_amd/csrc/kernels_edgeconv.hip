@@ -146,6 +146,7 @@ __device__ __forceinline__ float pow2_scale(float bound, float target) {      //
 // slots).  Same instructions on the same values in the same order per accumulator as the C++ loop below it -- bit-identical results;
 // the C++ loop stays for K != 20 and as the cross-check (sg_edgeconv_forward_x, flag 1).  MLP3's version keeps the 20 A fragments in
 // AGPRs and the point's base accumulator in LDS: 256 VGPRs + 80 AGPRs, ONE wave per SIMD.
+constexpr int kAsmK = 20;                  // the neighbour count the generated slot loops (edgeconv_slots_gen.h) are unrolled for
 template <int MODE, bool REREAD_A, bool kFused = false, bool kF16 = false, bool kAsm = false>
 __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gptr<const int32_t> knn, int N, int K,
                                               sg::gptr<const float> w1, sg::gptr<const float> shift1,
@@ -1323,7 +1324,9 @@ int edge_moments_partials(const float* d_x9m, const int32_t* d_knn, int N, int K
 int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mark)(void*, int), void* mark_arg, hipStream_t st) {
     if (bd.nslots == 0 || bd.max_N == 0) return SG_OK;
     const int ngroups = sg::cdiv(sg::cdiv(bd.max_N, 32), kWaves);
-    const bool hand = !g_compiler_loop;                           // the engine's layers all run K = 20 (SlotCtx::K; the kernel checks it)
+    // the generated slot loops are unrolled for K = 20 (neighbour rows at a fixed 80-byte stride): any other K in the group takes the
+    // compiler loop, which reads SlotCtx::K (nothing inside k_edgeconv_hb checks it)
+    const bool hand = !g_compiler_loop && bd.min_K == kAsmK && bd.max_K == kAsmK;
     const int nblocks = hand ? std::min(ngroups, std::max(1, resident_workgroups() / bd.nslots)) : ngroups;
     const dim3 grid(nblocks, bd.nslots), one(1, bd.nslots);
     // development knobs: SG_EC_STAGGER1 / SG_EC_STAGGER2 = start offset of the odd wave slot in units of 64 cycles

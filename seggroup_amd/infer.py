@@ -166,7 +166,7 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))
         dev = torch.device('cuda', torch.cuda.current_device())
         from .numa import bind_to_gpu_node
-        numa = bind_to_gpu_node(dev.index, getattr(args, 'numa', 'auto'))      # before any thread of this rank exists
+        numa = bind_to_gpu_node(dev.index, getattr(args, 'numa', 'auto'))      # every thread the process has by now (HIP runtime's included) and all later ones
         if numa['bound']:
             print('[rank %d] GPU %s on NUMA node %d: bound to %d of %d CPUs' % (rank, numa['pci'], numa['numa_node'], numa['cpus_after'], numa['cpus_before']), flush=True)
         model = SegModel(exp_name=args.exp_name, cuda=True, visualize=False, sem_infer=args.sem_infer, ins_infer=args.ins_infer,

@@ -98,10 +98,13 @@ class SceneResult:
     """Outputs of one forward: 14 (ins mode) or 6 (sem mode) int32 label vectors + metric tensors."""
 
     def __init__(self, labels: Optional[np.ndarray], n_vectors: int, res: hip.Result, tables: Optional[np.ndarray] = None,
-                 seg_of_vertex: Optional[np.ndarray] = None):
+                 seg_of_vertex: Optional[np.ndarray] = None, owner=None):
         self._labels = labels                     # [14, V] int32 (pinned) -- or None: compact transfer, expanded on first use
         self.tables = tables                      # [14, S] int32 (compact transfer only)
         self._sov = seg_of_vertex
+        # a scene in a native loader slot (cache.LoadedScene) lends its seg_of_vertex: the view dies with `release()`.  The result
+        # keeps the scene and refuses to expand from a released slot (ADVICE round 4) -- `detach()` takes a private copy first.
+        self._owner = owner if hasattr(owner, "released") else None
         self.n_vectors = n_vectors
         self.iou_sem = np.ctypeslib.as_array(res.iou_sem).reshape(1, 2, 40).copy()
         self.iou_ins = np.ctypeslib.as_array(res.iou_ins).reshape(1, 2, 40).copy()
@@ -114,6 +117,9 @@ class SceneResult:
     @property
     def labels(self) -> np.ndarray:
         if self._labels is None:                  # compact transfer: labels[t][v] = tables[t][seg_of_vertex[v]] (-1 outside), on the host
+            if self._owner is not None and self._owner.released:
+                raise RuntimeError("SceneResult.labels: the scene's loader slot was released before the label vectors were expanded "
+                                   "(read .labels or call .detach() before LoadedScene.release())")
             nv, S = self.tables.shape
             out = np.empty((nv, self._sov.shape[0]), dtype=np.int32)
             hip.check(hip.lib().sg_expand_labels(self.tables.ctypes.data, nv, S, self._sov.ctypes.data, self._sov.shape[0], out.ctypes.data))
@@ -123,6 +129,15 @@ class SceneResult:
     @labels.setter
     def labels(self, v):
         self._labels = v
+
+    def detach(self) -> "SceneResult":
+        """Make the result independent of the loader slot its scene lives in (a private copy of seg_of_vertex, 4 V bytes)."""
+        if self._owner is not None and self._labels is None:
+            if self._owner.released:
+                raise RuntimeError("SceneResult.detach: the scene's loader slot is already released")
+            self._sov = np.array(self._sov, copy=True)
+        self._owner = None
+        return self
 
     def label_dict(self) -> Dict[str, np.ndarray]:
         return {hip.LABEL_NAMES[i]: self.labels[i] for i in range(self.n_vectors)}
@@ -342,7 +357,7 @@ class Engine:
         out = []
         for i, s in enumerate(t.scenes):
             if getattr(t, "tables", None) is not None and s.h_seg_of_vertex is not None:
-                out.append(SceneResult(None, nvec, t.c_res[i], tables=t.tables[i][:nvec], seg_of_vertex=s.h_seg_of_vertex))
+                out.append(SceneResult(None, nvec, t.c_res[i], tables=t.tables[i][:nvec], seg_of_vertex=s.h_seg_of_vertex, owner=s))
             else:
                 out.append(SceneResult(lab[i].reshape(-1)[:nv * s.V].reshape(nv, s.V), nvec, t.c_res[i]))
         return out

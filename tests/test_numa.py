@@ -33,3 +33,47 @@ def test_bind_restricts_to_the_nodes_cpus_inside_the_granted_set(monkeypatch, tm
         assert not numa.bind_to_gpu_node(0, "off")["bound"]
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_bind_moves_threads_that_already_exist_and_unbound_gives_the_host_back(monkeypatch):
+    """sched_setaffinity(0, ...) binds only the caller; the HIP runtime's threads exist before the bind."""
+    import threading
+    before = os.sched_getaffinity(0)
+    if len(before) < 2:
+        return
+    keep = sorted(before)[:max(1, len(before) // 2)]
+    go, stop, seen = threading.Event(), threading.Event(), {}
+
+    def early():                                             # a thread that exists before the bind
+        go.wait(10)
+        seen["bound"] = os.sched_getaffinity(0)
+        stop.wait(10)
+        seen["restored"] = os.sched_getaffinity(0)
+    th = threading.Thread(target=early)
+    th.start()
+    monkeypatch.setattr(numa, "gpu_numa_node", lambda i: {"pci": "0000:00:00.0", "numa_node": 1})
+    monkeypatch.setattr(numa, "_unbound_mask", None)
+    real_read, real_listdir, real_isdir = numa._read, os.listdir, os.path.isdir
+    monkeypatch.setattr(numa, "_read", lambda p: ",".join(map(str, keep)) if p.endswith("node1/cpulist") else real_read(p))
+    monkeypatch.setattr(os, "listdir", lambda p: ["node0", "node1"] if p == "/sys/devices/system/node" else real_listdir(p))
+    monkeypatch.setattr(os.path, "isdir", lambda p: True if p == "/sys/devices/system/node" else real_isdir(p))
+    try:
+        info = numa.bind_to_gpu_node(0, "auto")
+        assert info["bound"] and info["threads"] >= 2
+        go.set()
+        with numa.unbound():
+            assert os.sched_getaffinity(0) == before         # the CPU-baseline leg sees the whole host
+        assert os.sched_getaffinity(0) == set(keep)
+        numa.set_affinity_all_threads(before)
+        stop.set()
+        th.join()
+        assert seen["bound"] == set(keep) and seen["restored"] == before
+    finally:
+        go.set(); stop.set()
+        numa.set_affinity_all_threads(before)
+
+
+def test_node_override_names_the_node(monkeypatch):
+    monkeypatch.setattr(numa, "gpu_numa_node", lambda i: {"pci": None, "numa_node": -1})
+    info = numa.bind_to_gpu_node(0, "off", node_override=3)
+    assert info["numa_node"] == 3 and info["node_override"] and not info["bound"]
