@@ -63,7 +63,48 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--batch', type=int, default=64, help='scenes per batch in the packed fast path (0 = the per-scene SegModel.forward loop)')
     p.add_argument('--inflight', type=int, default=80, help='scenes in flight per GPU in the packed fast path (engine groups of 8; two groups more than a batch fills)')
     p.add_argument('--no-cache', action='store_true', help='do not build / use packed scene files (dataset/scannet/cache/...)')
+    p.add_argument('--synthetic', type=int, default=0, metavar='N',
+                   help='write N synthetic ScanNet-shaped scenes in the reference\'s on-disk layout under --root (and a random-init '
+                        'checkpoint checkpoints/<exp>/models/last.t7 if there is none), then run on them (SURVEY.md section 5, config row); '
+                        'refuses a --root that already holds a scene list')
+    p.add_argument('--synthetic-points', type=int, default=150000, help='points per synthetic scene (BASELINE.json: 150k)')
+    p.add_argument('--synthetic-segments', type=int, default=1500, help='over-segments per synthetic scene (BASELINE.json: 1.5k)')
+    p.add_argument('--synthetic-profile', type=str, default='voronoi', choices=['voronoi', 'scannet'], help='segment-size profile of the synthetic scenes')
     return p
+
+
+def _synthetic_scene_job(job):
+    points, segments, seed, profile, name = job
+    from . import synthetic
+    kw = {} if profile == 'voronoi' else {'seg_profile': profile}
+    return synthetic.make_scene(points, segments, seed, name=name, **kw)
+
+
+def write_synthetic_tree(args) -> int:
+    """`--synthetic N`: the input tree infer.py reads (model.py:669-724, data.py:28-38) made of synthetic scenes, and a checkpoint to resume.
+    Runs BEFORE anything touches the GPU (the generator pool is a spawn-context process pool: NumPy / SciPy only)."""
+    import torch
+    from . import synthetic, weights
+    listing = os.path.join(args.root, 'dataset', 'scannet', 'scannetv2_train.txt')
+    if os.path.exists(listing):
+        print('--synthetic: %s exists; refusing to overwrite a dataset tree (choose an empty --root)' % listing)
+        raise SystemExit(1)
+    n = int(args.synthetic)
+    jobs = [(args.synthetic_points, args.synthetic_segments, 60000 + i, args.synthetic_profile, 'scene%04d_00' % i) for i in range(n)]
+    workers = max(1, min(int(args.workers), n, (os.cpu_count() or 1)))
+    if workers > 1 and n >= 4:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn')) as pool:
+            scenes = list(pool.map(_synthetic_scene_job, jobs))
+    else:
+        scenes = [_synthetic_scene_job(j) for j in jobs]
+    synthetic.write_reference_tree(args.root, scenes, label_style=args.label_style)
+    ck = os.path.join(args.root, 'checkpoints', args.exp_name, 'models')
+    os.makedirs(ck, exist_ok=True)
+    if not os.path.exists(os.path.join(ck, 'last.t7')):
+        torch.save({'state_dict': weights.to_full_state_dict(weights.make_weights(args.seed, bn1_gamma=2.0))}, os.path.join(ck, 'last.t7'))
+    return n
 
 
 from .util import IOStream  # noqa: E402,F401  (the reference keeps it in util.py)
@@ -359,6 +400,12 @@ def main(argv=None):
     if args.sem_infer == args.ins_infer:
         print("Please choose either '--sem_infer' or '--ins_infer'")       # infer.py:214-216
         raise SystemExit(1)
+    if args.synthetic > 0:                                                 # before the first HIP call: the generator pool spawns processes
+        if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            print('--synthetic writes the tree from ONE process: run it once without torchrun, then start the ranks on that --root')
+            raise SystemExit(1)
+        os.makedirs(os.path.join(args.root, 'checkpoints', args.exp_name), exist_ok=True)
+        n_syn = write_synthetic_tree(args)
     import torch
     if args.no_cuda or not torch.cuda.is_available():
         print('seggroup_amd runs on MI355X only: no CPU fallback (use oracle/cpu_ref.py for testing)')
@@ -368,6 +415,9 @@ def main(argv=None):
         io = IOStream(os.path.join(args.root, 'checkpoints', args.exp_name, 'run_infer.log'))
         io.cprint(str(args))
         io.cprint("Let's use " + str(torch.cuda.device_count()) + " GPUs!")
+        if args.synthetic > 0:
+            io.cprint('Wrote %d synthetic scenes (%d points / %d segments, %s) under %s' % (n_syn, args.synthetic_points, args.synthetic_segments,
+                                                                                         args.synthetic_profile, os.path.join(args.root, 'dataset', 'scannet')))
         io.close()
     torch.manual_seed(args.seed)
     np.random.seed(1)

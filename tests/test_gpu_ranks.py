@@ -167,3 +167,52 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu():
     assert j2["pseudo_label_mIoU"]["scenes"] == j1["pseudo_label_mIoU"]["scenes"] == 1201 * 2               # the timed steps' scenes, all-reduced
     assert j2["pseudo_label_mIoU"]["semantic"] == j1["pseudo_label_mIoU"]["semantic"]
     assert j2["pseudo_label_mIoU"]["instance"] == j1["pseudo_label_mIoU"]["instance"]
+
+
+def test_full_size_scenes_cross_the_rank_logic_and_the_synthetic_flag(tmp_path, weight_sets):
+    """(a) `infer.py --synthetic N` writes the tree it then runs (SURVEY section 5's config row); (b) configs[3]'s sharding
+    with FULL-SIZE scenes: four 150k-point / 1.5k-segment scenes written by that flag, then the same tree through two gloo ranks on cuda:0
+    (two scenes each, `i mod 2`) -- every scene's 28 label files byte-identical to the one-process run, the all-reduced metrics equal."""
+    import torch
+    import torch.multiprocessing as mp
+    from seggroup_amd import infer, weights
+    root = str(tmp_path)
+    common = ["--ins_infer", "--root", root, "--batch", "2", "--inflight", "4", "-j", "4"]
+    ck = os.path.join(root, "checkpoints", "w1", "models")
+    os.makedirs(ck)
+    torch.save({"state_dict": weights.to_full_state_dict(weight_sets["ins_infer"])}, os.path.join(ck, "last.t7"))
+    infer.main(["-n", "w1", "--world-size", "1", "--synthetic", "4"] + common)                 # writes dataset/ + runs W = 1
+    names = [l.strip() for l in open(os.path.join(root, "dataset", "scannet", "scannetv2_train.txt"))]
+    assert names == ["scene%04d_00" % i for i in range(4)]
+    with pytest.raises(SystemExit):                                                         # a tree that exists is never overwritten
+        infer.main(["-n", "w1", "--world-size", "1", "--synthetic", "4"] + common)
+    log = open(os.path.join(root, "checkpoints", "w1", "run_infer.log")).read()
+    assert "Wrote 4 synthetic scenes (150000 points / 1500 segments" in log and "==> Infer           Instance mIoU:" in log
+    ck = os.path.join(root, "checkpoints", "w2", "models")
+    os.makedirs(ck)
+    torch.save({"state_dict": weights.to_full_state_dict(weight_sets["ins_infer"])}, os.path.join(ck, "last.t7"))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker_full, args=(r, 2, root, port, "w2", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    two = q.get(timeout=900)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    a, b = _tree_digest(root, "w1", names), _tree_digest(root, "w2", names)
+    assert a == b, [n for n in names if a[n] != b[n]]
+    assert two["n"] == 4
+    V = np.load(os.path.join(root, "results", "w2", names[3], "ins_infer", "final.ins.npy")).shape[0]
+    assert V >= 150000
+
+
+def _rank_worker_full(rank, world, root, port, exp, q):
+    sys.path.insert(0, ROOT)
+    from seggroup_amd import infer
+    args = infer.build_parser().parse_args(["-n", exp, "--ins_infer", "--root", root, "--backend", "gloo", "--port", str(port),
+                                            "--batch", "2", "--inflight", "4", "-j", "4"])
+    r = infer.run_worker(rank, world, args)
+    if rank == 0:
+        q.put({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in r.items()})

@@ -89,3 +89,20 @@ def test_driver_loads_checkpoints_strictly(tmp_path):
     torch.save({"state_dict": foreign}, p)
     with pytest.raises(RuntimeError, match="mlp_9"):
         infer.load_checkpoint(net, p)
+
+
+def test_synthetic_flag_writes_a_tree_once(tmp_path):
+    """`infer.py --synthetic N`: the reference's on-disk layout + a checkpoint to resume, and never over an existing tree."""
+    import torch
+    from seggroup_amd import infer
+    from seggroup_amd.data import ScanNet
+    args = infer.build_parser().parse_args(["-n", "exp", "--ins_infer", "--root", str(tmp_path), "--synthetic", "2", "--synthetic-points", "2500",
+                                            "--synthetic-segments", "25", "-j", "1"])
+    assert infer.write_synthetic_tree(args) == 2
+    ds = ScanNet(label_style="manual", root=str(tmp_path))
+    data, weak, info = ds[1]
+    assert data.shape == (2500, 6) and weak.shape[0] == 2500
+    sd = torch.load(tmp_path / "checkpoints" / "exp" / "models" / "last.t7")["state_dict"]
+    assert any(k.startswith("module.") or "." in k for k in sd)
+    with pytest.raises(SystemExit):
+        infer.write_synthetic_tree(args)
