@@ -167,30 +167,31 @@ __global__ __launch_bounds__(256) void k_segment_sort_boxes_b(const sg::SlotCtx*
     segment_sort_boxes_body(c.data, c.seg_points, c.seg_off, c.seg_chunk_off, c.segbox, c.sperm, c.chunk_box, c.seg_sums, blockIdx.x);
 }
 
-// Segments of more than kSortCap points (floors, walls: 10k-30k points in ScanNet's over-segmentation) -- same outputs,
-// same order (ascending (morton30, index)), one 1024-thread block per segment, no library sort:
-//   1. box + coordinate sums;  2. keys into global scratch + LDS histogram of the TOP 12 Morton bits (16^3 cells);
-//   3. scan, scatter into cell order;  4. consecutive cells are packed greedily into runs of <= kSortCap keys and every
-//   run is sorted in LDS by the full 64-bit key (cells are already in order, so the concatenation is the total order);
-//   5. boxes of the 32-point chunks.  A cell with more than kSortCap points (> 2,048 points in 1/4096 of the segment's
-//   box: massive duplication) is cut into pieces that are sorted one by one -- the order inside such a cell is then not
-//   the full sort, which only loosens the chunk boxes there (the kNN tables do not depend on this order).
-// Blocks whose segment is small exit at once, so the launch covers every segment and needs no list of the big ones.
-constexpr int kBigBlock = 1024, kBins = 4096, kMaxRuns = 2048;
-__device__ __forceinline__ void bigseg_sort_boxes_body(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
-                                                       const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
-                                                       float* __restrict__ segbox, int32_t* __restrict__ sperm, float* __restrict__ chunk_box,
-                                                       double* __restrict__ seg_sums, unsigned long long* __restrict__ keysA,
-                                                       unsigned long long* __restrict__ keysB, int s) {
+// Segments of more than kSortCap points (floors, walls: 10k-40k points in ScanNet's over-segmentation) -- same outputs, same order
+// (ascending (morton30, index)), no library sort.  Round 5: three launches instead of one block per segment doing everything
+// (a 29k-point floor kept one workgroup busy for a millisecond: a serial run table by one thread and ~20 LDS sorts one after another):
+//   k_bigseg_bucket (one 1024-thread block per big segment; the others exit at once):  box + coordinate sums; keys into global scratch + LDS
+//       histogram of the TOP 12 Morton bits (16^3 cells); scan; scatter into cell order (keysB); the cells' first positions go to global
+//       memory (into the keysA range of the segment, which the scatter has finished reading: 4,096 ints <= 8 n bytes for n > 2,048);
+//   k_bigseg_runs (one block per window of kWin = 1,024 positions of the scene's sorted CSR):  the RUN that starts in the window -- from the
+//       first cell that starts in it to the first cell that starts in a later window: whole cells, <= kWin + the last cell's size - 1 keys
+//       -- is sorted in LDS by the full 64-bit key (cells are already in order, so the concatenation of the runs is the total order) and
+//       emitted as sorted positions.  Runs are independent: they sort side by side on as many CUs.  A cell of more than kWin points (1/4096
+//       of the segment's box: massive duplication) makes a run that is cut into kSortCap pieces sorted one by one -- the order inside such a
+//       cell is then not the full sort, which only loosens the chunk boxes there (the kNN tables do not depend on this order);
+//   k_bigseg_boxes (same windows):  boxes of the 32-point chunks that start in the window.
+constexpr int kBigBlock = 1024, kBins = 4096, kWin = 1024;
+static_assert(kBins * 4 <= (kSortCap + 1) * 8, "the cell table of a big segment lives in its own keysA range");
+__device__ __forceinline__ void bigseg_bucket_body(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                                                   const int32_t* __restrict__ seg_off, float* __restrict__ segbox, double* __restrict__ seg_sums,
+                                                   unsigned long long* __restrict__ keysA, unsigned long long* __restrict__ keysB, int s) {
     const int lo = seg_off[s], n = seg_off[s + 1] - lo;
     if (n <= kSortCap) return;
-    __shared__ unsigned long long key[kSortCap];
     __shared__ int hist[kBins];
-    __shared__ int run_end[kMaxRuns];
+    __shared__ int first[kBins];
     __shared__ float red[kBigBlock / 64][8];
     __shared__ double dred[kBigBlock / 64][3];
     __shared__ float bx[8];
-    __shared__ int n_runs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kW = kBigBlock / 64;
     // 1. box + sums
@@ -237,7 +238,7 @@ __device__ __forceinline__ void bigseg_sort_boxes_body(const float* __restrict__
         atomicAdd(&hist[m >> 18], 1);
     }
     __syncthreads();
-    // 3. exclusive scan of the 4096 counts (4 per thread), runs, scatter cursors
+    // 3. exclusive scan of the 4096 counts (4 per thread), scatter cursors
     {
         int c[4], sum = 0;
 #pragma unroll
@@ -253,22 +254,7 @@ __device__ __forceinline__ void bigseg_sort_boxes_body(const float* __restrict__
         int off = base + incl - sum;
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { hist[4 * tid + u] = off; off += c[u]; }      // hist[] now = first position of every cell
-    }
-    __syncthreads();
-    if (tid == 0) {
-        // greedy packing of consecutive cells into runs of <= kSortCap keys (an oversize cell is cut into pieces)
-        int nr = 0, start = 0;
-        for (int b = 0; b < kBins && nr < kMaxRuns - 1; ++b) {
-            const int end = b + 1 < kBins ? hist[b + 1] : n;
-            while (end - start > kSortCap && nr < kMaxRuns - 1) {
-                const int cell_lo = hist[b];
-                if (cell_lo > start) { run_end[nr++] = cell_lo; start = cell_lo; }          // close the run before this cell
-                else { run_end[nr++] = start + kSortCap; start += kSortCap; }                // a piece of an oversize cell
-            }
-        }
-        if (start < n || nr == 0) run_end[nr++] = n;
-        n_runs = nr;
+        for (int u = 0; u < 4; ++u) { hist[4 * tid + u] = off; first[4 * tid + u] = off; off += c[u]; }      // first position of every cell
     }
     __syncthreads();
     for (int i = tid; i < n; i += kBigBlock) {
@@ -276,14 +262,50 @@ __device__ __forceinline__ void bigseg_sort_boxes_body(const float* __restrict__
         const int pos = atomicAdd(&hist[(unsigned int)(k >> 32) >> 18], 1);
         keysB[lo + pos] = k;
     }
-    __syncthreads();
-    // 4. sort every run in LDS (bitonic, ascending), emit the sorted positions
-    const int nr = n_runs;
-    int r0 = 0;
-    for (int r = 0; r < nr; ++r) {
-        const int r1 = run_end[r];
-        for (int p0 = r0; p0 < r1; p0 += kSortCap) {              // one piece per run (more only if the run table overflowed)
-            const int m = min(kSortCap, r1 - p0);
+    __syncthreads();                                           // every read of keysA[lo ..] is done: its head now holds the cell table
+    int* cells = reinterpret_cast<int*>(keysA + lo);
+    for (int i = tid; i < kBins; i += kBigBlock) cells[i] = first[i];
+}
+
+// the segment that holds position p of the sorted CSR (seg_off ascending, seg_off[S] = N; empty segments are skipped by the upper bound)
+__device__ __forceinline__ int segment_of_position(const int32_t* __restrict__ seg_off, int S, int p) {
+    int a = 0, b = S;                                          // largest s with seg_off[s] <= p
+    while (b - a > 1) {
+        const int m = (a + b) >> 1;
+        if (seg_off[m] <= p) a = m; else b = m;
+    }
+    return a;
+}
+__device__ __forceinline__ int first_cell_at_or_behind(const int* __restrict__ cells, int x) {     // lower bound over the 4096 cell starts
+    int a = 0, b = kBins;
+    while (a < b) {
+        const int m = (a + b) >> 1;
+        if (cells[m] < x) a = m + 1; else b = m;
+    }
+    return a;
+}
+
+__device__ __forceinline__ void bigseg_runs_body(const int32_t* __restrict__ seg_off, int S, int N, const unsigned long long* __restrict__ keysA,
+                                                 const unsigned long long* __restrict__ keysB, int32_t* __restrict__ sperm, int win) {
+    __shared__ unsigned long long key[kSortCap];
+    const int tid = threadIdx.x;
+    const int w0 = win * kWin, w1 = min(N, w0 + kWin);
+    if (w0 >= N) return;
+    const int sa = segment_of_position(seg_off, S, w0), sb = segment_of_position(seg_off, S, w1 - 1);
+    // only the first and the last segment of a window can be big (those in between lie inside it: <= kWin points)
+    for (int pass = 0; pass < 2; ++pass) {
+        const int s = pass == 0 ? sa : sb;
+        if (pass == 1 && sb == sa) break;
+        const int lo = seg_off[s], n = seg_off[s + 1] - lo;
+        if (n <= kSortCap) continue;                             // block-uniform
+        const int* cells = reinterpret_cast<const int*>(keysA + lo);
+        const int b0 = first_cell_at_or_behind(cells, max(w0 - lo, 0));
+        const int h0 = b0 < kBins ? cells[b0] : n;
+        if (h0 >= n || lo + h0 >= w1) continue;                  // no cell starts in this window
+        const int b1 = first_cell_at_or_behind(cells, w1 - lo);
+        const int h1 = b1 < kBins ? cells[b1] : n;
+        for (int p0 = h0; p0 < h1; p0 += kSortCap) {             // one piece unless a cell holds more than kWin points
+            const int m = min(kSortCap, h1 - p0);
             int m2 = 64;
             while (m2 < m) m2 <<= 1;
             for (int i = tid; i < m2; i += kBigBlock) key[i] = i < m ? keysB[lo + p0 + i] : ~0ull;
@@ -301,40 +323,71 @@ __device__ __forceinline__ void bigseg_sort_boxes_body(const float* __restrict__
             for (int i = tid; i < m; i += kBigBlock) sperm[lo + p0 + i] = lo + (int)(key[i] & 0xffffffffull);
             __syncthreads();
         }
-        r0 = r1;
     }
-    // 5. boxes of the 32-point chunks (two per wave step); sperm[] of this segment was written by this block
-    const int c0 = seg_chunk_off[s], half = lane >> 5, l = lane & 31;
-    for (int j = 2 * wave + half; j * kChunkPts < n; j += 2 * kW) {
-        const int t = j * kChunkPts + l;
-        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY}, cxx = 0.f;
-        if (t < n) {
-            const float* r = data + (size_t)seg_points[sperm[lo + t]] * 6;
+}
+
+__device__ __forceinline__ void bigseg_boxes_body(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
+                                                  int S, int N, const int32_t* __restrict__ seg_chunk_off, const int32_t* __restrict__ sperm,
+                                                  float* __restrict__ chunk_box, int win) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l = lane & 31;
+    const int w0 = win * kWin, w1 = min(N, w0 + kWin);
+    if (w0 >= N) return;
+    const int sa = segment_of_position(seg_off, S, w0), sb = segment_of_position(seg_off, S, w1 - 1);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int s = pass == 0 ? sa : sb;
+        if (pass == 1 && sb == sa) break;
+        const int lo = seg_off[s], n = seg_off[s + 1] - lo;
+        if (n <= kSortCap) continue;
+        const int c0 = seg_chunk_off[s];
+        const int j0 = (max(w0 - lo, 0) + kChunkPts - 1) / kChunkPts;              // chunks whose first position lies in [w0, w1)
+        const int j1 = min((n + kChunkPts - 1) / kChunkPts, (w1 - lo + kChunkPts - 1) / kChunkPts);
+        for (int j = j0 + 2 * wave + half; j < j1 + half; j += 2 * (blockDim.x >> 6)) {      // both halves of a wave run the reductions together
+            const bool live = j < j1;
+            const int t = j * kChunkPts + l;
+            float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY}, cxx = 0.f;
+            if (live && t < n) {
+                const float* r = data + (size_t)seg_points[sperm[lo + t]] * 6;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { cmn[k] = r[k]; cmx[k] = r[k]; }
-            cxx = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
-        }
+                for (int k = 0; k < 3; ++k) { cmn[k] = r[k]; cmx[k] = r[k]; }
+                cxx = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+            }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { cmn[k] = sgw::half_min(cmn[k], lane); cmx[k] = sgw::half_max(cmx[k], lane); }
-        cxx = sgw::half_max(cxx, lane);
-        if (l == 0) {
-            float* b = chunk_box + (size_t)(c0 + j) * 8;
-            b[0] = cmn[0]; b[1] = cmn[1]; b[2] = cmn[2]; b[3] = cmx[0]; b[4] = cmx[1]; b[5] = cmx[2]; b[6] = cxx; b[7] = 0.f;
+            for (int k = 0; k < 3; ++k) { cmn[k] = sgw::half_min(cmn[k], lane); cmx[k] = sgw::half_max(cmx[k], lane); }
+            cxx = sgw::half_max(cxx, lane);
+            if (live && l == 0) {
+                float* b = chunk_box + (size_t)(c0 + j) * 8;
+                b[0] = cmn[0]; b[1] = cmn[1]; b[2] = cmn[2]; b[3] = cmx[0]; b[4] = cmx[1]; b[5] = cmx[2]; b[6] = cxx; b[7] = 0.f;
+            }
         }
     }
 }
-__global__ __launch_bounds__(kBigBlock) void k_bigseg_sort_boxes(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
-                                                                 const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
-                                                                 float* __restrict__ segbox, int32_t* __restrict__ sperm,
-                                                                 float* __restrict__ chunk_box, double* __restrict__ seg_sums,
-                                                                 unsigned long long* __restrict__ keysA, unsigned long long* __restrict__ keysB) {
-    bigseg_sort_boxes_body(data, seg_points, seg_off, seg_chunk_off, segbox, sperm, chunk_box, seg_sums, keysA, keysB, blockIdx.x);
+
+__global__ __launch_bounds__(kBigBlock) void k_bigseg_bucket(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
+                                                             const int32_t* __restrict__ seg_off, float* __restrict__ segbox, double* __restrict__ seg_sums,
+                                                             unsigned long long* __restrict__ keysA, unsigned long long* __restrict__ keysB) {
+    bigseg_bucket_body(data, seg_points, seg_off, segbox, seg_sums, keysA, keysB, blockIdx.x);
 }
-__global__ __launch_bounds__(kBigBlock) void k_bigseg_sort_boxes_b(const sg::SlotCtx* __restrict__ cx) {
+__global__ __launch_bounds__(kBigBlock) void k_bigseg_runs(const int32_t* __restrict__ seg_off, int S, int N, const unsigned long long* __restrict__ keysA,
+                                                           const unsigned long long* __restrict__ keysB, int32_t* __restrict__ sperm) {
+    bigseg_runs_body(seg_off, S, N, keysA, keysB, sperm, blockIdx.x);
+}
+__global__ __launch_bounds__(512) void k_bigseg_boxes(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
+                                                      int S, int N, const int32_t* __restrict__ seg_chunk_off, const int32_t* __restrict__ sperm,
+                                                      float* __restrict__ chunk_box) {
+    bigseg_boxes_body(data, seg_points, seg_off, S, N, seg_chunk_off, sperm, chunk_box, blockIdx.x);
+}
+__global__ __launch_bounds__(kBigBlock) void k_bigseg_bucket_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     if ((int)blockIdx.x >= c.S) return;
-    bigseg_sort_boxes_body(c.data, c.seg_points, c.seg_off, c.seg_chunk_off, c.segbox, c.sperm, c.chunk_box, c.seg_sums, c.sort_keys,
-                           c.sort_keys + c.N, blockIdx.x);
+    bigseg_bucket_body(c.data, c.seg_points, c.seg_off, c.segbox, c.seg_sums, c.sort_keys, c.sort_keys + c.N, blockIdx.x);
+}
+__global__ __launch_bounds__(kBigBlock) void k_bigseg_runs_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    bigseg_runs_body(c.seg_off, c.S, c.N, c.sort_keys, c.sort_keys + c.N, c.sperm, blockIdx.x);
+}
+__global__ __launch_bounds__(512) void k_bigseg_boxes_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    bigseg_boxes_body(c.data, c.seg_points, c.seg_off, c.S, c.N, c.seg_chunk_off, c.sperm, c.chunk_box, blockIdx.x);
 }
 
 // coordinate sums of every segment (the library-sort fallback of sg_segment_sort_boxes; same values as the fused kernel's)
@@ -604,6 +657,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
         }
     };
     bool ok = true;                                           // seeded: false while the segment at hand belongs to my former cluster
+    int dbg_scanned = 0;                                      // profiling builds: chunks this tile scanned
     // the fp32 score a candidate must reach to be worth a key: the score part of the larger threshold (key 0 = nothing yet = -inf;
     // an idle lane's all-ones key decodes to NaN, which no score reaches; +inf while the segment at hand is already covered)
     auto score_bound = [](unsigned long long key, bool open) {
@@ -618,6 +672,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
         if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[6], 1ull);
         if (!__any(ok && make_key(box_score_bound(me, bx), 0) >= use)) return;
         if ((dbg & 32) && lane == 0) atomicAdd(&g_knn5_stats[5], 1ull);
+        if (dbg & 16) ++dbg_scanned;
         __builtin_amdgcn_wave_barrier();
         if (lane < kChunkPts + kQuadS) {
             const bool in = lane < m;
@@ -691,7 +746,18 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     // 64 candidates are the queries' immediate neighbours and every later chunk meets a tight threshold.  (Walking a 1,300-chunk
     // floor from chunk 0 approaches the tile along the space-filling curve: nearly every chunk on the way is a little closer
     // than the best so far, passes its box test and is scanned.)
-    auto scan_segment = [&](int sg_m, int sg_c0, int d, const float* sbox, int pc, int& item, int start) {
+    // `two_sided`: the ring is walked OUTWARDS from `start` in both directions (start, start - 1, start + 1, start - 2, ...).  On a Z curve a
+    // query's spatial neighbours lie before AND behind it; walking forwards only, a lane whose neighbours are behind `start` keeps a loose
+    // threshold until the walk has come all the way round, and every chunk inside that loose radius is scanned for it (round 5: the slowest
+    // tile of a ScanNet-shaped scene, in a 29k-point floor, scanned 215 chunks where ~30 hold its neighbours -- and a launch is as long as
+    // its slowest tile).  The visiting order cannot change the result (exact top K under a total order).
+    auto ring_chunk = [](int start, int e, int nch, bool two_sided) {
+        int ch = start + (two_sided ? ((e & 1) ? -((e + 1) >> 1) : (e >> 1)) : e);
+        if (ch >= nch) ch -= nch;
+        if (ch < 0) ch += nch;
+        return ch;
+    };
+    auto scan_segment = [&](int sg_m, int sg_c0, int d, const float* sbox, int pc, int& item, int start, bool two_sided = false) {
         const int nch = (sg_m + kChunkPts - 1) / kChunkPts;
         const unsigned long long use = best_thr();
         if (kSeeded) ok = pc < 0 || pc != myprev;
@@ -701,8 +767,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
             // 32 chunk boxes per coalesced load (one per lane), staged in the wave's LDS strip; ONE call site of scan_chunk
             for (int j0 = 0; j0 < nch; j0 += 32) {
                 const int nb = min(32, nch - j0);
-                int mych = start + j0 + lane;                     // ring order from `start`
-                if (mych >= nch) mych -= nch;
+                const int mych = ring_chunk(start, min(j0 + lane, nch - 1), nch, two_sided);       // ring order from `start`
                 bool pass = lane < nb;
                 // the weakest score any lane still accepts (thresholds only rise: refreshed per 32 chunks; all lanes take part)
                 float weakest = -INFINITY;
@@ -730,8 +795,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
                 while (live) {
                     const int j = __ffsll((unsigned long long)live) - 1;
                     live &= live - 1;
-                    int ch = start + j0 + j;
-                    if (ch >= nch) ch -= nch;
+                    const int ch = ring_chunk(start, j0 + j, nch, two_sided);
                     scan_chunk(cbx + j * 8, d + ch * kChunkPts, min(kChunkPts, sg_m - ch * kChunkPts));
                 }
             }
@@ -759,7 +823,7 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
 #pragma unroll
         for (int k = 0; k < 7; ++k) sbox[k] = segbox[(size_t)sg * 8 + k];
         const int own_chunk = max(0, min((tile_lo[t] - dst[slot]) / kChunkPts, (seg_off[sg + 1] - seg_off[sg] - 1) / kChunkPts));
-        scan_segment(seg_off[sg + 1] - seg_off[sg], seg_chunk_off[sg], dst[slot], sbox, kSeeded ? seg_prevcl[sg] : -1, item, own_chunk);
+        scan_segment(seg_off[sg + 1] - seg_off[sg], seg_chunk_off[sg], dst[slot], sbox, kSeeded ? seg_prevcl[sg] : -1, item, own_chunk, kSlices == 1);
     }
     drain();
     const unsigned long long t1 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -828,6 +892,10 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
         atomicAdd(&g_knn5_stats[2], t2 - t1);
         atomicAdd(&g_knn5_stats[3], t3 - t2);
         atomicAdd(&g_knn5_stats[4], t4 - t3);
+        // the slowest tile: cycles (24 bits, saturated) | cluster points / 64 (14) | segments of the cluster (12) | chunks scanned (14)
+        atomicMax(&g_knn5_stats[13], (min(t4 - t0, 0xffffffull) << 40) | ((unsigned long long)min(n >> 6, 0x3fff) << 26) |
+                                     ((unsigned long long)min(nslots, 0xfff) << 14) | (unsigned long long)min(dbg_scanned, 0x3fff));
+        if (n > 2048) { atomicAdd(&g_knn5_stats[14], t4 - t0); atomicAdd(&g_knn5_stats[15], 1ull); }
     }
 }
 template <int K, int kSlices, bool kSeeded = false>
@@ -1121,7 +1189,12 @@ bool sort_boxes_fits_lds(int max_seg) { return max_seg <= kSortCap; }
 int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
     if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
     k_segment_sort_boxes_b<<<dim3(bd.max_S, bd.nslots), 256, 0, st>>>(d_ctx);
-    if (bd.max_seg > kSortCap) k_bigseg_sort_boxes_b<<<dim3(bd.max_S, bd.nslots), kBigBlock, 0, st>>>(d_ctx);     // small segments exit at once
+    if (bd.max_seg > kSortCap) {                                 // small segments / windows without a big segment exit at once
+        const int wins = sg::cdiv(bd.max_N, kWin);
+        k_bigseg_bucket_b<<<dim3(bd.max_S, bd.nslots), kBigBlock, 0, st>>>(d_ctx);
+        k_bigseg_runs_b<<<dim3(wins, bd.nslots), kBigBlock, 0, st>>>(d_ctx);
+        k_bigseg_boxes_b<<<dim3(wins, bd.nslots), 512, 0, st>>>(d_ctx);
+    }
     SG_LAUNCH_CHECK();
     return SG_OK;
 }
@@ -1206,8 +1279,10 @@ int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_point
     if (max_seg > kSortCap) {                                  // segments beyond one block's LDS: cell-bucketed LDS sort, scratch = 2 x N keys
         if (!d_ws || ws_bytes < sg_segment_sort_ws_bytes(N)) return sg::fail(SG_ENOMEM, "sg_segment_sort_boxes: workspace too small (%zu < %zu)", ws_bytes, sg_segment_sort_ws_bytes(N));
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(d_ws);
-        k_bigseg_sort_boxes<<<S, kBigBlock, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_seg_chunk_off, d_segbox, d_sperm,
-                                                                      d_chunk_box, d_seg_sums, keys, keys + N);
+        const int wins = sg::cdiv(N, kWin);
+        k_bigseg_bucket<<<S, kBigBlock, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_segbox, d_seg_sums, keys, keys + N);
+        k_bigseg_runs<<<wins, kBigBlock, 0, sg::as_stream(stream)>>>(d_seg_off, S, N, keys, keys + N, d_sperm);
+        k_bigseg_boxes<<<wins, 512, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, S, N, d_seg_chunk_off, d_sperm, d_chunk_box);
     }
     SG_LAUNCH_CHECK();
     return SG_OK;
