@@ -1,10 +1,11 @@
 // a4+a5: get_cluster_pointcloud + farthest_point_sampling (reference seggroup/model.py:319-426).
 //
-// One workgroup per cluster.  The cluster's XYZ and the running min-distance array live in LDS (up
-// to kLdsCap points; larger clusters spill to an L2-resident global scratch).  Each of the P%n
-// sampling steps is one strided pass (distance to the newest pick, min with the running array,
-// first-index argmax) followed by a wave-shuffle + LDS reduction.  Small clusters run on ONE wave
-// (no workgroup barriers at all); large ones on 16 waves.
+// One workgroup per cluster, three size classes: <= 512 points on ONE wave (no workgroup barriers at all), <= 2,048 on four waves,
+// larger ones on sixteen.  Up to 8 x BLOCK points the cluster's XYZ and running min-distances live in REGISTERS (eight points per
+// thread); beyond that (floors of a scan: 10k-40k points) a step visits only the 32-point chunks of the Morton-sorted segment that the
+// new pick can still improve, or -- without the sorted order -- walks the points in LDS / an L2-resident global scratch.  Each of the
+// P%n sampling steps is one pass (distance to the newest pick, min with the running value, first-index argmax) followed by a DPP wave
+// reduction and, with several waves, one barrier.
 //
 // Bit-exactness: squared distances are evaluated exactly like NumPy does for
 // ((a - b) ** 2).sum(axis=2) on float32 (model.py:326): three individually rounded squares added as
@@ -18,8 +19,10 @@
 
 namespace {
 
-constexpr int kLdsCap = 8192;        // points whose xyz+min-distance fit the LDS carve (16 B each)
-constexpr int kSmallMax = 2048;      // clusters up to this size run on a single wave
+constexpr int kLdsCap = 8192;        // entries of the LDS carve (16 B each): the chunk-pruned path's per-chunk records, the fallback's points
+constexpr int kSmallMax = 512;       // clusters up to this size run on a single wave (eight points per lane in registers)
+constexpr int kMidMax = 2048;        // ... up to this size on four waves, beyond on sixteen
+constexpr int kChunkCap = 2600;      // chunks of a segment whose per-chunk records (52 B) fit the LDS carve of the chunk-pruned path
 
 struct Best {
     float v;
@@ -77,18 +80,25 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
     const int tid = threadIdx.x;
 
     bool sampled = false;
-    if constexpr (BLOCK == 64) {
-        // Segments of <= 256 points (almost all of them): coordinates and running minima live in REGISTERS, four points per
-        // lane (point i = lane + 64 u, the same assignment as the strided loop below, so the first-index argmax is unchanged);
-        // the newest pick's coordinates come from its owner lane through v_readlane.  The 64 dependent steps of a segment
-        // were bound by LDS round trips (4 reads + 1 write per point and step, then 3 broadcast reads).
-        // kU = points per lane, picked by the segment's size (wave-uniform): a 100-point segment steps over two slots, not four
+    {
+        // Segments of <= 8 x BLOCK points (BLOCK = 64: almost all of them): coordinates and running minima live in REGISTERS, up to eight
+        // points per thread (point i = tid + BLOCK u, the same assignment as the strided loop of the fallback below, so the first-index
+        // argmax is unchanged).  The 64 dependent steps of a segment were bound by LDS round trips (4 reads + 1 write per point and step).
+        // One wave: the newest pick's coordinates come from its owner lane through v_readlane.  Several waves (round 5: 256 threads for
+        // 513-2,048 points, 1,024 for up to 8,192 -- the walls of a scan; one wave walking 2,048 points through LDS 63 times was 200 us):
+        // every wave reduces to its own winner and parks (distance, index, x, y, z) in LDS, ONE barrier, every thread picks the best of
+        // the BLOCK / 64 entries (larger distance, ties -> lower index: np.argmax).  The entries are double-buffered by step parity, so
+        // the next step's writes cannot overtake this step's reads and no second barrier is needed.
+        // kU = points per thread, picked by the segment's size (block-uniform): a 100-point segment steps over two slots, not eight
+        constexpr int kWv = BLOCK / 64;
+        struct Cand { float v; int i; float x, y, z; };
+        __shared__ Cand cand[2][kWv > 1 ? kWv : 1];
         auto in_registers = [&](auto ku) {
             constexpr int kU = decltype(ku)::value;
             float X[kU], Y[kU], Z[kU], M[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                const int i = tid + 64 * u;
+                const int i = tid + BLOCK * u;
                 X[u] = Y[u] = Z[u] = 0.f; M[u] = 0.f;
                 if (i < n) {
                     const float* row = data + (size_t)members[lo + i] * ch_in;
@@ -97,15 +107,17 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
             }
             // branch-free on purpose: written with `if (i < n)` / `if (d > b.v)` the step compiled to 35 branches and 45 exec-mask
             // saves for ~60 VALU of arithmetic, and a segment is a chain of 64 such steps.  A slot past the segment's end carries
-            // the running minimum -inf: it never wins the argmax (slot 0 always holds point 0, whose distance is >= 0).
+            // the running minimum -inf: it never wins the argmax (slot 0 of thread 0 always holds point 0, whose distance is >= 0).
             bool in[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) in[u] = tid + 64 * u < n;
-            auto pass = [&](float qx, float qy, float qz, bool reset) {
+            for (int u = 0; u < kU; ++u) in[u] = tid + BLOCK * u < n;
+            int parity = 0;
+            // one sampling step: distances to q, running minima, the block's argmax; returns the pick and leaves ITS coordinates in q
+            auto step = [&](float& qx, float& qy, float& qz, bool reset) {
                 Best b{-INFINITY, INT_MAX};
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
-                    const int i = tid + 64 * u;
+                    const int i = tid + BLOCK * u;
                     const float dx = X[u] - qx, dy = Y[u] - qy, dz = Z[u] - qz;
                     float d = (dx * dx + dy * dy) + dz * dz;
                     d = reset ? d : fminf(M[u], d);
@@ -116,35 +128,47 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
                     b.i = better_ ? i : b.i;
                 }
                 sgw::wave_argmax(b.v, b.i);
-                return b;
-            };
-            auto coords = [&](int cur, float& qx, float& qy, float& qz) {     // cur is wave-uniform
-                const int u = cur >> 6, l = cur & 63;
+                // the wave's winner is wave-uniform: say so, or selecting its coordinates becomes a branch tree
+                const int wi = __builtin_amdgcn_readfirstlane(b.i);
+                const int wu = wi < n ? wi / BLOCK : 0, wl = wi < n ? (wi % BLOCK) & 63 : 0;
                 float sx = X[0], sy = Y[0], sz = Z[0];
 #pragma unroll
-                for (int w = 1; w < kU; ++w) { sx = u == w ? X[w] : sx; sy = u == w ? Y[w] : sy; sz = u == w ? Z[w] : sz; }
-                qx = sgw::bcast(sx, l); qy = sgw::bcast(sy, l); qz = sgw::bcast(sz, l);
-            };
-            float qx, qy, qz;
-            coords(0, qx, qy, qz);
-            Best b = pass(qx, qy, qz, true);                          // start at member 0 (model.py:382-386)
-            int cur = __builtin_amdgcn_readfirstlane(b.i);      // wave-uniform: say so, or `coords` becomes a branch tree
-            if (tid == 0) picks[0] = cur;
-            coords(cur, qx, qy, qz);
-            b = pass(qx, qy, qz, true);
-            for (int it = 1; it < rem; ++it) {                       // model.py:389-394
-                cur = __builtin_amdgcn_readfirstlane(b.i);
-                if (tid == 0) picks[it] = cur;
-                if (it + 1 < rem) {
-                    coords(cur, qx, qy, qz);
-                    b = pass(qx, qy, qz, false);
+                for (int w = 1; w < kU; ++w) { sx = wu == w ? X[w] : sx; sy = wu == w ? Y[w] : sy; sz = wu == w ? Z[w] : sz; }
+                sx = sgw::bcast(sx, wl); sy = sgw::bcast(sy, wl); sz = sgw::bcast(sz, wl);
+                if constexpr (kWv == 1) {
+                    qx = sx; qy = sy; qz = sz;
+                    return wi;
+                } else {
+                    if ((tid & 63) == 0) cand[parity][tid >> 6] = Cand{b.v, wi, sx, sy, sz};
+                    __syncthreads();
+                    Cand r = cand[parity][0];
+#pragma unroll
+                    for (int w = 1; w < kWv; ++w) {
+                        const Cand c_ = cand[parity][w];
+                        const bool take = c_.v > r.v || (c_.v == r.v && c_.i < r.i);
+                        r.v = take ? c_.v : r.v; r.i = take ? c_.i : r.i; r.x = take ? c_.x : r.x; r.y = take ? c_.y : r.y; r.z = take ? c_.z : r.z;
+                    }
+                    parity ^= 1;
+                    qx = r.x; qy = r.y; qz = r.z;
+                    return r.i;
                 }
+            };
+            const float* row0 = data + (size_t)members[lo] * ch_in;       // start at member 0 (model.py:382-386)
+            float qx = row0[0], qy = row0[1], qz = row0[2];
+            int cur = step(qx, qy, qz, true);                             // the first pick: farthest from member 0 ...
+            if (tid == 0) picks[0] = cur;
+            int nxt = step(qx, qy, qz, true);                             // ... and the running minima RESET to it
+            for (int it = 1; it < rem; ++it) {                            // model.py:389-394
+                cur = nxt;
+                if (tid == 0) picks[it] = cur;
+                if (it + 1 < rem) nxt = step(qx, qy, qz, false);
             }
         };
-        if (rem > 0 && n <= 256) {
-            if (n <= 64) in_registers(std::integral_constant<int, 1>{});
-            else if (n <= 128) in_registers(std::integral_constant<int, 2>{});
-            else in_registers(std::integral_constant<int, 4>{});
+        if (rem > 0 && n <= 8 * BLOCK) {
+            if (n <= BLOCK) in_registers(std::integral_constant<int, 1>{});
+            else if (n <= 2 * BLOCK) in_registers(std::integral_constant<int, 2>{});
+            else if (n <= 4 * BLOCK) in_registers(std::integral_constant<int, 4>{});
+            else in_registers(std::integral_constant<int, 8>{});
             sampled = true;
         }
     }
@@ -157,99 +181,147 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
         // argmax is the argmax over the chunk maxima (ties -> lowest member index, as in the plain pass).  The first two passes
         // (start point, then the reset to the first pick: model.py:382-386) visit everything.  One block walking 40k points 64 times
         // through L2 was 0.55 ms per launch.
-        if (rem > 0 && !sampled && n > lds_pts && sperm && (n + 31) / 32 <= lds_pts) {
+        if (rem > 0 && !sampled && sperm && (n + 31) / 32 <= lds_pts) {
+            // Round 5: a step used to cost ~7 us alone on the GPU (a 29k-point floor: 436 us per launch) -- the chunk boxes and the new
+            // pick's coordinates came from global memory, every half wave waited out one chunk's loads at a time, the survivors were
+            // listed one LDS atomic each.  Now the carve holds 13 words per chunk (running maximum, its member index and coordinates,
+            // the chunk's box, the work list), the list is appended per wave, and a half wave has two chunks' loads in flight (four in
+            // the two full passes): one L2 round trip and three barriers per step.
             const int nch = (n + 31) / 32, c0 = seg_chunk_off[c];
-            float* cm = lds_f;                                                     // the carve is unused on this path: 4 x lds_pts words
+            float* cm = lds_f;
             int* ci = reinterpret_cast<int*>(lds_f + lds_pts);
-            int* cr = reinterpret_cast<int*>(lds_f + 2 * (size_t)lds_pts);
-            int* wl = reinterpret_cast<int*>(lds_f + 3 * (size_t)lds_pts);
+            float* cx = lds_f + 2 * (size_t)lds_pts; float* cy = lds_f + 3 * (size_t)lds_pts; float* cz = lds_f + 4 * (size_t)lds_pts;
+            int* wl = reinterpret_cast<int*>(lds_f + 5 * (size_t)lds_pts);
+            float* bxl = lds_f + 6 * (size_t)lds_pts;                              // [6][lds_pts]: min xyz, max xyz
             __shared__ int wl_n;
-            __shared__ float rv[16];
-            __shared__ int ri[16], rr[16];
+            struct ChunkCand { float v; int i; int ch; };
+            __shared__ ChunkCand cc[2][16];
             float* Xs = ws + lo; float* Ys = ws + (size_t)N + lo; float* Zs = ws + 2 * (size_t)N + lo; float* Ms = ws + 3 * (size_t)N + lo;
+#pragma unroll 4
             for (int r = tid; r < n; r += BLOCK) {
                 const float* row = data + (size_t)members[sperm[lo + r]] * ch_in;
                 Xs[r] = row[0]; Ys[r] = row[1]; Zs[r] = row[2];
             }
+            for (int ch = tid; ch < nch; ch += BLOCK) {
+                const float* bx = chunk_box + (size_t)(c0 + ch) * 8;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) bxl[(size_t)k * lds_pts + ch] = bx[k];
+            }
+            if (tid == 0) wl_n = 0;
             __syncthreads();
             const int lane = tid & 63, wave = tid >> 6, hl = lane & 31, half = lane >> 5;
-            // one chunk per half wave: distances to q, running minima, the chunk's (max, member index, sorted position)
-            auto visit = [&](int ch, float qx, float qy, float qz, bool reset) {
-                const int r = 32 * ch + hl;
-                const bool in = r < n;
-                float d = -INFINITY;
-                int li = INT_MAX;
-                if (in) {
-                    const float dx = Xs[r] - qx, dy = Ys[r] - qy, dz = Zs[r] - qz;
-                    d = (dx * dx + dy * dy) + dz * dz;
-                    if (!reset) d = fminf(Ms[r], d);
-                    Ms[r] = d;
-                    li = sperm[lo + r] - lo;
+            // kV chunks per half wave at a time: all their loads first, then distances, running minima and each chunk's (max, member index,
+            // coordinates).  `chs` may repeat a chunk (odd tails: both halves of a wave run the DPP reductions together): the same values
+            // are written again.
+            auto visit = [&](auto kv_, const int* chs, float qx, float qy, float qz, bool reset) {
+                constexpr int kV = decltype(kv_)::value;
+                float x[kV], y[kV], z[kV], mo[kV];
+                int li[kV];
+#pragma unroll
+                for (int v = 0; v < kV; ++v) {
+                    const int r = min(32 * chs[v] + hl, n - 1);
+                    x[v] = Xs[r]; y[v] = Ys[r]; z[v] = Zs[r];
+                    mo[v] = reset ? 0.f : Ms[r];
+                    li[v] = sperm[lo + r] - lo;
                 }
-                // maxima / minima of the 32 lanes of each half: rows of 16 on the DPP path, row 0 -> 1 and 2 -> 3, then lanes 31 / 63
-                float m = d;
-                m = fmaxf(m, sgw::dpp_f<sgw::kQuadXor1>(m, m)); m = fmaxf(m, sgw::dpp_f<sgw::kQuadXor2>(m, m));
-                m = fmaxf(m, sgw::dpp_f<sgw::kRowRor4>(m, m));  m = fmaxf(m, sgw::dpp_f<sgw::kRowRor8>(m, m));
-                m = fmaxf(m, sgw::dpp_f<sgw::kRowBcast15, 0xA>(m, m));
-                const float mh = half ? sgw::bcast(m, 63) : sgw::bcast(m, 31);
-                int k = d == mh ? li : INT_MAX;
-                k = min(k, sgw::dpp_i<sgw::kQuadXor1>(k, k)); k = min(k, sgw::dpp_i<sgw::kQuadXor2>(k, k));
-                k = min(k, sgw::dpp_i<sgw::kRowRor4>(k, k));  k = min(k, sgw::dpp_i<sgw::kRowRor8>(k, k));
-                k = min(k, sgw::dpp_i<sgw::kRowBcast15, 0xA>(k, k));
-                const int kh = half ? sgw::bcast(k, 63) : sgw::bcast(k, 31);
-                if (in && li == kh) { cm[ch] = mh; ci[ch] = kh; cr[ch] = r; }     // exactly one lane of the half
+#pragma unroll
+                for (int v = 0; v < kV; ++v) {
+                    const int r = 32 * chs[v] + hl;
+                    const bool in = r < n;
+                    const float dx = x[v] - qx, dy = y[v] - qy, dz = z[v] - qz;
+                    float d = (dx * dx + dy * dy) + dz * dz;
+                    if (!reset) d = fminf(mo[v], d);
+                    if (in) Ms[r] = d;
+                    d = in ? d : -INFINITY;
+                    const int lix = in ? li[v] : INT_MAX;
+                    // maxima / minima of the 32 lanes of each half: rows of 16 on the DPP path, row 0 -> 1 and 2 -> 3, then lanes 31 / 63
+                    float m = d;
+                    m = fmaxf(m, sgw::dpp_f<sgw::kQuadXor1>(m, m)); m = fmaxf(m, sgw::dpp_f<sgw::kQuadXor2>(m, m));
+                    m = fmaxf(m, sgw::dpp_f<sgw::kRowRor4>(m, m));  m = fmaxf(m, sgw::dpp_f<sgw::kRowRor8>(m, m));
+                    m = fmaxf(m, sgw::dpp_f<sgw::kRowBcast15, 0xA>(m, m));
+                    const float mh = half ? sgw::bcast(m, 63) : sgw::bcast(m, 31);
+                    int k = d == mh ? lix : INT_MAX;
+                    k = min(k, sgw::dpp_i<sgw::kQuadXor1>(k, k)); k = min(k, sgw::dpp_i<sgw::kQuadXor2>(k, k));
+                    k = min(k, sgw::dpp_i<sgw::kRowRor4>(k, k));  k = min(k, sgw::dpp_i<sgw::kRowRor8>(k, k));
+                    k = min(k, sgw::dpp_i<sgw::kRowBcast15, 0xA>(k, k));
+                    const int kh = half ? sgw::bcast(k, 63) : sgw::bcast(k, 31);
+                    if (in && lix == kh) { const int ch = chs[v]; cm[ch] = mh; ci[ch] = kh; cx[ch] = x[v]; cy[ch] = y[v]; cz[ch] = z[v]; }   // one lane of the half
+                }
             };
-            // argmax over the chunk maxima: larger value, ties -> lower member index; every thread returns the winner
-            auto pick = [&](float& bv, int& bi, int& br) {
-                float v = -INFINITY; int i = INT_MAX, r = 0;
+            // argmax over the chunk maxima: larger value, ties -> lower member index; every thread returns the winner and its coordinates
+            int parity = 0;
+            auto pick = [&](int& bi, float& qx, float& qy, float& qz) {
+                float v = -INFINITY; int i = INT_MAX, cch = 0;
                 for (int ch = tid; ch < nch; ch += BLOCK) {
                     const float cv = cm[ch]; const int cix = ci[ch];
-                    if (cv > v || (cv == v && cix < i)) { v = cv; i = cix; r = cr[ch]; }
+                    if (cv > v || (cv == v && cix < i)) { v = cv; i = cix; cch = ch; }
                 }
                 const float wm = sgw::wave_max(v);
                 const int wi = sgw::wave_min(v == wm ? i : INT_MAX);
-                const int wr = sgw::wave_min(v == wm && i == wi ? r : INT_MAX);
-                if (lane == 0) { rv[wave] = wm; ri[wave] = wi; rr[wave] = wr; }
+                const unsigned long long own = __ballot(v == wm && i == wi);
+                if (lane == __ffsll((unsigned long long)own) - 1) cc[parity][wave] = ChunkCand{wm, wi, cch};
                 __syncthreads();
-                bv = rv[0]; bi = ri[0]; br = rr[0];
+                ChunkCand r = cc[parity][0];
 #pragma unroll
-                for (int w = 1; w < 16; ++w)
-                    if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; br = rr[w]; }
-                __syncthreads();
+                for (int w = 1; w < 16; ++w) {
+                    const ChunkCand o = cc[parity][w];
+                    const bool take = o.v > r.v || (o.v == r.v && o.i < r.i);
+                    r.v = take ? o.v : r.v; r.i = take ? o.i : r.i; r.ch = take ? o.ch : r.ch;
+                }
+                parity ^= 1;
+                bi = r.i; qx = cx[r.ch]; qy = cy[r.ch]; qz = cz[r.ch];
             };
             auto full_pass = [&](float qx, float qy, float qz) {
-                for (int e = 2 * wave; e < nch; e += 32) visit(min(e + half, nch - 1), qx, qy, qz, true);   // both halves together (see below)
+                for (int e = 2 * wave; e < nch; e += 128) {                       // four chunks per half wave in flight
+                    const int chs[4] = {min(e + half, nch - 1), min(e + 32 + half, nch - 1), min(e + 64 + half, nch - 1), min(e + 96 + half, nch - 1)};
+                    visit(std::integral_constant<int, 4>{}, chs, qx, qy, qz, true);
+                }
                 __syncthreads();
             };
-            float bv; int bi, br;
+            int bi;
+            float qx, qy, qz;
             {
                 const float* row0 = data + (size_t)members[lo] * ch_in;           // start at member 0 (model.py:382-386)
                 full_pass(row0[0], row0[1], row0[2]);
-                pick(bv, bi, br);
+                pick(bi, qx, qy, qz);
             }
             int cur = bi;
             if (tid == 0) picks[0] = cur;
-            full_pass(Xs[br], Ys[br], Zs[br]);                                    // reset to the first pick
-            pick(bv, bi, br);
+            full_pass(qx, qy, qz);                                                // reset to the first pick
+            pick(bi, qx, qy, qz);
             for (int it = 1; it < rem; ++it) {                                    // model.py:389-394
                 cur = bi;
-                if (tid == 0) { picks[it] = cur; wl_n = 0; }
+                if (tid == 0) picks[it] = cur;
                 if (it + 1 < rem) {
-                    const float qx = Xs[br], qy = Ys[br], qz = Zs[br];
-                    __syncthreads();
-                    for (int ch = tid; ch < nch; ch += BLOCK) {
-                        const float* bx = chunk_box + (size_t)(c0 + ch) * 8;
-                        const float gx = fmaxf(fmaxf(bx[0] - qx, qx - bx[3]), 0.f), gy = fmaxf(fmaxf(bx[1] - qy, qy - bx[4]), 0.f),
-                                    gz = fmaxf(fmaxf(bx[2] - qz, qz - bx[5]), 0.f);
-                        if (((gx * gx + gy * gy) + gz * gz) * 0.999999f < cm[ch]) wl[atomicAdd(&wl_n, 1)] = ch;
+                    // the chunks the new pick can still improve, appended per wave (the barrier inside the last pick() separates this
+                    // step's list from the previous step's readers; wl_n is reset behind the barrier below)
+                    for (int ch0 = 0; ch0 < nch; ch0 += BLOCK) {
+                        const int ch = ch0 + tid;
+                        bool need = false;
+                        if (ch < nch) {
+                            const float gx = fmaxf(fmaxf(bxl[ch] - qx, qx - bxl[3 * (size_t)lds_pts + ch]), 0.f),
+                                        gy = fmaxf(fmaxf(bxl[(size_t)lds_pts + ch] - qy, qy - bxl[4 * (size_t)lds_pts + ch]), 0.f),
+                                        gz = fmaxf(fmaxf(bxl[2 * (size_t)lds_pts + ch] - qz, qz - bxl[5 * (size_t)lds_pts + ch]), 0.f);
+                            need = ((gx * gx + gy * gy) + gz * gz) * 0.999999f < cm[ch];
+                        }
+                        const unsigned long long mask = __ballot(need);
+                        int base = 0;
+                        if (lane == 0 && mask) base = atomicAdd(&wl_n, __popcll(mask));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (need) wl[base + __popcll(mask & ((1ull << lane) - 1ull))] = ch;
                     }
                     __syncthreads();
                     const int nw = wl_n;
                     // both halves of a wave must run visit() together (its reductions are wave-wide DPP networks): an odd tail
                     // revisits the last listed chunk, which changes nothing
-                    for (int e = 2 * wave; e < nw; e += 32) visit(wl[min(e + half, nw - 1)], qx, qy, qz, false);
+                    for (int e = 2 * wave; e < nw; e += 64) {
+                        const int chs[2] = {wl[min(e + half, nw - 1)], wl[min(e + 32 + half, nw - 1)]};
+                        if (e + 32 < nw) visit(std::integral_constant<int, 2>{}, chs, qx, qy, qz, false);
+                        else visit(std::integral_constant<int, 1>{}, chs, qx, qy, qz, false);
+                    }
                     __syncthreads();
-                    pick(bv, bi, br);
+                    if (tid == 0) wl_n = 0;
+                    pick(bi, qx, qy, qz);
                 }
             }
             sampled = true;
@@ -408,19 +480,20 @@ int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_memb
     static bool attr_set = false;
     if (!attr_set) {
         SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fps_sample<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(head + (size_t)kLdsCap * 16 + 4096 * 4)));
+                                   (int)(head + std::max((size_t)kLdsCap * 16, (size_t)kChunkCap * 52) + 4096 * 4)));
         attr_set = true;
     }
-    // single-wave class: clusters with n <= kSmallMax, LDS carve sized to the largest of them
-    const int small_pts = max_n < 0 ? kSmallMax : std::max(64, std::min(max_n, kSmallMax));
-    k_fps_sample<64><<<C, 64, head + (size_t)small_pts * 16, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform, 1,
-                                                                 kSmallMax, small_pts, d_samples, d_sel, (float*)d_ws);
-    // 16-wave class: everything larger (blocks whose cluster is small exit immediately); skipped when the
-    // host knows there is none
-    if (max_n < 0 || max_n > kSmallMax) {
+    // single-wave class: clusters with n <= kSmallMax (registers: no carve)
+    k_fps_sample<64><<<C, 64, head, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform, 1, kSmallMax, 0, d_samples, d_sel, (float*)d_ws);
+    // four- and sixteen-wave classes (blocks whose cluster is not theirs exit immediately); skipped when the host knows there is none
+    if (max_n < 0 || max_n > kSmallMax)
+        k_fps_sample<256><<<C, 256, head, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform, kSmallMax + 1, kMidMax, 0, d_samples, d_sel,
+                                               (float*)d_ws);
+    if (max_n < 0 || max_n > kMidMax) {
+        // beyond 8 x 1024 points (no sorted order on this entry): the points in the carve while they fit, in the global scratch otherwise
         const int big_pts = max_n < 0 ? kLdsCap : std::min(max_n, kLdsCap);
         k_fps_sample<1024><<<C, 1024, head + (size_t)big_pts * 16, st>>>(d_data, N, ch_in, d_members, d_cl_off, P, ch_out, transform,
-                                                                        kSmallMax + 1, INT_MAX, big_pts, d_samples, d_sel,
+                                                                        kMidMax + 1, INT_MAX, big_pts, d_samples, d_sel,
                                                                         (float*)d_ws);
     }
     SG_LAUNCH_CHECK();
@@ -434,14 +507,17 @@ int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, bool sort
     static bool attr_set = false;
     if (!attr_set) {
         SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fps_sample_b<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(head + (size_t)kLdsCap * 16 + 4096 * 4)));
+                                   (int)(head + std::max((size_t)kLdsCap * 16, (size_t)kChunkCap * 52) + 4096 * 4)));
         attr_set = true;
     }
-    const int small_pts = std::max(64, std::min(bd.max_seg, kSmallMax));
-    k_fps_sample_b<64><<<dim3(bd.max_S, bd.nslots), 64, head + (size_t)small_pts * 16, st>>>(d_ctx, 1, kSmallMax, small_pts, 0);
-    if (bd.max_seg > kSmallMax) {
-        const int big_pts = std::min(bd.max_seg, kLdsCap);
-        k_fps_sample_b<1024><<<dim3(bd.max_S, bd.nslots), 1024, head + (size_t)big_pts * 16, st>>>(d_ctx, kSmallMax + 1, INT_MAX, big_pts, sorted ? 1 : 0);
+    k_fps_sample_b<64><<<dim3(bd.max_S, bd.nslots), 64, head, st>>>(d_ctx, 1, kSmallMax, 0, 0);
+    if (bd.max_seg > kSmallMax) k_fps_sample_b<256><<<dim3(bd.max_S, bd.nslots), 256, head, st>>>(d_ctx, kSmallMax + 1, kMidMax, 0, 0);
+    if (bd.max_seg > kMidMax) {
+        // the carve: 13 words per chunk for the chunk-pruned path (segments beyond 8,192 points, Morton-sorted: up to kChunkCap chunks =
+        // ~83k points; a larger segment takes the fallback), or the fallback's points (16 bytes each)
+        const int big_pts = sorted ? std::max(64, std::min(sg::cdiv(bd.max_seg, 32), kChunkCap)) : std::max(64, std::min(bd.max_seg, kLdsCap));
+        k_fps_sample_b<1024><<<dim3(bd.max_S, bd.nslots), 1024, head + (size_t)big_pts * (sorted ? 52 : 16), st>>>(d_ctx, kMidMax + 1, INT_MAX, big_pts,
+                                                                                                                  sorted ? 1 : 0);
     }
     SG_LAUNCH_CHECK();
     return SG_OK;

@@ -197,6 +197,8 @@ __device__ __forceinline__ void bigseg_bucket_body(const float* __restrict__ dat
     // 1. box + sums
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, xx = 0.f;
     double sm[3] = {0.0, 0.0, 0.0};
+    // (a block is alone with its segment: the gathers of four trips are in flight together, or every trip waits out two dependent round trips)
+#pragma unroll 4
     for (int i = tid; i < n; i += kBigBlock) {
         const float* r = data + (size_t)seg_points[lo + i] * 6;
 #pragma unroll
@@ -231,6 +233,7 @@ __device__ __forceinline__ void bigseg_bucket_body(const float* __restrict__ dat
     }
     __syncthreads();
     // 2. keys + histogram of the top 12 bits
+#pragma unroll 4
     for (int i = tid; i < n; i += kBigBlock) {
         const float* r = data + (size_t)seg_points[lo + i] * 6;
         const unsigned int m = morton30(r, bx);
@@ -257,6 +260,7 @@ __device__ __forceinline__ void bigseg_bucket_body(const float* __restrict__ dat
         for (int u = 0; u < 4; ++u) { hist[4 * tid + u] = off; first[4 * tid + u] = off; off += c[u]; }      // first position of every cell
     }
     __syncthreads();
+#pragma unroll 4
     for (int i = tid; i < n; i += kBigBlock) {
         const unsigned long long k = keysA[lo + i];
         const int pos = atomicAdd(&hist[(unsigned int)(k >> 32) >> 18], 1);
