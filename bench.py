@@ -106,7 +106,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-files", action="store_true", help="skip the separate with-files measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra leg (scenes/s on the ScanNet-shaped segment profile)")
     ap.add_argument("--extra-train", type=int, default=8, help="training steps timed in the extra leg (rank 0, N = 1; 0 = skip)")
-    ap.add_argument("--extra-scannet", type=int, default=48, help="scenes of the ScanNet-shaped profile in the extra leg (rank 0, N = 1)")
+    ap.add_argument("--extra-scannet", type=int, default=64, help="scenes of the ScanNet-shaped profile in the extra leg (rank 0, N = 1)")
     ap.add_argument("--writer-threads", type=int, default=12, help="native writer threads for the with-files leg (tmpfs, txt + npy: 8 threads 1,690, 12 2,020, 16 1,830, 32 1,250-1,390 scenes/s once the text comes from a table: more threads only contend for memory bandwidth)")
     ap.add_argument("--gen-workers", type=int, default=0, help="scene generator processes (0 = min(16, cores))")
     ap.add_argument("--numa", default="auto", choices=["auto", "off"], help="auto = bind every rank's process (engine groups, writer pool) to the CPUs of its GPU's NUMA node")
@@ -572,22 +572,30 @@ def main(argv=None):
             runner.run(extra_scenes, hip.MODE_INS_INFER)
             torch.cuda.synchronize()
             runner.reset_stage_stats()
-            t1 = time.perf_counter()
-            reps, pend, res_x = 4, [], None
-            for _ in range(reps):                                  # queued two ahead, like the timed loop
-                pend.append(runner.submit(extra_scenes, hip.MODE_INS_INFER))
-                if len(pend) > 2:
+            # the second headline: timed like the main loop -- regions of `passes` passes over the 64 scenes, queued two
+            # ahead, back to back -- and reported like `repeat_values`
+            passes, regions_x, res_x = max(4, args.steps // 4), [], None
+            for _ in range(max(1, args.repeats)):
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                pend = []
+                for _p in range(passes):
+                    pend.append(runner.submit(extra_scenes, hip.MODE_INS_INFER))
+                    if len(pend) > 2:
+                        res_x = runner.wait(pend.pop(0))
+                while pend:
                     res_x = runner.wait(pend.pop(0))
-            while pend:
-                res_x = runner.wait(pend.pop(0))
-            dt = time.perf_counter() - t1
+                torch.cuda.synchronize()
+                regions_x.append(round(passes * len(extra_scenes) / (time.perf_counter() - t1), 3))
             solo2 = Pipeline(W, *caps, stream=None, device=dev)
             solo2.set_timing(0)
             same_x = all(label_digest(res_x[i]) == label_digest(solo2.forward(extra_scenes[i], hip.MODE_INS_INFER)) for i in range(min(4, len(extra_scenes))))
             solo2.close()
             seg_max = max(int(s_.h_seg_size.max()) for s_ in extra_scenes)
             stage_x = {k_: round(v, 4) for k_, v in runner.mean_stage_ms().items() if v > 0}
-            extras["scannet_profile"] = {"scenes_per_s": round(reps * len(extra_scenes) / dt, 3), "scenes": len(extra_scenes), "largest_segment_points": seg_max,
+            extras["scannet_profile"] = {"scenes_per_s": regions_x[0], "repeat_values": {"scenes_per_s": regions_x, "min": min(regions_x), "median": float(np.median(regions_x)),
+                                                                                        "what": f"{len(regions_x)} timed regions of {passes} passes over {len(extra_scenes)} scenes each"},
+                                         "ratio_to_value": round(float(np.median(regions_x)) / float(np.median(repeat_values)), 4),
+                                         "scenes": len(extra_scenes), "largest_segment_points": seg_max,
                                          "equals_single_pipeline": bool(same_x), "stage_ms": stage_x,
                                          "cluster_trace_scene0": list(res_x[0].trace)}
             if not same_x:
