@@ -154,9 +154,12 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                                               sg::gptr<const float> gamma_last,
                                               sg::gptr<float> ext, sg::gptr<double> partial, int bid,
                                               sg::gptr<const int32_t> cluster_of_pos = nullptr, int ext_stride = 64, int stagger = 0,
-                                              sg::gptr<const unsigned int> range_bits = nullptr, int nblk = 1 << 28) {
+                                              sg::gptr<const unsigned int> range_bits = nullptr, int nblk = 1 << 28, int walk_mode = 0) {
     using sg::gptr;
     __shared__ Lds lds;
+    // fused epilogue (round 5): the maximum of the wave's current run of tiles inside ONE cluster, per channel, and that cluster's id
+    __shared__ float carry_m[kFused ? kWaves : 1][64];
+    __shared__ int carry_c[kFused ? kWaves : 1];
     // the fused epilogue's stage (32 rows x 64 maxima per wave); during the slot loop of the fp16 variants: the lanes' neighbour ids [K][64]
     __shared__ float stage_or_ids[(kFused || kF16) ? kWaves : 1][(kFused || kF16) ? 32 * 65 : 1];
     __shared__ float flush_sums[kWaves][128];                     // a tile's 64 sums + 64 sums of squares on their way into lds.acc
@@ -277,17 +280,39 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     const float cx0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)x9m[0])));
     const float cx1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)x9m[1])));
     const float cx2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)x9m[2])));
-    auto own_row = [&](int grp) { const int p_ = (grp * kWaves + wave) * 32 + r; return (gptr<const float4>)(x9m + (size_t)(p_ < N ? p_ : 0) * 12); };
+    // Which tiles a workgroup walks.  walk_mode 0 (round 4): tile groups bid, bid + nblk, ...  walk_mode 1 (round 5, the engine's launches):
+    // workgroup bid owns ONE contiguous range of the scene's tile groups and each of its waves a contiguous quarter of the range's tiles, so
+    // that (a) a wave's consecutive tiles are consecutive rows -- in member order mostly the same cluster: the fused epilogue carries a
+    // cluster's maxima from tile to tile and leaves one atomic per (run, channel) instead of one per (tile, channel): 16 MB of atomic traffic
+    // per scene-launch in round 4 -- and (b) the ranges of the workgroups that share an XCD (linear workgroup id mod 8 = bid mod 8 when
+    // nblk is a multiple of 8) are neighbours: an L2 sees one eighth of a scene's rows and its gathers, not all of them.
+    int g0 = 0, glen = 0;
+    if (walk_mode) {
+        const int rho = (nblk & 7) == 0 ? (bid & 7) * (nblk >> 3) + (bid >> 3) : bid;
+        g0 = (int)((long long)rho * ngroups / nblk);
+        glen = (int)((long long)(rho + 1) * ngroups / nblk) - g0;
+    }
+    const int walk_n = walk_mode ? glen : (bid < ngroups ? (ngroups - bid + nblk - 1) / nblk : 0);
+    auto tile_of = [&](int it, int w_) { return walk_mode ? g0 * kWaves + w_ * glen + it : (bid + it * nblk) * kWaves + w_; };
+    auto own_row = [&](int it) { const int p_ = tile_of(it, wave) * 32 + r; return (gptr<const float4>)(x9m + (size_t)(p_ < N ? p_ : 0) * 12); };
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-    if (bid < ngroups) { const gptr<const float4> xr = own_row(bid); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
+    if (walk_n > 0) { const gptr<const float4> xr = own_row(0); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
     const int tid_outer = tid;
-    for (int grp = bid; grp < ngroups; grp += nblk) {
+    if constexpr (kFused) { if (lane == 0) carry_c[wave] = -1; }
+    // one atomic max per (cluster, channel): order-preserving integer view -- non-negative floats compare as ints, negative floats reversed as uints
+    auto cluster_max_out = [&](int c, float v, int ch) {
+        v *= unscale;                                             // one multiply per (cluster, channel) instead of 32 per lane and tile
+        float* addr = (float*)(ext + (size_t)c * ext_stride + ch);
+        if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+        else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+    };
+    for (int it = 0; it < walk_n; ++it) {
     // Everything a lane knows about itself is re-derived from the thread id here and again behind the slot loop: the statement of the
     // hand-scheduled loop leaves the compiler ten registers, and what is live across it goes to scratch and back (45 values per tile before)
     int tid = tid_outer;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
-    const int tile = grp * kWaves + wave;
+    const int tile = tile_of(it, wave);
     const int pt = tile * 32 + r;
     const bool valid = pt < N;
     [[maybe_unused]] const float vmask = valid ? 1.f : 0.f;
@@ -545,7 +570,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                     float c2x = q2.x;
                     asm volatile("" : "+v"(tid_c), "+v"(c0), "+v"(c1), "+v"(c2x));
                     const int lane_c = tid_c & 63, half_c = lane_c >> 5, r_c = lane_c & 31, wave_c = tid_c >> 6;
-                    const int pt_c = (grp * kWaves + wave_c) * 32 + r_c;
+                    const int pt_c = tile_of(it, wave_c) * 32 + r_c;
                     const unsigned koff = (unsigned)(pt_c < N ? pt_c : 0) * 80u;    // the lane's row of the kNN table (K = 20 ids)
                     const unsigned l16 = 16u * (unsigned)half_c;
                     const float xs_c[5] = {(half_c ? c1.x : c0.x) * Sd, (half_c ? c1.y : c0.y) * Sd, (half_c ? c1.z : c0.z) * Sd, (half_c ? c1.w : c0.w) * Sd,
@@ -629,12 +654,12 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         int tid = tid_outer;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
-        const int tile = grp * kWaves + wave;
+        const int tile = tile_of(it, wave);
         const int pt = tile * 32 + r;
         const bool valid = pt < N;
         const float vmask = valid ? 1.f : 0.f;
         const int ptc = valid ? pt : 0;
-        if (grp + nblk < ngroups) { const gptr<const float4> xn = own_row(grp + nblk); nq0 = xn[0]; nq1 = xn[1]; nq2 = xn[2]; }
+        if (it + 1 < walk_n) { const gptr<const float4> xn = own_row(it + 1); nq0 = xn[0]; nq1 = xn[1]; nq2 = xn[2]; }
         int myc = 0;
         if constexpr (kFused) myc = cluster_of_pos[ptc];      // asked for here, needed behind the statistics flush
         // sum over the 32 rows of each half on the DPP path (wave_ops.h; `__shfl_xor` is an LDS round trip per step on gfx950): quads,
@@ -742,16 +767,10 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                 for (int q = 0; q < 16; ++q) st[r * 65 + acc_channel(t, q, half)] = best[t][q];     // x unscale (> 0) behind the maximum: monotone, same bits
             __builtin_amdgcn_wave_barrier();
             const int rows_here = min(32, N - tile * 32);
-            int cprev = __builtin_amdgcn_readfirstlane(myc);
-            float m = -INFINITY;
-            auto flush = [&](int c, float v) {
-                v *= unscale;                                     // one multiply per (cluster, channel) instead of 32 per lane and tile
-                float* addr = (float*)(ext + (size_t)c * ext_stride + lane);
-                // order-preserving integer view: non-negative floats compare as ints, negative floats reversed as uints
-                if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
-                else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
-            };
-            if (rows_here == 32 && __builtin_amdgcn_ballot_w64(myc != cprev) == 0) {
+            const int cfirst = __builtin_amdgcn_readfirstlane(myc);
+            // the run carried over from the wave's previous tile: its cluster (wave-uniform) and, per channel, its maximum so far
+            const int cc = __builtin_amdgcn_readfirstlane(carry_c[wave]);
+            if (rows_here == 32 && __builtin_amdgcn_ballot_w64(myc != cfirst) == 0) {
                 // the usual case -- all 32 rows in one cluster: the channel's 32 values are requested together and folded by a tree
                 // (the walk below is a chain of 32 dependent LDS round trips)
                 float col[32];
@@ -761,15 +780,23 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                 for (int w_ = 16; w_ >= 1; w_ >>= 1)
 #pragma unroll
                     for (int rr = 0; rr < w_; ++rr) col[rr] = fmaxf(col[rr], col[rr + w_]);
-                flush(cprev, col[0]);
+                if (cc == cfirst) carry_m[wave][lane] = fmaxf(carry_m[wave][lane], col[0]);      // the run goes on
+                else {
+                    if (cc >= 0) cluster_max_out(cc, carry_m[wave][lane], lane);
+                    carry_m[wave][lane] = col[0];
+                    if (lane == 0) carry_c[wave] = cfirst;
+                }
             } else {
+                int cprev = cc >= 0 ? cc : cfirst;
+                float m = cc >= 0 ? carry_m[wave][lane] : -INFINITY;
                 for (int rr = 0; rr < rows_here; ++rr) {
                     const int cr = __builtin_amdgcn_readlane(myc, rr);
                     const float v = st[rr * 65 + lane];
-                    if (cr != cprev) { flush(cprev, m); m = v; cprev = cr; }
+                    if (cr != cprev) { cluster_max_out(cprev, m, lane); m = v; cprev = cr; }
                     else m = fmaxf(m, v);
                 }
-                flush(cprev, m);
+                carry_m[wave][lane] = m;
+                if (lane == 0) carry_c[wave] = cprev;
             }
             __builtin_amdgcn_wave_barrier();                    // the strip is the next tile's
         }
@@ -777,6 +804,11 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     stamp.mark(4);                                            // maxima out (store / cluster maxima)
     q0 = nq0; q1 = nq1; q2 = nq2;
     }   // tile groups
+    if constexpr (kFused) {                                       // the wave's last run
+        __builtin_amdgcn_wave_barrier();
+        const int cc = __builtin_amdgcn_readfirstlane(carry_c[wave]);
+        if (cc >= 0) cluster_max_out(cc, carry_m[wave][lane], lane);
+    }
 
     __syncthreads();
     if (tid < 128) {
@@ -815,7 +847,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_h(const float* __re
                                                         0, as_global(range_bits), gridDim.x);
 }
 template <int MODE>
-__global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_hb(const sg::SlotCtx* __restrict__ cx) {
+__global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_hb(const sg::SlotCtx* __restrict__ cx, int walk) {
     const sg::SlotCtx& c = cx[blockIdx.y];
     // gridDim.x workgroups walk the scene's ec_blocks tile groups (b_edgeconv sizes the grid by what is resident at once); a scene with
     // fewer groups than that uses one workgroup per group.  The workgroups that run are the ones that leave a row of partial sums.
@@ -824,11 +856,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_edgeconv_hb(const sg::SlotCt
     using sg::as_global;
     if constexpr (MODE == S1X) edgeconv_body<MODE, false, true, true, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global(c.ec_w1), nullptr, nullptr, nullptr,
                                                                as_global(c.ec_g1), as_global(c.cat + c.gm_D), as_global(c.ec_partial), blockIdx.x,
-                                                               as_global(c.cluster_of_pos), c.Dcat, 0, as_global((const unsigned int*)c.ec_range), nblk);
+                                                               as_global(c.cluster_of_pos), c.Dcat, 0, as_global((const unsigned int*)c.ec_range), nblk, walk);
     else edgeconv_body<MODE, true, true, true, true>(as_global(c.x9m), as_global(c.knn), c.N, c.K, as_global((const float*)c.ec_w1f),
                                              as_global((const float*)c.ec_sh1), as_global(reinterpret_cast<const u32x4*>(c.ec_w2img)),
                                              as_global((const float*)c.ec_scale), as_global(c.ec_g2), as_global(c.cat + c.gm_D),
-                                             as_global(c.ec_partial), blockIdx.x, as_global(c.cluster_of_pos), c.Dcat, 0, nullptr, nblk);
+                                             as_global(c.ec_partial), blockIdx.x, as_global(c.cluster_of_pos), c.Dcat, 0, nullptr, nblk, walk);
 }
 template <int MODE, bool REREAD_A>
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_edgeconv_b(const sg::SlotCtx* __restrict__ cx, int stagger) {
@@ -1329,12 +1361,13 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
     const bool hand = !g_compiler_loop && bd.min_K == kAsmK && bd.max_K == kAsmK;
     const int nblocks = hand ? std::min(ngroups, std::max(1, resident_workgroups() / bd.nslots)) : ngroups;
     const dim3 grid(nblocks, bd.nslots), one(1, bd.nslots);
+    static const int walk = getenv("SG_EC_WALK_MODE") ? atoi(getenv("SG_EC_WALK_MODE")) : 0;      // 0 = stride (default); 1 = contiguous ranges, XCD-grouped (edgeconv_body): measured, see there
     // development knobs: SG_EC_STAGGER1 / SG_EC_STAGGER2 = start offset of the odd wave slot in units of 64 cycles
     static const int stagger1 = getenv("SG_EC_STAGGER1") ? atoi(getenv("SG_EC_STAGGER1")) : kStagger1;
     static const int stagger2 = getenv("SG_EC_STAGGER2") ? atoi(getenv("SG_EC_STAGGER2")) : kStagger2;
     if (layers == 1) {
         if (mark) mark(mark_arg, 2);                                  // 2 / 3: in front of / behind the EdgeConv launch itself
-        if (hand) k_edgeconv_hb<S1X><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
+        if (hand) k_edgeconv_hb<S1X><<<grid, 64 * kWaves, 0, st>>>(d_ctx, walk);
         else k_edgeconv_b<S1X, false><<<grid, 64 * kWaves, 0, st>>>(d_ctx, stagger1);
         if (mark) mark(mark_arg, 3);
         k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 1, nblocks);
@@ -1344,7 +1377,7 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
         k_edge_moments_b<<<dim3(sg::cdiv(bd.max_N, 256), bd.nslots), 256, 0, st>>>(d_ctx);
         k_bn_fold_moments_b<<<one, 1024, 0, st>>>(d_ctx);
         if (mark) mark(mark_arg, 0);
-        if (hand) k_edgeconv_hb<S2X><<<grid, 64 * kWaves, 0, st>>>(d_ctx);
+        if (hand) k_edgeconv_hb<S2X><<<grid, 64 * kWaves, 0, st>>>(d_ctx, walk);
         else k_edgeconv_b<S2X, true><<<grid, 64 * kWaves, 0, st>>>(d_ctx, stagger2);
         if (mark) mark(mark_arg, 3);
         k_bn_fold_b<<<one, 1024, 0, st>>>(d_ctx, 2, nblocks);

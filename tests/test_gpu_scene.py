@@ -726,3 +726,43 @@ def test_fresh_full_size_seeds_match_oracle(weight_sets, seed, kw):
         nm = hip.LABEL_NAMES[i]
         assert np.array_equal(res.labels[i], ref["labels"][nm].astype(np.int32)), nm
     assert np.array_equal(res.iou_sem, ref["metrics"][0]) and np.array_equal(res.iou_ins, ref["metrics"][1])
+
+
+_WALK_CHILD = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from seggroup_amd import hip, synthetic, weights
+from seggroup_amd.model import BatchRunner
+from seggroup_amd.scene import DeviceScene
+W = weights.load_npz(os.path.join(sys.argv[1], "tests", "golden", "weights_g2.npz"))
+host = [synthetic.make_scene(20000 + 3100 * i, 200 + 17 * i, 87000 + i, **({"seg_profile": "scannet"} if i == 2 else {})) for i in range(5)]
+scenes = [DeviceScene.from_synthetic(h, device="cuda:0") for h in host]
+eng = BatchRunner(W, scenes, inflight=8, per_group=4, device="cuda:0")
+out = []
+for r in eng.run(scenes, hip.MODE_INS_INFER):
+    h = hashlib.sha256()
+    for i in range(r.n_vectors):
+        h.update(np.ascontiguousarray(r.labels[i]).tobytes())
+    h.update(np.asarray(r.trace, dtype=np.int32).tobytes())
+    out.append(h.hexdigest())
+eng.close()
+print("DIGESTS " + json.dumps(out))
+"""
+
+
+def test_edgeconv_walk_modes_give_the_same_labels():
+    """k_edgeconv_hb's two tile walks -- the default stride and SG_EC_WALK_MODE=1 (contiguous ranges, XCD-grouped, the fused epilogue's carried
+    cluster maxima doing real work) -- are development alternatives of one kernel: the label vectors of a ragged batch must not depend on
+    the walk.  (The knob is read once per process: each mode runs in a child.)"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    got = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, SG_EC_WALK_MODE=mode)
+        r = subprocess.run([sys.executable, "-c", _WALK_CHILD, ROOT], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("DIGESTS ")][-1][8:])
+    assert len(got["0"]) == 5 and got["0"] == got["1"]
