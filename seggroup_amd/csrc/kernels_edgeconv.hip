@@ -296,8 +296,23 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     auto tile_of = [&](int it, int w_) { return walk_mode ? g0 * kWaves + w_ * glen + it : (bid + it * nblk) * kWaves + w_; };
     auto own_row = [&](int it) { const int p_ = tile_of(it, wave) * 32 + r; return (gptr<const float4>)(x9m + (size_t)(p_ < N ? p_ : 0) * 12); };
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-    if (walk_n > 0) { const gptr<const float4> xr = own_row(0); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
+    if (walk_n > 0 && !(kAsm && kTwo)) { const gptr<const float4> xr = own_row(0); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
     const int tid_outer = tid;
+    // Round 5 (S2X: 84-108 bytes of scratch per lane -- the kernel's 17 MB of HBM writes per scene-launch were spill traffic, not atomics): what a
+    // lane knows about itself is rebuilt from v_mbcnt (a volatile statement: not common-subexpression'd across the slot loop) and the wave's
+    // number in an SGPR, instead of a copy of the thread id kept alive -- in scratch -- across the slot-loop statement
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto fresh_tid = [&]() {
+        if constexpr (kAsm && kTwo) {
+            int l_;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+            return wave_s * 64 + l_;
+        } else {
+            int t_ = tid_outer;
+            asm volatile("" : "+v"(t_));
+            return t_;
+        }
+    };
     if constexpr (kFused) { if (lane == 0) carry_c[wave] = -1; }
     // one atomic max per (cluster, channel): order-preserving integer view -- non-negative floats compare as ints, negative floats reversed as uints
     auto cluster_max_out = [&](int c, float v, int ch) {
@@ -309,15 +324,16 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     for (int it = 0; it < walk_n; ++it) {
     // Everything a lane knows about itself is re-derived from the thread id here and again behind the slot loop: the statement of the
     // hand-scheduled loop leaves the compiler ten registers, and what is live across it goes to scratch and back (45 values per tile before)
-    int tid = tid_outer;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+    const int tid = fresh_tid();
+    const int lane = tid & 63, wave = (kAsm && kTwo) ? wave_s : tid >> 6, r = lane & 31, half = lane >> 5;     // S2X: the wave's number stays scalar
     const int tile = tile_of(it, wave);
     const int pt = tile * 32 + r;
     const bool valid = pt < N;
     [[maybe_unused]] const float vmask = valid ? 1.f : 0.f;
     const int ptc = valid ? pt : 0;
     float4 nq0, nq1, nq2;                                       // the next tile's own row (requested behind the slot loop)
+    constexpr bool kRowAtTop = kAsm && kTwo;                     // S2X: no row carried round the loop (it lived in scratch: see fresh_tid)
+    if constexpr (kRowAtTop) { const gptr<const float4> xr = own_row(it); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
 
     if (tile * 32 < N) {
         // x_i (9 of the 12 floats of the padded row)
@@ -564,12 +580,12 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                     // The statement's operands are derived HERE, behind the base stores, from laundered copies of the thread id and the own row:
                     // computed earlier they sit in the registers base is built in, and the compiler parks them in scratch and fetches them back
                     // (7 scratch round trips in front of every tile's slot loop)
-                    int tid_c = tid_outer;
+                    int tid_c = fresh_tid();
                     using f32x4 = __attribute__((ext_vector_type(4))) float;
                     f32x4 c0 = {q0.x, q0.y, q0.z, q0.w}, c1 = {q1.x, q1.y, q1.z, q1.w};
                     float c2x = q2.x;
                     asm volatile("" : "+v"(tid_c), "+v"(c0), "+v"(c1), "+v"(c2x));
-                    const int lane_c = tid_c & 63, half_c = lane_c >> 5, r_c = lane_c & 31, wave_c = tid_c >> 6;
+                    const int lane_c = tid_c & 63, half_c = lane_c >> 5, r_c = lane_c & 31, wave_c = (kAsm && kTwo) ? wave_s : tid_c >> 6;
                     const int pt_c = tile_of(it, wave_c) * 32 + r_c;
                     const unsigned koff = (unsigned)(pt_c < N ? pt_c : 0) * 80u;    // the lane's row of the kNN table (K = 20 ids)
                     const unsigned l16 = 16u * (unsigned)half_c;
@@ -651,15 +667,14 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
 
         asm volatile("" :: "v"(stat_q[31]), "v"(best[0]));
         stamp.mark(2);                                        // the slot loop
-        int tid = tid_outer;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+        const int tid = fresh_tid();
+        const int lane = tid & 63, wave = (kAsm && kTwo) ? wave_s : tid >> 6, r = lane & 31, half = lane >> 5;
         const int tile = tile_of(it, wave);
         const int pt = tile * 32 + r;
         const bool valid = pt < N;
         const float vmask = valid ? 1.f : 0.f;
         const int ptc = valid ? pt : 0;
-        if (it + 1 < walk_n) { const gptr<const float4> xn = own_row(it + 1); nq0 = xn[0]; nq1 = xn[1]; nq2 = xn[2]; }
+        if (!kRowAtTop && it + 1 < walk_n) { const gptr<const float4> xn = own_row(it + 1); nq0 = xn[0]; nq1 = xn[1]; nq2 = xn[2]; }
         int myc = 0;
         if constexpr (kFused) myc = cluster_of_pos[ptc];      // asked for here, needed behind the statistics flush
         // sum over the 32 rows of each half on the DPP path (wave_ops.h; `__shfl_xor` is an LDS round trip per step on gfx950): quads,
@@ -736,8 +751,13 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         }
 #endif
         __builtin_amdgcn_wave_barrier();
-        lds.acc[wave][lane] += (double)fs[lane] * (double)unscale;                                  // power of two: exact
-        lds.acc[wave][64 + lane] += (double)fs[64 + lane] * ((double)unscale * (double)unscale);
+        {
+            int ub = __builtin_bit_cast(int, unscale);
+            if constexpr (kAsm && kTwo) asm volatile("" : "+s"(ub));    // keeps the two conversions inside the loop (hoisted, the doubles lived in scratch)
+            const double ud = (double)__builtin_bit_cast(float, ub);
+            lds.acc[wave][lane] += (double)fs[lane] * ud;                                  // power of two: exact
+            lds.acc[wave][64 + lane] += (double)fs[64 + lane] * (ud * ud);
+        }
         __builtin_amdgcn_wave_barrier();
         stamp.mark(3);                                        // statistics flush
         if constexpr (!kFused) {
@@ -802,7 +822,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         }
     }
     stamp.mark(4);                                            // maxima out (store / cluster maxima)
-    q0 = nq0; q1 = nq1; q2 = nq2;
+    if constexpr (!kRowAtTop) { q0 = nq0; q1 = nq1; q2 = nq2; }
     }   // tile groups
     if constexpr (kFused) {                                       // the wave's last run
         __builtin_amdgcn_wave_barrier();
