@@ -540,6 +540,12 @@ int sg_write_label_npy(const char* path, const int32_t* h_vec, int V);
  * ------------------------------------------------------------------------------------------- */
 typedef struct sg_loader sg_loader;
 sg_loader* sg_loader_create(int threads, int slots, size_t slot_bytes);
+/* The same with the device slots sized for packs of at most `max_edges` adjacency rows (slot_bytes + 16 max_edges instead of 3 x slot_bytes;
+ * 0 = unknown = sg_loader_create).  A pack with more edges fails its ticket with SG_ENOMEM. */
+sg_loader* sg_loader_create_sized(int threads, int slots, size_t slot_bytes, size_t max_edges);
+/* At most `uploads_in_flight` workers (default 2; env SG_LOADER_COPIES) are between the start and the end of a pack's host-to-device copy at a
+ * time: more bulk copies in flight saturate the copy engines and starve the scene engine's own small transfers (csrc/loader.cpp). */
+int  sg_loader_set_copy_limit(sg_loader* l, int uploads_in_flight);
 int  sg_loader_submit(sg_loader* l, const char* pack_path);
 int  sg_loader_wait(sg_loader* l, int ticket, sg_scene* out, int* slot, char* name, int name_capacity);
 int  sg_loader_release(sg_loader* l, int slot);

@@ -177,6 +177,16 @@ def _pinned(nbytes: int):
     return buf
 
 
+def pack_dims(path: str) -> Dict[str, int]:
+    """{'N', 'S', 'E0', 'V'} from a pack's header (a few hundred bytes read)."""
+    with open(path, "rb") as f:
+        if f.read(8) != MAGIC:
+            raise ValueError(f"{path}: not a SegGroup scene pack")
+        (hlen,) = struct.unpack("<I", f.read(4))
+        hdr = json.loads(f.read(hlen).decode())
+    return {k: int(hdr[k]) for k in ("N", "S", "E0", "V")}
+
+
 def load_pack(path: str, device="cuda"):
     """Pack -> DeviceScene with ONE host-to-device copy: the file is read into a pinned buffer, uploaded as one blob, and
     the device arrays are typed views into it (every array starts on a 64-byte boundary of the file)."""
@@ -263,16 +273,18 @@ class PackLoader:
     """`sg_loader_*` (csrc/loader.cpp): native threads read scene packs into pinned buffers and upload them into pre-allocated device
     slots.  submit(path) -> ticket at once; wait(ticket) -> LoadedScene; the scene's slot is free again after LoadedScene.release()."""
 
-    def __init__(self, threads: int, slots: int, slot_bytes: int, device=None):
+    def __init__(self, threads: int, slots: int, slot_bytes: int, device=None, max_edges: int = 0, copy_limit: int = 0):
         import torch
         from . import hip
         hip.require_device()
         self.lib = hip.lib()
         self.device = torch.device(device if device is not None else "cuda")
         with torch.cuda.device(self.device):
-            self.handle = self.lib.sg_loader_create(int(threads), int(slots), int(slot_bytes))
+            self.handle = self.lib.sg_loader_create_sized(int(threads), int(slots), int(slot_bytes), int(max_edges))
         if not self.handle:
             raise hip.SgError(hip.SG_ENOMEM, self.lib.sg_last_error().decode())
+        if copy_limit > 0:
+            hip.check(self.lib.sg_loader_set_copy_limit(self.handle, int(copy_limit)))
 
     def submit(self, path: str) -> int:
         from . import hip

@@ -178,6 +178,8 @@ SIGNATURES = {
     "sg_writer_create": (vp, [_I, _I]),
     "sg_writer_submit": (_I, [vp, C.c_char_p, vp, _I, _I]),
     "sg_loader_create": (vp, [_I, _I, _Z]),
+    "sg_loader_create_sized": (vp, [_I, _I, _Z, _Z]),
+    "sg_loader_set_copy_limit": (_I, [vp, _I]),
     "sg_loader_submit": (_I, [vp, C.c_char_p]),
     "sg_loader_wait": (_I, [vp, _I, vp, C.POINTER(C.c_int), C.c_char_p, _I]),
     "sg_loader_release": (_I, [vp, _I]),

@@ -293,7 +293,11 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
         # with one, the loop alternated between waiting for the loader and waiting for the engine)
         # eight loader threads read and upload ~2,800 packs/s (tools/time_loader.py: PCIe-bound at 45 GB/s from 16 on); more only take
         # cores from the writer pool
-        loader = cache.PackLoader(threads=min(6 if 'txt' not in formats else 8, workers), slots=4 * max(args.batch, 1), slot_bytes=slot_bytes, device=dev)
+        # the slots' size: the largest pack + the largest adjacency widened to int64 (every pack's header says how many edges it holds:
+        # ~20 us per file; sized by the worst case of 3 x the file, 256 slots of 150k-point packs were ~9 GB of device memory)
+        max_edges = max((cache.pack_dims(p)['E0'] for p in paths.values()), default=0)
+        loader = cache.PackLoader(threads=min(6 if 'txt' not in formats else 8, workers), slots=4 * max(args.batch, 1), slot_bytes=slot_bytes, device=dev,
+                                  max_edges=max_edges)
 
         class _Loaded:                                      # a future-like handle on a loader ticket
             def __init__(self, t):
