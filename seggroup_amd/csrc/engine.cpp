@@ -151,6 +151,20 @@ struct sg_engine {
             ev_stage[n_ev++] = stage;
         }
         int superstep(Run* r, int n, int mode, sg_writer* writer, int formats, long long tag);
+        // A phase's parameter block (H2D) and outbox (D2H), a few hundred KB each.  Round 5: moved by a KERNEL on the group's stream
+        // (pinned memory is mapped into the device's address space; the arenas are 64-byte aligned and sized in 64-byte steps) instead of
+        // hipMemcpyAsync: on the copy engines they queued behind whatever bulk transfers were in flight -- with the pack loader uploading
+        // 13 MB scenes beside the engine, every phase of every group waited for a few of those (tools/exp_h2d_interference.py).
+        // SG_ENGINE_COPY=sdma restores the copy-engine path.
+        int arena_copy(void* dst, const void* src, size_t bytes, bool to_device) {
+            static const bool sdma = getenv("SG_ENGINE_COPY") && std::string(getenv("SG_ENGINE_COPY")) == "sdma";
+            if (bytes == 0) return SG_OK;
+            if (sdma) {
+                if (hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, stream) != hipSuccess) return sg::fail(SG_EHIP, "engine: arena copy failed");
+                return SG_OK;
+            }
+            return sg::copy_by_kernel(dst, src, (bytes + 15) / 16 * 16, stream);      // (arenas: 64-byte aligned, capacities in 256-byte steps)
+        }
         int phase_p0(Run* r, int n, int mode);
         int phase_layer(Run* r, int n, int layer);
         int phase_end(Run* r, int n, int mode);
@@ -268,7 +282,7 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
     }
     if (!par.ok || !box.ok) return sg::fail(SG_ENOMEM, "engine: phase P0 exceeds the group's parameter / outbox arena");
     for (int i = 0; i < n; ++i) h_ctx[i] = runs_[i].ctx;
-    EG_HIP(hipMemcpyAsync(par.d, par.h, par.used, hipMemcpyHostToDevice, stream));
+    EG_CHECK(arena_copy(par.d, par.h, par.used, true));
     mark(-1);
     EG_CHECK(sg::b_contract(d_ctx, bd, stream));
     mark(0);
@@ -281,7 +295,7 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
     EG_CHECK(sg::b_mlp1(d_ctx, p0->w.p + p0->o_m1w, p0->w.p + p0->o_m1g, p0->w.p + p0->o_m1b, bd, stream));
     mark(2);
     EG_CHECK(sg::b_edge_distance(d_ctx, bd, stream));
-    EG_HIP(hipMemcpyAsync(box.h, box.d, box.used, hipMemcpyDeviceToHost, stream));
+    EG_CHECK(arena_copy(box.h, box.d, box.used, false));
     mark(3);
     EG_HIP(timed_sync(stream));
 
@@ -471,7 +485,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     }
     if (!par.ok || !box.ok) return sg::fail(SG_ENOMEM, "engine: a layer phase exceeds the group's parameter / outbox arena");
     for (int i = 0; i < n; ++i) h_ctx[i] = runs_[i].ctx;
-    EG_HIP(hipMemcpyAsync(par.d, par.h, par.used, hipMemcpyHostToDevice, stream));
+    EG_CHECK(arena_copy(par.d, par.h, par.used, true));
     const int sb = 4 + 6 * layer;
     mark(-1);
     EG_CHECK(sg::b_layer_layout(d_ctx, bd, stream));
@@ -497,7 +511,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     mark(sb + 4);
     EG_CHECK(sg::b_gcn(d_ctx, bd, 0.125f, stream));
     EG_CHECK(sg::b_edge_distance(d_ctx, bd, stream));
-    EG_HIP(hipMemcpyAsync(box.h, box.d, box.used, hipMemcpyDeviceToHost, stream));
+    EG_CHECK(arena_copy(box.h, box.d, box.used, false));
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
         if (!r.dist_in_outbox) {
@@ -595,7 +609,7 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
     }
     if (!par.ok || !box.ok) return sg::fail(SG_ENOMEM, "engine: the export phase exceeds the group's parameter / outbox arena");
     for (int i = 0; i < n; ++i) h_ctx[i] = runs_[i].ctx;
-    EG_HIP(hipMemcpyAsync(par.d, par.h, par.used, hipMemcpyHostToDevice, stream));
+    EG_CHECK(arena_copy(par.d, par.h, par.used, true));
     mark(-1);
     EG_CHECK(sg::b_export_eval(d_ctx, bd, stream));
     for (int i = 0; i < n; ++i) {
@@ -608,7 +622,7 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
         }
         if (r.out->h_tables) std::memcpy(r.out->h_tables, r.tab.data(), (size_t)r.n_tables * r.sc->S * 4);
     }
-    EG_HIP(hipMemcpyAsync(box.h, box.d, box.used, hipMemcpyDeviceToHost, stream));
+    EG_CHECK(arena_copy(box.h, box.d, box.used, false));
     mark(18);
     EG_HIP(timed_sync(stream));
     for (int i = 0; i < n; ++i) {

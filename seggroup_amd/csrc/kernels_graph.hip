@@ -457,6 +457,11 @@ __global__ void k_eval_first_sem_b(const SlotCtx* __restrict__ cx) {
     eval_first_sem_body(c.labels + (size_t)c.sem_row * c.V, c.max_ins, c.cnt, blockIdx.x);
 }
 
+// arena-to-arena copies by a kernel (sg::copy_by_kernel): 16 bytes per thread and trip
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -477,6 +482,14 @@ int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_o
     if (N == 0) return SG_OK;
     k_segment_max64<<<sg::cdiv(N, kRowsPerBlock), 256, 0, sg::as_stream(stream)>>>(d_rows, N, d_cluster_of_pos, d_out, out_stride, d_a,
                                                                                    d_shift);
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+}
+
+int copy_by_kernel(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return SG_OK;
+    const size_t n16 = (bytes + 15) / 16;
+    k_copy16<<<(unsigned)std::min<size_t>((n16 + 255) / 256, 2048), 256, 0, st>>>(reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

@@ -17,7 +17,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -132,6 +135,10 @@ struct sg_loader {
     // threads copying 13 MB buffers back to back (2,334 / 3,522 / 4,243 / 3,980 copies/s).  Workers still read their files side by side;
     // only `copy_limit` of them (default 2) are between hipMemcpyAsync and the end of their upload at a time.
     int copy_limit = 2, copies = 0;
+    // SG_LOADER_PROFILE=1: where a worker's time goes (ns summed over all packs): slot wait | open + header | pread | gate wait | issue | host arrays | sync
+    bool profile = false;
+    std::atomic<long long> prof[8] = {};
+    static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     std::condition_variable cv_copy;
     struct CopyGate {
         sg_loader* L;
@@ -150,9 +157,12 @@ struct sg_loader {
         (void)hipSetDevice(device);
         hipStream_t st = nullptr;
         char* pin = nullptr;
-        bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipHostMalloc((void**)&pin, slot_bytes, hipHostMallocDefault) == hipSuccess;
+        hipEvent_t ev = nullptr;
+        bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipHostMalloc((void**)&pin, slot_bytes, hipHostMallocDefault) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
         for (;;) {
             std::shared_ptr<Job> j;
+            const long long t_idle = profile ? now_ns() : 0;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_work.wait(lk, [&] { return stop || (!queue.empty() && !free_slots.empty()); });
@@ -161,7 +171,8 @@ struct sg_loader {
                 j->slot = free_slots.front(); free_slots.pop_front();
                 slots[j->slot].busy = true;
             }
-            int rc = ok ? load(*j, st, pin) : sg::fail(SG_EHIP, "sg_loader: no stream / pinned buffer for this worker");
+            if (profile) prof[0] += now_ns() - t_idle;
+            int rc = ok ? load(*j, st, pin, ev) : sg::fail(SG_EHIP, "sg_loader: no stream / pinned buffer for this worker");
             {
                 std::lock_guard<std::mutex> lk(mu);
                 j->rc = rc;
@@ -177,10 +188,13 @@ struct sg_loader {
             if (rc < 0) cv_work.notify_one();
         }
         if (pin) (void)hipHostFree(pin);
+        if (ev) (void)hipEventDestroy(ev);
         if (st) (void)hipStreamDestroy(st);
     }
 
-    int load(Job& j, hipStream_t st, char* pin) {
+    int load(Job& j, hipStream_t st, char* pin, hipEvent_t ev) {
+        long long t_ = profile ? now_ns() : 0;
+        auto lap = [&](int k) { if (profile) { const long long n_ = now_ns(); prof[k] += n_ - t_; t_ = n_; } };
         const int fd = open(j.path.c_str(), O_RDONLY | O_CLOEXEC);
         if (fd < 0) return sg::fail(SG_EINVAL, "sg_loader: cannot open %s: %s", j.path.c_str(), strerror(errno));
         struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
@@ -214,6 +228,7 @@ struct sg_loader {
             return sg::fail(SG_ENOMEM, "sg_loader: %s: no room for the widened adjacency (%zu + %zu > %zu)", j.path.c_str(), wide_off, (size_t)E0 * 16, blob_bytes);
         for (int i = 0; i < 11; ++i)
             if (a[i].off + a[i].bytes > size) return sg::fail(SG_EINVAL, "sg_loader: %s: array %s runs past the end of the file", j.path.c_str(), kNames[i]);
+        lap(1);
         size_t got = 0;
         while (got < size) {
             const ssize_t r = pread(fd, pin + got, size - got, (off_t)(base + got));
@@ -222,14 +237,20 @@ struct sg_loader {
             got += (size_t)r;
         }
         // one upload; the arrays are typed views into the slot's blob (every array starts on a 64-byte boundary of the file)
-        CopyGate gate(this);                                         // released when this function returns (behind the stream sync)
+        lap(2);
+        // the gate covers the COPY only (an event behind it): the widening kernel below waits for its turn on a busy GPU -- ~0.5 ms under the
+        // engine's load -- and held inside the gate that wait capped the loader at 2 / 0.8 ms = 2,400 packs/s
+        std::unique_ptr<CopyGate> gate(new CopyGate(this));
+        lap(3);
         if (hipMemcpyAsync(sl.d_blob, pin, size, hipMemcpyHostToDevice, st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
+        if (hipEventRecord(ev, st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
         if (adj32) {
             const size_t n2 = (size_t)E0 * 2;
             k_widen_adj<<<(unsigned)std::min<size_t>((n2 + 255) / 256, 1024), 256, 0, st>>>(reinterpret_cast<const int32_t*>(sl.d_blob + a[1].off),
                                                                                          reinterpret_cast<long long*>(sl.d_blob + wide_off), n2);
             if (hipGetLastError() != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: widening the adjacency of %s failed", j.path.c_str());
         }
+        lap(4);
         auto host = [&](int i, std::vector<int32_t>& v) { v.resize((size_t)S); memcpy(v.data(), pin + a[i].off, (size_t)S * 4); };
         host(7, sl.seg_first); host(8, sl.seg_size); host(9, sl.seg_ins); host(10, sl.seg_sem);
         // seg_of_vertex[v] = seg_of_point[unmap[v]] (-1 where unmap[v] is not a point): the host-side look-up of the compact label transfer
@@ -239,7 +260,12 @@ struct sg_loader {
             const int32_t* um = reinterpret_cast<const int32_t*>(pin + a[5].off);
             for (long long v = 0; v < V; ++v) { const int32_t p_ = um[v]; sl.seg_of_vertex[(size_t)v] = (p_ >= 0 && p_ < N) ? sop[p_] : -1; }
         }
+        lap(5);
+        if (hipEventSynchronize(ev) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
+        gate.reset();                                                // the pinned buffer has been read: the next worker's copy may start
+        lap(7);
         if (hipStreamSynchronize(st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
+        lap(6);
         sg_scene& sc = j.sc;
         sc.N = (int)N; sc.S = (int)S; sc.E0 = (int)E0; sc.V = (int)V;
         sc.d_data = reinterpret_cast<const float*>(sl.d_blob + a[0].off);
@@ -265,6 +291,7 @@ sg_loader* sg_loader_create_sized(int threads, int slots, size_t slot_bytes, siz
     if (hipGetDevice(&L->device) != hipSuccess) { sg::fail(SG_EHIP, "sg_loader_create: no HIP device"); delete L; return nullptr; }
     L->slot_bytes = (slot_bytes + 4095) / 4096 * 4096;
     if (const char* e = getenv("SG_LOADER_COPIES")) L->copy_limit = std::max(1, atoi(e));
+    L->profile = getenv("SG_LOADER_PROFILE") != nullptr;
     // a slot holds a pack and, behind it, its int32 adjacency widened to int64 (16 bytes per edge).  max_edges = 0: the caller does not know
     // its packs' edge counts -- the adjacency is at most the whole file, i.e. three times the pack at worst (~9 GB for 256
     // slots of 150k-point packs; with the edge count it is ~1.7 x the file).  ONE allocation for all slots (one hipMalloc / hipFree instead
@@ -348,6 +375,9 @@ void sg_loader_destroy(sg_loader* L) {
     }
     L->cv_work.notify_all();
     for (auto& t : L->threads) if (t.joinable()) t.join();
+    if (L->profile)
+        fprintf(stderr, "[sg_loader profile] %zu threads, ms summed over all packs: idle / slot wait %.1f | open + header %.1f | pread %.1f | gate wait %.1f | issue %.1f | host arrays %.1f | copy done %.1f | widen + sync %.1f\n",
+                L->threads.size(), L->prof[0] / 1e6, L->prof[1] / 1e6, L->prof[2] / 1e6, L->prof[3] / 1e6, L->prof[4] / 1e6, L->prof[5] / 1e6, L->prof[7] / 1e6, L->prof[6] / 1e6);
     if (L->arena) (void)hipFree(L->arena);
     delete L;
 }

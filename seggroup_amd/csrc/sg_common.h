@@ -93,6 +93,9 @@ constexpr int kEdgeFoldFloats = 64 * 18 + 64 + 64 * 64 + 64 + 4096 + 4 + 1024;  
 int edge_moments_partials(const float* d_x9m, const int32_t* d_knn, int N, int K, double* d_partial, hipStream_t st);   // kernels_edgeconv.hip, [cdiv(N,256)][189]
 int reduce_partials(const double* d_partial, int nblocks, int stride, int count, double* d_out, hipStream_t st);   // kernels_train_edge.hip
 int transpose_square(const float* d_src, float* d_dst, int D, hipStream_t st);      // kernels_train.hip
+// bytes moved by a KERNEL on `st` (kernels_graph.hip): either side may be pinned host memory (mapped into the device's address space) --
+// the engine's small per-phase transfers then do not queue behind bulk copies on the copy engines (engine.cpp).  16-byte aligned.
+int copy_by_kernel(void* dst, const void* src, size_t bytes, hipStream_t st);
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -296,7 +296,8 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
         # the slots' size: the largest pack + the largest adjacency widened to int64 (every pack's header says how many edges it holds:
         # ~20 us per file; sized by the worst case of 3 x the file, 256 slots of 150k-point packs were ~9 GB of device memory)
         max_edges = max((cache.pack_dims(p)['E0'] for p in paths.values()), default=0)
-        loader = cache.PackLoader(threads=min(6 if 'txt' not in formats else 8, workers), slots=4 * max(args.batch, 1), slot_bytes=slot_bytes, device=dev,
+        n_load = int(os.environ.get('SG_LOADER_THREADS', '0')) or min(6 if 'txt' not in formats else 8, workers)
+        loader = cache.PackLoader(threads=n_load, slots=4 * max(args.batch, 1), slot_bytes=slot_bytes, device=dev,
                                   max_edges=max_edges)
 
         class _Loaded:                                      # a future-like handle on a loader ticket
