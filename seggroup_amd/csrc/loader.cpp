@@ -137,6 +137,11 @@ struct sg_loader {
     int copy_limit = 2, copies = 0;
     // SG_LOADER_PROFILE=1: where a worker's time goes (ns summed over all packs): slot wait | open + header | pread | gate wait | issue | host arrays | sync
     bool profile = false;
+    // SG_LOADER_DRY=1 (tools/host_scale_rehearsal.py): no HIP call at all -- plain host buffers, the upload replaced by one pass of reads over the
+    // staging buffer (what the copy engine's DMA does to host memory); the scene's device pointers are null.  Eight pretend ranks can then
+    // share a box with one GPU (or none) and exercise the HOST side of the loader: file reads, header parsing, seg_of_vertex.
+    bool dry = false;
+    std::atomic<unsigned long long> dry_sink{0};
     std::atomic<long long> prof[8] = {};
     static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     std::condition_variable cv_copy;
@@ -154,12 +159,16 @@ struct sg_loader {
     };
 
     void run() {
-        (void)hipSetDevice(device);
         hipStream_t st = nullptr;
         char* pin = nullptr;
         hipEvent_t ev = nullptr;
-        bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipHostMalloc((void**)&pin, slot_bytes, hipHostMallocDefault) == hipSuccess &&
-                  hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        bool ok;
+        if (dry) { pin = static_cast<char*>(aligned_alloc(4096, slot_bytes)); ok = pin != nullptr; if (ok) memset(pin, 0, slot_bytes); }
+        else {
+            (void)hipSetDevice(device);
+            ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipHostMalloc((void**)&pin, slot_bytes, hipHostMallocDefault) == hipSuccess &&
+                 hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        }
         for (;;) {
             std::shared_ptr<Job> j;
             const long long t_idle = profile ? now_ns() : 0;
@@ -187,7 +196,7 @@ struct sg_loader {
             cv_done.notify_all();
             if (rc < 0) cv_work.notify_one();
         }
-        if (pin) (void)hipHostFree(pin);
+        if (pin) { if (dry) free(pin); else (void)hipHostFree(pin); }
         if (ev) (void)hipEventDestroy(ev);
         if (st) (void)hipStreamDestroy(st);
     }
@@ -224,7 +233,7 @@ struct sg_loader {
         const size_t size = (size_t)stt.st_size - base;
         if (size > slot_bytes) return sg::fail(SG_ENOMEM, "sg_loader: %s holds %zu bytes, a slot %zu", j.path.c_str(), size, slot_bytes);
         const size_t wide_off = (size + 255) / 256 * 256;                                  // the widened adjacency sits behind the file's bytes
-        if (adj32 && wide_off + (size_t)E0 * 16 > blob_bytes)
+        if (!dry && adj32 && wide_off + (size_t)E0 * 16 > blob_bytes)
             return sg::fail(SG_ENOMEM, "sg_loader: %s: no room for the widened adjacency (%zu + %zu > %zu)", j.path.c_str(), wide_off, (size_t)E0 * 16, blob_bytes);
         for (int i = 0; i < 11; ++i)
             if (a[i].off + a[i].bytes > size) return sg::fail(SG_EINVAL, "sg_loader: %s: array %s runs past the end of the file", j.path.c_str(), kNames[i]);
@@ -242,6 +251,12 @@ struct sg_loader {
         // engine's load -- and held inside the gate that wait capped the loader at 2 / 0.8 ms = 2,400 packs/s
         std::unique_ptr<CopyGate> gate(new CopyGate(this));
         lap(3);
+        if (dry) {
+            unsigned long long acc = 0;
+            const unsigned long long* w = reinterpret_cast<const unsigned long long*>(pin);
+            for (size_t i = 0; i < size / 8; ++i) acc += w[i];
+            dry_sink += acc;
+        } else {
         if (hipMemcpyAsync(sl.d_blob, pin, size, hipMemcpyHostToDevice, st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
         if (hipEventRecord(ev, st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
         if (adj32) {
@@ -249,6 +264,7 @@ struct sg_loader {
             k_widen_adj<<<(unsigned)std::min<size_t>((n2 + 255) / 256, 1024), 256, 0, st>>>(reinterpret_cast<const int32_t*>(sl.d_blob + a[1].off),
                                                                                          reinterpret_cast<long long*>(sl.d_blob + wide_off), n2);
             if (hipGetLastError() != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: widening the adjacency of %s failed", j.path.c_str());
+        }
         }
         lap(4);
         auto host = [&](int i, std::vector<int32_t>& v) { v.resize((size_t)S); memcpy(v.data(), pin + a[i].off, (size_t)S * 4); };
@@ -261,10 +277,10 @@ struct sg_loader {
             for (long long v = 0; v < V; ++v) { const int32_t p_ = um[v]; sl.seg_of_vertex[(size_t)v] = (p_ >= 0 && p_ < N) ? sop[p_] : -1; }
         }
         lap(5);
-        if (hipEventSynchronize(ev) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
+        if (!dry && hipEventSynchronize(ev) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
         gate.reset();                                                // the pinned buffer has been read: the next worker's copy may start
         lap(7);
-        if (hipStreamSynchronize(st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
+        if (!dry && hipStreamSynchronize(st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
         lap(6);
         sg_scene& sc = j.sc;
         sc.N = (int)N; sc.S = (int)S; sc.E0 = (int)E0; sc.V = (int)V;
@@ -288,7 +304,8 @@ sg_loader* sg_loader_create(int threads, int slots, size_t slot_bytes) { return 
 sg_loader* sg_loader_create_sized(int threads, int slots, size_t slot_bytes, size_t max_edges) {
     if (threads <= 0 || slots <= 0 || slot_bytes == 0) { sg::fail(SG_EINVAL, "sg_loader_create: bad arguments"); return nullptr; }
     auto* L = new sg_loader();
-    if (hipGetDevice(&L->device) != hipSuccess) { sg::fail(SG_EHIP, "sg_loader_create: no HIP device"); delete L; return nullptr; }
+    L->dry = getenv("SG_LOADER_DRY") != nullptr;
+    if (!L->dry && hipGetDevice(&L->device) != hipSuccess) { sg::fail(SG_EHIP, "sg_loader_create: no HIP device"); delete L; return nullptr; }
     L->slot_bytes = (slot_bytes + 4095) / 4096 * 4096;
     if (const char* e = getenv("SG_LOADER_COPIES")) L->copy_limit = std::max(1, atoi(e));
     L->profile = getenv("SG_LOADER_PROFILE") != nullptr;
@@ -298,7 +315,8 @@ sg_loader* sg_loader_create_sized(int threads, int slots, size_t slot_bytes, siz
     // of `slots` of them: start-up and tear-down of the driver)
     L->blob_bytes = max_edges > 0 ? L->slot_bytes + max_edges * 16 + 8192 : 3 * L->slot_bytes + 4096;
     L->slots.resize((size_t)slots);
-    if (hipMalloc((void**)&L->arena, (size_t)slots * L->blob_bytes) != hipSuccess) {
+    if (L->dry) L->blob_bytes = 0;                               // no device side: the scenes' device pointers are offsets from null
+    if (!L->dry && hipMalloc((void**)&L->arena, (size_t)slots * L->blob_bytes) != hipSuccess) {
         sg::fail(SG_ENOMEM, "sg_loader_create: cannot allocate %d device slots of %zu bytes", slots, L->blob_bytes);
         delete L;
         return nullptr;
@@ -378,7 +396,7 @@ void sg_loader_destroy(sg_loader* L) {
     if (L->profile)
         fprintf(stderr, "[sg_loader profile] %zu threads, ms summed over all packs: idle / slot wait %.1f | open + header %.1f | pread %.1f | gate wait %.1f | issue %.1f | host arrays %.1f | copy done %.1f | widen + sync %.1f\n",
                 L->threads.size(), L->prof[0] / 1e6, L->prof[1] / 1e6, L->prof[2] / 1e6, L->prof[3] / 1e6, L->prof[4] / 1e6, L->prof[5] / 1e6, L->prof[7] / 1e6, L->prof[6] / 1e6);
-    if (L->arena) (void)hipFree(L->arena);
+    if (L->arena && !L->dry) (void)hipFree(L->arena);
     delete L;
 }
 
