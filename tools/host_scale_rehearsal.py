@@ -49,7 +49,7 @@ def _rank(rank, world, cfg, barrier, q):
         layer = min(t // 3, 4)
         kind = t % 3 if t < 12 else t - 11                                 # seg / ins / sem rows, like LABEL_NAMES
         tables[t] = rng.integers(0, TRACE[layer], S) if kind == 0 else (rng.integers(-1, 60, S) if kind == 1 else rng.integers(-1, 40, S))
-    out_root = os.path.join(cfg["root"], "results", f"w{world}_r{rank}")
+    out_root = os.path.join(cfg["results_base"], "results", f"w{world}_r{rank}")
     dirs = [os.path.join(out_root, f"scene{i:04d}").encode() for i in range(cfg["out_dirs"])]
     for d in dirs:
         os.makedirs(d, exist_ok=True)
@@ -62,15 +62,27 @@ def _rank(rank, world, cfg, barrier, q):
     pend = [[lib.sg_loader_submit(L, p.encode()) for p in b] for b in batches[:2]]
     nxt, done, t_gpu_free, tag = 2, 0, t0, 0
     waits = {"loader": 0.0, "writer": 0.0, "pace": 0.0}
+    only = cfg.get("only", "")
+    kept = None                                                           # "writer only": the first batch's scenes, never released, reused
     for bi, b in enumerate(batches):
         ta = time.perf_counter()
-        scenes, slots = [], []
-        for tk in pend.pop(0):
-            sc, slot, name = hip.Scene(), C.c_int(-1), C.create_string_buffer(64)
-            hip.check(lib.sg_loader_wait(L, tk, C.byref(sc), C.byref(slot), name, 64))
-            scenes.append(sc); slots.append(slot.value)
+        if only == "writer" and kept is not None:
+            scenes, slots = kept, []
+        else:
+            scenes, slots = [], []
+            for tk in pend.pop(0):
+                sc, slot, name = hip.Scene(), C.c_int(-1), C.create_string_buffer(64)
+                hip.check(lib.sg_loader_wait(L, tk, C.byref(sc), C.byref(slot), name, 64))
+                scenes.append(sc); slots.append(slot.value)
+            if only == "writer":
+                kept, slots = scenes, []
+                for extra in pend:                                        # drain what was requested ahead
+                    for tk in extra:
+                        sc, slot, name = hip.Scene(), C.c_int(-1), C.create_string_buffer(64)
+                        hip.check(lib.sg_loader_wait(L, tk, C.byref(sc), C.byref(slot), name, 64))
+                pend = []
         waits["loader"] += time.perf_counter() - ta
-        if nxt < len(batches):
+        if only != "writer" and nxt < len(batches):
             pend.append([lib.sg_loader_submit(L, p.encode()) for p in batches[nxt]]); nxt += 1
         # the GPU stage: this batch leaves the engine batch / RATE seconds after the engine was last free
         t_gpu_free = max(t_gpu_free, time.perf_counter()) + len(b) / cfg["rate"]
@@ -79,7 +91,7 @@ def _rank(rank, world, cfg, barrier, q):
             time.sleep(t_gpu_free - ta)
         waits["pace"] += time.perf_counter() - ta
         ta = time.perf_counter()
-        for k, sc in enumerate(scenes):
+        for k, sc in enumerate(scenes if only != "loader" else []):
             tag += 1
             d = dirs[(done + k) % len(dirs)]
             if full:
@@ -115,6 +127,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=32)
     ap.add_argument("--base", default="/dev/shm")
     ap.add_argument("--numa", default="auto", choices=["auto", "off"])
+    ap.add_argument("--results-base", default="", help="where the label files go (default: beside the packs, i.e. --base)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     from seggroup_amd import cache, synthetic
@@ -129,11 +142,13 @@ def main():
             cache.write_pack(p, sc.name, cache.stage_arrays(sc.data, sc.weak_label, sc.seg, sc.adj, sc.unmap, sc.gt))
             paths.append(p)
         ctx = mp.get_context("spawn")
-        for leg, formats, full, lt, wt in (("npy, tables", "npy", False, 6, 6), ("txt+npy, tables", "txt,npy", False, 8, 8), ("npy, full label vectors", "npy", True, 6, 6)):
+        for leg, formats, full, lt, wt, only in (("npy, tables", "npy", False, 6, 6, ""), ("txt+npy, tables", "txt,npy", False, 8, 8, ""),
+                                                 ("npy, full label vectors", "npy", True, 6, 6, ""), ("loader only (no files written)", "npy", False, 6, 6, "loader"),
+                                                 ("writer only, npy, tables (one batch of scenes reused)", "npy", False, 6, 6, "writer")):
             rows = {}
             for W in [int(x) for x in a.ranks.split(",")]:
                 cfg = {"paths": paths, "scenes": a.scenes, "rate": a.rate, "batch": a.batch, "formats": formats, "full_labels": full, "loader_threads": lt,
-                       "writer_threads": wt, "root": root, "out_dirs": 96, "numa": a.numa}
+                       "writer_threads": wt, "root": root, "out_dirs": 96, "numa": a.numa, "only": only, "results_base": a.results_base or root}
                 barrier, q = ctx.Barrier(W), ctx.Queue()
                 procs = [ctx.Process(target=_rank, args=(r, W, cfg, barrier, q)) for r in range(W)]
                 for p in procs:
@@ -146,7 +161,7 @@ def main():
                                 "slowest_rank_scenes_per_s": round(min(r["scenes"] / r["seconds"] for r in res), 1),
                                 "nodes": sorted({r["node"] for r in res}), "cpus_per_rank": res[0]["cpus"],
                                 "main_thread_s_rank0": next(r["main_thread_s"] for r in res if r["rank"] == 0)}
-                shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
+                shutil.rmtree(os.path.join(a.results_base or root, "results"), ignore_errors=True)
                 print(leg, "W =", W, rows[str(W)], flush=True)
             base = rows.get("1", {}).get("aggregate_scenes_per_s")
             for W, r in rows.items():
