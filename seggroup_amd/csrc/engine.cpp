@@ -163,7 +163,7 @@ struct sg_engine {
                 if (hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, stream) != hipSuccess) return sg::fail(SG_EHIP, "engine: arena copy failed");
                 return SG_OK;
             }
-            return sg::copy_by_kernel(dst, src, (bytes + 15) / 16 * 16, stream);      // (arenas: 64-byte aligned, capacities in 256-byte steps)
+            return sg::copy_by_kernel(dst, src, (bytes + 15) / 16 * 16, stream);      // (arenas: 64-byte aligned blocks inside allocations with slack)
         }
         int phase_p0(Run* r, int n, int mode);
         int phase_layer(Run* r, int n, int layer);

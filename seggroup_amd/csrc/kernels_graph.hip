@@ -461,6 +461,9 @@ __global__ void k_eval_first_sem_b(const SlotCtx* __restrict__ cx) {
 __global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
+__global__ __launch_bounds__(256) void k_copy4(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
 
 }  // namespace
 
@@ -488,8 +491,15 @@ int segment_max_prefilled(const float* d_rows, int N, const int32_t* d_cluster_o
 
 int copy_by_kernel(void* dst, const void* src, size_t bytes, hipStream_t st) {
     if (bytes == 0) return SG_OK;
-    const size_t n16 = (bytes + 15) / 16;
-    k_copy16<<<(unsigned)std::min<size_t>((n16 + 255) / 256, 2048), 256, 0, st>>>(reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
+    const bool wide = (((size_t)dst | (size_t)src | bytes) & 15) == 0;
+    if (wide) {
+        const size_t n16 = bytes / 16;
+        k_copy16<<<(unsigned)std::min<size_t>((n16 + 255) / 256, 2048), 256, 0, st>>>(reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
+    } else {
+        if ((((size_t)dst | (size_t)src | bytes) & 3) != 0) return sg::fail(SG_EINVAL, "copy_by_kernel: addresses and size must be multiples of 4");
+        const size_t n4 = bytes / 4;
+        k_copy4<<<(unsigned)std::min<size_t>((n4 + 255) / 256, 2048), 256, 0, st>>>(reinterpret_cast<const uint32_t*>(src), reinterpret_cast<uint32_t*>(dst), n4);
+    }
     SG_LAUNCH_CHECK();
     return SG_OK;
 }

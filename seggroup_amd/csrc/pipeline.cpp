@@ -193,6 +193,17 @@ static hipError_t timed_event_sync(hipEvent_t ev) {
 #define PL_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { sg_partition_destroy(part); \
     return sg::fail(SG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); } } while (0)
 
+// Small transfers between the pipeline's pinned arena and the device go through a KERNEL on the scene's stream (sg::copy_by_kernel; pinned
+// memory is mapped into the device's address space): on the copy engines each of them cost a queue round trip of its own, and behind bulk
+// copies of other streams much more (engine.cpp, arena_copy).  SG_ENGINE_COPY=sdma restores hipMemcpyAsync.  Bulk data (the label vectors)
+// stays on the copy engines.
+static bool pl_sdma() { static const bool v = getenv("SG_ENGINE_COPY") && std::string(getenv("SG_ENGINE_COPY")) == "sdma"; return v; }
+#define PL_COPY(dst, src, bytes, kind, stream_)                                                                              \
+    do {                                                                                                                     \
+        if (pl_sdma()) { PL_HIP(hipMemcpyAsync((dst), (src), (bytes), (kind), (stream_))); }                                 \
+        else { PL_CHECK(sg::copy_by_kernel((void*)(dst), (const void*)(src), (size_t)(bytes), (stream_))); }                 \
+    } while (0)
+
 int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result* out, sg_debug* dbg) {
     if (!pl || !sc || !out) return sg::fail(SG_EINVAL, "sg_pipeline_forward: null argument");
     SG_REQUIRE(mode == SG_MODE_INS_INFER || mode == SG_MODE_SEM_INFER, "sg_pipeline_forward: bad mode %d", mode);
@@ -289,7 +300,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     pl->mark(-1);
     PL_CHECK(sg_contract_point_edges(sc->d_adj, E0, sc->d_seg_of_point, N, S, pl->adj1.p, cap1, pl->count.p, pl->ws_contract.p,
                                      pl->ws_contract.n, stv));
-    PL_HIP(hipMemcpyAsync(pl->h_count.p, pl->count.p, 4, hipMemcpyDeviceToHost, st));
+    PL_COPY(pl->h_count.p, pl->count.p, 4, hipMemcpyDeviceToHost, st);
     PL_HIP(hipEventRecord(pl->ev_count, st));
     pl->mark(0);
     int max_seg = 0;
@@ -302,10 +313,10 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
         int32_t* co = pl->h_chunk_off.p;
         co[0] = 0;
         for (int s = 0; s < S; ++s) co[s + 1] = co[s] + (sc->h_seg_size[s] + 31) / 32;
-        PL_HIP(hipMemcpyAsync(pl->seg_chunk_off.p, co, (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
+        PL_COPY(pl->seg_chunk_off.p, co, (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st);
         PL_CHECK(sg_segment_sort_boxes(sc->d_data, N, sc->d_seg_points, sc->d_seg_off, sc->d_seg_of_point, S, pl->seg_chunk_off.p, max_seg,
                                        pl->segbox.p, pl->sperm.p, pl->chunk_box.p, pl->seg_sums.p, pl->ws_sort.p, pl->ws_sort.n, stv));
-        PL_HIP(hipMemcpyAsync(pl->h_seg_sums.p, pl->seg_sums.p, (size_t)S * 3 * 8, hipMemcpyDeviceToHost, st));     // ready at the sync below
+        PL_COPY(pl->h_seg_sums.p, pl->seg_sums.p, (size_t)S * 3 * 8, hipMemcpyDeviceToHost, st);     // ready at the sync below
     }
     pl->mark(1);
     PL_CHECK(sg_mlp1_forward(pl->samples.p, S, W + pl->o_m1w, W + pl->o_m1g, W + pl->o_m1b, pl->feat1.p, 128, pl->ws_mlp1.p,
@@ -321,8 +332,8 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
     int E1 = pl->h_count.p[0];
     if (E1 > cap1) { sg_partition_destroy(part); return sg::fail(SG_ENOMEM, "adjacency capacity exceeded (%d > %d)", E1, cap1); }
     PL_CHECK(sg_edge_distance(pl->feat1.p, 128, 128, pl->adj1.p, E1, pl->dist.p, stv));
-    PL_HIP(hipMemcpyAsync(pl->h_adj.p, pl->adj1.p, (size_t)E1 * 8, hipMemcpyDeviceToHost, st));
-    PL_HIP(hipMemcpyAsync(pl->h_dist.p, pl->dist.p, (size_t)E1 * 4, hipMemcpyDeviceToHost, st));
+    PL_COPY(pl->h_adj.p, pl->adj1.p, (size_t)E1 * 8, hipMemcpyDeviceToHost, st);
+    PL_COPY(pl->h_dist.p, pl->dist.p, (size_t)E1 * 4, hipMemcpyDeviceToHost, st);
     if (dbg) {
         if (dbg->d_samples1) PL_HIP(hipMemcpyAsync(dbg->d_samples1, pl->samples.p, (size_t)S * 64 * 6 * 4, hipMemcpyDeviceToDevice, st));
         if (dbg->d_feat1) PL_HIP(hipMemcpyAsync(dbg->d_feat1, pl->feat1.p, (size_t)S * 128 * 4, hipMemcpyDeviceToDevice, st));
@@ -475,7 +486,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             o.total = cur;
             if (o.total > pl->desc.n) { sg_partition_destroy(part); return sg::fail(SG_ENOMEM, "descriptor buffer too small"); }
             lap(3);
-            PL_HIP(hipMemcpyAsync(pl->desc.p, pl->h_desc.p, o.total * 4, hipMemcpyHostToDevice, st));
+            PL_COPY(pl->desc.p, pl->h_desc.p, o.total * 4, hipMemcpyHostToDevice, st);
             const int32_t* dd = pl->desc.p;
 
             // member arrays + centred rows + sorted kNN operands of the layer: one launch
@@ -528,9 +539,9 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             PL_CHECK(sg::gcn_forward_wt(cat, C, Dcat, dd + o.adj, E, dd + o.rowptr, dd + o.col, dd + o.eid, W + (layer == 0 ? pl->o_g2t : pl->o_g3t),
                                     0.125f, gcn_out, pl->ws_gcn.p, pl->ws_gcn.n, stv));
             PL_CHECK(sg_edge_distance(gcn_out, Dcat, Dcat, dd + o.adj, E, pl->dist.p, stv));
-            PL_HIP(hipMemcpyAsync(pl->h_dist.p, pl->dist.p, (size_t)E * 4, hipMemcpyDeviceToHost, st));
+            PL_COPY(pl->h_dist.p, pl->dist.p, (size_t)E * 4, hipMemcpyDeviceToHost, st);
             if (layer == 1 || (dbg && dbg->h_gcn[layer]))
-                PL_HIP(hipMemcpyAsync(pl->h_feat.p, gcn_out, (size_t)C * Dcat * 4, hipMemcpyDeviceToHost, st));
+                PL_COPY(pl->h_feat.p, gcn_out, (size_t)C * Dcat * 4, hipMemcpyDeviceToHost, st);
             if (dbg) {
                 if (dbg->d_pointfeat[layer]) PL_CHECK(sg::edgeconv_apply(pl->pf.p, N, affine[0], affine[1], dbg->d_pointfeat[layer], stv));
                 if (dbg->d_knn[layer]) PL_HIP(hipMemcpyAsync(dbg->d_knn[layer], pl->knn.p, (size_t)N * 20 * 4, hipMemcpyDeviceToDevice, st));
@@ -603,7 +614,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             };
             const size_t o_order = put(L5.order, S), o_dst = put(L5.dst, S), o_cl = put(cl_of_order, S), o_off = put(L5.cl_pt_off, L5.C + 1);
             pl->mark(-1);
-            PL_HIP(hipMemcpyAsync(pl->desc.p, pl->h_desc.p, cur * 4, hipMemcpyHostToDevice, st));
+            PL_COPY(pl->desc.p, pl->h_desc.p, cur * 4, hipMemcpyHostToDevice, st);
             const int32_t* dd = pl->desc.p;
             PL_CHECK(sg_gather_members(sc->d_seg_points, sc->d_seg_off, S, dd + o_order, dd + o_dst, dd + o_cl, pl->members.p, nullptr, nullptr, nullptr, stv));
             int max_cl = 0;
