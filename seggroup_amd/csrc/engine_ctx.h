@@ -154,6 +154,7 @@ struct BatchDims {                       // maxima over the slots of a group (gr
     int max_C = 0, max_T = 0, max_E = 0, max_ins = 0;
     int max_prevC = 0;
     int max_lay_big = 0;                 // pieces of segments beyond kLayoutPiece rows (layout kernel)
+    int gcn_D = 0;                       // feature width of the layer's GCN (every slot of a launch is at the same layer: 192 | 256)
     int min_K = 0, max_K = 0;            // range of SlotCtx::K over the slots: the hand-scheduled EdgeConv loops are unrolled for K = 20 only
 };
 

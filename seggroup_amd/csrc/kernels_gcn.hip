@@ -5,6 +5,8 @@
 // row-normalised product is evaluated over the symmetric CSR built by the host grouping engine.
 // S <= a few thousand and D <= 256: this stage is latency-, not bandwidth-bound; sums are carried in
 // fp64 so the decision distances that follow are as close to exact arithmetic as fp32 features allow.
+#include <cstdlib>
+
 #include "engine_ctx.h"
 #include "sg_common.h"
 #include "wave_ops.h"
@@ -174,6 +176,82 @@ __global__ void k_gcn_fc_b(const sg::SlotCtx* __restrict__ cx) {
     gcn_fc_body(c.g_agg, c.C, c.Dcat, c.g_wt, c.g_out, c.g_out_copy, blockIdx.x);
 }
 
+
+// Round 5: the fc on the fp64 MATRIX pipe (v_mfma_f64_16x16x4_f64; layout probed by tools/micro/mfma_f64_layout.hip: A lane l = [l % 16][l / 16],
+// B lane l = [l / 16][l % 16], D lane l, register r = [l / 16 + 4 r][l % 16]).  k_gcn_fc (thread = one output column, the block's 8 rows
+// broadcast out of LDS) pulls 1 KB through the LDS return path per wave and (row, k pair): ~43 / 36 us per launch of 8 scenes for the two
+// layers against ~10 us of fp64 work.  Here a block owns 16 rows, its four waves a quarter of the D output columns each (3 | 4 tiles of
+// 16): per four k one 8-byte LDS read of the rows (as doubles, row stride D + 2: conflict-free), one coalesced weight load per column tile
+// (W^T, float -> double), one MFMA per tile; the next four k's operands are requested before this step's MFMAs.  fp64 products and sums
+// like the VALU fc, each output's k in ascending order inside the pipe; the results go through the same (float) cast and ReLU.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <int D>
+__device__ __forceinline__ void gcn_fc_mfma_body(const float* __restrict__ agg, int S, const float* __restrict__ wt, float* __restrict__ out,
+                                                 float* __restrict__ out2, int bid) {
+    constexpr int kT = D / 64;                                    // column tiles per wave
+    static_assert(D % 64 == 0, "four waves x kT tiles of 16 columns");
+    __shared__ double rows[16][D + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = bid * 16;
+    for (int i = tid; i < 16 * D; i += 256) {
+        const int rr = i / D, k = i - rr * D;
+        rows[rr][k] = (r0 + rr < S) ? (double)agg[(size_t)(r0 + rr) * D + k] : 0.0;
+    }
+    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;                     // A: row li, k offset lk;  B: k offset lk, column li
+    const int c0 = wave * (kT * 16);
+    f64x4 acc[kT];
+#pragma unroll
+    for (int t = 0; t < kT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const float* wp = wt + (size_t)lk * D + c0 + li;             // + 4 b D per k block, + 16 t per tile
+    // the weights of EIGHT k blocks in flight (a ring of 8 x kT registers, statically indexed: the loop is unrolled by eight): a layer of 134
+    // clusters is 9 blocks per scene, one wave per SIMD, and with one block of lookahead every MFMA group waited out an L2 round trip
+    constexpr int kPF = 8, kB = D / 4;
+    static_assert(kB % kPF == 0, "k blocks in groups of eight");
+    float bq[kPF][kT];
+#pragma unroll
+    for (int u = 0; u < kPF; ++u)
+#pragma unroll
+        for (int t = 0; t < kT; ++t) bq[u][t] = wp[(size_t)u * 4 * D + 16 * t];
+    for (int b0 = 0; b0 < kB; b0 += kPF) {
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) {
+            const int b = b0 + u;
+            const double a = rows[li][4 * b + lk];
+            double bd_[kT];
+#pragma unroll
+            for (int t = 0; t < kT; ++t) bd_[t] = (double)bq[u][t];
+            if (b + kPF < kB) {
+#pragma unroll
+                for (int t = 0; t < kT; ++t) bq[u][t] = wp[(size_t)(b + kPF) * 4 * D + 16 * t];
+            }
+#pragma unroll
+            for (int t = 0; t < kT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bd_[t], acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = r0 + lk + 4 * r;
+        if (row < S)
+#pragma unroll
+            for (int t = 0; t < kT; ++t) {
+                const float v = fmaxf((float)acc[t][r], 0.f);
+                out[(size_t)row * D + c0 + 16 * t + li] = v;
+                if (out2) out2[(size_t)row * D + c0 + 16 * t + li] = v;
+            }
+    }
+}
+template <int D>
+__global__ __launch_bounds__(256) void k_gcn_fc_mfma(const float* __restrict__ agg, int S, const float* __restrict__ wt, float* __restrict__ out) {
+    gcn_fc_mfma_body<D>(agg, S, wt, out, nullptr, blockIdx.x);
+}
+template <int D>
+__global__ __launch_bounds__(256) void k_gcn_fc_mfma_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    if ((int)blockIdx.x * 16 >= c.C) return;
+    gcn_fc_mfma_body<D>(c.g_agg, c.C, c.g_wt, c.g_out, c.g_out_copy, blockIdx.x);
+}
+
 }  // namespace
 
 namespace sg {
@@ -188,8 +266,11 @@ int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, 
     float* agg = cv.take<float>((size_t)S * D);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_gcn_forward: workspace too small (%zu < %zu)", ws_bytes, sg_gcn_ws_bytes(S, D, E));
     hipStream_t st = sg::as_stream(stream);
+    static const bool valu_fc = getenv("SG_GCN_VALU_FC") != nullptr;      // the thread = column fc of round 4, kept as the cross-check
     k_gcn_aggregate<<<S, 64 * sg::cdiv(D, 64), 0, st>>>(d_x, D, d_rowptr, d_col, d_eid, d_adj, dist, alpha, agg);
-    k_gcn_fc<<<sg::cdiv(S, kRows), 256, 0, st>>>(agg, S, D, d_wt, d_out);
+    if (D == 192 && !valu_fc) k_gcn_fc_mfma<192><<<sg::cdiv(S, 16), 256, 0, st>>>(agg, S, d_wt, d_out);
+    else if (D == 256 && !valu_fc) k_gcn_fc_mfma<256><<<sg::cdiv(S, 16), 256, 0, st>>>(agg, S, d_wt, d_out);
+    else k_gcn_fc<<<sg::cdiv(S, kRows), 256, 0, st>>>(agg, S, D, d_wt, d_out);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }
@@ -198,8 +279,12 @@ int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, 
 // edge distances of g_adj into g_dist as a by-product (sg::gcn_forward_wt)
 int b_gcn(const SlotCtx* d_ctx, const BatchDims& bd, float alpha, hipStream_t st) {
     if (bd.nslots == 0 || bd.max_C == 0) return SG_OK;
+    static const bool valu_fc = getenv("SG_GCN_VALU_FC") != nullptr;
     k_gcn_aggregate_b<<<dim3(bd.max_C, bd.nslots), 256, 0, st>>>(d_ctx, alpha);
-    k_gcn_fc_b<<<dim3(sg::cdiv(bd.max_C, kRows), bd.nslots), 256, 0, st>>>(d_ctx);
+    const dim3 g16(sg::cdiv(bd.max_C, 16), bd.nslots);
+    if (bd.gcn_D == 192 && !valu_fc) k_gcn_fc_mfma_b<192><<<g16, 256, 0, st>>>(d_ctx);
+    else if (bd.gcn_D == 256 && !valu_fc) k_gcn_fc_mfma_b<256><<<g16, 256, 0, st>>>(d_ctx);
+    else k_gcn_fc_b<<<dim3(sg::cdiv(bd.max_C, kRows), bd.nslots), 256, 0, st>>>(d_ctx);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }
