@@ -471,7 +471,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
         c.K = 20;
         bd.min_K = bd.min_K ? std::min(bd.min_K, c.K) : c.K; bd.max_K = std::max(bd.max_K, c.K);
         bd.gcn_D = Dcat;
-        c.pf = pl->pf.p; c.ec_blocks = sg::cdiv(sg::cdiv(N, 32), sg::kEdgeWaves); c.ec_mblocks = sg::cdiv(N, 256);
+        c.pf = pl->pf.p; c.ec_blocks = sg::cdiv(sg::cdiv(N, 32), sg::kEdgeWaves); c.ec_mblocks = sg::moments_blocks(N);
         c.g_wt = W + (layer == 0 ? pl->o_g2t : pl->o_g3t); c.g_dist = r.g_dist; c.g_agg = r.g_agg; c.g_out = pl->featB.p;
         // outbox: decision distances (+ the GCN output of layer 3, which the final clustering reads on the host)
         r.dist_in_outbox = E <= r.out_rows;

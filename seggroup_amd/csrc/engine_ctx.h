@@ -120,7 +120,7 @@ struct SlotCtx {
     float* pf;                         // [N,64] pre-activation maxima
     int K;                             // neighbours per point (20); a run-time value on purpose: as a literal the moments kernel unrolls all slots
     int ec_blocks;                     // ceil(ceil(N/32)/4)
-    int ec_mblocks;                    // ceil(N/256)
+    int ec_mblocks;                    // sg::moments_blocks(N)
 
     // ---- a14: GCN ----
     const int32_t* g_adj;

@@ -926,9 +926,11 @@ constexpr int kMom = 189;
 
 __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m, const int32_t* __restrict__ knn, int N, int K,
                                                   double* __restrict__ partial, int bid) {
-    __shared__ double red[16][kMom];                            // one partial per 16-lane row (4 waves x 4 rows)
+    __shared__ double red[16][kMom];                            // one partial per 16-lane row (4 waves x 4 rows), summed over the block's chunks
     const int tid = threadIdx.x, lane = tid & 63;
-    const int pt = bid * 256 + tid;
+    for (int chunk = 0; chunk < sg::kMomPts / 256; ++chunk) {
+    const int pt = (bid * (sg::kMomPts / 256) + chunk) * 256 + tid;
+    if (chunk > 0 && (bid * (sg::kMomPts / 256) + chunk) * 256 >= N) break;      // block-uniform: nothing left
     const bool valid = pt < N;
     float a[9], D[45], xi[9];
 #pragma unroll
@@ -985,7 +987,7 @@ __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m,
         v += sgw::dpp_f<sgw::kQuadXor2>(v, v);
         v += sgw::dpp_f<sgw::kRowRor4>(v, v);
         v += sgw::dpp_f<sgw::kRowRor8>(v, v);
-        if ((lane & 15) == 0) red[row16][slot] = (double)v;
+        if ((lane & 15) == 0) red[row16][slot] = chunk == 0 ? (double)v : red[row16][slot] + (double)v;      // the row's own entry: no other thread touches it
     };
     int t = 0;
 #pragma unroll
@@ -1002,6 +1004,7 @@ __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m,
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int l = k; l < 9; ++l) { wsum(Kf * xi[k] * xi[l], 144 + t); ++t; }
+    }   // chunks
     __syncthreads();
     if (tid < kMom) {
         double t16 = red[0][tid];
@@ -1321,7 +1324,7 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
     const bool hand = k == 20 && d_range_bits && !(flags & SG_EDGECONV_COMPILER_LOOP) && !g_compiler_loop;    // the hand-scheduled slot loop is written for K = 20
     const int nblocks = hand ? std::min(ngroups, resident_workgroups()) : ngroups;       // = rows of partial sums
     sg::Carver cv(d_ws, ws_bytes);
-    double* partial = cv.take<double>(std::max((size_t)nblocks * 128, (size_t)sg::cdiv(N, 256) * kMom));
+    double* partial = cv.take<double>(std::max((size_t)nblocks * 128, (size_t)sg::moments_blocks(N) * kMom));
     float* fold = cv.take<float>(sg::kEdgeFoldFloats + 128);
     if (!cv.ok) return sg::fail(SG_ENOMEM, "sg_edgeconv_forward: workspace too small (%zu < %zu)", ws_bytes, sg_edgeconv_ws_bytes(N));
     float* w1f = fold;
@@ -1346,7 +1349,7 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
         else k_bn_lrelu_apply<<<egrid, 256, 0, st>>>(d_out, n4, w1f, sh1);
         if (mark) mark(1);
     } else {
-        const int mblocks = sg::cdiv(N, 256);
+        const int mblocks = sg::moments_blocks(N);
         k_edge_moments<<<mblocks, 256, 0, st>>>(d_x9m, d_knn, N, k, partial);
         k_bn_fold_moments<<<1, 1024, 0, st>>>(partial, mblocks, rows, d_g1, d_b1, d_w1, w1f, sh1, d_w2, d_g2, w2img, scales, d_range_bits,
                                               d_range_bits ? reinterpret_cast<u32x4*>(scales + 4) : nullptr);
@@ -1365,10 +1368,10 @@ int edgeconv_forward_marked(const float* d_x9m, const int32_t* d_knn, int N, int
 }
 
 // the edge-feature moments on their own, for the training step's BatchNorm backward (kernels_train_edge.hip): per-block partials
-// [cdiv(N, 256)][189] in edge_moments_body's layout (a | K x_i | D upper | a x_i^T | K x_i x_i^T upper; x_i XYZ relative to row 0)
+// [moments_blocks(N)][189] in edge_moments_body's layout (a | K x_i | D upper | a x_i^T | K x_i x_i^T upper; x_i XYZ relative to row 0)
 int edge_moments_partials(const float* d_x9m, const int32_t* d_knn, int N, int K, double* d_partial, hipStream_t st) {
     if (N <= 0) return SG_OK;
-    k_edge_moments<<<sg::cdiv(N, 256), 256, 0, st>>>(d_x9m, d_knn, N, K, d_partial);
+    k_edge_moments<<<sg::moments_blocks(N), 256, 0, st>>>(d_x9m, d_knn, N, K, d_partial);
     SG_LAUNCH_CHECK();
     return SG_OK;
 }
@@ -1394,7 +1397,7 @@ int b_edgeconv(const SlotCtx* d_ctx, const BatchDims& bd, int layers, void (*mar
         k_cluster_affine_b<<<dim3(sg::cdiv(bd.max_C * 16, 256), bd.nslots), 256, 0, st>>>(d_ctx, 1);
         if (mark) mark(mark_arg, 0);
     } else {
-        k_edge_moments_b<<<dim3(sg::cdiv(bd.max_N, 256), bd.nslots), 256, 0, st>>>(d_ctx);
+        k_edge_moments_b<<<dim3(sg::moments_blocks(bd.max_N), bd.nslots), 256, 0, st>>>(d_ctx);
         k_bn_fold_moments_b<<<one, 1024, 0, st>>>(d_ctx);
         if (mark) mark(mark_arg, 0);
         if (hand) k_edgeconv_hb<S2X><<<grid, 64 * kWaves, 0, st>>>(d_ctx, walk);
@@ -1414,7 +1417,7 @@ extern "C" {
 
 size_t sg_edgeconv_ws_bytes(int N) {
     const size_t nblocks = (size_t)sg::cdiv(sg::cdiv(std::max(N, 1), 32), kWaves);
-    const size_t mblocks = (size_t)sg::cdiv(std::max(N, 1), 256);
+    const size_t mblocks = (size_t)sg::moments_blocks(std::max(N, 1));
     return sg::align_up(std::max(nblocks * 128, mblocks * 189) * 8) + sg::align_up((sg::kEdgeFoldFloats + 128) * 4);
 }
 

@@ -805,7 +805,7 @@ int sg_edgeconv_backward(const float* d_x9m, const int32_t* d_knn, int N, int k,
     const double rows = (double)N * (double)k;
     k_eb_init<<<1, 64, 0, st>>>(d_x9m, cst);
     {
-        const int mb = sg::cdiv(N, 256);
+        const int mb = sg::moments_blocks(N);
         double* m189 = red + kMom;                               // red has kPart3 doubles
         SG_REQUIRE((size_t)mb * 189 <= 512 * (size_t)kPart3, "sg_edgeconv_backward: partial buffer");
         if (int rc = sg::edge_moments_partials(d_x9m, d_knn, N, k, partial, st)) return rc;

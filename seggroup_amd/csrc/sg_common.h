@@ -88,6 +88,11 @@ int gcn_forward_wt(const float* d_x, int S, int D, const int32_t* d_adj, int E, 
                    const int32_t* d_eid, const float* d_wt, float alpha, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
 
 // EdgeConv's fold buffer: w1f [64*18] | sh1 [64] | w2f [64*64] | sh2 [64] | S2X's fp16 weight image [4096] | its scales [4]
+// k_edge_moments: points per workgroup, in chunks of 256.  Measured (round 5, per launch of 8 scenes): four chunks per block leave the one-block-
+// per-scene fold kernel a quarter of the partial rows [189] to add up (k_bn_fold_moments_b 33.5 -> 22.1 us) but take the gather-bound moments
+// kernel's latency cover with them (149 -> 224 us): one chunk per block stays.
+constexpr int kMomPts = 256;
+inline int moments_blocks(int N) { return (N + kMomPts - 1) / kMomPts; }
 constexpr int kRangeWords = 256;          // EdgeConv's range: the maximum of this many words (k_layer_layout spreads its atomics over them)
 constexpr int kEdgeFoldFloats = 64 * 18 + 64 + 64 * 64 + 64 + 4096 + 4 + 1024;    // ... | conv2' image | scales | conv1' fp16 image
 int edge_moments_partials(const float* d_x9m, const int32_t* d_knn, int N, int K, double* d_partial, hipStream_t st);   // kernels_edgeconv.hip, [cdiv(N,256)][189]
