@@ -66,7 +66,7 @@ S2X_EXECUTED_FLOP_PER_ROW = 3 * 2 * 64 * 64 + CONV1_EXEC_FLOP_PER_ROW
 # sustains, not the two of the SIMD-32 data path (round 2 priced the kNN against 1,229 G instructions/s).  1024 SIMDs / 2.0 ns:
 VALU_ISSUE_NS = 2.0
 VALU_PEAK_GINST = 1024 / VALU_ISSUE_NS
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 DTYPE = "f32 (fp32 accumulate; operands split into 2 x fp16 pieces on v_mfma_f32_32x32x16_f16; kNN / FPS scores in exact fp32 order)"
 
 

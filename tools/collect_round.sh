@@ -15,6 +15,11 @@ timeout 500 bash tools/prof_engine.sh solo8 1 8 | head -30
 timeout 900 bash tools/pmc_engine.sh $TAG 1 8 > gpurun_out/${TAG}_pmc.log 2>&1
 (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -- python3 $R/tools/time_train.py --steps 6 > $R/gpurun_out/prof_train.log 2>&1)
 timeout 600 bash tools/stress_500k.sh $TAG > gpurun_out/${TAG}_stress.log 2>&1
+# round 5: the ScanNet-shaped profile's kernels (one group of 8 alone), the driver end to end on tmpfs, the host-side rehearsal of 1 / 2 / 4 / 8 ranks
+timeout 600 bash tools/r05_prof_solo.sh scannet . > gpurun_out/${TAG}_solo_scannet.log 2>&1
+cp gpurun_out/solo_scannet_kernel_stats.csv profiles/${TAG}_solo_batched_scannet_kernel_stats_raw.csv 2>/dev/null
+timeout 900 python3 tools/time_driver.py --scenes 2048 --base /dev/shm --skip-nopack --skip-loop --distinct 32 --out-format "npy@6;txt,npy@8" --out profiles/${TAG}_driver_end_to_end.json > gpurun_out/${TAG}_driver.log 2>&1
+timeout 900 python3 tools/host_scale_rehearsal.py --ranks 1,2,4,8 --scenes 768 --rate 3000 --out profiles/${TAG}_host_scale.json > gpurun_out/${TAG}_rehearsal.log 2>&1
 python3 tools/summarise_profiles.py $TAG | tail -30
 timeout 1200 python3 bench.py --scene-cache $SG_SCENE_CACHE > gpurun_out/bench_line.json 2> gpurun_out/bench_line.err
 cp gpurun_out/bench_line.json profiles/${TAG}_bench.json
