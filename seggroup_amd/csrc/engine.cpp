@@ -137,6 +137,8 @@ struct sg_engine {
         sg_engine* eng = nullptr;
         int index = 0;
         hipStream_t stream = nullptr;
+        hipStream_t side = nullptr;                 // phase P0's big-segment chain (sort + FPS of segments beyond 2,048 points)
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
         std::vector<sg_pipeline*> slots;
         Arena par, box;
         hipEvent_t ev[kMaxGroupEvents];
@@ -286,10 +288,28 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
     mark(-1);
     EG_CHECK(sg::b_contract(d_ctx, bd, stream));
     mark(0);
-    if (mode == SG_MODE_INS_INFER) {
-        EG_CHECK(sg::b_sort_boxes(d_ctx, bd, stream));              // first: the sampling of the largest segments walks its chunk boxes
+    // Segments beyond 2,048 points (floors and walls of a scan) take a chain of skinny launches -- bucket / runs / boxes of the Morton sort, then a
+    // chunk-pruned FPS that one workgroup per segment walks for hundreds of microseconds -- that has nothing to do with the thousand small segments'
+    // sort and sampling: the two chains run side by side, the big one on the group's SIDE stream (fork behind the parameter block and the
+    // contraction's launches, join in front of MLP1, which reads every segment's samples).  Solo, per launch of 8 ScanNet-shaped scenes: ~680 us of
+    // critical path instead of ~860.  Batches without such a segment launch nothing on the side stream.
+    static const bool no_fork = getenv("SG_ENGINE_NO_FORK") != nullptr;
+    const bool fork = !no_fork && side && sg::fps_has_big_class(bd);
+    if (fork) {
+        EG_HIP(hipEventRecord(ev_fork, stream));
+        EG_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        if (mode == SG_MODE_INS_INFER) EG_CHECK(sg::b_sort_boxes(d_ctx, bd, side, 2));
+        EG_CHECK(sg::b_fps64(d_ctx, bd, side, mode == SG_MODE_INS_INFER, 2));
+        EG_HIP(hipEventRecord(ev_join, side));
+        if (mode == SG_MODE_INS_INFER) EG_CHECK(sg::b_sort_boxes(d_ctx, bd, stream, 1));
+        EG_CHECK(sg::b_fps64(d_ctx, bd, stream, mode == SG_MODE_INS_INFER, 1));
+        EG_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+    } else {
+        if (mode == SG_MODE_INS_INFER) {
+            EG_CHECK(sg::b_sort_boxes(d_ctx, bd, stream));          // first: the sampling of the largest segments walks its chunk boxes
+        }
+        EG_CHECK(sg::b_fps64(d_ctx, bd, stream, mode == SG_MODE_INS_INFER));
     }
-    EG_CHECK(sg::b_fps64(d_ctx, bd, stream, mode == SG_MODE_INS_INFER));
     mark(1);
     sg_pipeline* p0 = runs_[0].pl;
     EG_CHECK(sg::b_mlp1(d_ctx, p0->w.p + p0->o_m1w, p0->w.p + p0->o_m1g, p0->w.p + p0->o_m1b, bd, stream));
@@ -769,6 +789,9 @@ void sg_engine_destroy(sg_engine* e) {
         if (g->par.d) (void)hipFree(g->par.d);
         if (g->box.h) (void)hipHostFree(g->box.h);
         if (g->box.d) (void)hipFree(g->box.d);
+        if (g->side) (void)hipStreamDestroy(g->side);
+        if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+        if (g->ev_join) (void)hipEventDestroy(g->ev_join);
         if (g->stream) (void)hipStreamDestroy(g->stream);
     }
     delete e;
@@ -799,6 +822,8 @@ sg_engine* sg_engine_create(int maxN, int maxS, int maxE, int maxV, const sg_wei
         grp->eng = e.get(); grp->index = g;
         for (int i = 0; i < kMaxGroupEvents; ++i) grp->ev[i] = nullptr;
         if (hipStreamCreateWithFlags(&grp->stream, hipStreamNonBlocking) != hipSuccess) { sg::fail(SG_EHIP, "hipStreamCreate failed"); return nullptr; }
+        if (hipStreamCreateWithFlags(&grp->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&grp->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&grp->ev_join, hipEventDisableTiming) != hipSuccess) { sg::fail(SG_EHIP, "hipStreamCreate failed"); return nullptr; }
         for (int i = 0; i < kMaxGroupEvents; ++i)
             if (hipEventCreate(&grp->ev[i]) != hipSuccess) { sg::fail(SG_EHIP, "hipEventCreate failed"); return nullptr; }
         grp->runs.resize(scenes_per_group);

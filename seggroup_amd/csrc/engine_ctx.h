@@ -160,9 +160,10 @@ struct BatchDims {                       // maxima over the slots of a group (gr
 
 int b_contract(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);
 // sorted: k_*_sort_boxes of the same scenes has run on this stream (segments beyond the LDS carve then sample chunk-pruned)
-int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, bool sorted);
+int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, bool sorted, int which = 3);    // which: 1 = segments <= 2,048 points, 2 = larger, 3 = all
+bool fps_has_big_class(const BatchDims& bd);
 bool sort_boxes_fits_lds(int max_seg);
-int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);
+int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, int which = 3);      // which: 1 = segments <= 2,048 points, 2 = larger, 3 = all
 int b_mlp1(const SlotCtx* d_ctx, const float* d_w, const float* d_g, const float* d_b, const BatchDims& bd, hipStream_t st);
 int b_edge_distance(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);
 int b_layer_layout(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st);

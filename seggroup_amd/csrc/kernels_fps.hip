@@ -500,7 +500,9 @@ int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_memb
     return SG_OK;
 }
 
-int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, bool sorted) {
+bool fps_has_big_class(const BatchDims& bd) { return bd.max_seg > kMidMax; }
+
+int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, bool sorted, int which) {
     if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
     const int P = 64;
     const size_t head = (size_t)P * 4 + 16 * sizeof(Best);
@@ -510,9 +512,11 @@ int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, bool sort
                                    (int)(head + std::max((size_t)kLdsCap * 16, (size_t)kChunkCap * 52) + 4096 * 4)));
         attr_set = true;
     }
-    k_fps_sample_b<64><<<dim3(bd.max_S, bd.nslots), 64, head, st>>>(d_ctx, 1, kSmallMax, 0, 0);
-    if (bd.max_seg > kSmallMax) k_fps_sample_b<256><<<dim3(bd.max_S, bd.nslots), 256, head, st>>>(d_ctx, kSmallMax + 1, kMidMax, 0, 0);
-    if (bd.max_seg > kMidMax) {
+    if (which & 1) {
+        k_fps_sample_b<64><<<dim3(bd.max_S, bd.nslots), 64, head, st>>>(d_ctx, 1, kSmallMax, 0, 0);
+        if (bd.max_seg > kSmallMax) k_fps_sample_b<256><<<dim3(bd.max_S, bd.nslots), 256, head, st>>>(d_ctx, kSmallMax + 1, kMidMax, 0, 0);
+    }
+    if ((which & 2) && bd.max_seg > kMidMax) {
         // the carve: 13 words per chunk for the chunk-pruned path (segments beyond 8,192 points, Morton-sorted: up to kChunkCap chunks =
         // ~83k points; a larger segment takes the fallback), or the fallback's points (16 bytes each)
         const int big_pts = sorted ? std::max(64, std::min(sg::cdiv(bd.max_seg, 32), kChunkCap)) : std::max(64, std::min(bd.max_seg, kLdsCap));

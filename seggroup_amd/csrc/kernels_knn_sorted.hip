@@ -1190,10 +1190,11 @@ namespace sg {
 // larger segments through the single-scene library-sort path
 bool sort_boxes_fits_lds(int max_seg) { return max_seg <= kSortCap; }
 
-int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st) {
+// which: 1 = the segments of <= kSortCap points, 2 = the larger ones, 3 = both (the engine runs the two chains on two streams: engine.cpp, phase P0)
+int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, int which) {
     if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
-    k_segment_sort_boxes_b<<<dim3(bd.max_S, bd.nslots), 256, 0, st>>>(d_ctx);
-    if (bd.max_seg > kSortCap) {                                 // small segments / windows without a big segment exit at once
+    if (which & 1) k_segment_sort_boxes_b<<<dim3(bd.max_S, bd.nslots), 256, 0, st>>>(d_ctx);
+    if ((which & 2) && bd.max_seg > kSortCap) {                                 // small segments / windows without a big segment exit at once
         const int wins = sg::cdiv(bd.max_N, kWin);
         k_bigseg_bucket_b<<<dim3(bd.max_S, bd.nslots), kBigBlock, 0, st>>>(d_ctx);
         k_bigseg_runs_b<<<dim3(wins, bd.nslots), kBigBlock, 0, st>>>(d_ctx);

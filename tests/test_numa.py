@@ -42,11 +42,12 @@ def test_bind_moves_threads_that_already_exist_and_unbound_gives_the_host_back(m
     if len(before) < 2:
         return
     keep = sorted(before)[:max(1, len(before) // 2)]
-    go, stop, seen = threading.Event(), threading.Event(), {}
+    go, stop, looked, seen = threading.Event(), threading.Event(), threading.Event(), {}
 
     def early():                                             # a thread that exists before the bind
         go.wait(10)
         seen["bound"] = os.sched_getaffinity(0)
+        looked.set()
         stop.wait(10)
         seen["restored"] = os.sched_getaffinity(0)
     th = threading.Thread(target=early)
@@ -61,6 +62,7 @@ def test_bind_moves_threads_that_already_exist_and_unbound_gives_the_host_back(m
         info = numa.bind_to_gpu_node(0, "auto")
         assert info["bound"] and info["threads"] >= 2
         go.set()
+        assert looked.wait(10)                               # the early thread has read its mask before the leg below changes it again
         with numa.unbound():
             assert os.sched_getaffinity(0) == before         # the CPU-baseline leg sees the whole host
         assert os.sched_getaffinity(0) == set(keep)
