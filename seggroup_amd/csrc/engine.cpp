@@ -293,8 +293,11 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
     // sort and sampling: the two chains run side by side, the big one on the group's SIDE stream (fork behind the parameter block and the
     // contraction's launches, join in front of MLP1, which reads every segment's samples).  Solo, per launch of 8 ScanNet-shaped scenes: ~680 us of
     // critical path instead of ~860.  Batches without such a segment launch nothing on the side stream.
-    static const bool no_fork = getenv("SG_ENGINE_NO_FORK") != nullptr;
-    const bool fork = !no_fork && side && sg::fps_has_big_class(bd);
+    // MEASURED AND NOT THE DEFAULT (round 5, bench --seg-profile scannet, three regions each): side by side 2,977-2,990 scenes/s, one after
+    // the other 3,009-3,054 -- under the load of ten groups the chain's latency is covered anyway and a second stream per group only adds
+    // launches that wait for each other.  SG_ENGINE_FORK=1 turns it on (single-group latency experiments).
+    static const bool want_fork = getenv("SG_ENGINE_FORK") != nullptr;
+    const bool fork = want_fork && side && sg::fps_has_big_class(bd);
     if (fork) {
         EG_HIP(hipEventRecord(ev_fork, stream));
         EG_HIP(hipStreamWaitEvent(side, ev_fork, 0));
