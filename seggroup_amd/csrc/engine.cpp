@@ -263,6 +263,21 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
         r.o_adj1 = box.take<int32_t>(2 * (size_t)r.out_rows, &c.adj1_out);
         r.o_dist = box.take<float>((size_t)r.out_rows, &c.dist1_out);
         c.samples = pl->samples.p; c.ws_fps = reinterpret_cast<float*>(pl->ws_fps.p);
+        {
+            // the segments of the larger size classes (kernels_fps.hip: 513-2,048 points on four waves, beyond on sixteen; kernels_knn_sorted.hip:
+            // beyond 2,048 points the cell-bucketed sort): their launches index these lists instead of testing every segment
+            int n_mid = 0, n_big = 0;
+            for (int s = 0; s < S; ++s) { const int z = sc->h_seg_size[s]; n_mid += z > sg::kSegSmallMax && z <= sg::kSegMidMax; n_big += z > sg::kSegMidMax; }
+            int32_t *d_mid = nullptr, *d_big = nullptr;
+            int32_t* mid = par.take<int32_t>((size_t)std::max(n_mid, 1), &d_mid);
+            int32_t* big = par.take<int32_t>((size_t)std::max(n_big, 1), &d_big);
+            if (mid && big) {
+                int a = 0, b = 0;
+                for (int s = 0; s < S; ++s) { const int z = sc->h_seg_size[s]; if (z > sg::kSegMidMax) big[b++] = s; else if (z > sg::kSegSmallMax) mid[a++] = s; }
+            }
+            c.mid_segs = d_mid; c.big_segs = d_big; c.n_mid = n_mid; c.n_big = n_big;
+            bd.max_mid = std::max(bd.max_mid, n_mid); bd.max_big = std::max(bd.max_big, n_big);
+        }
         if (mode == SG_MODE_INS_INFER) {
             r.chunk_off.resize((size_t)S + 1);
             r.chunk_off[0] = 0;
@@ -858,7 +873,7 @@ sg_engine* sg_engine_create(int maxN, int maxS, int maxE, int maxV, const sg_wei
         }
         // parameter arena: SlotCtx array + every slot's descriptors (the single-scene pipeline's descriptor capacity + tables)
         const size_t T = (size_t)maxN / 64 + S + 1;
-        const size_t par_slot = sizeof(SlotCtx) + (20 * S + 64 + 3 * T + 6 * maxE1 + 256 + 2 * ((size_t)maxN / sg::kLayoutPiece + 1)) * 4 + SG_NUM_LABEL_VECTORS * S * 4 + 2048;
+        const size_t par_slot = sizeof(SlotCtx) + (21 * S + 192 + 3 * T + 6 * maxE1 + 256 + 2 * ((size_t)maxN / sg::kLayoutPiece + 1)) * 4 + SG_NUM_LABEL_VECTORS * S * 4 + 2048;
         const size_t box_slot = 256 + S * 24 + out_rows * 12 + S * 256 * 4 + (128 + 5 * (S + 2)) * 4 + 1024;
         grp->par.cap = par_slot * scenes_per_group;
         grp->box.cap = box_slot * scenes_per_group;

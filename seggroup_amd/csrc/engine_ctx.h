@@ -42,6 +42,11 @@ struct SlotCtx {
 
     // ---- once per scene: Morton order inside segments, chunk boxes, segment sums ----
     const int32_t* seg_chunk_off;      // [S+1] (params block)
+    // the segments of the two larger size classes, listed by the host (params block): a launch over ALL segments dispatched ~12,000 workgroups of
+    // 1,024 threads per batch for the ~60 that had work (k_bigseg_bucket_b 183 us against 88 us for the same segments one scene at a time)
+    const int32_t* mid_segs;           // segments of 513-2,048 points (FPS on four waves)
+    const int32_t* big_segs;           // segments beyond 2,048 points (sixteen-wave FPS, cell-bucketed Morton sort)
+    int n_mid, n_big;
     float* segbox;                     // [S,8]
     int32_t* sperm;                    // [N]
     float* chunk_box;
@@ -147,6 +152,9 @@ struct SlotCtx {
 constexpr int kEdgeWaves = 4;             // tiles (waves) per EdgeConv workgroup: grid and partial-sum sizing (kernels_edgeconv.hip)
 constexpr int kLayoutPiece = 1024;       // rows of a segment one layout block walks (k_layer_layout_b / _big_b)
 
+// size classes of the over-segments (kernels_fps.hip, kernels_knn_sorted.hip; the engine lists the classes' segments on the host)
+constexpr int kSegSmallMax = 512, kSegMidMax = 2048;
+
 struct BatchDims {                       // maxima over the slots of a group (grid.x sizes)
     int nslots = 0;
     int max_N = 0, max_S = 0, max_E0 = 0, max_V = 0;
@@ -155,6 +163,7 @@ struct BatchDims {                       // maxima over the slots of a group (gr
     int max_prevC = 0;
     int max_lay_big = 0;                 // pieces of segments beyond kLayoutPiece rows (layout kernel)
     int gcn_D = 0;                       // feature width of the layer's GCN (every slot of a launch is at the same layer: 192 | 256)
+    int max_mid = 0, max_big = 0;        // largest SlotCtx::n_mid / n_big of the group
     int min_K = 0, max_K = 0;            // range of SlotCtx::K over the slots: the hand-scheduled EdgeConv loops are unrolled for K = 20 only
 };
 

@@ -20,8 +20,8 @@
 namespace {
 
 constexpr int kLdsCap = 8192;        // entries of the LDS carve (16 B each): the chunk-pruned path's per-chunk records, the fallback's points
-constexpr int kSmallMax = 512;       // clusters up to this size run on a single wave (eight points per lane in registers)
-constexpr int kMidMax = 2048;        // ... up to this size on four waves, beyond on sixteen
+constexpr int kSmallMax = sg::kSegSmallMax;       // clusters up to this size run on a single wave (eight points per lane in registers)
+constexpr int kMidMax = sg::kSegMidMax;        // ... up to this size on four waves, beyond on sixteen
 constexpr int kChunkCap = 2600;      // chunks of a segment whose per-chunk records (52 B) fit the LDS carve of the chunk-pruned path
 
 struct Best {
@@ -314,10 +314,18 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
                     const int nw = wl_n;
                     // both halves of a wave must run visit() together (its reductions are wave-wide DPP networks): an odd tail
                     // revisits the last listed chunk, which changes nothing
-                    for (int e = 2 * wave; e < nw; e += 64) {
-                        const int chs[2] = {wl[min(e + half, nw - 1)], wl[min(e + 32 + half, nw - 1)]};
-                        if (e + 32 < nw) visit(std::integral_constant<int, 2>{}, chs, qx, qy, qz, false);
-                        else visit(std::integral_constant<int, 1>{}, chs, qx, qy, qz, false);
+                    // (long lists -- the first steps touch most of the segment -- four chunks per half wave in flight, short ones two or one)
+                    if (nw > 256) {
+                        for (int e = 2 * wave; e < nw; e += 128) {
+                            const int chs[4] = {wl[min(e + half, nw - 1)], wl[min(e + 32 + half, nw - 1)], wl[min(e + 64 + half, nw - 1)], wl[min(e + 96 + half, nw - 1)]};
+                            visit(std::integral_constant<int, 4>{}, chs, qx, qy, qz, false);
+                        }
+                    } else {
+                        for (int e = 2 * wave; e < nw; e += 64) {
+                            const int chs[2] = {wl[min(e + half, nw - 1)], wl[min(e + 32 + half, nw - 1)]};
+                            if (e + 32 < nw) visit(std::integral_constant<int, 2>{}, chs, qx, qy, qz, false);
+                            else visit(std::integral_constant<int, 1>{}, chs, qx, qy, qz, false);
+                        }
                     }
                     __syncthreads();
                     if (tid == 0) wl_n = 0;
@@ -458,8 +466,11 @@ __global__ __launch_bounds__(BLOCK) void k_fps_sample(const float* __restrict__ 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_fps_sample_b(const sg::SlotCtx* __restrict__ cx, int n_lo, int n_hi, int lds_pts, int sorted) {
     const sg::SlotCtx& c = cx[blockIdx.y];
-    if ((int)blockIdx.x >= c.S) return;
-    fps_sample_body<BLOCK>(c.data, c.N, 6, c.seg_points, c.seg_off, 64, 6, 1, n_lo, n_hi, lds_pts, c.samples, nullptr, c.ws_fps, blockIdx.x,
+    int seg = blockIdx.x;
+    if constexpr (BLOCK == 64) { if (seg >= c.S) return; }
+    else if constexpr (BLOCK == 256) { if (seg >= c.n_mid) return; seg = c.mid_segs[seg]; }      // the host's list of this class's segments
+    else { if (seg >= c.n_big) return; seg = c.big_segs[seg]; }
+    fps_sample_body<BLOCK>(c.data, c.N, 6, c.seg_points, c.seg_off, 64, 6, 1, n_lo, n_hi, lds_pts, c.samples, nullptr, c.ws_fps, seg,
                            sorted ? c.sperm : nullptr, c.chunk_box, c.seg_chunk_off);
 }
 
@@ -500,7 +511,7 @@ int fps_sample_hint(const float* d_data, int N, int ch_in, const int32_t* d_memb
     return SG_OK;
 }
 
-bool fps_has_big_class(const BatchDims& bd) { return bd.max_seg > kMidMax; }
+bool fps_has_big_class(const BatchDims& bd) { return bd.max_big > 0; }
 
 int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, bool sorted, int which) {
     if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
@@ -514,13 +525,13 @@ int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, bool sort
     }
     if (which & 1) {
         k_fps_sample_b<64><<<dim3(bd.max_S, bd.nslots), 64, head, st>>>(d_ctx, 1, kSmallMax, 0, 0);
-        if (bd.max_seg > kSmallMax) k_fps_sample_b<256><<<dim3(bd.max_S, bd.nslots), 256, head, st>>>(d_ctx, kSmallMax + 1, kMidMax, 0, 0);
+        if (bd.max_mid > 0) k_fps_sample_b<256><<<dim3(bd.max_mid, bd.nslots), 256, head, st>>>(d_ctx, kSmallMax + 1, kMidMax, 0, 0);
     }
-    if ((which & 2) && bd.max_seg > kMidMax) {
+    if ((which & 2) && bd.max_big > 0) {
         // the carve: 13 words per chunk for the chunk-pruned path (segments beyond 8,192 points, Morton-sorted: up to kChunkCap chunks =
         // ~83k points; a larger segment takes the fallback), or the fallback's points (16 bytes each)
         const int big_pts = sorted ? std::max(64, std::min(sg::cdiv(bd.max_seg, 32), kChunkCap)) : std::max(64, std::min(bd.max_seg, kLdsCap));
-        k_fps_sample_b<1024><<<dim3(bd.max_S, bd.nslots), 1024, head + (size_t)big_pts * (sorted ? 52 : 16), st>>>(d_ctx, kMidMax + 1, INT_MAX, big_pts,
+        k_fps_sample_b<1024><<<dim3(bd.max_big, bd.nslots), 1024, head + (size_t)big_pts * (sorted ? 52 : 16), st>>>(d_ctx, kMidMax + 1, INT_MAX, big_pts,
                                                                                                                   sorted ? 1 : 0);
     }
     SG_LAUNCH_CHECK();

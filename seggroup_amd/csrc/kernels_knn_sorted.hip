@@ -68,7 +68,7 @@ __device__ inline unsigned int spread10(unsigned int v) {      // 10 bits -> eve
 // index) in LDS with a bitonic network -- the local index in the low bits reproduces the radix sort's stable order exactly
 // -- and boxes its 32-point chunks.  At ~1000 scenes/s the pipelines issue ~100k runtime calls per second, so launches
 // saved are throughput.
-constexpr int kSortCap = 2048;
+constexpr int kSortCap = sg::kSegMidMax;      // = the boundary of the engine's list of big segments (SlotCtx::big_segs)
 __device__ __forceinline__ void segment_sort_boxes_body(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
                                                         const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_chunk_off,
                                                         float* __restrict__ segbox, int32_t* __restrict__ sperm,
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(512) void k_bigseg_boxes(const float* __restrict__ 
 }
 __global__ __launch_bounds__(kBigBlock) void k_bigseg_bucket_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
-    if ((int)blockIdx.x >= c.S) return;
-    bigseg_bucket_body(c.data, c.seg_points, c.seg_off, c.segbox, c.seg_sums, c.sort_keys, c.sort_keys + c.N, blockIdx.x);
+    if ((int)blockIdx.x >= c.n_big) return;                      // the host's list of segments beyond kSortCap points
+    bigseg_bucket_body(c.data, c.seg_points, c.seg_off, c.segbox, c.seg_sums, c.sort_keys, c.sort_keys + c.N, c.big_segs[blockIdx.x]);
 }
 __global__ __launch_bounds__(kBigBlock) void k_bigseg_runs_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
@@ -1194,9 +1194,9 @@ bool sort_boxes_fits_lds(int max_seg) { return max_seg <= kSortCap; }
 int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, int which) {
     if (bd.nslots == 0 || bd.max_S == 0) return SG_OK;
     if (which & 1) k_segment_sort_boxes_b<<<dim3(bd.max_S, bd.nslots), 256, 0, st>>>(d_ctx);
-    if ((which & 2) && bd.max_seg > kSortCap) {                                 // small segments / windows without a big segment exit at once
+    if ((which & 2) && bd.max_big > 0) {                                       // windows without a big segment exit at once
         const int wins = sg::cdiv(bd.max_N, kWin);
-        k_bigseg_bucket_b<<<dim3(bd.max_S, bd.nslots), kBigBlock, 0, st>>>(d_ctx);
+        k_bigseg_bucket_b<<<dim3(bd.max_big, bd.nslots), kBigBlock, 0, st>>>(d_ctx);
         k_bigseg_runs_b<<<dim3(wins, bd.nslots), kBigBlock, 0, st>>>(d_ctx);
         k_bigseg_boxes_b<<<dim3(wins, bd.nslots), 512, 0, st>>>(d_ctx);
     }
