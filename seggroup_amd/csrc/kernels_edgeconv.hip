@@ -381,6 +381,11 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         stamp.mark(1);                                        // own row, base accumulator
         float stat_s[32], stat_q[32];
         f32x16 best[2];
+        // Round 5 (MLP2 on fp16 pieces): the SUMS over the K slots are taken on the input side -- conv1 is linear: sum_j y_j = (K - 1) base +
+        // (base + conv1(sum_j d_j)) -- five adds per slot into dsum instead of 32 on the outputs, one more conv1 behind the last slot
+        // (`sums_from_dsum` below; the hand-scheduled loop does the same inside its statement: gen_edgeconv_asm.py, sums_s1x)
+        constexpr bool kSumsLinear = kF16 && !kTwo;
+        [[maybe_unused]] float dsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 32; ++q) { stat_s[q] = 0.f; stat_q[q] = 0.f; }
 #pragma unroll
@@ -410,6 +415,10 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
 #pragma unroll
                 for (int q = 0; q < 5; ++q) ds[q] = __builtin_fmaf(nv[q], Sd, -xs_s[q]);
                 ds[5] = 0.f;
+                if constexpr (kSumsLinear) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) dsum[q] += ds[q];
+                }
                 unsigned int ph[3], pl_[3];
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
@@ -469,9 +478,11 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                         // the packed adds / fmas sit on aligned pairs (left to the vectoriser they came out shifted by one, with a move
                         // per operand)
                         const f32x2 y = {acc1[t][q], acc1[t][q + 1]};
-                        const f32x2 s2 = f32x2{stat_s[16 * t + q], stat_s[16 * t + q + 1]} + y;
                         const f32x2 q2 = __builtin_elementwise_fma(y, y, f32x2{stat_q[16 * t + q], stat_q[16 * t + q + 1]});
-                        stat_s[16 * t + q] = s2.x; stat_s[16 * t + q + 1] = s2.y;
+                        if constexpr (!kSumsLinear) {
+                            const f32x2 s2 = f32x2{stat_s[16 * t + q], stat_s[16 * t + q + 1]} + y;
+                            stat_s[16 * t + q] = s2.x; stat_s[16 * t + q + 1] = s2.y;
+                        }
                         stat_q[16 * t + q] = q2.x; stat_q[16 * t + q + 1] = q2.y;
                         best[t][q] = fmaxf(best[t][q], y.x); best[t][q + 1] = fmaxf(best[t][q + 1], y.y);
                     }
@@ -648,6 +659,33 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                 }
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(eb[0]), "+v"(eb[1]), "+v"(stat_q[31]));       // nothing may still be in flight into registers the code below reuses
                 if constexpr (kNB > 2) asm volatile("" : "+v"(rb[kNB - 2]), "+v"(rb[kNB - 1]), "+v"(eb[kNB - 2]), "+v"(eb[kNB - 1]));
+                if constexpr (kSumsLinear) {
+                    // sums_from_dsum: dsum cut like a slot's d, the slot's four MFMAs on top of base, then (K - 1) base on top of that
+                    unsigned int ph[3], pl_[3];
+                    const float dq[6] = {dsum[0], dsum[1], dsum[2], dsum[3], dsum[4], 0.f};
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const f32x2 v = {dq[2 * u], dq[2 * u + 1]};
+                        const f16x2 hi = __builtin_convertvector(v, f16x2);
+                        const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
+                        ph[u] = __builtin_bit_cast(unsigned int, hi);
+                        pl_[u] = __builtin_bit_cast(unsigned int, lo);
+                    }
+                    const f16x8 x0 = __builtin_bit_cast(f16x8, u32x4{ph[0], ph[1], pl_[0], pl_[1]});
+                    const f16x8 x1 = __builtin_bit_cast(f16x8, u32x4{ph[0], ph[1], ph[2], pl_[2]});
+                    const f16x8 wa0 = __builtin_bit_cast(f16x8, kFrag ? fr16[0] : lds.a1p[0][0][lane]), wb0 = __builtin_bit_cast(f16x8, kFrag ? fr16[1] : lds.a1p[0][1][lane]);
+                    const f16x8 wa1 = __builtin_bit_cast(f16x8, kFrag ? fr16[2] : lds.a1p[1][0][lane]), wb1 = __builtin_bit_cast(f16x8, kFrag ? fr16[3] : lds.a1p[1][1][lane]);
+                    f32x16 accs[2];
+                    accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, x1, base[0], 0, 0, 0);
+                    accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb1, x1, base[1], 0, 0, 0);
+                    accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, x0, accs[0], 0, 0, 0);
+                    accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb0, x0, accs[1], 0, 0, 0);
+                    const float km1 = (float)(K - 1);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) stat_s[16 * t + q] = __builtin_fmaf(base[t][q], km1, accs[t][q]);
+                }
             }
             __builtin_amdgcn_wave_barrier();                      // the ids are dead: the strip is the epilogue's now
         } else {

@@ -384,6 +384,10 @@ class MapS1X:
     T48 = 221
     OFF = 222
     END = 223
+    # Round 5: the sums over the 20 slots are not accumulated per OUTPUT (16 v_pk_add_f32 = 32 issue slots per slot) but per INPUT: conv1 is
+    # linear, sum_j y_j = 19 base + conv1(sum_j d_j): five v_add_f32 per slot into DSUM, one more conv1 behind the last slot.  DSUM lives in
+    # the last five registers of the STAT_S output range (written only by the epilogue, behind the cut that consumes DSUM).
+    DSUM = 12 + 27
 
 
 def d_cut(p, m, j, row, sd, xs):
@@ -397,8 +401,19 @@ def _d_cut(p, m, j, row, sd, xs):
     ds = m.DS
     for q in range(5):
         p.valu("v_fma_f32 v%d, v%d, %s, -%s" % (ds + q, row + q, sd, xs[q]), vr(row + q) + rd(xs[q]), vr(ds + q), tag="D%d" % j)
+    if m is MapS1X:                                        # sum_j d_j (scaled by Sd like d): slot 0 writes it
+        for q in range(5):
+            if j == 0:
+                p.valu("v_add_f32 v%d, 0, v%d" % (m.DSUM + q, ds + q), vr(ds + q), vr(m.DSUM + q))
+            else:
+                p.valu("v_add_f32 v%d, v%d, v%d" % (m.DSUM + q, m.DSUM + q, ds + q), vr(m.DSUM + q) + vr(ds + q), vr(m.DSUM + q))
+    _cut5(p, m, ds, j)
+
+
+def _cut5(p, m, ds, j):
+    """five scaled values in registers ds..ds+4 -> x0, x1 (fp16 hi / lo pieces), destroying ds"""
     # hi pieces straight into x1[0..2]
-    p.valu("v_cvt_pk_f16_f32 v%d, v%d, v%d" % (m.X1, ds, ds + 1), vr(ds, 2), vr(m.X1), tag="D%d" % j)
+    p.valu("v_cvt_pk_f16_f32 v%d, v%d, v%d" % (m.X1, ds, ds + 1), vr(ds, 2), vr(m.X1), tag="D%s" % j)
     p.valu("v_cvt_pk_f16_f32 v%d, v%d, v%d" % (m.X1 + 1, ds + 2, ds + 3), vr(ds + 2, 2), vr(m.X1 + 1))
     p.valu("v_cvt_pk_f16_f32 v%d, v%d, 0" % (m.X1 + 2, ds + 4), vr(ds + 4), vr(m.X1 + 2))
     if MIXLO and m is MapS2X:
@@ -496,35 +511,46 @@ def program_s1x(pk_stats):
             stats_s1x(p, m, j, pk_stats)
     if m.ACC[0] != m.ACC[1]:
         stats_s1x(p, m, K - 1, pk_stats)
+    sums_s1x(p, m)
     return p
 
 
 def stats_s1x(p, m, j, pk):
-    """slot j's 32 outputs into the running sums / sums of squares / maxima.  Slot 0 WRITES them (0 + y, y * y, y: the same bits as adding to
-    zeroed registers, without the 96 v_mov of an initialisation per tile)"""
+    """slot j's 32 outputs into the running sums of squares / maxima (the SUMS come from DSUM: sums_s1x).  Slot 0 WRITES them (y * y, y: the same
+    bits as accumulating into zeroed registers, without the moves of an initialisation per tile)"""
     acc = m.ACC[j & 1]
     for q in range(0, 32, 2):
         y0, y1 = acc + q, acc + q + 1
         if j == 0:
             for y in (y0, y1):
                 o = y - acc
-                p.valu("v_add_f32 v%d, 0, v%d" % (m.STAT_S + o, y), vr(y), vr(m.STAT_S + o), tag="S%d" % j)
                 if not pk:
-                    p.valu("v_mul_f32 v%d, v%d, v%d" % (m.STAT_Q + o, y, y), vr(y), vr(m.STAT_Q + o))
-                p.valu("v_mov_b32 v%d, v%d" % (m.BEST + o, y), vr(y), vr(m.BEST + o))
+                    p.valu("v_mul_f32 v%d, v%d, v%d" % (m.STAT_Q + o, y, y), vr(y), vr(m.STAT_Q + o), tag="S%d" % j)
+                p.valu("v_mov_b32 v%d, v%d" % (m.BEST + o, y), vr(y), vr(m.BEST + o), tag="S%d" % j)
             if pk:
                 p.valu("v_pk_mul_f32 %s, %s, %s" % (vt(m.STAT_Q + q, 2), vt(y0, 2), vt(y0, 2)), vr(y0, 2), vr(m.STAT_Q + q, 2))
             continue
         if pk:
-            p.valu("v_pk_add_f32 %s, %s, %s" % (vt(m.STAT_S + q, 2), vt(m.STAT_S + q, 2), vt(y0, 2)), vr(m.STAT_S + q, 2) + vr(y0, 2), vr(m.STAT_S + q, 2), tag="S%d" % j)
-            p.valu("v_pk_fma_f32 %s, %s, %s, %s" % (vt(m.STAT_Q + q, 2), vt(y0, 2), vt(y0, 2), vt(m.STAT_Q + q, 2)), vr(m.STAT_Q + q, 2) + vr(y0, 2), vr(m.STAT_Q + q, 2))
+            p.valu("v_pk_fma_f32 %s, %s, %s, %s" % (vt(m.STAT_Q + q, 2), vt(y0, 2), vt(y0, 2), vt(m.STAT_Q + q, 2)), vr(m.STAT_Q + q, 2) + vr(y0, 2), vr(m.STAT_Q + q, 2), tag="S%d" % j)
         else:
             for y in (y0, y1):
                 o = y - acc
-                p.valu("v_add_f32 v%d, v%d, v%d" % (m.STAT_S + o, m.STAT_S + o, y), vr(m.STAT_S + o) + vr(y), vr(m.STAT_S + o), tag="S%d" % j)
-                p.valu("v_fma_f32 v%d, v%d, v%d, v%d" % (m.STAT_Q + o, y, y, m.STAT_Q + o), vr(m.STAT_Q + o) + vr(y), vr(m.STAT_Q + o))
+                p.valu("v_fma_f32 v%d, v%d, v%d, v%d" % (m.STAT_Q + o, y, y, m.STAT_Q + o), vr(m.STAT_Q + o) + vr(y), vr(m.STAT_Q + o), tag="S%d" % j)
         p.valu("v_max_f32 v%d, v%d, v%d" % (m.BEST + q, m.BEST + q, y0), vr(m.BEST + q) + vr(y0), vr(m.BEST + q))
         p.valu("v_max_f32 v%d, v%d, v%d" % (m.BEST + q + 1, m.BEST + q + 1, y1), vr(m.BEST + q + 1) + vr(y1), vr(m.BEST + q + 1))
+
+
+def sums_s1x(p, m):
+    """behind the last slot: sum_j y_j = (K - 1) base + (base + conv1(sum_j d_j)) -- DSUM cut like a slot's d, the slot's four MFMAs, one
+    v_fmamk_f32 per output (K - 1 = 19.0 as the literal)"""
+    _cut5(p, m, m.DSUM, "E")
+    acc = m.ACC[0]
+    for t in range(2):
+        p.mfma(acc + 16 * t, vt(m.FRAG + 4 * (2 + t), 4), vr(m.FRAG + 4 * (2 + t), 4), m.X1, m.BASE + 16 * t, tag="C1 E")
+    for t in range(2):
+        p.mfma(acc + 16 * t, vt(m.FRAG + 4 * t, 4), vr(m.FRAG + 4 * t, 4), m.X0, acc + 16 * t)
+    for q in range(32):
+        p.valu("v_fmamk_f32 v%d, v%d, 0x%08x, v%d" % (m.STAT_S + q, m.BASE + q, 0x41980000, acc + q), vr(m.BASE + q) + vr(acc + q), vr(m.STAT_S + q), tag="SE")
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
