@@ -875,8 +875,8 @@ sg_engine* sg_engine_create(int maxN, int maxS, int maxE, int maxV, const sg_wei
         const size_t T = (size_t)maxN / 64 + S + 1;
         const size_t par_slot = sizeof(SlotCtx) + (21 * S + 192 + 3 * T + 6 * maxE1 + 256 + 2 * ((size_t)maxN / sg::kLayoutPiece + 1)) * 4 + SG_NUM_LABEL_VECTORS * S * 4 + 2048;
         const size_t box_slot = 256 + S * 24 + out_rows * 12 + S * 256 * 4 + (128 + 5 * (S + 2)) * 4 + 1024;
-        grp->par.cap = par_slot * scenes_per_group;
-        grp->box.cap = box_slot * scenes_per_group;
+        grp->par.cap = (par_slot * scenes_per_group + 255) / 256 * 256;      // whole 256-byte steps: arena_copy moves 16 bytes per thread
+        grp->box.cap = (box_slot * scenes_per_group + 255) / 256 * 256;
         if (hipHostMalloc((void**)&grp->par.h, grp->par.cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&grp->par.d, grp->par.cap) != hipSuccess ||
             hipHostMalloc((void**)&grp->box.h, grp->box.cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&grp->box.d, grp->box.cap) != hipSuccess) {
             sg::fail(SG_ENOMEM, "sg_engine_create: arena allocation failed");
