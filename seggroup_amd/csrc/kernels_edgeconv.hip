@@ -660,9 +660,11 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(eb[0]), "+v"(eb[1]), "+v"(stat_q[31]));       // nothing may still be in flight into registers the code below reuses
                 if constexpr (kNB > 2) asm volatile("" : "+v"(rb[kNB - 2]), "+v"(rb[kNB - 1]), "+v"(eb[kNB - 2]), "+v"(eb[kNB - 1]));
                 if constexpr (kSumsLinear) {
-                    // sums_from_dsum: dsum cut like a slot's d, the slot's four MFMAs on top of base, then (K - 1) base on top of that
+                    // sums_from_dsum: dsum cut like a slot's d, the slot's four MFMAs on top of base
                     unsigned int ph[3], pl_[3];
-                    const float dq[6] = {dsum[0], dsum[1], dsum[2], dsum[3], dsum[4], 0.f};
+                    // (scaled by 2^-5 first, exactly: one slot's scaled d fits fp16, twenty of them -- a row padded with point 0 repeats one far
+                    // neighbour, model.py:513 -- need not; acc = base + conv1(dsum / 32), sum = 32 acc + (K - 32) base)
+                    const float dq[6] = {dsum[0] * 0.03125f, dsum[1] * 0.03125f, dsum[2] * 0.03125f, dsum[3] * 0.03125f, dsum[4] * 0.03125f, 0.f};
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
                         const f32x2 v = {dq[2 * u], dq[2 * u + 1]};
@@ -680,11 +682,11 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                     accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb1, x1, base[1], 0, 0, 0);
                     accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, x0, accs[0], 0, 0, 0);
                     accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb0, x0, accs[1], 0, 0, 0);
-                    const float km1 = (float)(K - 1);
+                    const float km32 = (float)(K - 32);
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) stat_s[16 * t + q] = __builtin_fmaf(base[t][q], km1, accs[t][q]);
+                        for (int q = 0; q < 16; ++q) stat_s[16 * t + q] = __builtin_fmaf(accs[t][q], 32.0f, km32 * base[t][q]);
                 }
             }
             __builtin_amdgcn_wave_barrier();                      // the ids are dead: the strip is the epilogue's now
@@ -990,6 +992,9 @@ __device__ __forceinline__ void edge_moments_body(const float* __restrict__ x9m,
         for (int j0 = 0; j0 < K; j0 += kG) {
             float4 r0[kG], r1[kG];
             float r2[kG];                                            // channel 8 alone: the row's last 12 bytes are padding (same time, 12 fewer registers)
+            // (Round 5, measured wrong and not kept: taking d8 from d2 -- channels 6..8 are channels 0..2 minus the cluster's mean -- to save the
+            // third gather.  It holds inside a cluster, but rows padded with POINT 0 (clusters of <= K points, model.py:513) have a neighbour from
+            // another cluster, with another mean: 19 GPU tests failed.)
 #pragma unroll
             for (int u = 0; u < kG; ++u) {
                 const float* xrow = x9m + (size_t)ids[u] * 12;

@@ -541,8 +541,13 @@ def stats_s1x(p, m, j, pk):
 
 
 def sums_s1x(p, m):
-    """behind the last slot: sum_j y_j = (K - 1) base + (base + conv1(sum_j d_j)) -- DSUM cut like a slot's d, the slot's four MFMAs, one
-    v_fmamk_f32 per output (K - 1 = 19.0 as the literal)"""
+    """behind the last slot: sum_j y_j = K base + conv1(sum_j d_j).  DSUM is scaled by 2^-5 first (exact): a slot's scaled d fits fp16 (2^16),
+    the sum of twenty of them need not -- rows padded with point 0 (clusters of <= K points, model.py:513) repeat one far neighbour up to twenty
+    times -- and 20 x 2^16 x 2^-5 does.  Then the slot's cut and four MFMAs on top of a ZERO accumulator... the C operand is `base` like every
+    slot's (the fragments and the operand registers are the slot's), so acc = base + conv1(DSUM / 32), and
+    sum = 32 acc + (K - 32) base: one v_mul_f32 + one v_fmamk_f32 per output, K = 20"""
+    for q in range(5):
+        p.valu("v_mul_f32 v%d, 0x3d000000, v%d" % (m.DSUM + q, m.DSUM + q), vr(m.DSUM + q), vr(m.DSUM + q), tag="SE")       # x 2^-5
     _cut5(p, m, m.DSUM, "E")
     acc = m.ACC[0]
     for t in range(2):
@@ -550,7 +555,8 @@ def sums_s1x(p, m):
     for t in range(2):
         p.mfma(acc + 16 * t, vt(m.FRAG + 4 * t, 4), vr(m.FRAG + 4 * t, 4), m.X0, acc + 16 * t)
     for q in range(32):
-        p.valu("v_fmamk_f32 v%d, v%d, 0x%08x, v%d" % (m.STAT_S + q, m.BASE + q, 0x41980000, acc + q), vr(m.BASE + q) + vr(acc + q), vr(m.STAT_S + q), tag="SE")
+        p.valu("v_mul_f32 v%d, 0x%08x, v%d" % (m.STAT_S + q, 0xc1400000, m.BASE + q), vr(m.BASE + q), vr(m.STAT_S + q), tag="SE")                    # (K - 32) base = -12 base
+        p.valu("v_fmamk_f32 v%d, v%d, 0x%08x, v%d" % (m.STAT_S + q, acc + q, 0x42000000, m.STAT_S + q), vr(acc + q) + vr(m.STAT_S + q), vr(m.STAT_S + q))   # + 32 acc
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
