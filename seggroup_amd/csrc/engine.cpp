@@ -25,6 +25,7 @@
 #include <condition_variable>
 #include <deque>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -195,6 +196,23 @@ namespace {
     return sg::fail(SG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); } while (0)
 #define EG_CHECK(call) do { int rc__ = (call); if (rc__ < 0) return rc__; } while (0)
 
+// SG_ENGINE_HASH=1 (debugging aid): after every phase, one line per scene on stderr with FNV-1a digests of the phase's device results --
+// two runs of the same scenes must print the same lines, whatever the group shape (tools/r05_repro.py compares them)
+static const bool g_hash = getenv("SG_ENGINE_HASH") != nullptr;
+thread_local hipStream_t tl_hash_stream = nullptr;          // the calling group's stream: the copies must not touch the null stream (it would serialise the groups)
+int fetch(void* h, const void* d, size_t bytes) {
+    if (bytes == 0) return 0;
+    if (hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, tl_hash_stream) != hipSuccess) return -1;
+    return hipStreamSynchronize(tl_hash_stream) == hipSuccess ? 0 : -1;
+}
+uint64_t dev_digest(const void* d, size_t bytes) {
+    std::vector<unsigned char> h(bytes);
+    if (fetch(h.data(), d, bytes) != 0) return 0;
+    uint64_t x = 1469598103934665603ull;
+    for (size_t i = 0; i < bytes; ++i) { x ^= h[i]; x *= 1099511628211ull; }
+    return x;
+}
+
 int tables_for(Run& r, int first_row, bool with_seg) {
     const int S = r.sc->S;
     int32_t* a = r.tab.data() + (size_t)first_row * S;
@@ -342,6 +360,12 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
         Run& r = runs_[i];
         const int S = r.sc->S;
         const int E1 = r.o_count[0];
+        if (g_hash) tl_hash_stream = stream;
+        if (g_hash)
+            std::fprintf(stderr, "SGHASH %p P0 E1=%d sperm=%016llx samples=%016llx feat1=%016llx adj1=%016llx dist=%016llx\n", (const void*)r.sc->d_data, E1,
+                         (unsigned long long)(mode == SG_MODE_INS_INFER ? dev_digest(r.pl->sperm.p, (size_t)r.sc->N * 4) : 0),
+                         (unsigned long long)dev_digest(r.pl->samples.p, (size_t)S * 64 * 6 * 4), (unsigned long long)dev_digest(r.pl->feat1.p, (size_t)S * 128 * 4),
+                         (unsigned long long)dev_digest(r.pl->adj1.p, (size_t)std::min(E1, r.cap1) * 8), (unsigned long long)dev_digest(r.pl->dist.p, (size_t)std::min(E1, r.cap1) * 4));
         if (E1 > r.cap1) return sg::fail(SG_ENOMEM, "adjacency capacity exceeded (%d > %d)", E1, r.cap1);
         const float* h_dist = r.o_dist;
         if (E1 > r.out_rows) {                                    // rare: denser than the outbox assumes -- fetch the full arrays
@@ -564,6 +588,49 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
         const int Dcat = r.feat_prev_dim + 64;
+        if (g_hash) tl_hash_stream = stream;
+        if (g_hash)
+            std::fprintf(stderr, "SGHASH %p L%d C=%d E=%d knn=%016llx x9m=%016llx fold=%016llx cat=%016llx gcn=%016llx dist=%016llx\n", (const void*)r.sc->d_data, layer, r.Lnew.C, r.E,
+                         (unsigned long long)dev_digest(r.pl->knn.p, (size_t)r.sc->N * 20 * 4), (unsigned long long)dev_digest(r.pl->x9m.p, (size_t)r.sc->N * 12 * 4),
+                         (unsigned long long)dev_digest(r.ctx.ec_w1f, layer == 0 ? (size_t)(64 * 18 + 64) * 4 : (size_t)((r.ctx.ec_scale + 4) - r.ctx.ec_w1f) * 4),
+                         (unsigned long long)dev_digest(r.pl->featA.p, (size_t)r.Lnew.C * Dcat * 4), (unsigned long long)dev_digest(r.pl->featB.p, (size_t)r.Lnew.C * Dcat * 4),
+                         (unsigned long long)dev_digest(r.dist_in_outbox ? (const void*)r.ctx.dist : (const void*)r.pl->dist.p, (size_t)r.E * 4));
+        if (g_hash) {
+            // the first table seen for (scene, layer) is kept; later ones are compared row by row
+            static std::mutex mu_dbg;
+            static std::map<std::pair<const void*, int>, std::vector<int32_t>> seen;
+            const int N = r.sc->N;
+            std::vector<int32_t> knn((size_t)N * 20), seed((size_t)N * 20), cop(N), sid(N);
+            (void)fetch(knn.data(), r.pl->knn.p, knn.size() * 4);
+            (void)fetch(seed.data(), r.pl->knn_seed.p, seed.size() * 4);
+            (void)fetch(cop.data(), r.pl->cluster_of_pos.p, cop.size() * 4);
+            (void)fetch(sid.data(), r.pl->seed_id.p, sid.size() * 4);
+            std::fprintf(stderr, "SGHASH %p S%d seed=%016llx rec=%016llx sid=%016llx sxyzw=%016llx smpos=%016llx\n", (const void*)r.sc->d_data, layer,
+                         (unsigned long long)dev_digest(r.pl->knn_seed.p, (size_t)N * 80), (unsigned long long)(layer == 1 ? dev_digest(r.pl->point_rec.p, (size_t)N * 16) : 0),
+                         (unsigned long long)dev_digest(r.pl->seed_id.p, (size_t)N * 4), (unsigned long long)dev_digest(r.pl->xyzw.p, (size_t)N * 16),
+                         (unsigned long long)dev_digest(r.pl->smpos.p, (size_t)N * 4));
+            std::lock_guard<std::mutex> g(mu_dbg);
+            auto key = std::make_pair((const void*)r.sc->d_data, layer);
+            auto it = seen.find(key);
+            if (it == seen.end()) seen[key] = knn;
+            else {
+                int shown = 0, rows = 0;
+                for (int q = 0; q < N; ++q) {
+                    if (std::memcmp(&knn[(size_t)q * 20], &it->second[(size_t)q * 20], 80) == 0) continue;
+                    ++rows;
+                    if (shown++ >= 3) continue;
+                    const int cc = cop[q], n = r.Lnew.cl_pt_off[cc + 1] - r.Lnew.cl_pt_off[cc];
+                    std::fprintf(stderr, "SGROW %p L%d row %d cluster %d (%d points, from %d) seed id %d\n   now  :", (const void*)r.sc->d_data, layer, q, cc, n, r.Lnew.cl_pt_off[cc], sid[q]);
+                    for (int j = 0; j < 20; ++j) std::fprintf(stderr, " %d", knn[(size_t)q * 20 + j]);
+                    std::fprintf(stderr, "\n   first:");
+                    for (int j = 0; j < 20; ++j) std::fprintf(stderr, " %d", it->second[(size_t)q * 20 + j]);
+                    std::fprintf(stderr, "\n   seeds:");
+                    for (int j = 0; j < 20; ++j) std::fprintf(stderr, " %d", seed[(size_t)sid[q] * 20 + j]);
+                    std::fprintf(stderr, "\n");
+                }
+                if (rows) std::fprintf(stderr, "SGROW %p L%d: %d rows differ\n", (const void*)r.sc->d_data, layer, rows);
+            }
+        }
         r.Lcur = r.Lnew;
         EG_CHECK(regroup(r, r.dist_in_outbox ? r.o_dist : r.pl->h_dist.p, 2.0f));
         r.out->trace[2 + layer] = r.Lnew.C;

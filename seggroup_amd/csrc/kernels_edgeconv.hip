@@ -294,9 +294,10 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     }
     const int walk_n = walk_mode ? glen : (bid < ngroups ? (ngroups - bid + nblk - 1) / nblk : 0);
     auto tile_of = [&](int it, int w_) { return walk_mode ? g0 * kWaves + w_ * glen + it : (bid + it * nblk) * kWaves + w_; };
-    auto own_row = [&](int it) { const int p_ = tile_of(it, wave) * 32 + r; return (gptr<const float4>)(x9m + (size_t)(p_ < N ? p_ : 0) * 12); };
+    // (the lane's identity comes in as arguments: captured from the outer scope it stayed alive -- in scratch -- across the slot-loop statement)
+    auto own_row = [&](int it, int w_, int r_) { const int p_ = tile_of(it, w_) * 32 + r_; return (gptr<const float4>)(x9m + (size_t)(p_ < N ? p_ : 0) * 12); };
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-    if (walk_n > 0 && !(kAsm && kTwo)) { const gptr<const float4> xr = own_row(0); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
+    if (walk_n > 0 && !(kAsm && kTwo)) { const gptr<const float4> xr = own_row(0, wave, r); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
     const int tid_outer = tid;
     // Round 5 (S2X: 84-108 bytes of scratch per lane -- the kernel's 17 MB of HBM writes per scene-launch were spill traffic, not atomics): what a
     // lane knows about itself is rebuilt from v_mbcnt (a volatile statement: not common-subexpression'd across the slot loop) and the wave's
@@ -315,11 +316,15 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     };
     if constexpr (kFused) { if (lane == 0) carry_c[wave] = -1; }
     // one atomic max per (cluster, channel): order-preserving integer view -- non-negative floats compare as ints, negative floats reversed as uints
+    // (`c` is wave-uniform at every call: the row's address stays in SGPRs and the lane adds its channel as a 32-bit offset -- written on a
+    // generic pointer the 64-bit lane address kept a zero register alive in scratch across the whole walk)
     auto cluster_max_out = [&](int c, float v, int ch) {
         v *= unscale;                                             // one multiply per (cluster, channel) instead of 32 per lane and tile
-        float* addr = (float*)(ext + (size_t)c * ext_stride + ch);
-        if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
-        else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+        const gptr<float> row = ext + (size_t)__builtin_amdgcn_readfirstlane(c) * ext_stride;
+        const unsigned off = 4u * (unsigned)ch;
+        // (as statements: from C++ the compiler builds a 64-bit lane address whose zero high half it parks in scratch for the whole walk)
+        if (v >= 0.0f) asm volatile("global_atomic_smax %0, %1, %2" :: "v"(off), "v"(v), "s"(row) : "memory");
+        else asm volatile("global_atomic_umin %0, %1, %2" :: "v"(off), "v"(v), "s"(row) : "memory");
     };
     for (int it = 0; it < walk_n; ++it) {
     // Everything a lane knows about itself is re-derived from the thread id here and again behind the slot loop: the statement of the
@@ -333,7 +338,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     const int ptc = valid ? pt : 0;
     float4 nq0, nq1, nq2;                                       // the next tile's own row (requested behind the slot loop)
     constexpr bool kRowAtTop = kAsm && kTwo;                     // S2X: no row carried round the loop (it lived in scratch: see fresh_tid)
-    if constexpr (kRowAtTop) { const gptr<const float4> xr = own_row(it); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
+    if constexpr (kRowAtTop) { const gptr<const float4> xr = own_row(it, wave, r); q0 = xr[0]; q1 = xr[1]; q2 = xr[2]; }
 
     if (tile * 32 < N) {
         // x_i (9 of the 12 floats of the padded row)
@@ -607,12 +612,24 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                     static_assert(offsetof(Lds, a2h) - offsetof(Lds, a1p) == 12288, "edgeconv_slots_gen.h addresses conv2's fragments relative to conv1's");
                     const unsigned a_frag = (unsigned)(size_t)(SG_LDS const u32x4*)(&lds.a1p[0][0][lane_c]);
                     if constexpr (!kTwo) {
+                        // The PLAIN variant of the generated loop (sums of squares as 32 v_fma_f32 per slot), not the packed one (16 v_pk_fma_f32: -1.3 us per
+                        // scene): packed fp32 arithmetic is not dependable on the MI355X boxes of this pool once waves of other kernels share the SIMD
+                        //  -- a lost v_pk_fma here is one y^2 missing from a BatchNorm variance, and a scene's labels then depend
+                        // on the run.  -DSG_EC_S1X_PACKED builds the packed loop (measurements only).
+#ifdef SG_EC_S1X_PACKED
                         asm volatile(SG_EC_S1X_SLOTS_PK
+#else
+                        asm volatile(SG_EC_S1X_SLOTS
+#endif
                                      : "=&" SG_EC_S1X_STAT_S0(ss0), "=&" SG_EC_S1X_STAT_S1(ss1), "=&" SG_EC_S1X_STAT_Q0(sq0), "=&" SG_EC_S1X_STAT_Q1(sq1),
                                        "=&" SG_EC_S1X_BEST0(bb0), "=&" SG_EC_S1X_BEST1(bb1)
                                      : [x9m] "s"(x9m), [knn] "s"(knn), [sd] "s"(sd_u), [koff] "v"(koff), [l16] "v"(l16), [base] "v"(a_base), [frag] "v"(a_frag),
                                        [xs0] "v"(xs_c[0]), [xs1] "v"(xs_c[1]), [xs2] "v"(xs_c[2]), [xs3] "v"(xs_c[3]), [xs4] "v"(xs_c[4])
+#ifdef SG_EC_S1X_PACKED
                                      : "memory", SG_EC_S1X_SLOTS_PK_CLOBBERS);
+#else
+                                     : "memory", SG_EC_S1X_SLOTS_CLOBBERS);
+#endif
                     } else {
                         const unsigned long long c02 = 0x3e4ccccd3e4ccccdull;     // LeakyReLU's 0.2f twice: v_pk_mul_f32 takes no literal
                         asm volatile(SG_EC_S2X_SLOTS
@@ -714,7 +731,7 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         const bool valid = pt < N;
         const float vmask = valid ? 1.f : 0.f;
         const int ptc = valid ? pt : 0;
-        if (!kRowAtTop && it + 1 < walk_n) { const gptr<const float4> xn = own_row(it + 1); nq0 = xn[0]; nq1 = xn[1]; nq2 = xn[2]; }
+        if (!kRowAtTop && it + 1 < walk_n) { const gptr<const float4> xn = own_row(it + 1, wave, r); nq0 = xn[0]; nq1 = xn[1]; nq2 = xn[2]; }
         int myc = 0;
         if constexpr (kFused) myc = cluster_of_pos[ptc];      // asked for here, needed behind the statistics flush
         // sum over the 32 rows of each half on the DPP path (wave_ops.h; `__shfl_xor` is an LDS round trip per step on gfx950): quads,
@@ -760,7 +777,9 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const float keep = k4 ? w4[q + 2] : w4[q], send = k4 ? w4[q] : w4[q + 2];
-                w2[q] = keep + __shfl_xor(send, 16);
+                // lane xor 16 as a swizzle (bit mode: and 0x1f, xor 0x10): no address register -- __shfl_xor's lane id is loop-invariant to the
+                // compiler, which kept it in scratch across the slot-loop statement
+                w2[q] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x401F));
             }
             // which two: value index Q = 32 k3 + 16 k2 + 8 k0 + 4 k1 + 2 k4 + {0, 1}; Q < 32 = sum of accumulator register Q, else sum of squares of Q - 32
             const int reg = (k2 ? 16 : 0) + (k0 ? 8 : 0) + (k1 ? 4 : 0) + (k4 ? 2 : 0);
@@ -803,14 +822,16 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
         if constexpr (!kFused) {
             if (valid) {
                 // E = max_j y'_j : 4 consecutive channels per float4 store
-                const gptr<float> orow = ext + (size_t)pt * 64;
+                // the lane's BYTE offset in 32 bits (N <= 2^20 rows of 256 bytes) on top of the uniform base: the stores take the base from SGPRs --
+                // a 64-bit lane address kept its zero high half alive, in scratch, across the slot-loop statement
+                const gptr<char> orow = (gptr<char>)ext + ((unsigned)pt * 256u + 16u * (unsigned)half);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float4 v = make_float4(best[t][4 * g] * unscale, best[t][4 * g + 1] * unscale, best[t][4 * g + 2] * unscale,
                                                      best[t][4 * g + 3] * unscale);
-                        *(gptr<float4>)(orow + 32 * t + 8 * g + 4 * half) = v;
+                        *(gptr<float4>)(orow + 128 * t + 32 * g) = v;
                     }
             }
         } else {
@@ -864,18 +885,20 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
     stamp.mark(4);                                            // maxima out (store / cluster maxima)
     if constexpr (!kRowAtTop) { q0 = nq0; q1 = nq1; q2 = nq2; }
     }   // tile groups
+    const int tid_end = fresh_tid();                              // (not the outer copy: that one would live in scratch across the walk)
     if constexpr (kFused) {                                       // the wave's last run
         __builtin_amdgcn_wave_barrier();
-        const int cc = __builtin_amdgcn_readfirstlane(carry_c[wave]);
-        if (cc >= 0) cluster_max_out(cc, carry_m[wave][lane], lane);
+        const int wave_e = (kAsm && kTwo) ? wave_s : tid_end >> 6, lane_e = tid_end & 63;
+        const int cc = __builtin_amdgcn_readfirstlane(carry_c[wave_e]);
+        if (cc >= 0) cluster_max_out(cc, carry_m[wave_e][lane_e], lane_e);
     }
 
     __syncthreads();
-    if (tid < 128) {
+    if (tid_end < 128) {
         double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) s += lds.acc[w][tid];
-        partial[(size_t)bid * 128 + tid] = s;
+        for (int w = 0; w < kWaves; ++w) s += lds.acc[w][tid_end];
+        partial[(size_t)bid * 128 + tid_end] = s;
     }
     stamp.mark(5);                                            // barrier + partial sums
 }

@@ -516,6 +516,11 @@ __global__ void k_knn_operands(const float* __restrict__ data, const int32_t* __
 // [5] chunks scanned (wave level), [6] chunks tested, [7] segments tested, [8] lane appends, [9] drain iterations,
 // [10] drains, [11] drains with nothing buffered, [12] drains merged twelve at a time
 __device__ unsigned long long g_knn5_stats[16];
+#ifdef SG_KNN_SELFCHECK
+// debugging aid (make SELFCHECK=1): [0] seeded lists that were not in order right after seeding, [1] lists not in order at the output stage,
+// [2] tiles checked; [8..] one example: the lane's 20 seed ids, record positions and score bits
+__device__ unsigned long long g_knn_check[8 + 128];
+#endif
 
 // kSlices = waves per 64-query tile (1, 2 or 4): the cluster's candidate chunks are dealt round-robin to them.  More
 // slices shorten a tile's critical path but every slice warms up its own top-K list: at 150k points one tile costs
@@ -564,11 +569,16 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     const int myrow = active ? smpos[q] : 0;                  // member position = output row
     if (n <= K) {                                            // model.py:516-518 (block-uniform)
         if (active && wave == 0) {
-            const sg::gptr<int32_t> o = knn + (size_t)myrow * K;
+            // (its own look-up of the row: the compiler lays this block out behind the main path and, sharing `myrow` with it, kept the
+            // register alive -- in scratch -- through both phases; see the output stage below)
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int row_e = smpos[tile_lo[t] + lane_e];
+            const sg::gptr<int32_t> o = knn + (size_t)row_e * K;
 #pragma unroll
             for (int j = 0; j < K; ++j) o[j] = j < n ? clo + j : pos0;
             if (seed_out) {
-                const sg::gptr<int32_t> so = seed_out + (size_t)members[myrow] * K;
+                const sg::gptr<int32_t> so = seed_out + (size_t)members[row_e] * K;
 #pragma unroll
                 for (int j = 0; j < K; ++j) so[j] = members[j < n ? clo + j : pos0];
             }
@@ -594,8 +604,32 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
                                          __float_as_int(rec.w) - clo));
             }
             thr = from_list(kv[K - 1]);
+#ifdef SG_KNN_SELFCHECK
+            bool bad_ = false;
+#pragma unroll
+            for (int j = 0; j + 1 < K; ++j) bad_ |= from_list(kv[j]) <= from_list(kv[j + 1]);
+            if (bad_ && atomicAdd(&g_knn_check[0], 1ull) == 0ull) {
+                for (int j = 0; j < K; ++j) {
+                    const float4 rec = point_rec[sp[j]];
+                    g_knn_check[8 + j] = ((unsigned long long)(unsigned)sp[j] << 32) | (unsigned)(__float_as_int(rec.w) - clo);
+                    g_knn_check[8 + 20 + j] = from_list(kv[j]);
+                    const float again = score4(me, make_float4(rec.x, rec.y, rec.z, (rec.x * rec.x + rec.y * rec.y) + rec.z * rec.z));
+                    g_knn_check[8 + 64 + j] = ((unsigned long long)__float_as_uint(again) << 32) | __float_as_uint(rec.x);
+                    g_knn_check[8 + 84 + j] = ((unsigned long long)__float_as_uint(rec.y) << 32) | __float_as_uint(rec.z);
+                }
+                g_knn_check[8 + 44] = ((unsigned long long)__float_as_uint(me.x) << 32) | __float_as_uint(me.y);
+                g_knn_check[8 + 45] = ((unsigned long long)__float_as_uint(me.z) << 32) | __float_as_uint(me.w);
+                { const float4 m2 = sxyzw[q]; g_knn_check[8 + 46] = ((unsigned long long)__float_as_uint(m2.x) << 32) | __float_as_uint(m2.w); }
+                g_knn_check[8 + 40] = ((unsigned long long)(unsigned)myrow << 32) | (unsigned)members[myrow];
+                g_knn_check[8 + 41] = ((unsigned long long)(unsigned)clo << 32) | (unsigned)n;
+                g_knn_check[8 + 42] = ((unsigned long long)(unsigned)myprev << 32) | (unsigned)t;
+            }
+#endif
         }
     }
+#ifdef SG_KNN_SELFCHECK
+    if (kSeeded && lane == 0) atomicAdd(&g_knn_check[2], 1ull);
+#endif
     thr_pub[wave][lane] = (unsigned int)(thr >> 32);
     thr5_pub[wave][lane] = 0u;
     int cnt = 0;
@@ -854,13 +888,27 @@ __device__ __forceinline__ void cluster_knn_sorted_body(
     }
     drain();
     const unsigned long long t3 = (dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+#ifdef SG_KNN_SELFCHECK
+    if (kSeeded && active) {
+        bool bad_ = false;
+#pragma unroll
+        for (int j = 0; j + 1 < K; ++j) bad_ |= from_list(kv[j]) <= from_list(kv[j + 1]);
+        if (bad_) atomicAdd(&g_knn_check[1], 1ull);
+    }
+#endif
     if (kSlices == 1) {
         if (active) {
-            const sg::gptr<int32_t> o = knn + (size_t)myrow * K;
+            // the output row is looked up AGAIN (from a laundered lane number: not the load at the top): kept from there it was the one
+            // register too many of the seeded kernel at 128 VGPRs and lived in scratch across both phases (tests/test_build.py keeps the
+            // kernels of the inference path free of scratch)
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int row_o = smpos[tile_lo[t] + lane_o];
+            const sg::gptr<int32_t> o = knn + (size_t)row_o * K;
 #pragma unroll
             for (int j = 0; j < K; ++j) o[j] = clo + list_index(kv[j]);
             if (seed_out) {
-                const sg::gptr<int32_t> so = seed_out + (size_t)members[myrow] * K;
+                const sg::gptr<int32_t> so = seed_out + (size_t)members[row_o] * K;
 #pragma unroll
                 for (int j = 0; j < K; ++j) so[j] = members[clo + list_index(kv[j])];
             }
@@ -1254,6 +1302,15 @@ int sg_debug_knn5_stats(unsigned long long* h_out) {
     SG_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_knn5_stats), sizeof(unsigned long long) * 16));
     unsigned long long z[16] = {0};
     SG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_knn5_stats), z, sizeof z));
+    return SG_OK;
+}
+#endif
+
+#ifdef SG_KNN_SELFCHECK
+int sg_debug_knn_check(unsigned long long* h_out) {
+    SG_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_knn_check), sizeof(unsigned long long) * 136));
+    unsigned long long z[136] = {0};
+    SG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_check), z, sizeof z));
     return SG_OK;
 }
 #endif

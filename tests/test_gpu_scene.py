@@ -766,3 +766,30 @@ def test_edgeconv_walk_modes_give_the_same_labels():
         assert r.returncode == 0, r.stderr[-2000:]
         got[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("DIGESTS ")][-1][8:])
     assert len(got["0"]) == 5 and got["0"] == got["1"]
+
+
+def test_a_scenes_labels_do_not_depend_on_the_run_or_the_group_shape(weight_sets):
+    """Round 5: with more groups than scenes per group (16 x 1, 6 x 5 -- the tail of every driver run, and ranks with few scenes) the groups fall out
+    of step, waves of DIFFERENT kernels share a SIMD, and packed fp32 instructions (v_pk_fma_f32 in the hand-scheduled MLP2 loop, v_pk_add_f32 the
+    compiler's SLP pass had put into the seeded kNN) lost results: about one scene in a hundred came out with other labels than the single pipeline
+    gives, another one each run (tests/test_build.py keeps such instructions out of the library).  24 full-size scenes, two shapes,
+    six runs each: every result must equal the single pipeline's."""
+    from concurrent.futures import ThreadPoolExecutor
+    from seggroup_amd import hip, synthetic
+    from seggroup_amd.model import Engine, Pipeline
+    from seggroup_amd.scene import DeviceScene
+    W = weight_sets["ins_infer"]
+    with ThreadPoolExecutor(8) as ex:
+        host = list(ex.map(lambda seed: synthetic.make_scene(150000, 1500, seed), range(41000, 41024)))
+    scenes = [DeviceScene.from_synthetic(h, device="cuda:0") for h in host]
+    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+    solo = Pipeline(W, *caps, device="cuda:0")
+    want = [_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
+    solo.close()
+    for groups, per in ((16, 1), (6, 5)):
+        eng = Engine(W, caps, groups=groups, per_group=per, device="cuda:0", timing=0)
+        for rep in range(6):
+            got = [_digest(r) for r in eng.run(scenes, hip.MODE_INS_INFER)]
+            bad = [i for i in range(len(scenes)) if got[i] != want[i]]
+            assert not bad, f"engine {groups} x {per}, run {rep}: scenes {bad} differ from the single pipeline"
+        eng.close()
