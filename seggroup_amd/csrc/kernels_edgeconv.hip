@@ -612,8 +612,8 @@ __device__ __forceinline__ void edgeconv_body(sg::gptr<const float> x9m, sg::gpt
                     static_assert(offsetof(Lds, a2h) - offsetof(Lds, a1p) == 12288, "edgeconv_slots_gen.h addresses conv2's fragments relative to conv1's");
                     const unsigned a_frag = (unsigned)(size_t)(SG_LDS const u32x4*)(&lds.a1p[0][0][lane_c]);
                     if constexpr (!kTwo) {
-                        // The PLAIN variant of the generated loop (sums of squares as 32 v_fma_f32 per slot), not the packed one (16 v_pk_fma_f32: -1.3 us per
-                        // scene): packed fp32 arithmetic is not dependable on the MI355X boxes of this pool once waves of other kernels share the SIMD
+                        // The PLAIN variant of the generated loop (sums of squares as 32 v_fma_f32 per slot), not the packed one (16 v_pk_fma_f32: ~0.2 us per
+                        // scene faster): packed fp32 arithmetic is not dependable on the MI355X boxes of this pool while MFMA kernels start and stop on the SIMD
                         //  -- a lost v_pk_fma here is one y^2 missing from a BatchNorm variance, and a scene's labels then depend
                         // on the run.  -DSG_EC_S1X_PACKED builds the packed loop (measurements only).
 #ifdef SG_EC_S1X_PACKED
