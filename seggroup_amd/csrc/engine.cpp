@@ -592,7 +592,8 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
         if (g_hash)
             std::fprintf(stderr, "SGHASH %p L%d C=%d E=%d knn=%016llx x9m=%016llx fold=%016llx cat=%016llx gcn=%016llx dist=%016llx\n", (const void*)r.sc->d_data, layer, r.Lnew.C, r.E,
                          (unsigned long long)dev_digest(r.pl->knn.p, (size_t)r.sc->N * 20 * 4), (unsigned long long)dev_digest(r.pl->x9m.p, (size_t)r.sc->N * 12 * 4),
-                         (unsigned long long)dev_digest(r.ctx.ec_w1f, layer == 0 ? (size_t)(64 * 18 + 64) * 4 : (size_t)((r.ctx.ec_scale + 4) - r.ctx.ec_w1f) * 4),
+                         (unsigned long long)(layer == 0 ? dev_digest(r.ctx.ec_w1f, 64 * 4) ^ (dev_digest(r.ctx.ec_sh1, 64 * 4) << 1)      /* MLP2: |a| [64] and the shifts [64] only */
+                                                                 : dev_digest(r.ctx.ec_w1f, (size_t)((r.ctx.ec_scale + 4) - r.ctx.ec_w1f) * 4)),
                          (unsigned long long)dev_digest(r.pl->featA.p, (size_t)r.Lnew.C * Dcat * 4), (unsigned long long)dev_digest(r.pl->featB.p, (size_t)r.Lnew.C * Dcat * 4),
                          (unsigned long long)dev_digest(r.dist_in_outbox ? (const void*)r.ctx.dist : (const void*)r.pl->dist.p, (size_t)r.E * 4));
         if (g_hash) {

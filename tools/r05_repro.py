@@ -57,6 +57,7 @@ def main():
         eng = Engine(W, caps, groups=groups, per_group=per, device="cuda:0", timing=0)
         wrong = 0
         events = 0
+        tally = {}
         for rep in range(reps):
             with Stderr() as cap:
                 got = [bench.label_digest(r) for r in eng.run(scenes, hip.MODE_INS_INFER)]
@@ -70,11 +71,13 @@ def main():
                     if key in first and first[key] != d[key]:
                         fields = [a.split("=")[0] for a, b in zip(d[key], first[key]) if a != b]
                         note += f" [{key[0]} {key[1]}: {','.join(fields)}]"
+                        for f_ in fields: tally[(key[1], f_)] = tally.get((key[1], f_), 0) + 1
             rows = [l for l in cap.text.splitlines() if l.startswith("SGROW") or l.startswith("   ")]
             if rows and os.environ.get("SG_SHOW_ROWS"): print("\n".join(rows[:int(os.environ["SG_SHOW_ROWS"])]), flush=True)
             events += note.count("knn")
             if (bad or note) and not os.environ.get("SG_QUIET"): print(f"  engine {groups}x{per} run {rep}: scenes differing from the pipeline {bad}{note}", flush=True)
         print(f"engine {groups}x{per}: {wrong} wrong scene results in {reps} runs of {n}" + (f", {events} kNN tables that differ from the first run's" if first else ""), flush=True)
+        if first: print("   digests that differ from the first run's, by (phase, field): " + (", ".join(f"{k[0]}.{k[1]} {v}" for k, v in sorted(tally.items())) or "none"), flush=True)
         eng.close()
         try:
             import ctypes
