@@ -361,6 +361,43 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
         const int S = r.sc->S;
         const int E1 = r.o_count[0];
         if (g_hash) tl_hash_stream = stream;
+        if (g_hash) {
+            // the first sample set seen for a scene is kept; later ones are compared segment by segment
+            static std::mutex mu_dbg0;
+            static std::map<const void*, std::vector<float>> seen0;
+            std::vector<float> smp((size_t)S * 64 * 6);
+            (void)fetch(smp.data(), r.pl->samples.p, smp.size() * 4);
+            {
+                // the same sampling once more through the single-scene entry (no Morton order: its large segments take the plain strided passes)
+                float* d_ref = nullptr; void* d_wsr = nullptr;
+                if (hipMalloc((void**)&d_ref, smp.size() * 4) == hipSuccess && hipMalloc(&d_wsr, (size_t)r.sc->N * 16) == hipSuccess &&
+                    sg::fps_sample_hint(r.sc->d_data, r.sc->N, 6, r.sc->d_seg_points, r.sc->d_seg_off, S, 64, 6, 1, d_ref, nullptr, d_wsr, (size_t)r.sc->N * 16,
+                                        (void*)stream, r.max_seg) == SG_OK) {
+                    std::vector<float> ref(smp.size());
+                    (void)fetch(ref.data(), d_ref, ref.size() * 4);
+                    for (int sg_ = 0; sg_ < S; ++sg_)
+                        if (std::memcmp(&smp[(size_t)sg_ * 384], &ref[(size_t)sg_ * 384], 384 * 4) != 0)
+                            std::fprintf(stderr, "SGROW %p P0 segment %d (%d points): the engine's samples differ from the single-scene entry's\n", (const void*)r.sc->d_data, sg_, r.sc->h_seg_size[sg_]);
+                }
+                (void)hipStreamSynchronize(stream);
+                if (d_ref) (void)hipFree(d_ref);
+                if (d_wsr) (void)hipFree(d_wsr);
+            }
+            std::lock_guard<std::mutex> g(mu_dbg0);
+            auto it = seen0.find((const void*)r.sc->d_data);
+            if (it == seen0.end()) seen0[(const void*)r.sc->d_data] = smp;
+            else {
+                int shown = 0;
+                for (int sg_ = 0; sg_ < S; ++sg_) {
+                    const float* a = &smp[(size_t)sg_ * 384];
+                    const float* b = &it->second[(size_t)sg_ * 384];
+                    if (std::memcmp(a, b, 384 * 4) == 0) continue;
+                    int rows = 0, first_row = -1;
+                    for (int k = 0; k < 64; ++k) if (std::memcmp(a + 6 * k, b + 6 * k, 24) != 0) { ++rows; if (first_row < 0) first_row = k; }
+                    if (shown++ < 6) std::fprintf(stderr, "SGROW %p P0 segment %d (%d points): %d of its 64 sample rows differ, the first is row %d\n", (const void*)r.sc->d_data, sg_, r.sc->h_seg_size[sg_], rows, first_row);
+                }
+            }
+        }
         if (g_hash)
             std::fprintf(stderr, "SGHASH %p P0 E1=%d sperm=%016llx samples=%016llx feat1=%016llx adj1=%016llx dist=%016llx\n", (const void*)r.sc->d_data, E1,
                          (unsigned long long)(mode == SG_MODE_INS_INFER ? dev_digest(r.pl->sperm.p, (size_t)r.sc->N * 4) : 0),

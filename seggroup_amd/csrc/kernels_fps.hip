@@ -63,6 +63,11 @@ __device__ inline Best fps_pass(const float* X, const float* Y, const float* Z, 
     return block_argmax<BLOCK>(b, red);
 }
 
+#ifdef SG_FPS_SELFCHECK
+// debugging aid (make SELFCHECK=1): [0] half-wave maxima that a shuffle butterfly computes differently, [1] the same for the first index,
+// [2] picks that a second, serial evaluation by one wave finds differently, [3] picks checked, [4] Ms values read back differently
+__device__ unsigned long long g_fps_check[8];
+#endif
 template <int BLOCK>
 __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, int N, int ch_in,
                                                 const int32_t* __restrict__ members, const int32_t* __restrict__ cl_off,
@@ -221,7 +226,11 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
                 for (int v = 0; v < kV; ++v) {
                     const int r = min(32 * chs[v] + hl, n - 1);
                     x[v] = Xs[r]; y[v] = Ys[r]; z[v] = Zs[r];
-                    mo[v] = reset ? 0.f : Ms[r];
+                    // (device-scope load and store: past the CU's vector L1.  A chunk's minima are read and written by another wave every step,
+                    // and a chunk shares its first and last cache line with its neighbours -- which other waves visit in the SAME step: a line one
+                    // wave fetches while another wave writes its part of it can sit in the L1 with that part stale, and the next step's visitor
+                    // of the neighbour then reads old minima.  Round 5: one sample set in ~5,000 big segments differed from run to run.)
+                    mo[v] = reset ? 0.f : __hip_atomic_load(&Ms[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     li[v] = sperm[lo + r] - lo;
                 }
 #pragma unroll
@@ -231,7 +240,7 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
                     const float dx = x[v] - qx, dy = y[v] - qy, dz = z[v] - qz;
                     float d = (dx * dx + dy * dy) + dz * dz;
                     if (!reset) d = fminf(mo[v], d);
-                    if (in) Ms[r] = d;
+                    if (in) __hip_atomic_store(&Ms[r], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     d = in ? d : -INFINITY;
                     const int lix = in ? li[v] : INT_MAX;
                     // maxima / minima of the 32 lanes of each half: rows of 16 on the DPP path, row 0 -> 1 and 2 -> 3, then lanes 31 / 63
@@ -245,6 +254,16 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
                     k = min(k, sgw::dpp_i<sgw::kRowRor4>(k, k));  k = min(k, sgw::dpp_i<sgw::kRowRor8>(k, k));
                     k = min(k, sgw::dpp_i<sgw::kRowBcast15, 0xA>(k, k));
                     const int kh = half ? sgw::bcast(k, 63) : sgw::bcast(k, 31);
+#ifdef SG_FPS_SELFCHECK
+                    {
+                        float m2 = d;
+                        for (int o = 16; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o));        // butterfly inside the 32 lanes of the half
+                        int k2 = d == m2 ? lix : INT_MAX;
+                        for (int o = 16; o > 0; o >>= 1) k2 = min(k2, __shfl_xor(k2, o));
+                        if (m2 != mh && hl == 0) atomicAdd(&g_fps_check[0], 1ull);
+                        if (k2 != kh && hl == 0) atomicAdd(&g_fps_check[1], 1ull);
+                    }
+#endif
                     if (in && lix == kh) { const int ch = chs[v]; cm[ch] = mh; ci[ch] = kh; cx[ch] = x[v]; cy[ch] = y[v]; cz[ch] = z[v]; }   // one lane of the half
                 }
             };
@@ -270,8 +289,23 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
                 }
                 parity ^= 1;
                 bi = r.i; qx = cx[r.ch]; qy = cy[r.ch]; qz = cz[r.ch];
+#ifdef SG_FPS_SELFCHECK
+                if (tid == 0) {
+                    float bv = -INFINITY; int bix = INT_MAX;
+                    for (int ch = 0; ch < nch; ++ch) { const float cv = cm[ch]; const int cix = ci[ch]; if (cv > bv || (cv == bv && cix < bix)) { bv = cv; bix = cix; } }
+                    atomicAdd(&g_fps_check[3], 1ull);
+                    if (bix != bi) atomicAdd(&g_fps_check[2], 1ull);
+                }
+                __syncthreads();
+#endif
             };
             auto full_pass = [&](float qx, float qy, float qz) {
+                // A pass rewrites every chunk's record, the winner's coordinates included -- which the waves behind the last pick()'s barrier may still
+                // be reading (qx = cx[r.ch] ...).  Round 5: without this barrier about one sample set in 4,000 big segments was wrong, a wave having
+                // read the first pick's x from the old record and its y or z from the new one (found by tools/r05_repro.py with SG_ENGINE_HASH=1,
+                // which samples every scene a second time through the single-scene entry).  The steps of the main loop need none: their
+                // visits come behind the work list's barrier.
+                __syncthreads();
                 for (int e = 2 * wave; e < nch; e += 128) {                       // four chunks per half wave in flight
                     const int chs[4] = {min(e + half, nch - 1), min(e + 32 + half, nch - 1), min(e + 64 + half, nch - 1), min(e + 96 + half, nch - 1)};
                     visit(std::integral_constant<int, 4>{}, chs, qx, qy, qz, true);
@@ -541,6 +575,15 @@ int b_fps64(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, bool sort
 }  // namespace sg
 
 extern "C" {
+
+#ifdef SG_FPS_SELFCHECK
+int sg_debug_fps_check(unsigned long long* h_out) {
+    SG_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_fps_check), sizeof(unsigned long long) * 8));
+    unsigned long long z[8] = {0};
+    SG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fps_check), z, sizeof z));
+    return SG_OK;
+}
+#endif
 
 size_t sg_fps_ws_bytes(int N) { return sg::align_up((size_t)std::max(N, 1) * 16); }
 

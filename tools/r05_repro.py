@@ -2,7 +2,7 @@
 """Do a scene's labels depend on the batch it runs in, or on the run?  N scenes through the engine in different group shapes, several times, against
 the single pipeline.  With SG_ENGINE_HASH=1 the engine prints digests of every phase's device results; the first differing phase of a scene is shown.
 
-    python3 tools/r05_repro.py [N=64] [seed0=40000] [shapes=10x8,6x5,16x1,3x8] [reps=2]
+    python3 tools/r05_repro.py [N=64] [seed0=40000] [shapes=10x8,6x5,16x1,3x8] [reps=2]          (SG_REPRO_PROFILE=scannet: the ScanNet-shaped scenes)
 """
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,13 +39,21 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
     shapes = [tuple(int(v) for v in s.split("x")) for s in (sys.argv[3] if len(sys.argv) > 3 else "10x8,6x5,16x1,3x8").split(",")]
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-    jobs = [(150000, 1500, seed0 + i, "voronoi", "/tmp/sg_scenes") for i in range(n)]
+    profile = os.environ.get("SG_REPRO_PROFILE", "voronoi")              # "scannet": surfaces, 10k-40k-point floors / walls (the other size classes of FPS, sort, layout)
+    jobs = [(150000, 1500, seed0 + i, profile, "/tmp/sg_scenes") for i in range(n)]
     it, pool = bench.generate_scenes(jobs, 16)
     from seggroup_amd import hip, weights
     from seggroup_amd.model import Engine, Pipeline
     from seggroup_amd.scene import DeviceScene
     scenes = [DeviceScene.from_synthetic(s, device="cuda:0") for s in it]
     if pool is not None: pool.shutdown()
+    if os.environ.get("SG_REPRO_ONLY"):                                    # "i,j,...": only these scenes, repeated to fill n
+        keep = [int(v) for v in os.environ["SG_REPRO_ONLY"].split(",")]
+        scenes = [scenes[keep[i % len(keep)]] for i in range(n)]
+    if os.environ.get("SG_REPRO_LIST_BIG"):
+        for i, sc_ in enumerate(scenes):
+            big = [(int(k), int(v)) for k, v in enumerate(sc_.h_seg_size) if v > 8192]
+            print(f"   scene {i}: segments beyond 8,192 points (index, points): {big}", flush=True)
     W = weights.load_npz(os.path.join(ROOT, "tests", "golden", "weights_g2.npz"))
     caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
     solo = Pipeline(W, *caps, device="cuda:0")
@@ -79,6 +87,13 @@ def main():
         print(f"engine {groups}x{per}: {wrong} wrong scene results in {reps} runs of {n}" + (f", {events} kNN tables that differ from the first run's" if first else ""), flush=True)
         if first: print("   digests that differ from the first run's, by (phase, field): " + (", ".join(f"{k[0]}.{k[1]} {v}" for k, v in sorted(tally.items())) or "none"), flush=True)
         eng.close()
+        try:
+            import ctypes
+            fb = (ctypes.c_ulonglong * 8)()
+            hip.lib().sg_debug_fps_check(fb)
+            print(f"   FPS self-check (chunk-pruned path): {fb[3]} picks checked, {fb[2]} differ from a serial evaluation; half-wave maxima / first indices that a shuffle butterfly computes differently: {fb[0]} / {fb[1]}", flush=True)
+        except AttributeError:
+            pass
         try:
             import ctypes
             buf = (ctypes.c_ulonglong * 136)()
