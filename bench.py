@@ -372,6 +372,15 @@ def main(argv=None):
     solo.set_timing(0)
     solo_digests = [label_digest(solo.forward(last_batch[i], hip.MODE_INS_INFER)) for i in range(n_par)]
     parity_ok = batch_digests == solo_digests
+    # ---- the same scenes once more with the groups OUT OF STEP: sixteen groups of one scene each, so that waves of different kernels share the
+    # SIMDs (the tail of every driver run; round 5 found results that depended on the run only there: DESIGN.md 5e).  Untimed. ----
+    oos = Engine(W, caps, groups=16, per_group=1, device=dev, timing=0)
+    oos_runs, oos_wrong = 3, 0
+    for _ in range(oos_runs):
+        got = [label_digest(r_) for r_ in oos.run(list(last_batch[:n_par]), hip.MODE_INS_INFER)]
+        oos_wrong += sum(1 for a_, b_ in zip(got, solo_digests) if a_ != b_)
+    oos.close()
+    parity_ok = parity_ok and oos_wrong == 0
     ok = torch.tensor([1.0 if parity_ok else 0.0], dtype=torch.float64)
     if world > 1:
         if args.backend == "nccl":
@@ -719,6 +728,7 @@ def main(argv=None):
                               "what": f"{len(repeat_values)} timed regions of {args.steps} steps each, back to back; `value` is the first"},
             "roofline": roofline, "cpu_baseline": cpu,
             "parity_check": {"scenes_per_rank": n_par, "ranks_equal": parity_all,
+                             "out_of_step": {"engine": "16 groups x 1 scene", "runs": oos_runs, "scene_results": oos_runs * n_par, "wrong_on_rank0": oos_wrong},
                              "what": "sha256 over the 14 label vectors + metric tensors + cluster trace of every checked scene of the last timed batch "
                                      "== the same scenes through one default-stream pipeline (and the extra legs' own checks)"},
             "with_label_files_scenes_per_s": with_files or None,
