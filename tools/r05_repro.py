@@ -39,8 +39,10 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
     shapes = [tuple(int(v) for v in s.split("x")) for s in (sys.argv[3] if len(sys.argv) > 3 else "10x8,6x5,16x1,3x8").split(",")]
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    pts, segs = (int(v) for v in os.environ.get("SG_REPRO_SIZE", "150000,1500").split(","))
+    sem = bool(os.environ.get("SG_REPRO_SEM"))                            # sem_infer (structural threshold 3, weights_g1) instead of ins_infer
     profile = os.environ.get("SG_REPRO_PROFILE", "voronoi")              # "scannet": surfaces, 10k-40k-point floors / walls (the other size classes of FPS, sort, layout)
-    jobs = [(150000, 1500, seed0 + i, profile, "/tmp/sg_scenes") for i in range(n)]
+    jobs = [(pts, segs, seed0 + i, profile, "/tmp/sg_scenes") for i in range(n)]
     it, pool = bench.generate_scenes(jobs, 16)
     from seggroup_amd import hip, weights
     from seggroup_amd.model import Engine, Pipeline
@@ -54,11 +56,12 @@ def main():
         for i, sc_ in enumerate(scenes):
             big = [(int(k), int(v)) for k, v in enumerate(sc_.h_seg_size) if v > 8192]
             print(f"   scene {i}: segments beyond 8,192 points (index, points): {big}", flush=True)
-    W = weights.load_npz(os.path.join(ROOT, "tests", "golden", "weights_g2.npz"))
+    W = weights.load_npz(os.path.join(ROOT, "tests", "golden", "weights_g1.npz" if sem else "weights_g2.npz"))
+    mode = hip.MODE_SEM_INFER if sem else hip.MODE_INS_INFER
     caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
     solo = Pipeline(W, *caps, device="cuda:0")
-    want = [bench.label_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
-    again = [bench.label_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
+    want = [bench.label_digest(solo.forward(s, mode)) for s in scenes]
+    again = [bench.label_digest(solo.forward(s, mode)) for s in scenes]
     print("pipeline twice equal:", want == again, flush=True)
     first = None
     for groups, per in shapes:
@@ -68,7 +71,7 @@ def main():
         tally = {}
         for rep in range(reps):
             with Stderr() as cap:
-                got = [bench.label_digest(r) for r in eng.run(scenes, hip.MODE_INS_INFER)]
+                got = [bench.label_digest(r) for r in eng.run(scenes, mode)]
             bad = [i for i in range(n) if got[i] != want[i]]
             wrong += len(bad)
             d = digests(cap.text)
