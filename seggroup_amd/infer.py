@@ -275,7 +275,7 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
 def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     from concurrent.futures import ThreadPoolExecutor
     from . import cache, hip
-    from .model import AsyncLabelWriter, BatchRunner
+    from .model import AsyncLabelWriter, BatchRunner, Engine
 
     names = [scene_list[i][:-1] for i in mine]
     formats = tuple(args.out_format.split(','))
@@ -285,7 +285,7 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     # Scene packs come through the native loader (csrc/loader.cpp): worker threads read them into pinned buffers and upload them into
     # device slots allocated here, once.  --no-cache
     # stages straight from the reference's files in Python threads (no pack written).
-    loader = None
+    loader, all_caps = None, None
     if not args.no_cache:
         paths = {n: cache.pack_scene(args.root, n, args.label_style) for n in dict.fromkeys(names)}
         slot_bytes = max((os.path.getsize(p) for p in paths.values()), default=1 << 20)
@@ -295,7 +295,11 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
         # cores from the writer pool
         # the slots' size: the largest pack + the largest adjacency widened to int64 (every pack's header says how many edges it holds:
         # ~20 us per file; sized by the worst case of 3 x the file, 256 slots of 150k-point packs were ~9 GB of device memory)
-        max_edges = max((cache.pack_dims(p)['E0'] for p in paths.values()), default=0)
+        dims = [cache.pack_dims(p) for p in paths.values()]
+        max_edges = max((d['E0'] for d in dims), default=0)
+        # ... and how large an engine this rank's scenes need: it is created below WHILE the loader reads the first batches (it used to be
+        # sized by the first batch once that had arrived: ~0.1 s of 124 MB device slots allocated with nothing beside them)
+        all_caps = tuple(max(d[k] for d in dims) for k in ('N', 'S', 'E0', 'V')) if dims else None
         n_load = int(os.environ.get('SG_LOADER_THREADS', '0')) or min(6 if 'txt' not in formats else 8, workers)
         loader = cache.PackLoader(threads=n_load, slots=4 * max(args.batch, 1), slot_bytes=slot_bytes, device=dev,
                                   max_edges=max_edges)
@@ -327,6 +331,12 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     runner, done, stalled = None, 0, []
     w = model.export_weights()
     tickets = []
+    t_start, startup = time.time(), None
+    if all_caps is not None and all(c > 0 for c in (all_caps[0], all_caps[1], all_caps[3])):
+        per_group = min(8, max(1, args.inflight // 2))         # (BatchRunner's shape)
+        runner = Engine(w, all_caps, groups=max(1, args.inflight // per_group), per_group=per_group, device=dev, timing=0,
+                        label_transfer=args.label_transfer)
+    t_engine = time.time() - t_start
 
     prof = {"load_wait": 0.0, "submit": 0.0, "engine_wait": 0.0, "log": 0.0} if os.environ.get("SG_DRIVER_PROFILE") else None
 
@@ -352,7 +362,6 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
         if prof is not None:
             prof["log"] += time.time() - t_a
 
-    t_start, startup = time.time(), None
     for bi, batch in enumerate(batches):
         t_a = time.time()
         scenes = [f.result() for f in pending_q.pop(0)]
@@ -385,7 +394,8 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     writer.flush()
     if prof is not None:
         prof["final_flush"] = time.time() - t_a
-        print("[driver profile] %s total %.3f s" % ({k: round(v, 3) for k, v in prof.items()}, time.time() - t_start), flush=True)
+        print("[driver profile] %s engine created in %.3f s, start-up %.3f s, total %.3f s" % ({k: round(v, 3) for k, v in prof.items()}, t_engine, startup or 0.0,
+                                                                                              time.time() - t_start), flush=True)
     writer.close()
     if runner is not None:
         runner.close()
