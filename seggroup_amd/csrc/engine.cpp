@@ -723,6 +723,7 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
                                            nullptr, (void*)stream));
                 int max_cl = 0;
                 for (int cc = 0; cc < L5.C; ++cc) max_cl = std::max(max_cl, L5.cl_pt_off[cc + 1] - L5.cl_pt_off[cc]);
+                EG_CHECK(pl->need_fallback_buffers());
                 EG_CHECK(sg::fps_sample_hint(sc->d_data, sc->N, 6, pl->members.p, dd + o_off, L5.C, 1024, 3, 0, pl->samples_big.p, nullptr,
                                              pl->ws_fps.p, pl->ws_fps.n, (void*)stream, max_cl));
                 EG_HIP(hipMemcpyAsync(pl->h_samples.p, pl->samples_big.p, (size_t)L5.C * 1024 * 3 * 4, hipMemcpyDeviceToHost, stream));

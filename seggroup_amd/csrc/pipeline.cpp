@@ -156,12 +156,12 @@ sg_pipeline* sg_pipeline_create(int maxN, int maxS, int maxE, int maxV, const sg
     D(pl->knn, N * 20); D(pl->knn_seed, N * 20); D(pl->seed_id, N); D(pl->ec_range, sg::kRangeWords);
     D(pl->desc, 15 * S + 16 + 4 * T + 2 * maxE1 + 4 * maxE1 + 128);
     D(pl->tables, SG_NUM_LABEL_VECTORS * S); D(pl->labels, SG_NUM_LABEL_VECTORS * V);
-    D(pl->samples, S * 64 * 6); D(pl->samples_big, S * 1024 * 3);
+    D(pl->samples, S * 64 * 6);                                 // (samples_big / h_samples: sg_pipeline::need_fallback_buffers, on first use)
     D(pl->feat1, S * 128); D(pl->featA, S * 256); D(pl->featB, S * 256);
     D(pl->seg_sums, S * 3); P(pl->h_seg_sums, S * 3); D(pl->segbox, S * 8); D(pl->chunk_box, (N / 32 + S + 1) * 8); D(pl->chunk_table, (N / 32 + S + 1) * 8); D(pl->sperm, N); D(pl->smpos, N); D(pl->seg_chunk_off, S + 1);
     D(pl->ws_sort, sg_segment_sort_ws_bytes(maxN)); D(pl->dist, maxE1); D(pl->x9m, N * 12); D(pl->xyzw, N * 4); D(pl->pf, N * 64); D(pl->point_rec, N * 4);
     P(pl->h_adj, 2 * maxE1); P(pl->h_desc, pl->desc.n); P(pl->h_tables, SG_NUM_LABEL_VECTORS * S); P(pl->h_count, 4); P(pl->h_chunk_off, S + 1); P(pl->h_eval, pl->ws_eval.n / 4 + 16);
-    P(pl->h_dist, maxE1); P(pl->h_feat, S * 256); P(pl->h_samples, S * 1024 * 3);
+    P(pl->h_dist, maxE1); P(pl->h_feat, S * 256);
     if (!bad && hipMalloc((void**)&pl->dev_arena, dev) != hipSuccess) bad = 1;
     if (!bad && hipHostMalloc((void**)&pl->pin_arena, pin, hipHostMallocDefault) != hipSuccess) bad = 1;
     if (bad) { sg::fail(SG_ENOMEM, "sg_pipeline_create: device/pinned allocation failed (N=%d S=%d E=%d V=%d)", maxN, maxS, maxE, maxV); return nullptr; }
@@ -619,6 +619,7 @@ int sg_pipeline_forward(sg_pipeline* pl, const sg_scene* sc, int mode, sg_result
             PL_CHECK(sg_gather_members(sc->d_seg_points, sc->d_seg_off, S, dd + o_order, dd + o_dst, dd + o_cl, pl->members.p, nullptr, nullptr, nullptr, stv));
             int max_cl = 0;
             for (int c = 0; c < L5.C; ++c) max_cl = std::max(max_cl, L5.cl_pt_off[c + 1] - L5.cl_pt_off[c]);
+            PL_CHECK(pl->need_fallback_buffers());
             PL_CHECK(sg::fps_sample_hint(sc->d_data, N, 6, pl->members.p, dd + o_off, L5.C, 1024, 3, 0, pl->samples_big.p, nullptr,
                                          pl->ws_fps.p, pl->ws_fps.n, stv, max_cl));
             PL_HIP(hipMemcpyAsync(pl->h_samples.p, pl->samples_big.p, (size_t)L5.C * 1024 * 3 * 4, hipMemcpyDeviceToHost, st));

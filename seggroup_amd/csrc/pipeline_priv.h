@@ -78,6 +78,16 @@ struct sg_pipeline {
     sgp::DevBuf<double> seg_sums;          // [S,3] coordinate sums of every over-segment (layer-invariant)
     sgp::PinBuf<double> h_seg_sums;
 
+    // The FPS-1024 fallback of the final clustering (model.py:479; an unlabeled, disconnected component: rare) samples into [S,1024,3] floats on
+    // the device and on the host: 18 MB each at S = 1,500.  Allocated on first use -- as part of every pipeline's arenas the eighty slots of an
+    // engine pinned 1.5 GB for it at start-up (round 5: most of the 0.17 s `sg_engine_create` took).
+    int need_fallback_buffers() {
+        const size_t n = (size_t)maxS * 1024 * 3;
+        if (!samples_big.p && samples_big.alloc(n) != 0) return sg::fail(SG_ENOMEM, "FPS-1024 fallback: device allocation of %zu floats failed", n);
+        if (!h_samples.p && h_samples.alloc(n) != 0) return sg::fail(SG_ENOMEM, "FPS-1024 fallback: pinned allocation of %zu floats failed", n);
+        return SG_OK;
+    }
+
     hipEvent_t ev[sgp::kNumEvents];
     hipEvent_t ev_count = nullptr;      // behind the D2H of the contracted edge count: the host waits for THAT, not for the whole structural layer
     // label rows leave as soon as their tables exist (round 4): H2D of a layer's table rows, the export kernel for them and the D2H of the vectors run
