@@ -66,7 +66,7 @@ S2X_EXECUTED_FLOP_PER_ROW = 3 * 2 * 64 * 64 + CONV1_EXEC_FLOP_PER_ROW
 # sustains, not the two of the SIMD-32 data path (round 2 priced the kNN against 1,229 G instructions/s).  1024 SIMDs / 2.0 ns:
 VALU_ISSUE_NS = 2.0
 VALU_PEAK_GINST = 1024 / VALU_ISSUE_NS
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 DTYPE = "f32 (fp32 accumulate; operands split into 2 x fp16 pieces on v_mfma_f32_32x32x16_f16; kNN / FPS scores in exact fp32 order)"
 
 
@@ -111,7 +111,11 @@ def parse_args(argv=None):
     ap.add_argument("--gen-workers", type=int, default=0, help="scene generator processes (0 = min(16, cores))")
     ap.add_argument("--numa", default="auto", choices=["auto", "off"], help="auto = bind every rank's process (engine groups, writer pool) to the CPUs of its GPU's NUMA node")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU rehearsals of the reduction)")
-    ap.add_argument("--parity-scenes", type=int, default=64, help="scenes of the last batch re-run on a single pipeline and compared (default: all 64)")
+    ap.add_argument("--parity-scenes", type=int, default=64, help="scenes of the last batch re-run on a single pipeline and compared (default: all 64); 0 = no parity legs at all "
+                                                                  "(profiled runs: the out-of-step leg launches the batched kernels with ONE scene each, which dilutes per-launch profile averages)")
+    ap.add_argument("--no-oos", action="store_true", help="skip the out-of-step parity leg (16 groups x 1 scene) only")
+    ap.add_argument("--profile", action="store_true", help="roctx ranges around the bench's legs and, inside the engine's group threads, around every phase and stage "
+                                                           "(rocprofv3 --kernel-trace --marker-trace --stats -- python3 bench.py --profile ...; tools/prof_ranges.sh)")
     ap.add_argument("--extra-strong", type=int, default=1201, help="extra leg (rank 0, N = 1): ONE pass over this many distinct scenes = BASELINE configs[3] "
                                                                     "at W = 1 (0 = skip)")
     ap.add_argument("--extra-stress", type=int, default=500000, help="extra leg: single-scene latency of a scene with this many points / 100 (0 = skip)")
@@ -215,6 +219,46 @@ def reduce_accumulators(vec: np.ndarray, world: int, backend: str, dev=None) -> 
     return t.cpu().numpy()
 
 
+def comm_probe(world: int, backend: str, dev) -> dict:
+    """What the collective layer saw: the backend, the communicator's own world size, the result of an all-reduce of
+    ones over it (= the number of ranks that took part) and whether librccl is mapped into this process.  Called by EVERY rank (the all-reduce is
+    a collective); at N = 1 without a launcher a one-rank communicator of the same backend is made for the probe and destroyed again."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+    info = {"backend": backend, "world_size": None, "allreduce_of_ones": None, "librccl_mapped": False}
+    own = False
+    try:
+        if not dist.is_initialized():
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            kw = {"device_id": dev} if backend == "nccl" else {}
+            dist.init_process_group(backend=backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
+            own = True
+        t = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        info["world_size"] = dist.get_world_size()
+        info["allreduce_of_ones"] = float(t.item())
+        info["expected"] = world
+    except Exception as e:                                  # the probe must not take the bench line with it
+        info["error"] = repr(e)[:200]
+    finally:
+        if own:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+    try:
+        with open("/proc/self/maps") as f:
+            info["librccl_mapped"] = any("librccl" in ln for ln in f)
+    except OSError:
+        pass
+    return info
+
+
 def digest_of_digests(results) -> str:
     h = hashlib.sha256()
     for r in results:
@@ -260,6 +304,8 @@ def main(argv=None):
         print(f"bench.py: {n_gen} scenes in {args.scene_cache or '(no cache directory given)'} ({time.time() - t_gen:.1f} s)", file=sys.stderr)
         return
 
+    if args.profile:
+        os.environ["SG_ROCTX"] = "1"                            # read when the library loads (engine group threads push their own ranges)
     import torch
     import torch.distributed as dist
 
@@ -298,6 +344,7 @@ def main(argv=None):
     extra_scenes, scenes = scenes[n_main:], scenes[:n_main]
 
     from seggroup_amd.model import Engine, Pipeline
+    from seggroup_amd.hip import roctx_range as rng            # no-ops unless --profile (SG_ROCTX) is on
     every = scenes + extra_scenes + strong_scenes
     caps = (max(s.N for s in every), max(s.S for s in every), max(s.E0 for s in every), max(s.V for s in every))
     # stage timing: a handful of HIP events per batched launch sequence (per group of scenes, not per scene)
@@ -348,9 +395,11 @@ def main(argv=None):
         return el, last_
 
     runner.profile(enable=True)
-    run_batches(batches, args.warmup)
+    with rng("warmup"):
+        run_batches(batches, args.warmup)
     runner.reset_stage_stats()
-    elapsed, last_results = timed(args.steps, record)           # THE timed region: exactly --steps steps
+    with rng("timed_region"):
+        elapsed, last_results = timed(args.steps, record)       # THE timed region: exactly --steps steps
     engine_profile = {k_: round(v, 3) for k_, v in runner.profile().items()}
     mean_ms = runner.mean_stage_ms()
     scenes_per_step = args.scenes_total if args.scenes_total > 0 else world * args.batch
@@ -366,20 +415,24 @@ def main(argv=None):
         repeat_values.append(round(scenes_per_step * args.steps / el, 3))
 
     vec = reduce_accumulators(np.concatenate([acc["iou_sem"], acc["iou_ins"], acc["acc"], [acc["n"]]]), world, args.backend, dev)
+    comm = comm_probe(world, args.backend, dev)
 
     # ---- parity of the concurrent path: EVERY scene of the LAST timed batch vs a single default-stream pipeline ----
     solo = Pipeline(W, *caps, stream=None, device=dev)
     solo.set_timing(0)
-    solo_digests = [label_digest(solo.forward(last_batch[i], hip.MODE_INS_INFER)) for i in range(n_par)]
+    with rng("parity.single_pipeline"):
+        solo_digests = [label_digest(solo.forward(last_batch[i], hip.MODE_INS_INFER)) for i in range(n_par)]
     parity_ok = batch_digests == solo_digests
     # ---- the same scenes once more with the groups OUT OF STEP: sixteen groups of one scene each, so that waves of different kernels share the
     # SIMDs (the tail of every driver run; round 5 found results that depended on the run only there: DESIGN.md 5e).  Untimed. ----
-    oos = Engine(W, caps, groups=16, per_group=1, device=dev, timing=0)
-    oos_runs, oos_wrong = 3, 0
-    for _ in range(oos_runs):
-        got = [label_digest(r_) for r_ in oos.run(list(last_batch[:n_par]), hip.MODE_INS_INFER)]
-        oos_wrong += sum(1 for a_, b_ in zip(got, solo_digests) if a_ != b_)
-    oos.close()
+    oos_runs, oos_wrong = (0 if (n_par == 0 or args.no_oos) else 3), 0
+    if oos_runs:
+        with rng("parity.out_of_step"):
+            oos = Engine(W, caps, groups=16, per_group=1, device=dev, timing=0)
+            for _ in range(oos_runs):
+                got = [label_digest(r_) for r_ in oos.run(list(last_batch[:n_par]), hip.MODE_INS_INFER)]
+                oos_wrong += sum(1 for a_, b_ in zip(got, solo_digests) if a_ != b_)
+            oos.close()
     parity_ok = parity_ok and oos_wrong == 0
     ok = torch.tensor([1.0 if parity_ok else 0.0], dtype=torch.float64)
     if world > 1:
@@ -402,8 +455,9 @@ def main(argv=None):
         sb = Engine(W, caps, groups=1, per_group=args.per_group, device=dev, timing=1)
         sb.run(scenes[:args.per_group], hip.MODE_INS_INFER)
         sb.reset_stage_stats()
-        for k0 in range(0, len(scenes), args.per_group):
-            sb.run(scenes[k0:k0 + args.per_group], hip.MODE_INS_INFER)
+        with rng("solo_batched"):
+            for k0 in range(0, len(scenes) - args.per_group + 1, args.per_group):       # full launches only
+                sb.run(scenes[k0:k0 + args.per_group], hip.MODE_INS_INFER)
         sb_ms = sb.mean_stage_ms()
         sb.close()
         solo_b = per_kernel(sb_ms)
@@ -726,7 +780,7 @@ def main(argv=None):
             "timed_region_s": round(elapsed, 3),
             "repeat_values": {"scenes_per_s": repeat_values, "min": min(repeat_values), "median": float(np.median(repeat_values)),
                               "what": f"{len(repeat_values)} timed regions of {args.steps} steps each, back to back; `value` is the first"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "comm": comm,
             "parity_check": {"scenes_per_rank": n_par, "ranks_equal": parity_all,
                              "out_of_step": {"engine": "16 groups x 1 scene", "runs": oos_runs, "scene_results": oos_runs * n_par, "wrong_on_rank0": oos_wrong},
                              "what": "sha256 over the 14 label vectors + metric tensors + cluster trace of every checked scene of the last timed batch "

@@ -1,7 +1,9 @@
 // Error plumbing, version / device probe, and the label-file writers (a16 file side,
 // reference seggroup/model.py:536-547) of libseggroup_hip.so.
 #include <cerrno>
+#include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <fcntl.h>
 #include <sys/uio.h>
@@ -28,6 +30,27 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// roctx (sg_common.h): resolved once, at the first range; SG_ROCTX unset = two null pointers and nothing else happens
+namespace {
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        if (!getenv("SG_ROCTX")) return;
+        void* h = nullptr;
+        for (const char* n : {"librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so"})
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const RoctxApi& roctx_api() { static const RoctxApi a; return a; }
+}  // namespace
+void roctx_push(const char* name) { if (roctx_api().push) (void)roctx_api().push(name); }
+void roctx_pop() { if (roctx_api().pop) (void)roctx_api().pop(); }
 
 }  // namespace sg
 

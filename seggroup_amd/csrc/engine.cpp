@@ -55,6 +55,14 @@ inline hipError_t timed_sync(hipStream_t st) {
     return e;
 }
 
+// consecutive roctx ranges of a phase (sg_common.h: no-ops unless SG_ROCTX): next() closes the open one; the destructor closes the last, also
+// on an early return
+struct Stages {
+    bool open = false;
+    void next(const char* name) { if (open) sg::roctx_pop(); sg::roctx_push(name); open = true; }
+    ~Stages() { if (open) sg::roctx_pop(); }
+};
+
 // bump allocator over a pinned buffer whose device twin has the same layout
 struct Arena {
     char* h = nullptr;
@@ -138,7 +146,9 @@ struct sg_engine {
         sg_engine* eng = nullptr;
         int index = 0;
         hipStream_t stream = nullptr;
-        hipStream_t side = nullptr;                 // phase P0's big-segment chain (sort + FPS of segments beyond 2,048 points)
+        hipStream_t side = nullptr;                 // phase P0's big-segment chain (sort + FPS of segments beyond 2,048 points): only with SG_ENGINE_FORK
+        hipStream_t heavy = nullptr;                // SG_ENGINE_CUMASK=heavy:<n>[:knn]: the EdgeConv (and kNN) launches on a stream confined to n CUs
+        bool heavy_knn = false;
         hipEvent_t ev_fork = nullptr, ev_join = nullptr;
         std::vector<sg_pipeline*> slots;
         Arena par, box;
@@ -242,6 +252,8 @@ int regroup(Run& r, const float* h_dist, float th) {
 // P0: graph initialisation + structural layer up to its decision distances (model.py:710-757)
 // ---------------------------------------------------------------------------------------------------------------------
 int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
+    Stages rg;
+    rg.next("P0.describe");
     par.reset(); box.reset();
     SlotCtx* d_ctx = nullptr;
     SlotCtx* h_ctx = par.take<SlotCtx>(n, &d_ctx);
@@ -319,8 +331,10 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
     for (int i = 0; i < n; ++i) h_ctx[i] = runs_[i].ctx;
     EG_CHECK(arena_copy(par.d, par.h, par.used, true));
     mark(-1);
+    rg.next("P0.contract");
     EG_CHECK(sg::b_contract(d_ctx, bd, stream));
     mark(0);
+    rg.next("P0.sort_boxes+fps64");
     // Segments beyond 2,048 points (floors and walls of a scan) take a chain of skinny launches -- bucket / runs / boxes of the Morton sort, then a
     // chunk-pruned FPS that one workgroup per segment walks for hundreds of microseconds -- that has nothing to do with the thousand small segments'
     // sort and sampling: the two chains run side by side, the big one on the group's SIDE stream (fork behind the parameter block and the
@@ -347,13 +361,17 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
         EG_CHECK(sg::b_fps64(d_ctx, bd, stream, mode == SG_MODE_INS_INFER));
     }
     mark(1);
+    rg.next("P0.mlp1");
     sg_pipeline* p0 = runs_[0].pl;
     EG_CHECK(sg::b_mlp1(d_ctx, p0->w.p + p0->o_m1w, p0->w.p + p0->o_m1g, p0->w.p + p0->o_m1b, bd, stream));
     mark(2);
+    rg.next("P0.edge_distance");
     EG_CHECK(sg::b_edge_distance(d_ctx, bd, stream));
     EG_CHECK(arena_copy(box.h, box.d, box.used, false));
     mark(3);
+    rg.next("P0.sync");
     EG_HIP(timed_sync(stream));
+    rg.next("P0.host_grouping");
 
     // ---- host: layer 1 tables, structural grouping, layer 2 tables ----
     for (int i = 0; i < n; ++i) {
@@ -433,6 +451,8 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
 // L2 / L3: one semantic grouping layer (model.py:786-865)
 // ---------------------------------------------------------------------------------------------------------------------
 int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
+    Stages rg;
+    rg.next(layer == 0 ? "L2.describe" : "L3.describe");
     par.reset(); box.reset();
     SlotCtx* d_ctx = nullptr;
     SlotCtx* h_ctx = par.take<SlotCtx>(n, &d_ctx);
@@ -588,6 +608,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     EG_CHECK(arena_copy(par.d, par.h, par.used, true));
     const int sb = 4 + 6 * layer;
     mark(-1);
+    rg.next(layer == 0 ? "L2.layout" : "L3.layout");
     EG_CHECK(sg::b_layer_layout(d_ctx, bd, stream));
     EG_CHECK(sg::b_group_max_fill(d_ctx, bd, stream));              // + -inf into the 64 columns the point->cluster max fills below
     mark(sb + 0);
@@ -597,18 +618,35 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     const bool seeded = variant == 8 && layer == 1;
     const int waves = variant == 8 ? 1 : variant;
     bool wrote_seed = false;
-    EG_CHECK(sg::b_cluster_knn(d_ctx, bd, waves, seeded, stream, layer == 0, &wrote_seed));
-    if (layer == 0 && !wrote_seed) EG_CHECK(sg::b_knn_seed_points(d_ctx, bd, stream));
-    mark(sb + 2);
+    // SG_ENGINE_CUMASK=heavy:<n>[:knn] (experiment): the issue-bound launches run on the group's CU-confined stream, so that
+    // 256 - n CUs stay free of them for the other groups' latency-bound launches
+    auto hop = [&](hipStream_t from, hipStream_t to, hipEvent_t ev) -> int {
+        EG_HIP(hipEventRecord(ev, from));
+        EG_HIP(hipStreamWaitEvent(to, ev, 0));
+        return SG_OK;
+    };
+    const bool knn_heavy = heavy && heavy_knn;
+    rg.next(layer == 0 ? "L2.knn" : "L3.knn");
+    if (knn_heavy) EG_CHECK(hop(stream, heavy, ev_fork));
+    EG_CHECK(sg::b_cluster_knn(d_ctx, bd, waves, seeded, knn_heavy ? heavy : stream, layer == 0, &wrote_seed));
+    if (layer == 0 && !wrote_seed) EG_CHECK(sg::b_knn_seed_points(d_ctx, bd, knn_heavy ? heavy : stream));
+    if (!heavy) mark(sb + 2);
     // marks 0 / 1 close the sub-passes (statistics pass(es)), 2 / 3 bracket the EdgeConv launch itself: an interval that starts at mark 2
     // belongs to the stage in front of it (the kNN), the one that ends at mark 3 is the kernel alone
     struct MarkArg { Group* g; int sub0, before, kernel; } ma{this, layer == 0 ? 19 : 21, sb + 2, 24 + layer};
+    rg.next(layer == 0 ? "L2.edgeconv" : "L3.edgeconv");
+    if (heavy) {
+        if (!knn_heavy) EG_CHECK(hop(stream, heavy, ev_fork));
+        EG_CHECK(sg::b_edgeconv(d_ctx, bd, layer + 1, nullptr, nullptr, heavy));       // (no stage marks: they are events on the main stream)
+        EG_CHECK(hop(heavy, stream, ev_join));
+    } else
     EG_CHECK(sg::b_edgeconv(d_ctx, bd, layer + 1, [](void* a, int i) {
         auto* m = static_cast<MarkArg*>(a);
         m->g->mark(i == 2 ? m->before : i == 3 ? m->kernel : m->sub0 + i);
     }, &ma, stream));
     // (the point -> cluster max rides inside the EdgeConv launches, the last BN + LeakyReLU in b_edgeconv's k_cluster_affine)
     mark(sb + 4);
+    rg.next(layer == 0 ? "L2.gcn+edge_distance" : "L3.gcn+edge_distance");
     EG_CHECK(sg::b_gcn(d_ctx, bd, 0.125f, stream));
     EG_CHECK(sg::b_edge_distance(d_ctx, bd, stream));
     EG_CHECK(arena_copy(box.h, box.d, box.used, false));
@@ -619,7 +657,9 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
         }
     }
     mark(sb + 5);
+    rg.next(layer == 0 ? "L2.sync" : "L3.sync");
     EG_HIP(timed_sync(stream));
+    rg.next(layer == 0 ? "L2.host_grouping" : "L3.host_grouping");
 
     // ---- host: grouping on the GCN features (model.py:802-815 / 843-856) ----
     for (int i = 0; i < n; ++i) {
@@ -684,6 +724,8 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
 // final clustering (host; FPS-1024 fallback scene by scene, rare), export + evaluate (model.py:868-897, 525-655)
 // ---------------------------------------------------------------------------------------------------------------------
 int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
+    Stages rg;
+    rg.next("END.final_clustering");
     if (mode == SG_MODE_INS_INFER) {
         for (int i = 0; i < n; ++i) {
             Run& r = runs_[i];
@@ -756,6 +798,7 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
     for (int i = 0; i < n; ++i) h_ctx[i] = runs_[i].ctx;
     EG_CHECK(arena_copy(par.d, par.h, par.used, true));
     mark(-1);
+    rg.next("END.export+evaluate");
     EG_CHECK(sg::b_export_eval(d_ctx, bd, stream));
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
@@ -769,6 +812,7 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
     }
     EG_CHECK(arena_copy(box.h, box.d, box.used, false));
     mark(18);
+    rg.next("END.sync");
     EG_HIP(timed_sync(stream));
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
@@ -890,6 +934,59 @@ void sg_engine::Group::loop() {
     }
 }
 
+namespace {
+
+// The group's streams.  Plain: one non-blocking stream.  The SIDE stream of SG_ENGINE_FORK (phase P0's big-segment chain; measured slower,
+// off by default) and its events exist only when that variable is set (no handles for a path that is off).
+// SG_ENGINE_CUMASK (experiments of round 6; hipExtStreamCreateWithCUMask -- bit i of the mask is CU i / 8 of XCD i % 8 on
+// this part, tools/micro/cu_mask_probe.hip):
+//   all:<n>          every group's stream confined to CUs [0, n)                      (control: must cost 256 / n)
+//   rot:<h>          group g's stream excludes the h CUs [g h, g h + h) mod 256       (every group leaves a different slice free)
+//   halfcu | halfxcd groups alternate between the two halves of every XCD | between XCDs 0-3 and 4-7
+//   heavy:<n>[:knn]  main streams unconfined; EdgeConv (and with :knn the in-cluster kNN) on a second stream per group confined to CUs [0, n)
+int create_group_streams(sg_engine::Group& grp, int g, int groups) {
+    static const char* spec = getenv("SG_ENGINE_CUMASK");
+    auto masked = [](hipStream_t* st, const uint32_t* m) {
+        return hipExtStreamCreateWithCUMask(st, 8, m) == hipSuccess ? SG_OK : sg::fail(SG_EHIP, "hipExtStreamCreateWithCUMask failed");
+    };
+    auto range_mask = [](uint32_t* m, int lo, int hi, bool set) {          // bits [lo, hi) mod 256
+        for (int b = lo; b < hi; ++b) { const int i = ((b % 256) + 256) % 256; if (set) m[i / 32] |= 1u << (i % 32); else m[i / 32] &= ~(1u << (i % 32)); }
+    };
+    uint32_t m[8];
+    const std::string sp = spec ? spec : "";
+    int rc = SG_OK;
+    bool want_events = getenv("SG_ENGINE_FORK") != nullptr;
+    if (sp.rfind("all:", 0) == 0) {
+        std::fill(m, m + 8, 0u); range_mask(m, 0, std::max(8, std::min(256, atoi(sp.c_str() + 4))), true);
+        rc = masked(&grp.stream, m);
+    } else if (sp.rfind("rot:", 0) == 0) {
+        const int h = std::max(0, std::min(224, atoi(sp.c_str() + 4)));
+        std::fill(m, m + 8, ~0u); range_mask(m, g * h, g * h + h, false);
+        rc = masked(&grp.stream, m);
+    } else if (sp == "halfcu") {
+        std::fill(m, m + 8, 0u); range_mask(m, (g & 1) * 128, (g & 1) * 128 + 128, true);
+        rc = masked(&grp.stream, m);
+    } else if (sp == "halfxcd") {
+        for (int w = 0; w < 8; ++w) m[w] = (g & 1) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+        rc = masked(&grp.stream, m);
+    } else {
+        if (hipStreamCreateWithFlags(&grp.stream, hipStreamNonBlocking) != hipSuccess) rc = sg::fail(SG_EHIP, "hipStreamCreate failed");
+        if (rc == SG_OK && sp.rfind("heavy:", 0) == 0) {
+            std::fill(m, m + 8, 0u); range_mask(m, 0, std::max(8, std::min(256, atoi(sp.c_str() + 6))), true);
+            rc = masked(&grp.heavy, m);
+            grp.heavy_knn = sp.find(":knn") != std::string::npos;
+            want_events = true;
+        } else if (rc == SG_OK && !sp.empty() && sp != "0") rc = sg::fail(SG_EINVAL, "SG_ENGINE_CUMASK=%s: not one of all:<n> rot:<h> halfcu halfxcd heavy:<n>[:knn]", sp.c_str());
+    }
+    if (rc != SG_OK) return rc;
+    (void)groups;
+    if (getenv("SG_ENGINE_FORK") && hipStreamCreateWithFlags(&grp.side, hipStreamNonBlocking) != hipSuccess) return sg::fail(SG_EHIP, "hipStreamCreate failed");
+    if (want_events && (hipEventCreateWithFlags(&grp.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&grp.ev_join, hipEventDisableTiming) != hipSuccess)) return sg::fail(SG_EHIP, "hipEventCreate failed");
+    return SG_OK;
+}
+}  // namespace
+
 extern "C" {
 
 void sg_engine_destroy(sg_engine* e) {
@@ -914,6 +1011,7 @@ void sg_engine_destroy(sg_engine* e) {
         if (g->box.h) (void)hipHostFree(g->box.h);
         if (g->box.d) (void)hipFree(g->box.d);
         if (g->side) (void)hipStreamDestroy(g->side);
+        if (g->heavy) (void)hipStreamDestroy(g->heavy);
         if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
         if (g->ev_join) (void)hipEventDestroy(g->ev_join);
         if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -945,9 +1043,7 @@ sg_engine* sg_engine_create(int maxN, int maxS, int maxE, int maxV, const sg_wei
         std::unique_ptr<sg_engine::Group> grp(new sg_engine::Group());
         grp->eng = e.get(); grp->index = g;
         for (int i = 0; i < kMaxGroupEvents; ++i) grp->ev[i] = nullptr;
-        if (hipStreamCreateWithFlags(&grp->stream, hipStreamNonBlocking) != hipSuccess) { sg::fail(SG_EHIP, "hipStreamCreate failed"); return nullptr; }
-        if (hipStreamCreateWithFlags(&grp->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&grp->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&grp->ev_join, hipEventDisableTiming) != hipSuccess) { sg::fail(SG_EHIP, "hipStreamCreate failed"); return nullptr; }
+        if (create_group_streams(*grp, g, groups) != SG_OK) return nullptr;
         for (int i = 0; i < kMaxGroupEvents; ++i)
             if (hipEventCreate(&grp->ev[i]) != hipSuccess) { sg::fail(SG_EHIP, "hipEventCreate failed"); return nullptr; }
         grp->runs.resize(scenes_per_group);

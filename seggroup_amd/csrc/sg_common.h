@@ -37,6 +37,17 @@ int fail(int code, const char* fmt, ...);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// roctx ranges (capi.cpp): no-ops unless SG_ROCTX is set when the library loads and librocprofiler-sdk-roctx.so can be opened;
+// `rocprofv3 --kernel-trace --marker-trace` then shows the engine's phases and stages per group thread (bench.py --profile)
+void roctx_push(const char* name);
+void roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { roctx_push(name); }
+    ~RoctxRange() { roctx_pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 #define SG_HIP(call)                                                                      \
     do {                                                                                  \
         hipError_t e__ = (call);                                                          \

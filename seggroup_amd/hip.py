@@ -5,6 +5,7 @@ visible when a device entry point is needed, this module raises -- it never rout
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import Optional
@@ -251,6 +252,35 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+_roctx = None
+
+
+@contextlib.contextmanager
+def roctx_range(name: str):
+    """A roctx range around a block of host code (`bench.py --profile`, SG_ROCTX=1); does nothing otherwise.  The engine's group threads push
+    their own ranges per phase and stage (csrc/engine.cpp); `rocprofv3 --kernel-trace --marker-trace` shows both."""
+    global _roctx
+    if not os.environ.get("SG_ROCTX"):
+        yield
+        return
+    if _roctx is None:
+        _roctx = False
+        for cand in ("librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so"):
+            try:
+                _roctx = C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                break
+            except OSError:
+                continue
+    if not _roctx:
+        yield
+        return
+    _roctx.roctxRangePushA(name.encode())
+    try:
+        yield
+    finally:
+        _roctx.roctxRangePop()
 
 
 def check(rc: int) -> int:

@@ -85,10 +85,11 @@ def _bench_reduce_worker(rank, world, port, q):
         s, n_, a = _stub_forward(i)
         vec[:80] += s.reshape(-1); vec[80:160] += n_.reshape(-1); vec[160:164] += a; vec[164] += 1
     out = bench.reduce_accumulators(vec, world, "gloo")
+    comm = bench.comm_probe(world, "gloo", None)                  # the bench line's `comm` object: what the collective layer saw
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        q.put(out.tolist())
+        q.put((out.tolist(), comm))
 
 
 def test_bench_reduction_two_ranks_equal_one_rank():
@@ -101,15 +102,28 @@ def test_bench_reduction_two_ranks_equal_one_rank():
     procs = [ctx.Process(target=_bench_reduce_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = np.asarray(q.get(timeout=180))
+    got, comm = q.get(timeout=180)
+    got = np.asarray(got)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    assert comm["backend"] == "gloo" and comm["world_size"] == 2 and comm["allreduce_of_ones"] == 2.0 and "error" not in comm, comm
     want = np.zeros(165)
     for i in range(1201):
         s, n_, a = _stub_forward(i)
         want[:80] += s.reshape(-1); want[80:160] += n_.reshape(-1); want[160:164] += a; want[164] += 1
     assert got[164] == 1201 and np.array_equal(got[:160], want[:160]) and np.allclose(got[160:164], want[160:164], rtol=0, atol=1e-9)
+
+
+def test_comm_probe_without_a_process_group_makes_its_own_one_rank_communicator():
+    """bench.py at N = 1 without a launcher: the probe builds a one-rank communicator of the asked backend, reduces over it and removes it."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    assert not dist.is_initialized()
+    comm = bench.comm_probe(1, "gloo", None)
+    assert comm["world_size"] == 1 and comm["allreduce_of_ones"] == 1.0 and comm["expected"] == 1 and "error" not in comm, comm
+    assert not dist.is_initialized()
 
 
 def test_bench_refuses_a_multi_gpu_label_without_the_gpus():

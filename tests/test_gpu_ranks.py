@@ -216,3 +216,77 @@ def _rank_worker_full(rank, world, root, port, exp, q):
     r = infer.run_worker(rank, world, args)
     if rank == 0:
         q.put({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in r.items()})
+
+
+def test_eight_ranks_on_one_gpu_driver(tmp_path, golden_index, weight_sets):
+    """nothing had run more than TWO ranks.  Eight processes (gloo rendezvous, all on cuda:0, each with its own engine,
+    loader, writer pool and NUMA bind) over a 19-scene tree -- `i mod 8` leaves ranks with three and with two scenes -- must write byte-identical
+    files to the one-process run and all-reduce to the same metric vector."""
+    import torch
+    import torch.multiprocessing as mp
+    from seggroup_amd import infer, synthetic, weights
+    root = str(tmp_path)
+    n_scenes = 19
+    scenes = []
+    for i in range(n_scenes):
+        if i == 0:
+            e = golden_index["tiny_4k"]
+            scenes.append(synthetic.make_scene(e["n"], e["s"], e["seed"], name=f"scene{i:04d}_00", **e["kw"]))
+        else:
+            scenes.append(synthetic.make_scene(3000 + 211 * i, 30 + 3 * i, 85000 + i, name=f"scene{i:04d}_00", **({"dup_frac": 0.05} if i % 4 == 0 else {})))
+    synthetic.write_reference_tree(root, scenes)
+    names = [s.name for s in scenes]
+    for exp in ("w1", "w8"):
+        ck = os.path.join(root, "checkpoints", exp, "models")
+        os.makedirs(ck)
+        torch.save({"state_dict": weights.to_full_state_dict(weight_sets["ins_infer"])}, os.path.join(ck, "last.t7"))
+    one = infer.run_worker(0, 1, infer.build_parser().parse_args(
+        ["-n", "w1", "--ins_infer", "--root", root, "--world-size", "1", "--batch", "5", "--inflight", "4", "-j", "2"]))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 8, root, port, "shard", "w8", q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    eight = q.get(timeout=900)
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    a, b = _tree_digest(root, "w1", names), _tree_digest(root, "w8", names)
+    assert a == b, [n for n in names if a[n] != b[n]]
+    g = load_golden("tiny_4k")
+    from seggroup_amd import hip
+    for nm in hip.LABEL_NAMES:
+        assert np.array_equal(np.load(os.path.join(root, "results", "w8", names[0], "ins_infer", nm + ".npy")), g[f"ins.label.{nm}"]), nm
+    assert eight["n"] == one["n"] == n_scenes
+    for k in one:
+        if k not in ("elapsed_s", "startup_s", "first_batch"):
+            assert np.array_equal(np.asarray(one[k]), np.asarray(eight[k]), equal_nan=True), k
+
+
+def test_bench_eight_ranks_on_one_gpu_and_the_comm_field():
+    """`bench.py --gpus 8` as the round-end driver launches it (torch.distributed.run, eight ranks) on the one GPU a test box has (gloo; small
+    scenes): the line's `comm` object must show what the collective layer saw -- eight ranks in the communicator, an all-reduce of ones = 8 --
+    and the strong-scaling set must reduce to the same pseudo-label mIoU as at one rank.  At N = 1 the field is there too, over a one-rank RCCL
+    communicator made for the probe."""
+    import json
+    import subprocess
+    common = ["--scenes-total", "97", "--points", "3000", "--segments", "30", "--steps", "2", "--warmup", "1", "--repeats", "1",
+              "--no-cpu-baseline", "--no-files", "--no-extras", "--batch", "8", "--parity-scenes", "4", "--groups", "2", "--per-group", "4"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    eight = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo"] + common,
+                           capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert eight.returncode == 0, eight.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl"] + common, capture_output=True, text=True,
+                         timeout=900, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j8 = json.loads([l for l in eight.stdout.splitlines() if l.startswith("{")][-1])
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j8["n_gpus"] == 8 and j8["scaling"] == "strong" and j8["parity_check"]["ranks_equal"] and j1["parity_check"]["ranks_equal"]
+    assert j8["comm"]["backend"] == "gloo" and j8["comm"]["world_size"] == 8 and j8["comm"]["allreduce_of_ones"] == 8.0, j8["comm"]
+    assert j1["comm"]["backend"] == "nccl" and j1["comm"]["world_size"] == 1 and j1["comm"]["allreduce_of_ones"] == 1.0 and j1["comm"]["librccl_mapped"], j1["comm"]
+    assert j8["pseudo_label_mIoU"]["scenes"] == j1["pseudo_label_mIoU"]["scenes"] == 97 * 2
+    assert j8["pseudo_label_mIoU"]["semantic"] == j1["pseudo_label_mIoU"]["semantic"]
+    assert j8["pseudo_label_mIoU"]["instance"] == j1["pseudo_label_mIoU"]["instance"]

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() {
   local name=$1; shift
   local out=$R/gpurun_out/pmc_ec_$name
-  timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-files --groups 1 --per-group 8 --parity-scenes 1 --no-extras --repeats 1 --gen-workers 1 --scene-cache $SG_SCENE_CACHE > $out.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-files --groups 1 --per-group 8 --parity-scenes 0 --no-extras --repeats 1 --gen-workers 1 --scene-cache $SG_SCENE_CACHE > $out.log 2>&1
   python3 - "$out" <<'PY'
 import csv, glob, sys, collections, re
 fs = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() {   # name, counters...
   local name=$1; shift
   local out=$R/gpurun_out/${TAG}_pmc_raw_$name
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-files --groups $G --per-group $B --parity-scenes 1 --no-extras --repeats 1 --gen-workers 1 --scene-cache $CACHE > $out.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-files --groups $G --per-group $B --parity-scenes 0 --no-extras --repeats 1 --gen-workers 1 --scene-cache $CACHE > $out.log 2>&1
   python3 - "$out" "$R/gpurun_out/${TAG}_pmc_$name.json" "$G" "$B" <<'PY'
 import csv, glob, json, sys, collections, re
 src, dst, G, B = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
@@ -23,6 +23,9 @@ for f in fs:
 out = {"engine": f"{G} groups x {B} scenes per launch", "kernels": {}}
 for k, c in agg.items():
     out["kernels"][k] = {"launches": len(next(iter(c.values()))), **{n: sum(v) / len(v) for n, v in c.items()}}
+    for n in ("SQ_WAVES", "SQ_INSTS_MFMA"):                    # deterministic per launch: tools/summarise_profiles.py holds min == max == the launch model
+        if n in c:
+            out["kernels"][k][n + "__min"], out["kernels"][k][n + "__max"] = min(c[n]), max(c[n])
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 top = sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", kv[1].get("SQ_BUSY_CYCLES", kv[1].get("FETCH_SIZE", kv[1].get("WRITE_SIZE", 0)))))[:10]
 for k, v in top:

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-solo8_scannet}; G=${2:-1}; B=${3:-8}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --batch 16 --no-cpu-baseline --no-files --groups $G --per-group $B --no-extras --seg-profile scannet --parity-scenes 1 --repeats 1 --gen-workers 1 --scene-cache ${SG_SCENE_CACHE:-/tmp/sg_scenes} > $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --batch 16 --no-cpu-baseline --no-files --groups $G --per-group $B --no-extras --seg-profile scannet --parity-scenes 0 --repeats 1 --gen-workers 1 --scene-cache ${SG_SCENE_CACHE:-/tmp/sg_scenes} > $R/gpurun_out/prof_$TAG.log 2>&1
 f=$(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys

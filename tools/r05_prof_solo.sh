@@ -6,7 +6,7 @@ export SG_SCENE_CACHE=/tmp/sg_scenes
 cd $R; mkdir -p gpurun_out
 timeout 600 python3 bench.py --generate-only --no-extras --seg-profile $P --scene-cache $SG_SCENE_CACHE --batch 16 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_solo_$P -- python3 $R/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-files --groups 1 --per-group 8 --no-extras --gen-workers 1 --seg-profile $P --batch 16 --scene-cache $SG_SCENE_CACHE > $R/gpurun_out/prof_solo_$P.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_solo_$P -- python3 $R/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-files --groups 1 --per-group 8 --parity-scenes 0 --no-extras --gen-workers 1 --seg-profile $P --batch 16 --scene-cache $SG_SCENE_CACHE > $R/gpurun_out/prof_solo_$P.log 2>&1
 f=$(find $R/gpurun_out/prof_solo_$P -name "*kernel_stats.csv" | head -1)
 cp $f $R/gpurun_out/solo_${P}_kernel_stats.csv
 rm -rf $R/gpurun_out/prof_solo_$P
