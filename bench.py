@@ -272,6 +272,12 @@ def main(argv=None):
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args, argv))
 
+    # stdout carries ONE line, the result: everything else a rank's process writes to fd 1 -- Python prints, and C stdio of the libraries (RCCL
+    # prints its version banner there, buffered until exit, i.e. BEHIND the JSON line) -- goes to stderr from here on
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -791,7 +797,7 @@ def main(argv=None):
             "engine_profile": engine_profile, "numa": numa_info,
             "cluster_trace_scene0": batch_trace0, "scene_generation_s": round(gen_s, 1),
         }
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
         if not parity_all:
             print("bench.py: PARITY FAILURE -- the concurrent path's labels differ from the single-pipeline path", file=sys.stderr)
             rc = 4

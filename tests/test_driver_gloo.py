@@ -140,3 +140,48 @@ def test_bench_refuses_a_multi_gpu_label_without_the_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True,
                        text=True, timeout=300, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and '{"metric"' not in r.stdout
+
+
+# ---- run_infer.log against the reference's own transcript (tools/capture_transcript.py) ---------------------------------
+def _transcript_spec(golden_index):
+    meta = __import__("json").load(open(os.path.join(ROOT, "tests", "golden", "transcript.json")))
+    return meta
+
+
+def _log_from_first_progress_line(path):
+    text = open(path).read()
+    at = text.index("Infer(0001/")
+    return text[:at], text[at:]
+
+
+@pytest.mark.parametrize("mode", ["ins_infer", "sem_infer"])
+def test_driver_log_equals_the_reference_transcript_on_cpu(tmp_path, golden_index, weight_sets, mode):
+    """`tests/golden/transcript_<mode>.log` is what the reference's OWN `infer()` (infer.py:127-190) logged over an eight-scene tree (the four full
+    fixtures among four small scenes), world size 1, its DistributedSampler's shuffled order.  The driver's loop, accumulation and format strings
+    (`seggroup_amd/infer.py`: scene_indices, Accumulator, progress_line, final_report) must reproduce that text BYTE FOR BYTE from per-scene metric
+    tensors -- here the reference's captured ones (fixtures) and the oracle's (small scenes); the GPU twin of this test feeds the HIP path's."""
+    from oracle import cpu_ref
+    from seggroup_amd import infer, synthetic
+    from conftest import load_golden
+    meta = _transcript_spec(golden_index)
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "dataset", "scannet"))
+    with open(os.path.join(root, "dataset", "scannet", "scannetv2_train.txt"), "w") as f:
+        f.write("".join(s["name"] + "\n" for s in meta["scenes"]))
+    fixture_of = {(e["n"], e["s"], e["seed"]): k for k, e in golden_index.items()}
+    pre = "ins" if mode == "ins_infer" else "sem"
+
+    def forward(i):
+        s = meta["scenes"][i]
+        fx = fixture_of.get((s["n"], s["s"], s["seed"]))
+        if fx is not None:
+            g = load_golden(fx)
+            return g[f"{pre}.metric.0"], g[f"{pre}.metric.1"], g[f"{pre}.metric.2"]
+        r = cpu_ref.forward_scene(synthetic.make_scene(s["n"], s["s"], s["seed"], name=s["name"], **s["kw"]), weight_sets[mode], mode)
+        return r["metrics"]
+    args = infer.build_parser().parse_args(["-n", "exp", f"--{mode}", "--root", root, "--world-size", "1", "--sampler", "reference"])
+    assert infer.scene_indices(len(meta["scenes"]), 0, 1, "reference") == meta[mode]["sampler_order"]
+    infer.run_worker(0, 1, args, forward_fn=forward)
+    _, tail = _log_from_first_progress_line(os.path.join(root, "checkpoints", "exp", "run_infer.log"))
+    want = open(os.path.join(ROOT, "tests", "golden", f"transcript_{mode}.log")).read()
+    assert tail == want

@@ -791,6 +791,39 @@ def test_seeded_knn_equals_bruteforce(env, golden_index, name, fine, coarse):
     assert np.array_equal(a_, b_), f"{int(np.any(a_ != b_, axis=1).sum())} rows differ between brute force and seeded"
 
 
+@pytest.mark.parametrize("n,s,seed,target,kw", [(3000, 30, 40000, 30, {}), (3000, 30, 40007, 9, {}), (2400, 400, 91, 60, dict(min_seg=1)),
+                                                (2400, 400, 92, 25, dict(min_seg=1, dup_frac=0.2)), (1500, 60, 93, 60, dict(min_seg=2))],
+                         ids=["3000pts-30clusters", "3000pts-9clusters", "6pt-segments-40pt-clusters", "6pt-segments-dups", "25pt-clusters"])
+def test_multi_wave_knn_with_slices_short_of_candidates(env, n, s, seed, target, kw):
+    """Gate for kNN changes.  With two or four waves per tile the cluster's chunks are dealt round-robin to the
+    waves and every wave publishes bounds from its OWN list; in small clusters a wave's slice holds fewer than 20 (or fewer than 20 / waves)
+    real candidates, its list ends in padding entries (key 0: score -inf) and the bound it publishes is the padding's.  Round 5's list-form
+    thresholds decoded such a bound to a NaN -- only scenes of ~3,000 points take these kernels inside the engine, and no operator test fed
+    them small clusters.  Every variant, clusters of 21 .. ~300 points (and <= 20: the padded rows), against the brute-force kernel; the
+    brute-force table against the oracle."""
+    lib, torch, hip = env
+    from oracle import cpu_ref as O
+    from seggroup_amd import synthetic
+    sc = synthetic.make_scene(n, s, seed, **kw)
+    part, L = _semantic_inputs(sc, target)
+    sizes = np.array([len(m) for m in L.members])
+    assert ((sizes > 20) & (sizes < 80)).any() or n == 3000, sizes          # clusters whose slices run short
+    d = _knn_layer_setup(lib, torch, hip, sc, L)
+    N = sc.num_points
+    a = d["brute"].cpu().numpy()
+    ref = O.cluster_knn(sc.data[:, :3], L, 20)[d["members_np"]]
+    assert np.array_equal(d["members_np"][a], ref)
+    for variant in (4, 2, 1, 0):
+        out = torch.full((N, 20), -7, dtype=torch.int32, device="cuda:0")
+        hip.check(lib.sg_cluster_knn_sorted_w(d["sxyzw"].data_ptr(), d["smpos"].data_ptr(), N, d["off"].data_ptr(), d["tc4"].data_ptr(), d["lo4"].data_ptr(),
+                                              d["hi4"].data_ptr(), d["nt4"], d["cso"].data_ptr(), d["order"].data_ptr(), d["dst"].data_ptr(),
+                                              d["segoff"].data_ptr(), d["co"].data_ptr(), d["box"].data_ptr(), d["cbox"].data_ptr(), d["slot"].data_ptr(), 20,
+                                              d["pos0"], variant, out.data_ptr(), None))
+        b = out.cpu().numpy()
+        assert b.min() >= 0 and b.max() < N, f"variant {variant}: entries outside the scene ({b.min()} .. {b.max()}): a padding entry reached the table"
+        assert np.array_equal(a, b), f"variant {variant}: {int(np.any(a != b, axis=1).sum())} rows differ between brute force and sorted"
+
+
 @pytest.mark.parametrize("cfg", [(30000, 6, 140, dict(min_seg=4)), (60000, 600, 70000, dict(seg_profile="scannet")),
                                  (60000, 600, 70001, dict(seg_profile="scannet")), (20000, 3, 142, dict(min_seg=4, dup_frac=0.3))],
                          ids=["5k-point-segments", "scannet-subsampled", "scannet-tiled", "7k-segments-30pct-duplicates"])

@@ -290,3 +290,32 @@ def test_bench_eight_ranks_on_one_gpu_and_the_comm_field():
     assert j8["pseudo_label_mIoU"]["scenes"] == j1["pseudo_label_mIoU"]["scenes"] == 97 * 2
     assert j8["pseudo_label_mIoU"]["semantic"] == j1["pseudo_label_mIoU"]["semantic"]
     assert j8["pseudo_label_mIoU"]["instance"] == j1["pseudo_label_mIoU"]["instance"]
+
+
+@pytest.mark.parametrize("mode", ["ins_infer", "sem_infer"])
+def test_run_infer_log_equals_the_reference_transcript(tmp_path, golden_index, weight_sets, mode):
+    """`tests/golden/transcript_<mode>.log` is what the reference's own `infer()` logged (tools/capture_transcript.py: the
+    unmodified infer.py:127-190 over an eight-scene tree, world size 1, its DistributedSampler's order).  The same tree through `seggroup_amd.infer`
+    on the GPU (`--sampler reference`, the packed fast path): `run_infer.log` from the first `Infer(` line on is the transcript BYTE FOR BYTE --
+    every running mIoU / accuracy, the `==> Infer` line, both per-class tables with their `nan%` rows -- and the header carries the reference's
+    parameter count."""
+    import json
+    import torch
+    from seggroup_amd import infer, synthetic, weights
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "transcript.json")))
+    root = str(tmp_path)
+    scenes = [synthetic.make_scene(s["n"], s["s"], s["seed"], name=s["name"], **s["kw"]) for s in meta["scenes"]]
+    synthetic.write_reference_tree(root, scenes)
+    ck = os.path.join(root, "checkpoints", "exp", "models")
+    os.makedirs(ck)
+    torch.save({"state_dict": weights.to_full_state_dict(weight_sets[mode])}, os.path.join(ck, "last.t7"))
+    args = infer.build_parser().parse_args(["-n", "exp", f"--{mode}", "--root", root, "--world-size", "1", "--sampler", "reference", "--batch", "3",
+                                            "--inflight", "4", "-j", "2"])
+    infer.run_worker(0, 1, args)
+    text = open(os.path.join(root, "checkpoints", "exp", "run_infer.log")).read()
+    at = text.index("Infer(0001/")
+    want = open(os.path.join(ROOT, "tests", "golden", f"transcript_{mode}.log")).read()
+    assert text[at:] == want
+    head = text[:at].splitlines()
+    assert "Network parameters: %d" % meta[mode]["network_parameters"] in head                 # infer.py:92
+    assert any(l.startswith("Load model from ") and l.endswith("checkpoints/exp/models/last.t7") for l in head)      # infer.py:119

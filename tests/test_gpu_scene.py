@@ -796,3 +796,37 @@ def test_a_scenes_labels_do_not_depend_on_the_run_or_the_group_shape(weight_sets
             bad = [i for i in range(len(scenes)) if got[i] != want[i]]
             assert not bad, f"engine {groups} x {per}, run {rep}: scenes {bad} differ from the single pipeline"
         eng.close()
+
+
+
+@pytest.mark.parametrize("mode_name", ["ins_infer", "sem_infer"])
+def test_small_scenes_engine_equals_pipeline_in_every_group_shape(mode_name):
+    """Gate for kNN changes (tools/r05_repro.py with SG_REPRO_SIZE=3000,30 as a test).  Scenes of 3,000 points / 30 segments take
+    the kNN kernels with several waves per tile and clusters whose slices hold fewer than 20 candidates -- the case round 5's list-form thresholds got wrong
+    (a NaN bound from a padding candidate), found by a memory fault in the two-rank bench test and by nothing in the suite.  96 such scenes through the
+    engine in three shapes (lock-step 4 x 16, the bench's 10 x 8, out of step 16 x 1 and 6 x 5), twice each: every scene's labels, metric tensors and cluster
+    trace equal the single pipeline's."""
+    import torch
+    import bench
+    from conftest import ROOT
+    from seggroup_amd import hip, synthetic, weights
+    from seggroup_amd.model import Engine, Pipeline
+    from seggroup_amd.scene import DeviceScene
+    sem = mode_name == "sem_infer"
+    W = weights.load_npz(os.path.join(ROOT, "tests", "golden", "weights_g1.npz" if sem else "weights_g2.npz"))
+    mode = hip.MODE_SEM_INFER if sem else hip.MODE_INS_INFER
+    n = 96
+    scenes = [DeviceScene.from_synthetic(synthetic.make_scene(3000, 30, 40000 + i), device="cuda:0") for i in range(n)]
+    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+    solo = Pipeline(W, *caps, device="cuda:0")
+    want = [bench.label_digest(solo.forward(s, mode)) for s in scenes]
+    assert want == [bench.label_digest(solo.forward(s, mode)) for s in scenes]
+    solo.close()
+    for groups, per in ((4, 16), (10, 8), (16, 1), (6, 5)):
+        eng = Engine(W, caps, groups=groups, per_group=per, device="cuda:0", timing=0)
+        for rep in range(2):
+            got = [bench.label_digest(r) for r in eng.run(scenes, mode)]
+            bad = [i for i in range(n) if got[i] != want[i]]
+            assert not bad, f"engine {groups} x {per}, run {rep}: scenes whose results differ from the single pipeline's: {bad}"
+        eng.close()
+    torch.cuda.synchronize()
