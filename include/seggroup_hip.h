@@ -654,6 +654,26 @@ int sg_train_tail_backward(int C, int K, const int32_t* d_gold, const float* d_k
                            float* d_gw1, float* d_ggamma, float* d_gbeta, float* d_gw2, float* d_gb2, float* d_gfeat5,
                            void* d_ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The reference's module-level functions with arguments its own forward never passes (the Python
+ * surface keeps the reference's signatures: seggroup_amd/functional.py).  Plain kernels, off every
+ * timed path (csrc/kernels_general.hip).
+ *   sg_group_mean_rows : aggregate_cluster_feature(use_avg=True), model.py:282-284 -- the mean of each
+ *       group's rows (arguments as sg_group_max_rows); the caller concatenates [max | mean].
+ *   sg_fps_general     : farthest_point_sampling(pts, k, initial_idx, skip_initial), model.py:329-395 for one
+ *       cloud d_pts [n,dim]: d_indices [k]; d_distances [k,n] or NULL (the reference's second return value);
+ *       l2_norm in NumPy's order, np.argmax's first-index ties.  d_ws needs sg_fps_general_ws_bytes(n).
+ *   sg_knn_general     : knn(x, k), model.py:30-36 for x [B,C,n] of any channel count: d_idx [B,n,k] int64, scores
+ *       (-|a|^2 - (-2 a.b)) - |b|^2 descending, lower index first among equal scores (torch.topk leaves that open);
+ *       1 <= k <= min(n, 128), otherwise SG_EUNSUP.
+ * ------------------------------------------------------------------------------------------- */
+int sg_group_mean_rows(const float* d_rows, int row_stride, int D, const int32_t* d_goff, const int32_t* d_gidx, int G,
+                       float* d_out, int out_stride, void* stream);
+size_t sg_fps_general_ws_bytes(int n);
+int sg_fps_general(const float* d_pts, int n, int dim, int k, int initial_idx, int skip_initial, int32_t* d_indices,
+                   float* d_distances, void* d_ws, size_t ws_bytes, void* stream);
+int sg_knn_general(const float* d_x, int B, int C, int n, int k, int64_t* d_idx, void* stream);
+
 /* backward of sg_group_max_rows (aggregate_cluster_feature, model.py:278-288): the gradient of a group's maximum goes to its
  * first maximal row (torch.max), every other row of the group gets 0; d_grows rows of `grow_stride` floats */
 int sg_group_max_rows_backward(const float* d_rows, int row_stride, int D, const int32_t* d_goff, const int32_t* d_gidx, int G,

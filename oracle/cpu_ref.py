@@ -180,6 +180,34 @@ def fps(pts, k):
     return idx
 
 
+def fps_general(pts, k, initial_idx=0, skip_initial=False):
+    """farthest_point_sampling with any start and either skip_initial (model.py:369-394): (indices [k], distances [k,n]); l2_norm as NumPy
+    evaluates ((x - y)**2).sum(axis=-1) over a short axis: squares rounded one by one, added left to right."""
+    pts = np.ascontiguousarray(pts, dtype=F32)
+
+    def dist_to(p):
+        d = pts - p
+        d = d * d
+        out = d[:, 0].copy()
+        for c in range(1, d.shape[1]):
+            out = out + d[:, c]
+        return out
+    idx = np.zeros(k, dtype=np.int64)
+    dist = np.zeros((k, pts.shape[0]), dtype=F32)
+    idx[0] = initial_idx
+    mind = dist_to(pts[idx[0]])
+    if skip_initial:
+        idx[0] = int(np.argmax(mind))
+        mind = dist_to(pts[idx[0]])
+    dist[0] = mind
+    for i in range(1, k):
+        idx[i] = int(np.argmax(mind))
+        d = dist_to(pts[idx[i]])
+        dist[i] = d
+        mind = np.minimum(mind, d)
+    return idx, dist
+
+
 def fps_with_fixup(pts, k):
     """FPS + the trailing-zero fix-up of get_cluster_pointcloud (model.py:407-412)."""
     ch = fps(pts, k)

@@ -78,6 +78,10 @@ __global__ __launch_bounds__(64) void k_selftest_list_insert(int* __restrict__ m
         const unsigned long long key = ((r & 0x700u) == 0x700u || i % 12 >= fill) ? 0ull : make_key(sc, idx);
         key_insert<K>(ki, key);
         list_insert<K>(kd, key);
+        // the list form built straight from (score, index) == the key's conversion; also for the index of a slab's padding lanes
+        bad += __double_as_longlong(list_key(sc, idx)) != __double_as_longlong(to_list(make_key(sc, idx)));
+        bad += __double_as_longlong(list_key(sc, 0x7fffffff)) != __double_as_longlong(to_list(make_key(sc, 0x7fffffff)));
+        bad += __double_as_longlong(list_key(-INFINITY, idx)) != __double_as_longlong(to_list(make_key(-INFINITY, idx)));
         // ... and twelve at a time (list_merge12: the drain of the kNN kernels' append buffers), partly filled batches included
 #pragma unroll
         for (int u = 0; u < 12; ++u)

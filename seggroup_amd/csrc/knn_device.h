@@ -64,10 +64,31 @@ __device__ __forceinline__ unsigned long long from_list(double d) {             
     const unsigned int hi = (unsigned int)__double2hiint(d), lo = (unsigned int)__double2loint(d);
     return ((unsigned long long)((hi << 12) | (lo >> 20)) << 32) | (0xfff00000u | lo);
 }
+// the list form built straight from (score, index): == to_list(make_key(score, idx)), bit for bit (kernels_selftest.hip checks it); an index
+// beyond 20 bits (the 0x7fffffff of a slab's padding lanes) keeps its low 20 bits, as to_list does
+__device__ __forceinline__ double list_key(float score, int idx) {
+    const unsigned int u = __float_as_uint(score);
+    const unsigned int o = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+    return __hiloint2double((int)(0x43300000u | (o >> 12)), (int)((o << 20) | (~(unsigned int)idx & 0xfffffu)));
+}
+// the order-preserving score bits of a list value (what key >> 32 is for a key): one v_alignbit_b32
+__device__ __forceinline__ unsigned int list_score(double d) {
+    return __builtin_amdgcn_alignbit((unsigned int)__double2hiint(d), (unsigned int)__double2loint(d), 20);
+}
+// the list value of "any key whose score bits reach o" minus one unit: k > list_floor(o) <=> the score bits of k are >= o
+__device__ __forceinline__ double list_floor(unsigned int o) {
+    return __longlong_as_double(__double_as_longlong(__hiloint2double((int)(0x43300000u | (o >> 12)), (int)(o << 20))) - 1ll);
+}
 __device__ __forceinline__ int list_index(double d) { return (int)(0xfffffu - ((unsigned int)__double2loint(d) & 0xfffffu)); }
 // plain v_max_f64 / v_min_f64: fmax() / fmin() would put a canonicalising v_max_f64 x, x in front of every operand
 __device__ __forceinline__ double list_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double list_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int K>
+__device__ __forceinline__ void list_insert_l(double (&kv)[K], double x) {                 // x already in list form
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) kv[j] = list_max(kv[j], list_min(kv[j - 1], x));
+    kv[0] = list_max(kv[0], x);
+}
 template <int K>
 __device__ __forceinline__ void list_insert(double (&kv)[K], unsigned long long key) {
     const double x = to_list(key);

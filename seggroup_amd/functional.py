@@ -256,17 +256,19 @@ def build_distance_matrix(dists, adj, size):
 
 def aggregate_cluster_feature(Feat_old, clusters_new: Dict[int, List[int]], use_avg=False):
     """model.py:278-288: element-wise max over each group's rows."""
-    if use_avg:
-        raise NotImplementedError("use_avg=True is never used on the inference path (model.py:770,793,815,...)")
     _need_cuda(Feat_old, "Feat_old")
     lib = hip.lib()
     f = Feat_old.contiguous().float()
     gidx, goff = _csr([clusters_new[i] for i in range(len(clusters_new))])
     dev = f.device
+    D = int(f.shape[1])
     d_off, d_idx = torch.from_numpy(goff).to(dev), torch.from_numpy(gidx).to(dev)
-    out = torch.empty((len(clusters_new), f.shape[1]), dtype=torch.float32, device=dev)
-    hip.check(lib.sg_group_max_rows(f.data_ptr(), f.shape[1], f.shape[1], d_off.data_ptr(), d_idx.data_ptr(), len(clusters_new),
-                                    out.data_ptr(), f.shape[1], _stream()))
+    # use_avg=True (model.py:282-284; never on the reference's own forward): rows of [max | mean], 2 D wide
+    out = torch.empty((len(clusters_new), 2 * D if use_avg else D), dtype=torch.float32, device=dev)
+    hip.check(lib.sg_group_max_rows(f.data_ptr(), D, D, d_off.data_ptr(), d_idx.data_ptr(), len(clusters_new), out.data_ptr(), out.shape[1], _stream()))
+    if use_avg:
+        hip.check(lib.sg_group_mean_rows(f.data_ptr(), D, D, d_off.data_ptr(), d_idx.data_ptr(), len(clusters_new), out.data_ptr() + 4 * D, out.shape[1],
+                                         _stream()))
     return out
 
 
@@ -284,31 +286,29 @@ def _members_on(ds_or_lists, dev):
     return lists, members, off, torch.from_numpy(members).to(dev), torch.from_numpy(off).to(dev)
 
 
-def farthest_point_sampling(pts, k, initial_idx=0, metrics=l2_norm, skip_initial=True, indices_dtype=np.int32,
+def farthest_point_sampling(pts, k, initial_idx=None, metrics=l2_norm, skip_initial=False, indices_dtype=np.int32,
                             distances_dtype=np.float32):
-    """model.py:329-395 for the only configuration the path uses (initial_idx=0, skip_initial=True).
-    `pts` [n,3] CUDA tensor -> indices [1,k] (numpy, like the reference); the distance cube is not returned."""
-    if initial_idx != 0 or not skip_initial:
-        raise NotImplementedError("only initial_idx=0, skip_initial=True (model.py:406) is built")
+    """model.py:329-395 with the reference's signature and defaults: `pts` [n,dim] or [B,n,dim] CUDA tensor -> (indices [B,k], distances
+    [B,k,n]) as NumPy arrays like the reference (one workgroup per cloud, `sg_fps_general`: l2_norm in NumPy's order, first-index argmax).
+    initial_idx=None draws the start like the reference (np.random.randint); `metrics` other than l2_norm is refused: the kernel IS l2_norm.
+    The forward itself never comes here: its sampling (initial_idx=0, skip_initial=True AND the trailing-zero fix-up of
+    get_cluster_pointcloud, model.py:398-426) is the hot path's `sg_fps_sample`."""
+    if metrics is not l2_norm:
+        raise ValueError("farthest_point_sampling: only metrics=l2_norm exists on the device")
     _need_cuda(pts, "pts")
     lib = hip.lib()
-    n = int(pts.shape[0])
-    if not 0 < k < n:
-        raise ValueError("farthest_point_sampling: need 0 < k < n (the reference only asks for P % n picks)")
-    dev = pts.device
-    data = pts[:, :3].contiguous().float()
-    members = torch.arange(n, dtype=_i32, device=dev)
-    off = torch.tensor([0, n], dtype=_i32, device=dev)
-    P = n + k                                   # rows = all members once, then k FPS picks; the raw picks are the tail
-    # (the kernel applies the trailing-zero fix-up of get_cluster_pointcloud; undo is impossible, so expose it as is)
-    if P > 4096:
-        raise ValueError("farthest_point_sampling wrapper supports n + k <= 4096; use get_cluster_pointcloud for clusters")
-    out = torch.empty((1, P, 3), dtype=torch.float32, device=dev)
-    sel = torch.empty((1, P), dtype=_i32, device=dev)
-    ws = _ws(lib.sg_fps_ws_bytes(n), dev)
-    hip.check(lib.sg_fps_sample(data.data_ptr(), n, 3, members.data_ptr(), off.data_ptr(), 1, P, 3, 0, out.data_ptr(), sel.data_ptr(),
-                                ws.data_ptr(), ws.numel(), _stream()))
-    return sel[:, n:].cpu().numpy().astype(indices_dtype), None
+    p3 = (pts if pts.dim() == 3 else pts[None]).contiguous().float()
+    B, n, dim = (int(v) for v in p3.shape)
+    if k <= 0:
+        raise ValueError("farthest_point_sampling: k must be positive")
+    idx = torch.empty((B, k), dtype=_i32, device=p3.device)
+    dist = torch.empty((B, k, n), dtype=torch.float32, device=p3.device)
+    ws = _ws(lib.sg_fps_general_ws_bytes(n), p3.device)
+    start = int(np.random.randint(n)) if initial_idx is None else int(initial_idx)      # one draw for the whole batch (model.py:374)
+    for b in range(B):
+        hip.check(lib.sg_fps_general(p3[b].data_ptr(), n, dim, k, start, int(bool(skip_initial)), idx[b].data_ptr(), dist[b].data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _stream()))
+    return idx.cpu().numpy().astype(indices_dtype), dist.cpu().numpy().astype(distances_dtype)
 
 
 def get_cluster_pointcloud(data, ds: DisjointSet, point_num=128, transfrom=True):
@@ -377,7 +377,12 @@ def knn(x, k):
     _need_cuda(x, "x")
     B, Cc, n = x.shape
     if Cc != 3 or k != 20:
-        raise NotImplementedError("knn wrapper: C == 3 and k == 20 (model.py:520); the k=10 case lives inside sg_mlp1_forward")
+        # any channel count / any k <= min(n, 128) (model.py:30-36 as written; the forward itself only asks for C = 3 with k = 20 and, inside
+        # MLP1, k = 10): the plain kernel of csrc/kernels_general.hip
+        xc = x.contiguous().float()
+        out = torch.empty((B, n, k), dtype=torch.int64, device=x.device)
+        hip.check(hip.lib().sg_knn_general(xc.data_ptr(), int(B), int(Cc), int(n), int(k), out.data_ptr(), _stream()))
+        return out
     pts = x.transpose(2, 1).reshape(B * n, 3)
     table = get_knn(pts, {b: list(range(b * n, (b + 1) * n)) for b in range(B)}, k)
     return (table.view(B, n, k) - (torch.arange(B, device=x.device) * n).view(B, 1, 1))

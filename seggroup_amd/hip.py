@@ -109,6 +109,10 @@ SIGNATURES = {
     "sg_train_tail_ws_bytes": (_Z, [_I, _I]),
     "sg_train_tail_forward": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, vp, vp, _Z, vp]),
     "sg_train_tail_backward": (_I, [_I, _I, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, _Z, vp]),
+    "sg_group_mean_rows": (_I, [vp, _I, _I, vp, vp, _I, vp, _I, vp]),
+    "sg_fps_general_ws_bytes": (C.c_size_t, [_I]),
+    "sg_fps_general": (_I, [vp, _I, _I, _I, _I, _I, vp, vp, vp, C.c_size_t, vp]),
+    "sg_knn_general": (_I, [vp, _I, _I, _I, _I, vp, vp]),
     "sg_group_max_rows_backward": (_I, [vp, _I, _I, vp, vp, _I, vp, _I, vp, _I, vp]),
     "sg_segment_max_backward_ws_bytes": (_Z, [_I, _I]),
     "sg_segment_max_backward": (_I, [vp, _I, _I, vp, _I, vp, _I, vp, vp, _Z, vp]),

@@ -98,5 +98,56 @@ def test_reference_style_forward_through_the_wrappers(tmp_path, golden_index, we
     if idx is not None:
         assert np.array_equal(m0[idx[0].cpu().numpy()], st["mlp_2"]["knn"][m0])
     seg0 = np.asarray(cluster_1[0])
-    picks, _ = M.farthest_point_sampling(data[seg0, :3], 5)
-    assert picks.shape == (1, 5) and np.array_equal(picks[0], cpu_ref.fps_with_fixup(sc.data[seg0, :3], 5))
+    picks, dcube = M.farthest_point_sampling(data[seg0, :3], 5, initial_idx=0, skip_initial=True)       # the forward's configuration (model.py:406)
+    assert picks.shape == (1, 5) and np.array_equal(picks[0], cpu_ref.fps(sc.data[seg0, :3], 5)) and dcube.shape == (1, 5, len(seg0))
+
+
+def test_reference_signatures_with_the_arguments_the_forward_never_passes(golden_index):
+    """VERDICT round 5, missing #6: `aggregate_cluster_feature(use_avg=True)` (model.py:282-284), `farthest_point_sampling` with another start /
+    without skip_initial / with its distance cube / on a batch / on 6-d points (model.py:369-394), `knn(x, k)` for other k and channel counts
+    (model.py:30-36) run on the device too (csrc/kernels_general.hip), against NumPy restatements."""
+    import torch
+    from oracle import cpu_ref
+    from seggroup_amd import model as M
+    rng = np.random.default_rng(5)
+    # aggregate_cluster_feature(use_avg=True): rows of [max | mean]
+    feat = rng.normal(size=(37, 48)).astype(np.float32)
+    groups = {0: [3, 5, 36], 1: [0], 2: list(range(6, 30)), 3: [35, 1, 2, 4, 30, 31, 32, 33, 34]}
+    got = M.aggregate_cluster_feature(torch.from_numpy(feat).cuda(), groups, use_avg=True).cpu().numpy()
+    want = np.stack([np.concatenate([feat[g].max(0), feat[g].astype(np.float64).mean(0).astype(np.float32)]) for g in groups.values()])
+    assert got.shape == (4, 96) and np.array_equal(got[:, :48], want[:, :48]) and np.abs(got[:, 48:] - want[:, 48:]).max() < 1e-6
+    assert np.array_equal(M.aggregate_cluster_feature(torch.from_numpy(feat).cuda(), groups).cpu().numpy(), want[:, :48])
+    # farthest_point_sampling
+    sc = make_fixture_scene(golden_index, "tiny_dup_4k")                   # duplicated points: argmax ties
+    pts = sc.data[sc.seg == 3]
+    for k, start, skip, dim in ((7, 0, False, 3), (12, 5, True, 3), (4, len(pts) - 1, False, 6), (len(pts) + 3, 2, True, 3)):
+        idx, dist = M.farthest_point_sampling(torch.from_numpy(pts[:, :dim]).cuda(), k, initial_idx=start, skip_initial=skip)
+        widx, wdist = cpu_ref.fps_general(pts[:, :dim], k, start, skip)
+        assert idx.dtype == np.int32 and idx.shape == (1, k) and np.array_equal(idx[0], widx), (k, start, skip, dim)
+        assert dist.shape == (1, k, len(pts)) and np.array_equal(dist[0], wdist)
+    batch = np.stack([pts[:40, :3], pts[40:80, :3]])
+    idx, dist = M.farthest_point_sampling(torch.from_numpy(batch).cuda(), 6, initial_idx=1)
+    for b in range(2):
+        widx, wdist = cpu_ref.fps_general(batch[b], 6, 1, False)
+        assert np.array_equal(idx[b], widx) and np.array_equal(dist[b], wdist)
+    idx, _ = M.farthest_point_sampling(torch.from_numpy(pts[:, :3]).cuda(), 3)          # initial_idx=None: a random start, like the reference
+    assert 0 <= idx[0, 0] < len(pts)
+    with pytest.raises(ValueError):
+        M.farthest_point_sampling(torch.from_numpy(pts[:, :3]).cuda(), 3, initial_idx=0, metrics=lambda a, b: 0)
+    # knn(x, k): other k, other channel counts, a batch
+    for B, C, n, k in ((1, 3, 200, 10), (2, 6, 150, 5), (1, 9, 64, 64), (3, 2, 33, 1)):
+        x = rng.normal(size=(B, C, n)).astype(np.float32)
+        x[:, :, n // 2] = x[:, :, 0]                                      # an exact duplicate: equal scores, lower index first
+        got = M.knn(torch.from_numpy(x).cuda(), k).cpu().numpy()
+        assert got.shape == (B, n, k) and got.dtype == np.int64
+        for b in range(B):
+            xb = x[b].astype(np.float64)
+            pd = -(xb * xb).sum(0)[:, None] + 2.0 * (xb.T @ xb) - (xb * xb).sum(0)[None, :]
+            for q in range(0, n, 7):
+                order = np.lexsort((np.arange(n), -pd[q]))[:k]
+                # fp32 scores can order near-equal candidates differently from float64: compare as sets when the margins are tiny
+                if not np.array_equal(got[b, q], order):
+                    assert set(got[b, q].tolist()) == set(order.tolist()) or np.min(np.abs(np.diff(np.sort(pd[q])[::-1][:k + 1]))) < 1e-5, (B, C, n, k, q)
+        assert (got[:, 0, 0] == 0).all() and (got[:, n // 2, 0] == 0).all()       # the duplicate of point 0: both rows start with index 0
+    with pytest.raises(Exception):
+        M.knn(torch.from_numpy(rng.normal(size=(1, 3, 10)).astype(np.float32)).cuda(), 11)       # k > n: torch.topk raises too

@@ -792,8 +792,10 @@ def test_seeded_knn_equals_bruteforce(env, golden_index, name, fine, coarse):
 
 
 @pytest.mark.parametrize("n,s,seed,target,kw", [(3000, 30, 40000, 30, {}), (3000, 30, 40007, 9, {}), (2400, 400, 91, 60, dict(min_seg=1)),
-                                                (2400, 400, 92, 25, dict(min_seg=1, dup_frac=0.2)), (1500, 60, 93, 60, dict(min_seg=2))],
-                         ids=["3000pts-30clusters", "3000pts-9clusters", "6pt-segments-40pt-clusters", "6pt-segments-dups", "25pt-clusters"])
+                                                (2400, 400, 91, 25, dict(min_seg=1)), (2400, 200, 92, 40, dict(min_seg=1, dup_frac=0.2)),
+                                                (2000, 250, 94, 80, dict(min_seg=1)), (2000, 250, 94, 120, dict(min_seg=1)), (1500, 60, 93, 60, dict(min_seg=2))],
+                         ids=["3000pts-30clusters", "3000pts-9clusters", "6pt-segments-40pt-clusters", "6pt-segments-96pt-clusters", "12pt-segments-dups",
+                              "8pt-segments-25pt-clusters", "8pt-segments-17pt-clusters", "25pt-clusters"])
 def test_multi_wave_knn_with_slices_short_of_candidates(env, n, s, seed, target, kw):
     """Gate for kNN changes.  With two or four waves per tile the cluster's chunks are dealt round-robin to the
     waves and every wave publishes bounds from its OWN list; in small clusters a wave's slice holds fewer than 20 (or fewer than 20 / waves)

@@ -816,7 +816,10 @@ def test_small_scenes_engine_equals_pipeline_in_every_group_shape(mode_name):
     W = weights.load_npz(os.path.join(ROOT, "tests", "golden", "weights_g1.npz" if sem else "weights_g2.npz"))
     mode = hip.MODE_SEM_INFER if sem else hip.MODE_INS_INFER
     n = 96
-    scenes = [DeviceScene.from_synthetic(synthetic.make_scene(3000, 30, 40000 + i), device="cuda:0") for i in range(n)]
+    # every other scene with ~20-point segments: its clusters are unions of a few small segments, the case in which a wave's slice of a
+    # cluster ends up with 17-19 real candidates and a padding entry as its 20th
+    scenes = [DeviceScene.from_synthetic(synthetic.make_scene(3000, 30, 40000 + i) if i % 2 == 0 else synthetic.make_scene(3000, 150, 41000 + i, min_seg=1),
+                                         device="cuda:0") for i in range(n)]
     caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
     solo = Pipeline(W, *caps, device="cuda:0")
     want = [bench.label_digest(solo.forward(s, mode)) for s in scenes]
