@@ -206,8 +206,12 @@ namespace {
     return sg::fail(SG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); } while (0)
 #define EG_CHECK(call) do { int rc__ = (call); if (rc__ < 0) return rc__; } while (0)
 
-// SG_ENGINE_HASH=1 (debugging aid): after every phase, one line per scene on stderr with FNV-1a digests of the phase's device results --
-// two runs of the same scenes must print the same lines, whatever the group shape (tools/r05_repro.py compares them)
+// SG_ENGINE_HASH=1 in a DEBUG build (make DEBUG=1: -DSG_ENGINE_DEBUG; ADVICE round 5 -- the release library carries none of this): after every phase,
+// one line per scene on stderr with FNV-1a digests of the phase's device results -- two runs of the same scenes must print the same lines, whatever the
+// group shape (tools/r05_repro.py compares them).  The first sample set / kNN table seen for a scene is kept and later ones are compared with it; the
+// store is keyed by a digest of the scene's INPUT (device slots are reused for other scenes by the pack loader: a pointer is not a scene) and is emptied
+// when an engine is destroyed.
+#ifdef SG_ENGINE_DEBUG
 static const bool g_hash = getenv("SG_ENGINE_HASH") != nullptr;
 thread_local hipStream_t tl_hash_stream = nullptr;          // the calling group's stream: the copies must not touch the null stream (it would serialise the groups)
 int fetch(void* h, const void* d, size_t bytes) {
@@ -222,6 +226,14 @@ uint64_t dev_digest(const void* d, size_t bytes) {
     for (size_t i = 0; i < bytes; ++i) { x ^= h[i]; x *= 1099511628211ull; }
     return x;
 }
+std::mutex g_dbg_mu;
+std::map<uint64_t, std::vector<float>> g_dbg_samples;                           // scene digest -> first sample set seen
+std::map<std::pair<uint64_t, int>, std::vector<int32_t>> g_dbg_knn;               // (scene digest, layer) -> first kNN table seen
+uint64_t scene_key(const sg_scene* sc) { return dev_digest(sc->d_data, (size_t)sc->N * 24) ^ ((uint64_t)sc->N << 40) ^ (uint64_t)sc->S; }
+void debug_reset() { std::lock_guard<std::mutex> g(g_dbg_mu); g_dbg_samples.clear(); g_dbg_knn.clear(); }
+#else
+inline void debug_reset() {}
+#endif
 
 int tables_for(Run& r, int first_row, bool with_seg) {
     const int S = r.sc->S;
@@ -378,11 +390,11 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
         Run& r = runs_[i];
         const int S = r.sc->S;
         const int E1 = r.o_count[0];
+#ifdef SG_ENGINE_DEBUG
         if (g_hash) tl_hash_stream = stream;
         if (g_hash) {
             // the first sample set seen for a scene is kept; later ones are compared segment by segment
-            static std::mutex mu_dbg0;
-            static std::map<const void*, std::vector<float>> seen0;
+            const uint64_t skey = scene_key(r.sc);
             std::vector<float> smp((size_t)S * 64 * 6);
             (void)fetch(smp.data(), r.pl->samples.p, smp.size() * 4);
             {
@@ -401,9 +413,9 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
                 if (d_ref) (void)hipFree(d_ref);
                 if (d_wsr) (void)hipFree(d_wsr);
             }
-            std::lock_guard<std::mutex> g(mu_dbg0);
-            auto it = seen0.find((const void*)r.sc->d_data);
-            if (it == seen0.end()) seen0[(const void*)r.sc->d_data] = smp;
+            std::lock_guard<std::mutex> g(g_dbg_mu);
+            auto it = g_dbg_samples.find(skey);
+            if (it == g_dbg_samples.end()) g_dbg_samples[skey] = smp;
             else {
                 int shown = 0;
                 for (int sg_ = 0; sg_ < S; ++sg_) {
@@ -421,6 +433,7 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
                          (unsigned long long)(mode == SG_MODE_INS_INFER ? dev_digest(r.pl->sperm.p, (size_t)r.sc->N * 4) : 0),
                          (unsigned long long)dev_digest(r.pl->samples.p, (size_t)S * 64 * 6 * 4), (unsigned long long)dev_digest(r.pl->feat1.p, (size_t)S * 128 * 4),
                          (unsigned long long)dev_digest(r.pl->adj1.p, (size_t)std::min(E1, r.cap1) * 8), (unsigned long long)dev_digest(r.pl->dist.p, (size_t)std::min(E1, r.cap1) * 4));
+#endif
         if (E1 > r.cap1) return sg::fail(SG_ENOMEM, "adjacency capacity exceeded (%d > %d)", E1, r.cap1);
         const float* h_dist = r.o_dist;
         if (E1 > r.out_rows) {                                    // rare: denser than the outbox assumes -- fetch the full arrays
@@ -665,6 +678,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
         const int Dcat = r.feat_prev_dim + 64;
+#ifdef SG_ENGINE_DEBUG
         if (g_hash) tl_hash_stream = stream;
         if (g_hash)
             std::fprintf(stderr, "SGHASH %p L%d C=%d E=%d knn=%016llx x9m=%016llx fold=%016llx cat=%016llx gcn=%016llx dist=%016llx\n", (const void*)r.sc->d_data, layer, r.Lnew.C, r.E,
@@ -675,8 +689,6 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
                          (unsigned long long)dev_digest(r.dist_in_outbox ? (const void*)r.ctx.dist : (const void*)r.pl->dist.p, (size_t)r.E * 4));
         if (g_hash) {
             // the first table seen for (scene, layer) is kept; later ones are compared row by row
-            static std::mutex mu_dbg;
-            static std::map<std::pair<const void*, int>, std::vector<int32_t>> seen;
             const int N = r.sc->N;
             std::vector<int32_t> knn((size_t)N * 20), seed((size_t)N * 20), cop(N), sid(N);
             (void)fetch(knn.data(), r.pl->knn.p, knn.size() * 4);
@@ -687,10 +699,10 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
                          (unsigned long long)dev_digest(r.pl->knn_seed.p, (size_t)N * 80), (unsigned long long)(layer == 1 ? dev_digest(r.pl->point_rec.p, (size_t)N * 16) : 0),
                          (unsigned long long)dev_digest(r.pl->seed_id.p, (size_t)N * 4), (unsigned long long)dev_digest(r.pl->xyzw.p, (size_t)N * 16),
                          (unsigned long long)dev_digest(r.pl->smpos.p, (size_t)N * 4));
-            std::lock_guard<std::mutex> g(mu_dbg);
-            auto key = std::make_pair((const void*)r.sc->d_data, layer);
-            auto it = seen.find(key);
-            if (it == seen.end()) seen[key] = knn;
+            const auto key = std::make_pair(scene_key(r.sc), layer);
+            std::lock_guard<std::mutex> g(g_dbg_mu);
+            auto it = g_dbg_knn.find(key);
+            if (it == g_dbg_knn.end()) g_dbg_knn[key] = knn;
             else {
                 int shown = 0, rows = 0;
                 for (int q = 0; q < N; ++q) {
@@ -709,6 +721,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
                 if (rows) std::fprintf(stderr, "SGROW %p L%d: %d rows differ\n", (const void*)r.sc->d_data, layer, rows);
             }
         }
+#endif
         r.Lcur = r.Lnew;
         EG_CHECK(regroup(r, r.dist_in_outbox ? r.o_dist : r.pl->h_dist.p, 2.0f));
         r.out->trace[2 + layer] = r.Lnew.C;
@@ -997,6 +1010,7 @@ void sg_engine_destroy(sg_engine* e) {
     }
     e->cv_work.notify_all();
     for (auto& g : e->groups) if (g->th.joinable()) g->th.join();
+    debug_reset();
     if (g_profile_print && e->n_steps.load() > 0) {
         const double n = (double)e->n_steps.load(), sc = (double)e->n_step_scenes.load();
         const double step = e->ns_step.load() / n * 1e-6, syn = e->ns_sync.load() / n * 1e-6, idle = e->ns_idle.load() / n * 1e-6;

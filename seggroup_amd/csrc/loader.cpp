@@ -319,7 +319,9 @@ sg_loader* sg_loader_create_sized(int threads, int slots, size_t slot_bytes, siz
     // its packs' edge counts -- the adjacency is at most the whole file, i.e. three times the pack at worst (~9 GB for 256
     // slots of 150k-point packs; with the edge count it is ~1.7 x the file).  ONE allocation for all slots (one hipMalloc / hipFree instead
     // of `slots` of them: start-up and tear-down of the driver)
-    L->blob_bytes = max_edges > 0 ? L->slot_bytes + max_edges * 16 + 8192 : 3 * L->slot_bytes + 4096;
+    // a multiple of 256: every slot starts where the first one does modulo a cache line, so the packs' "every array starts on a 64-byte boundary"
+    // holds on the device for slots 1 .. n - 1 too (the sized stride was only a multiple of 16)
+    L->blob_bytes = sg::align_up(max_edges > 0 ? L->slot_bytes + max_edges * 16 + 8192 : 3 * L->slot_bytes + 4096, 256);
     L->slots.resize((size_t)slots);
     if (L->dry) L->blob_bytes = 0;                               // no device side: the scenes' device pointers are offsets from null
     if (!L->dry && hipMalloc((void**)&L->arena, (size_t)slots * L->blob_bytes) != hipSuccess) {

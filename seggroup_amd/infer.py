@@ -198,7 +198,10 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         # the reference gives every rank workers / ngpus loader processes (infer.py:94); the spawn context (not the order
         # of calls) is what keeps these children clear of this process's GPU state
         per_rank = max(1, -(-int(args.workers) // max(world, 1)))
-        built = cache.build_missing(args.root, sorted(set(mine_names)), args.label_style, workers=per_rank)
+        # ... the ONE-OFF pack build of a tree seen for the first time takes the rank's share of the host instead: a pack is ~20 ms of file
+        # reads, a JSON parse and a 13 MB write that release the GIL (round 6: 260 -> see profiles/r06_driver_end_to_end.json `packed_cold`)
+        cold = max(per_rank, min(32, (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)) // max(world, 1)))
+        built = cache.build_missing(args.root, sorted(set(mine_names)), args.label_style, workers=cold)
         if built and rank == 0:
             io.cprint('Built %d scene packs under dataset/scannet/cache/%s' % (built, args.label_style))
     if forward_fn is None:
@@ -333,9 +336,8 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
     tickets = []
     t_start, startup = time.time(), None
     if all_caps is not None and all(c > 0 for c in (all_caps[0], all_caps[1], all_caps[3])):
-        per_group = min(8, max(1, args.inflight // 2))         # (BatchRunner's shape)
-        runner = Engine(w, all_caps, groups=max(1, args.inflight // per_group), per_group=per_group, device=dev, timing=0,
-                        label_transfer=args.label_transfer)
+        groups, per_group = BatchRunner.shape(args.inflight)
+        runner = Engine(w, all_caps, groups=groups, per_group=per_group, device=dev, timing=0, label_transfer=args.label_transfer)
     t_engine = time.time() - t_start
 
     prof = {"load_wait": 0.0, "submit": 0.0, "engine_wait": 0.0, "log": 0.0} if os.environ.get("SG_DRIVER_PROFILE") else None
@@ -419,8 +421,8 @@ def main(argv=None):
         if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
             print('--synthetic writes the tree from ONE process: run it once without torchrun, then start the ranks on that --root')
             raise SystemExit(1)
+        n_syn = write_synthetic_tree(args)                                 # refuses an existing tree before it creates anything
         os.makedirs(os.path.join(args.root, 'checkpoints', args.exp_name), exist_ok=True)
-        n_syn = write_synthetic_tree(args)
     import torch
     if args.no_cuda or not torch.cuda.is_available():
         print('seggroup_amd runs on MI355X only: no CPU fallback (use oracle/cpu_ref.py for testing)')

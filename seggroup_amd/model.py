@@ -419,10 +419,16 @@ class BatchRunner(Engine):
         caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
         if min_caps is not None:                    # regrowing: never shrink below the previous capacities
             caps = tuple(max(a, b) for a, b in zip(caps, min_caps))
+        groups, per_group = self.shape(inflight, per_group)
+        super().__init__(w, caps, groups=groups, per_group=per_group, device=dev, timing=timing, label_transfer=label_transfer)
+
+    @staticmethod
+    def shape(inflight: int, per_group: Optional[int] = None):
+        """(groups, scenes per group) for `inflight` scenes in flight: groups of 8 from 16 scenes on.  The ONE statement of that rule: the driver,
+        which creates its engine before the first batch has arrived, asks here too (it restated the formula by hand)."""
         if per_group is None:
             per_group = min(8, max(1, inflight // 2))
-        super().__init__(w, caps, groups=max(1, inflight // per_group), per_group=per_group, device=dev, timing=timing,
-                         label_transfer=label_transfer)
+        return max(1, inflight // per_group), per_group
 
 
 class AsyncLabelWriter:

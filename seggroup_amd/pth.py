@@ -55,7 +55,28 @@ class _Unpickler(pickle.Unpickler):
         kind, storage, key, _location, _numel = pid
         if kind != "storage" or not isinstance(storage, _Storage):
             raise pickle.UnpicklingError("unexpected persistent id")
-        return self.zf.read(f"{self.prefix}/data/{key}"), storage.dtype
+        return _read_stored(self.zf, f"{self.prefix}/data/{key}"), storage.dtype
+
+
+def _read_stored(zf: zipfile.ZipFile, name: str):
+    """The bytes of a STORED member straight from the file (one read at the member's data offset): `ZipFile.read` runs zlib.crc32 over every
+    byte it hands out -- 17 of the ~40 ms a 150k-point scene's pack took to build (round 6; tools/time_driver.py `packed_cold`).  The archive is
+    `torch.save`'s own and was just written or is about to be checked against its consumers' results; a damaged file shows up as a shape /
+    bounds error in `_rebuild_tensor_v2` or as wrong labels in the parity tests, not silently.  Compressed members go through `ZipFile.read`."""
+    zi = zf.getinfo(name)
+    if zi.compress_type != zipfile.ZIP_STORED or zf.fp is None or not hasattr(zf, "filename") or zf.filename is None:
+        return zf.read(name)
+    with open(zf.filename, "rb") as f:
+        f.seek(zi.header_offset)
+        hdr = f.read(30)
+        if len(hdr) != 30 or hdr[:4] != b"PK\x03\x04":
+            return zf.read(name)
+        nlen, elen = int.from_bytes(hdr[26:28], "little"), int.from_bytes(hdr[28:30], "little")
+        f.seek(zi.header_offset + 30 + nlen + elen)
+        buf = f.read(zi.file_size)
+    if len(buf) != zi.file_size:
+        raise ValueError(f"{zf.filename}: member {name} is truncated")
+    return buf
 
 
 def load_tensor(path: str) -> np.ndarray:

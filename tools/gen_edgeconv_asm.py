@@ -26,6 +26,16 @@ from collections import defaultdict
 K = 20
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("SG_EC_OUT") or os.path.join(HERE, "..", "seggroup_amd", "csrc", "edgeconv_slots_gen.h")
+# The SG_EC_* experiment knobs below (packed statistics, other register files, omitted stages ...) change the emitted code: they are read ONLY
+# when the generator is started with --experimental (tools/build_ec_variant.sh does), so that a stray variable in the environment of a build --
+# the Makefile regenerates the header when this file is newer -- cannot put packed fp32 back into the library.  SG_EC_OUT
+# (where to write) is not an experiment.
+EXPERIMENTAL = "--experimental" in sys.argv[1:]
+
+
+def knob(name, default=""):
+    return os.environ.get(name, default) if EXPERIMENTAL else default
+
 
 MFMA_TO_READ = 14      # instructions between an MFMA and a non-MFMA reader / overwriter of its D (hipcc: s_nop 11 = 12 states; + margin)
 VALU_TO_MFMA = 3       # instructions between a VALU write and the MFMA reading it (hipcc: s_nop 1 = 2 states)
@@ -53,7 +63,7 @@ def vr(n, cnt=1):
 
 
 def ar(n, cnt=1):
-    if os.environ.get("SG_EC_AVGPR"):
+    if knob("SG_EC_AVGPR"):
         return ["v%d" % (12 + n + i) for i in range(cnt)]
     return ["a%d" % (n + i) for i in range(cnt)]
 
@@ -63,7 +73,7 @@ def vt(n, cnt):
     return "v[%d:%d]" % (n, n + cnt - 1) if cnt > 1 else "v%d" % n
 
 
-A_IN_VGPR = bool(os.environ.get("SG_EC_AVGPR"))       # timing experiment (with SG_EC_OMIT=L,S,...): the A fragments in v[12:91] instead of AGPRs
+A_IN_VGPR = bool(knob("SG_EC_AVGPR"))       # timing experiment (with SG_EC_OMIT=L,S,...): the A fragments in v[12:91] instead of AGPRs
 
 
 def at(n, cnt):
@@ -175,7 +185,7 @@ def build_deps(ops):
             readers[r] = []
 
 
-DEP_DIST = int(os.environ.get("SG_EC_DEP_DIST", "2"))     # keep a VALU this many instructions away from the VALU whose result it reads
+DEP_DIST = int(knob("SG_EC_DEP_DIST", "2"))     # keep a VALU this many instructions away from the VALU whose result it reads
 LAT = {"lgkm": 32, "vm": 250}          # instructions after which a load of the class is taken to have landed (placement only; the s_waitcnt is exact)
 
 
@@ -677,8 +687,28 @@ def conv2(p, m, j):
             first = False
 
 
+EXTRA_MFMA = int(knob("SG_EC_EXTRA_MFMA", "0"))       # timing experiment (with SG_EC_OMIT=Q): this many more MFMAs per slot, accumulating into the freed
+                                                      # sum / sum-of-squares registers, A fragments from LDS like conv2's -- the ISSUE MIX of "BatchNorm 2's
+                                                      # statistics from second moments of h1 on the matrix pipe" without its transposes (results are garbage)
+
+
 def stats_s2x(p, m, j, ot):
     if "S" in OMIT:
+        return
+    if "Q" in OMIT:                                    # timing experiment: the maxima only (no sums, no sums of squares: 64 of a slot's 244 VALU)
+        for q in range(16):
+            z = m.ACC2 + 16 * ot + q
+            o = 16 * ot + q
+            if j == 0:
+                p.valu("v_mov_b32 v%d, v%d" % (m.BEST + o, z), vr(z), vr(m.BEST + o), tag="S%d.%d" % (j, ot) if q == 0 else "")
+            else:
+                p.valu("v_max_f32 v%d, v%d, v%d" % (m.BEST + o, m.BEST + o, z), vr(m.BEST + o) + vr(z), vr(m.BEST + o), tag="S%d.%d" % (j, ot) if q == 0 else "")
+        if ot == 1:
+            buf, ext = m.BUF[j & 1], m.EXT[j & 1]
+            for e in range(EXTRA_MFMA):
+                d = (m.STAT_S if (e & 1) == 0 else m.STAT_Q) + 16 * ((e >> 1) & 1)
+                x = ext if (e % 4) == 0 else buf + 8 * ((e % 4) - 1) + 4
+                p.mfma_frag(d, m.A2 + 1024 * (e % 24), x, None if (j == 0 and e < 4) else d, tag="X%d" % j if e == 0 else "")
         return
     for q in range(0, 16 if S2X_PKSTAT else 0, 2):
         z = m.ACC2 + 16 * ot + q
@@ -701,11 +731,11 @@ def stats_s2x(p, m, j, ot):
         p.valu("v_max_f32 v%d, v%d, v%d" % (m.BEST + o, m.BEST + o, z), vr(m.BEST + o) + vr(z), vr(m.BEST + o))
 
 
-ID_STRIDE = int(os.environ.get("SG_EC_ID_STRIDE", "4"))            # bytes between a lane's consecutive neighbour ids: 4 = row-major [N][20] table; 128 = slot-major per 32-row tile
-MIXLO = bool(int(os.environ.get("SG_EC_MIXLO", "0")))             # S2X: the low fp16 pieces of conv2's operand straight from v_fma_mixlo/hi_f16
-LRELU_PK = bool(int(os.environ.get("SG_EC_LRELU_PK", "0")))       # S2X: LeakyReLU's 0.2 x as v_pk_mul_f32 (asm operand %[c02] = the constant twice, in SGPRs)
-S2X_PKSTAT = bool(int(os.environ.get("SG_EC_S2X_PKSTAT", "0")))   # S2X: packed sums / sums of squares
-OMIT = set(x for x in os.environ.get("SG_EC_OMIT", "").split(",") if x)       # timing experiments: leave stages out (results are garbage)
+ID_STRIDE = int(knob("SG_EC_ID_STRIDE", "4"))            # bytes between a lane's consecutive neighbour ids: 4 = row-major [N][20] table; 128 = slot-major per 32-row tile
+MIXLO = bool(int(knob("SG_EC_MIXLO", "0")))             # S2X: the low fp16 pieces of conv2's operand straight from v_fma_mixlo/hi_f16
+LRELU_PK = bool(int(knob("SG_EC_LRELU_PK", "0")))       # S2X: LeakyReLU's 0.2 x as v_pk_mul_f32 (asm operand %[c02] = the constant twice, in SGPRs)
+S2X_PKSTAT = bool(int(knob("SG_EC_S2X_PKSTAT", "0")))   # S2X: packed sums / sums of squares
+OMIT = set(x for x in knob("SG_EC_OMIT", "").split(",") if x)       # timing experiments: leave stages out (results are garbage)
 
 
 def program_s2x():
@@ -771,7 +801,7 @@ def count(sched):
 
 
 def main():
-    fill = int(os.environ.get("SG_EC_FILL", "6"))
+    fill = int(knob("SG_EC_FILL", "6"))
     out = []
     out.append("// GENERATED by tools/gen_edgeconv_asm.py -- do not edit by hand (re-run the generator).")
     out.append("// The neighbour-slot loops of k_edgeconv_h<S1X / S2X> (kernels_edgeconv.hip) as hand-scheduled gfx950 instruction streams.")

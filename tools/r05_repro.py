@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Do a scene's labels depend on the batch it runs in, or on the run?  N scenes through the engine in different group shapes, several times, against
-the single pipeline.  With SG_ENGINE_HASH=1 the engine prints digests of every phase's device results; the first differing phase of a scene is shown.
+the single pipeline.  With SG_ENGINE_HASH=1 and a library built with `make DEBUG=1` (the release build carries no debugging code) the engine prints
+digests of every phase's device results; the first differing phase of a scene is shown.
 
     python3 tools/r05_repro.py [N=64] [seed0=40000] [shapes=10x8,6x5,16x1,3x8] [reps=2]          (SG_REPRO_PROFILE=scannet: the ScanNet-shaped scenes)
 """
