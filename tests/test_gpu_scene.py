@@ -768,35 +768,88 @@ def test_edgeconv_walk_modes_give_the_same_labels():
     assert len(got["0"]) == 5 and got["0"] == got["1"]
 
 
-def test_a_scenes_labels_do_not_depend_on_the_run_or_the_group_shape(weight_sets):
+_OUT_OF_STEP_CHILD = r"""
+import ctypes, hashlib, json, os, sys
+root, cache, runs = sys.argv[1], sys.argv[2], int(sys.argv[3])
+sys.path.insert(0, root)
+import numpy as np
+import bench
+from seggroup_amd import hip, weights
+from seggroup_amd.model import Engine, Pipeline
+from seggroup_amd.scene import DeviceScene
+jobs = [(150000, 1500, 41000 + i, "voronoi", cache) for i in range(56)] + [(150000, 1500, 41100 + i, "scannet", cache) for i in range(8)]
+it, pool = bench.generate_scenes(jobs, 16)
+scenes = [DeviceScene.from_synthetic(h, device="cuda:0") for h in it]
+if pool is not None:
+    pool.shutdown()
+W = weights.load_npz(os.path.join(root, "tests", "golden", "weights_g2.npz"))
+caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+solo = Pipeline(W, *caps, device="cuda:0")
+want = [bench.label_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
+solo.close()
+out = {"scenes": len(scenes), "wrong": {}, "results": 0}
+for groups, per in ((16, 1), (6, 5), (10, 8)):
+    eng = Engine(W, caps, groups=groups, per_group=per, device="cuda:0", timing=0)
+    bad = []
+    for rep in range(runs):
+        got = [bench.label_digest(r) for r in eng.run(scenes, hip.MODE_INS_INFER)]
+        bad += [(rep, i) for i in range(len(scenes)) if got[i] != want[i]]
+        out["results"] += len(scenes)
+    out["wrong"]["%dx%d" % (groups, per)] = bad
+    eng.close()
+lib = hip.lib()
+if hasattr(lib, "sg_debug_knn_check"):                       # the self-checking twin (make selfcheck)
+    buf = (ctypes.c_ulonglong * 136)()
+    lib.sg_debug_knn_check(buf)
+    out["knn_check"] = {"seeded_tiles": int(buf[2]), "lists_out_of_order_after_seeding": int(buf[0]), "at_the_output_stage": int(buf[1])}
+if hasattr(lib, "sg_debug_fps_check"):
+    fb = (ctypes.c_ulonglong * 8)()
+    lib.sg_debug_fps_check(fb)
+    out["fps_check"] = {"picks_checked": int(fb[3]), "picks_that_differ": int(fb[2]), "half_wave_maxima_that_differ": int(fb[0]), "first_indices_that_differ": int(fb[1])}
+print("RESULT " + json.dumps(out), flush=True)
+"""
+
+
+def _out_of_step_run(tmp_path, lib_path, runs):
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    if lib_path:
+        env["SEGGROUP_HIP_LIB"] = lib_path
+    cache = os.path.join(os.path.dirname(str(tmp_path)), "sg_out_of_step_scenes")          # shared by the two tests of a session
+    r = subprocess.run([sys.executable, "-c", _OUT_OF_STEP_CHILD, ROOT, cache, str(runs)], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+def test_a_scenes_labels_do_not_depend_on_the_run_or_the_group_shape(tmp_path):
     """Round 5: with more groups than scenes per group (16 x 1, 6 x 5 -- the tail of every driver run, and ranks with few scenes) the groups fall out
     of step, waves of DIFFERENT kernels share a SIMD, and packed fp32 instructions (v_pk_fma_f32 in the hand-scheduled MLP2 loop, v_pk_add_f32 the
     compiler's SLP pass had put into the seeded kNN) lost results: about one scene in a hundred came out with other labels than the single pipeline
-    gives, another one each run (tests/test_build.py keeps such instructions out of the library).  24 full-size scenes, two shapes,
-    six runs each: every result must equal the single pipeline's."""
-    from concurrent.futures import ThreadPoolExecutor
-    from seggroup_amd import hip, synthetic
-    from seggroup_amd.model import Engine, Pipeline
-    from seggroup_amd.scene import DeviceScene
-    W = weight_sets["ins_infer"]
-    with ThreadPoolExecutor(8) as ex:
-        host = list(ex.map(lambda seed: synthetic.make_scene(150000, 1500, seed), range(41000, 41024)))
-        # + ScanNet-shaped scenes: the other size classes of FPS / sort / layout run beside the rest (the chunk-pruned FPS of segments beyond 8,192
-        # points had a missing barrier, one wrong sample set in ~4,000 such segments: far too rare for this test, which only keeps the path covered)
-        host += list(ex.map(lambda seed: synthetic.make_scene(150000, 1500, seed, seg_profile="scannet"), range(41100, 41108)))
-    scenes = [DeviceScene.from_synthetic(h, device="cuda:0") for h in host]
-    caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
-    solo = Pipeline(W, *caps, device="cuda:0")
-    want = [_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
-    solo.close()
-    for groups, per in ((16, 1), (6, 5)):
-        eng = Engine(W, caps, groups=groups, per_group=per, device="cuda:0", timing=0)
-        for rep in range(6):
-            got = [_digest(r) for r in eng.run(scenes, hip.MODE_INS_INFER)]
-            bad = [i for i in range(len(scenes)) if got[i] != want[i]]
-            assert not bad, f"engine {groups} x {per}, run {rep}: scenes {bad} differ from the single pipeline"
-        eng.close()
+    gives, another one each run (tests/test_build.py keeps such instructions out of the library).  Round 6: 64
+    full-size scenes (56 uniform + 8 ScanNet-shaped: the other size classes of FPS / sort / layout beside the rest), THREE shapes -- 16 x 1, 6 x 5
+    and the bench's 10 x 8 -- three runs each = 576 scene results (the fault rate was ~1 %): every one must equal the single pipeline's."""
+    got = _out_of_step_run(tmp_path, None, 3)
+    assert got["scenes"] == 64 and got["results"] == 576
+    assert all(not v for v in got["wrong"].values()), got["wrong"]
 
+
+def test_selfcheck_library_finds_nothing(tmp_path):
+    """`make selfcheck` (built by __graft_entry__.build()): the seeded kNN checks every list right after seeding and at the output stage, the
+    chunk-pruned FPS of segments beyond 8,192 points re-evaluates every half-wave reduction and every pick serially -- the two places where round 5
+    found results that depended on the run.  The same 64 scenes x three out-of-step shapes through that library: labels equal the single
+    pipeline's, millions of lists and every pick checked, none wrong."""
+    from seggroup_amd import hip
+    twin = os.path.join(os.path.dirname(hip.LIB_PATH), "libseggroup_hip_selfcheck.so")
+    assert os.path.exists(twin), "the self-checking twin is missing: python -c 'import __graft_entry__ as g; g.build()'"
+    got = _out_of_step_run(tmp_path, twin, 2)
+    assert all(not v for v in got["wrong"].values()), got["wrong"]
+    k, f = got["knn_check"], got["fps_check"]
+    assert k["seeded_tiles"] > 100000 and k["lists_out_of_order_after_seeding"] == 0 and k["at_the_output_stage"] == 0, k
+    assert f["picks_checked"] > 1000 and f["picks_that_differ"] == 0 and f["half_wave_maxima_that_differ"] == 0 and f["first_indices_that_differ"] == 0, f
 
 
 @pytest.mark.parametrize("mode_name", ["ins_infer", "sem_infer"])
