@@ -773,6 +773,16 @@ int sg_parse_seg_json(const char* path, int N, int32_t* h_seg_of_point);
 int sg_stage_segments(const int32_t* h_seg_of_point, int N, int S, int32_t* h_seg_points, int32_t* h_seg_off,
                       int32_t* h_seg_first, int32_t* h_seg_size);
 
+/* One scene pack (`<scene>.sgpack`, seggroup_amd/cache.py: magic | header | the staged arrays, 64-byte aligned) from the reference's six per-scene
+ * files, natively: src_paths6 = {<s>.pcl.pth, <s>.unmap.pth, weak <s>.label.pth, <s>.seg.json, raw <s>.label.pth, <s>.adj.pth} (data.py:28-38,
+ * model.py:696-724 read the same files).  The `.pth` containers are torch.save's STORED zip + a protocol-2 pickle of one tensor; anything
+ * else (compressed members, other pickles, float index tensors, names that need JSON escaping) is SG_EINVAL and the caller builds that pack in
+ * Python.  Written atomically (temporary file + rename); byte-identical to cache.write_pack's output.
+ * sg_pack_build_many: n scenes (src_paths = n x 6 paths) on `threads` plain threads; h_status[i] = SG_OK or the scene's error; returns the number built. */
+int sg_pack_build(const char* const* src_paths6, const char* name, const char* out_path);
+int sg_pack_build_many(const char* const* src_paths, const char* const* names, const char* const* out_paths, int n, int threads,
+                       int32_t* h_status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,14 +154,44 @@ def build_missing(root: str, scene_names, label_style: str = "manual", workers: 
     todo = [n for n in scene_names if not is_current(root, n, label_style)]
     if not todo:
         return 0
+    # Round 6: the native builder first (csrc/packbuild.cpp: plain threads, no interpreter in the loop -- the Python path below is ~2,000
+    # interpreter-level calls per scene under the GIL, ~260 scenes/s whatever the thread count); scenes it refuses (a container it does not
+    # know) are built in Python as before.  SG_PACK_BUILD=python skips it.
+    n_todo = len(todo)
+    if os.environ.get("SG_PACK_BUILD", "native") != "python":
+        todo = _build_native(root, todo, label_style, workers)
+        if not todo:
+            return n_todo
     if len(todo) < 4 or workers <= 1:
         for n in todo:
             pack_scene(root, n, label_style)
-        return len(todo)
+        return n_todo
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(workers, len(todo))) as pool:
         list(pool.map(_pack_job, [(root, n, label_style) for n in todo]))
-    return len(todo)
+    return n_todo
+
+
+def _build_native(root: str, todo, label_style: str, workers: int):
+    """sg_pack_build_many over `todo`; returns the scenes that still need the Python builder."""
+    import ctypes as C
+    from . import hip
+    lib = hip.lib()
+    n = len(todo)
+    srcs, outs = [], []
+    for name in todo:
+        srcs += source_files(root, name, label_style)
+        out = pack_path(root, name, label_style)
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        outs.append(out)
+    a_src = (C.c_char_p * (6 * n))(*[p.encode() for p in srcs])
+    a_names = (C.c_char_p * n)(*[t.encode() for t in todo])
+    a_out = (C.c_char_p * n)(*[p.encode() for p in outs])
+    status = (C.c_int32 * n)()
+    rc = lib.sg_pack_build_many(a_src, a_names, a_out, n, max(1, int(workers)), status)
+    if rc < 0:
+        return list(todo)
+    return [name for name, st in zip(todo, status) if st != 0]
 
 
 _tls = __import__("threading").local()

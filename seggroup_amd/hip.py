@@ -192,6 +192,8 @@ SIGNATURES = {
     "sg_writer_submit_scene": (_I, [vp, C.c_char_p, vp, _I, _I, _I, C.c_longlong]),
     "sg_writer_submit_scene_tables": (_I, [vp, C.c_char_p, vp, _I, vp, _I, _I, _I, C.c_longlong]),
     "sg_expand_labels": (_I, [vp, _I, _I, vp, _I, vp]),
+    "sg_pack_build": (_I, [vp, C.c_char_p, C.c_char_p]),
+    "sg_pack_build_many": (_I, [vp, vp, vp, _I, _I, vp]),
     "sg_writer_wait_tag": (_I, [vp, C.c_longlong]),
     "sg_writer_flush": (_I, [vp]),
     "sg_writer_destroy": (None, [vp]),

@@ -96,3 +96,99 @@ def test_writer_pool_scene_jobs_by_reference(sg_lib, tmp_path):
     hip.check(lib.sg_writer_submit_scene(w, str(tmp_path / "nope").encode(), v.ctypes.data, v.shape[0], 1, 2, 9))
     assert lib.sg_writer_flush(w) < 0
     lib.sg_writer_destroy(w)
+
+
+# ---- native pack builder (csrc/packbuild.cpp): runs under ASan / UBSan with the tests above --------------------------------------
+def _tree(tmp_path, golden_index, names=("tiny_4k", "tiny_dup_4k")):
+    from seggroup_amd import synthetic
+    scenes = []
+    for i, fx in enumerate(names):
+        e = golden_index[fx]
+        scenes.append(synthetic.make_scene(e["n"], e["s"], e["seed"], name=f"scene{i:04d}_00", **e["kw"]))
+    scenes.append(synthetic.make_scene(2400, 300, 41001, name="scene0009_00", min_seg=1))       # one-point segments
+    root = str(tmp_path)
+    synthetic.write_reference_tree(root, scenes)
+    return root, [s.name for s in scenes]
+
+
+def _native_build(sg_lib, root, names, threads=2, style="manual"):
+    import ctypes as C
+    from seggroup_amd import cache
+    srcs, outs = [], []
+    for n in names:
+        srcs += cache.source_files(root, n, style)
+        out = cache.pack_path(root, n, style) + ".native"
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        outs.append(out)
+    a_src = (C.c_char_p * len(srcs))(*[p.encode() for p in srcs])
+    a_names = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    a_out = (C.c_char_p * len(names))(*[p.encode() for p in outs])
+    status = (C.c_int32 * len(names))()
+    rc = sg_lib.sg_pack_build_many(a_src, a_names, a_out, len(names), threads, status)
+    return rc, list(status), outs
+
+
+def test_native_pack_builder_writes_what_the_python_builder_writes(sg_lib, tmp_path, golden_index):
+    """sg_pack_build_many (zip + pickle + seg.json + staging + pack write in C++ threads) against cache.pack_scene (zipfile, pickle, NumPy):
+    the same bytes, for V == N, V != N with a non-identity unmapper, and a scene with one-point segments."""
+    from seggroup_amd import cache
+    root, names = _tree(tmp_path, golden_index)
+    rc, status, outs = _native_build(sg_lib, root, names)
+    assert rc == len(names) and status == [0] * len(names), (rc, status, sg_lib.sg_last_error())
+    for n, out in zip(names, outs):
+        want = open(cache.pack_scene(root, n, force=True), "rb").read()
+        assert open(out, "rb").read() == want, n
+        assert not [f for f in os.listdir(os.path.dirname(out)) if ".tmp" in f]          # written atomically, nothing left behind
+
+
+def test_native_pack_builder_refuses_what_it_does_not_know_and_the_python_builder_takes_over(sg_lib, tmp_path, golden_index, monkeypatch):
+    import numpy as np
+    import torch
+    from seggroup_amd import cache
+    root, names = _tree(tmp_path, golden_index, names=("tiny_4k",))
+    src = cache.source_files(root, names[0])
+    good = {p: open(p, "rb").read() for p in src}
+
+    def status_with(path, data):
+        open(path, "wb").write(data)
+        rc, status, _ = _native_build(sg_lib, root, names[:1], threads=1)
+        msg = sg_lib.sg_last_error().decode()
+        open(path, "wb").write(good[path])
+        return rc, status[0], msg
+    # a truncated archive, a file that is not a zip, a tensor view that reaches beyond its storage, a compressed archive, a dict instead of a tensor
+    rc, st, msg = status_with(src[0], good[src[0]][:len(good[src[0]]) // 2])
+    assert rc == 0 and st < 0 and "sg_pack_build" in msg
+    rc, st, msg = status_with(src[5], b"not a zip archive at all" * 10)
+    assert rc == 0 and st < 0
+    tmp = os.path.join(str(tmp_path), "t.pth")
+    import zipfile
+    with zipfile.ZipFile(tmp + ".z", "w", zipfile.ZIP_DEFLATED) as zf:   # ... a compressed archive is not
+        with zipfile.ZipFile(src[1]) as zin:
+            for n in zin.namelist():
+                zf.writestr(n, zin.read(n))
+    rc, st, msg = status_with(src[1], open(tmp + ".z", "rb").read())
+    assert rc == 0 and st < 0 and ("compressed" in msg or "data.pkl" in msg)
+    torch.save({"a": torch.zeros(3)}, tmp)
+    rc, st, msg = status_with(src[2], open(tmp, "rb").read())
+    assert rc == 0 and st < 0 and ("plain tensor file" in msg or "single tensor" in msg)
+    # a pickle whose tensor claims 200 elements of a 4-element storage (the size operand of a real file patched): refused, not read out of bounds
+    torch.save(torch.arange(4), tmp)
+    with zipfile.ZipFile(tmp) as zin:
+        members = {n: zin.read(n) for n in zin.namelist()}
+    pk = [n for n in members if n.endswith("data.pkl")][0]
+    at = members[pk].index(b"K\x04\x85")                                # BININT1 4, TUPLE1 = size (4,)
+    members[pk] = members[pk][:at] + b"K\xc8\x85" + members[pk][at + 3:]
+    with zipfile.ZipFile(tmp + ".big", "w", zipfile.ZIP_STORED) as zf:
+        for n, v in members.items():
+            zf.writestr(n, v)
+    rc, st, msg = status_with(src[1], open(tmp + ".big", "rb").read())
+    assert rc == 0 and st < 0 and "beyond its storage" in msg, msg
+    # cache.build_missing: a scene the native builder refuses is built by the Python builder (here: a float64 point cloud is fine natively,
+    # a scene NAME that needs JSON escaping is not)
+    os.makedirs(os.path.join(root, "x"), exist_ok=True)
+    calls = []
+    real = cache.pack_scene
+    monkeypatch.setattr(cache, "pack_scene", lambda *a, **k: (calls.append(a[1]), real(*a, **k))[1])
+    monkeypatch.setattr(cache, "_build_native", lambda root_, todo, style, workers: list(todo))       # "refused everything"
+    assert cache.build_missing(root, names, workers=2) == len(names) and sorted(calls) == sorted(names)
+    assert all(cache.is_current(root, n) for n in names)
