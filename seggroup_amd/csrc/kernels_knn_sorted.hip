@@ -181,25 +181,50 @@ __global__ __launch_bounds__(256) void k_segment_sort_boxes_b(const sg::SlotCtx*
 //       cell is then not the full sort, which only loosens the chunk boxes there (the kNN tables do not depend on this order);
 //   k_bigseg_boxes (same windows):  boxes of the 32-point chunks that start in the window.
 constexpr int kBigBlock = 1024, kBins = 4096, kWin = 1024;
-static_assert(kBins * 4 <= (kSortCap + 1) * 8, "the cell table of a big segment lives in its own keysA range");
-__device__ __forceinline__ void bigseg_bucket_body(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
-                                                   const int32_t* __restrict__ seg_off, float* __restrict__ segbox, double* __restrict__ seg_sums,
-                                                   unsigned long long* __restrict__ keysA, unsigned long long* __restrict__ keysB, int s) {
+// Round 6: the bucket step is SPLIT OVER kBigPieces WORKGROUPS PER SEGMENT, in three launches (box | keys + histogram | scan + scatter).  One
+// 1,024-thread block per segment did all of it: three passes of dependent gathers (seg_points[i] -> data row) over 30-40k points through ONE
+// CU's memory pipeline, 176-188 us per launch of 8 ScanNet-shaped scenes -- the longest link but one of phase P0's chain of skinny launches
+// (DESIGN.md 5c).  The passes are embarrassingly parallel but for three hand-overs (the segment's box before any key, all counts before the scan,
+// the scan before the scatter), and a launch boundary is the cheapest device-wide hand-over there is.  Per big segment a scratch record
+// (BigScratch, indexed by lo / (kSortCap + 1): two big segments start at least kSortCap + 1 positions apart) behind the two key arrays holds
+// the pieces' partial boxes / sums, the cell histogram, the scatter cursors and the cells' first positions (what k_bigseg_runs looks its runs
+// up in: round 5 kept that table in the head of the segment's own keysA range, written by the one block when it was done with it).
+// The order INSIDE a cell is now the order in which pieces' atomics land -- k_bigseg_runs sorts every run by the full 64-bit key, so the sorted
+// order, the boxes and everything behind them are the same bits as before; the coordinate sums are combined piece by piece in a fixed order.
+constexpr int kBigPieces = 16, kPieceBlock = 256;
+struct BigScratch {
+    float box[kBigPieces][8];          // per piece: min xyz | max xyz | max |p|^2 | -
+    double sums[kBigPieces][4];        // per piece: sum x | y | z | -
+    int hist[kBins];                   // points per cell (top 12 Morton bits)
+    int cursor[kBins];                 // scatter cursors
+    int first[kBins];                  // exclusive scan of hist: first position of every cell
+};
+static_assert(kBins % kBigPieces == 0 && kBins / kBigPieces == kPieceBlock, "every piece zeroes its own slice of the histogram: one entry per thread");
+__host__ __device__ inline size_t bigseg_scratch_slots(int N) { return (size_t)N / (kSortCap + 1) + 1; }
+__device__ __forceinline__ BigScratch& bigseg_scratch(unsigned long long* keysA, int N, int lo) {
+    return reinterpret_cast<BigScratch*>(keysA + 2 * (size_t)N)[lo / (kSortCap + 1)];
+}
+__device__ __forceinline__ void piece_range(int n, int piece, int& i0, int& i1) {
+    const int L = (n + kBigPieces - 1) / kBigPieces;
+    i0 = min(n, piece * L); i1 = min(n, i0 + L);
+}
+
+// launch 1: partial box + coordinate sums of one piece; the piece's slice of the histogram and of the cursors is cleared
+__device__ __forceinline__ void bigseg_box_body(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
+                                                unsigned long long* __restrict__ keysA, int N, int s, int piece) {
     const int lo = seg_off[s], n = seg_off[s + 1] - lo;
     if (n <= kSortCap) return;
-    __shared__ int hist[kBins];
-    __shared__ int first[kBins];
-    __shared__ float red[kBigBlock / 64][8];
-    __shared__ double dred[kBigBlock / 64][3];
-    __shared__ float bx[8];
+    BigScratch& sc = bigseg_scratch(keysA, N, lo);
+    __shared__ float red[kPieceBlock / 64][8];
+    __shared__ double dred[kPieceBlock / 64][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int kW = kBigBlock / 64;
-    // 1. box + sums
+    constexpr int kW = kPieceBlock / 64;
+    int i0, i1;
+    piece_range(n, piece, i0, i1);
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, xx = 0.f;
     double sm[3] = {0.0, 0.0, 0.0};
-    // (a block is alone with its segment: the gathers of four trips are in flight together, or every trip waits out two dependent round trips)
 #pragma unroll 4
-    for (int i = tid; i < n; i += kBigBlock) {
+    for (int i = i0 + tid; i < i1; i += kPieceBlock) {
         const float* r = data + (size_t)seg_points[lo + i] * 6;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], r[k]); mx[k] = fmaxf(mx[k], r[k]); sm[k] += (double)r[k]; }
@@ -215,60 +240,90 @@ __device__ __forceinline__ void bigseg_bucket_body(const float* __restrict__ dat
         red[wave][0] = mn[0]; red[wave][1] = mn[1]; red[wave][2] = mn[2]; red[wave][3] = mx[0]; red[wave][4] = mx[1]; red[wave][5] = mx[2]; red[wave][6] = xx;
         dred[wave][0] = sm[0]; dred[wave][1] = sm[1]; dred[wave][2] = sm[2];
     }
-    for (int i = tid; i < kBins; i += kBigBlock) hist[i] = 0;
+    sc.hist[piece * kPieceBlock + tid] = 0;
+    sc.cursor[piece * kPieceBlock + tid] = 0;
     __syncthreads();
     if (tid < 7) {
         float v = red[0][tid];
         for (int w = 1; w < kW; ++w) v = tid < 3 ? fminf(v, red[w][tid]) : fmaxf(v, red[w][tid]);
-        bx[tid] = v;
-        segbox[(size_t)s * 8 + tid] = v;
+        sc.box[piece][tid] = v;
     }
-    if (tid == 7) segbox[(size_t)s * 8 + 7] = 0.f;
-    if (seg_sums && tid >= 8 && tid < 11) {
-        // NOTE: the sum is carried in double; its grouping (16 waves here, 4 in the small kernel) does not show in the fp32
-        // centroids the host forms from it
+    if (tid >= 8 && tid < 11) {
         double t = 0.0;
         for (int w = 0; w < kW; ++w) t += dred[w][tid - 8];
+        sc.sums[piece][tid - 8] = t;
+    }
+}
+
+// launch 2: the segment's box from the pieces' (every piece combines them itself, in piece order; piece 0 publishes box and sums), then the
+// piece's keys and their cells' counts
+__device__ __forceinline__ void bigseg_keys_body(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
+                                                 float* __restrict__ segbox, double* __restrict__ seg_sums, unsigned long long* __restrict__ keysA, int N,
+                                                 int s, int piece) {
+    const int lo = seg_off[s], n = seg_off[s + 1] - lo;
+    if (n <= kSortCap) return;
+    BigScratch& sc = bigseg_scratch(keysA, N, lo);
+    __shared__ float bx[8];
+    const int tid = threadIdx.x;
+    if (tid < 7) {
+        float v = sc.box[0][tid];
+        for (int p = 1; p < kBigPieces; ++p) v = tid < 3 ? fminf(v, sc.box[p][tid]) : fmaxf(v, sc.box[p][tid]);
+        bx[tid] = v;
+        if (piece == 0) segbox[(size_t)s * 8 + tid] = v;
+    }
+    if (piece == 0 && tid == 7) segbox[(size_t)s * 8 + 7] = 0.f;
+    if (piece == 0 && seg_sums && tid >= 8 && tid < 11) {
+        // NOTE: the sum is carried in double; its grouping (pieces x waves here, 4 waves in the small kernel) does not show in the fp32
+        // centroids the host forms from it
+        double t = 0.0;
+        for (int p = 0; p < kBigPieces; ++p) t += sc.sums[p][tid - 8];
         seg_sums[(size_t)s * 3 + (tid - 8)] = t;
     }
     __syncthreads();
-    // 2. keys + histogram of the top 12 bits
+    int i0, i1;
+    piece_range(n, piece, i0, i1);
 #pragma unroll 4
-    for (int i = tid; i < n; i += kBigBlock) {
+    for (int i = i0 + tid; i < i1; i += kPieceBlock) {
         const float* r = data + (size_t)seg_points[lo + i] * 6;
         const unsigned int m = morton30(r, bx);
         keysA[lo + i] = ((unsigned long long)m << 32) | (unsigned int)i;
-        atomicAdd(&hist[m >> 18], 1);
+        atomicAdd(&sc.hist[m >> 18], 1);
     }
+}
+
+// launch 3: exclusive scan of the 4096 counts (every piece for itself: 16 KB out of L2; piece 0 publishes the cells' first positions), then
+// the piece's keys go to their cells
+__device__ __forceinline__ void bigseg_scatter_body(const int32_t* __restrict__ seg_off, unsigned long long* __restrict__ keysA,
+                                                    unsigned long long* __restrict__ keysB, int N, int s, int piece) {
+    const int lo = seg_off[s], n = seg_off[s + 1] - lo;
+    if (n <= kSortCap) return;
+    BigScratch& sc = bigseg_scratch(keysA, N, lo);
+    __shared__ int first[kBins];
+    __shared__ int wsum[kPieceBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kPer = kBins / kPieceBlock;                   // 16 consecutive cells per thread
+    int c[kPer], sum = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) { c[u] = sc.hist[kPer * tid + u]; sum += c[u]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    // 3. exclusive scan of the 4096 counts (4 per thread), scatter cursors
-    {
-        int c[4], sum = 0;
+    int off = incl - sum;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { c[u] = hist[4 * tid + u]; sum += c[u]; }
-        int incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-        __shared__ int wsum[kW];
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        int off = base + incl - sum;
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { hist[4 * tid + u] = off; first[4 * tid + u] = off; off += c[u]; }      // first position of every cell
-    }
+    for (int u = 0; u < kPer; ++u) { first[kPer * tid + u] = off; if (piece == 0) sc.first[kPer * tid + u] = off; off += c[u]; }
     __syncthreads();
+    int i0, i1;
+    piece_range(n, piece, i0, i1);
 #pragma unroll 4
-    for (int i = tid; i < n; i += kBigBlock) {
+    for (int i = i0 + tid; i < i1; i += kPieceBlock) {
         const unsigned long long k = keysA[lo + i];
-        const int pos = atomicAdd(&hist[(unsigned int)(k >> 32) >> 18], 1);
+        const unsigned int cell = (unsigned int)(k >> 32) >> 18;
+        const int pos = first[cell] + atomicAdd(&sc.cursor[cell], 1);
         keysB[lo + pos] = k;
     }
-    __syncthreads();                                           // every read of keysA[lo ..] is done: its head now holds the cell table
-    int* cells = reinterpret_cast<int*>(keysA + lo);
-    for (int i = tid; i < kBins; i += kBigBlock) cells[i] = first[i];
 }
 
 // the segment that holds position p of the sorted CSR (seg_off ascending, seg_off[S] = N; empty segments are skipped by the upper bound)
@@ -302,7 +357,7 @@ __device__ __forceinline__ void bigseg_runs_body(const int32_t* __restrict__ seg
         if (pass == 1 && sb == sa) break;
         const int lo = seg_off[s], n = seg_off[s + 1] - lo;
         if (n <= kSortCap) continue;                             // block-uniform
-        const int* cells = reinterpret_cast<const int*>(keysA + lo);
+        const int* cells = bigseg_scratch(const_cast<unsigned long long*>(keysA), N, lo).first;
         const int b0 = first_cell_at_or_behind(cells, max(w0 - lo, 0));
         const int h0 = b0 < kBins ? cells[b0] : n;
         if (h0 >= n || lo + h0 >= w1) continue;                  // no cell starts in this window
@@ -366,10 +421,18 @@ __device__ __forceinline__ void bigseg_boxes_body(const float* __restrict__ data
     }
 }
 
-__global__ __launch_bounds__(kBigBlock) void k_bigseg_bucket(const float* __restrict__ data, const int32_t* __restrict__ seg_points,
-                                                             const int32_t* __restrict__ seg_off, float* __restrict__ segbox, double* __restrict__ seg_sums,
-                                                             unsigned long long* __restrict__ keysA, unsigned long long* __restrict__ keysB) {
-    bigseg_bucket_body(data, seg_points, seg_off, segbox, seg_sums, keysA, keysB, blockIdx.x);
+// grid (segments, kBigPieces): a block is one piece of one segment (small segments exit at once)
+__global__ __launch_bounds__(kPieceBlock) void k_bigseg_box(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
+                                                            unsigned long long* __restrict__ keysA, int N) {
+    bigseg_box_body(data, seg_points, seg_off, keysA, N, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(kPieceBlock) void k_bigseg_keys(const float* __restrict__ data, const int32_t* __restrict__ seg_points, const int32_t* __restrict__ seg_off,
+                                                             float* __restrict__ segbox, double* __restrict__ seg_sums, unsigned long long* __restrict__ keysA, int N) {
+    bigseg_keys_body(data, seg_points, seg_off, segbox, seg_sums, keysA, N, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(kPieceBlock) void k_bigseg_scatter(const int32_t* __restrict__ seg_off, unsigned long long* __restrict__ keysA,
+                                                                unsigned long long* __restrict__ keysB, int N) {
+    bigseg_scatter_body(seg_off, keysA, keysB, N, blockIdx.x, blockIdx.y);
 }
 __global__ __launch_bounds__(kBigBlock) void k_bigseg_runs(const int32_t* __restrict__ seg_off, int S, int N, const unsigned long long* __restrict__ keysA,
                                                            const unsigned long long* __restrict__ keysB, int32_t* __restrict__ sperm) {
@@ -380,10 +443,24 @@ __global__ __launch_bounds__(512) void k_bigseg_boxes(const float* __restrict__ 
                                                       float* __restrict__ chunk_box) {
     bigseg_boxes_body(data, seg_points, seg_off, S, N, seg_chunk_off, sperm, chunk_box, blockIdx.x);
 }
-__global__ __launch_bounds__(kBigBlock) void k_bigseg_bucket_b(const sg::SlotCtx* __restrict__ cx) {
+// batched: grid (big segment of the host's list x piece, scene)
+__global__ __launch_bounds__(kPieceBlock) void k_bigseg_box_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
-    if ((int)blockIdx.x >= c.n_big) return;                      // the host's list of segments beyond kSortCap points
-    bigseg_bucket_body(c.data, c.seg_points, c.seg_off, c.segbox, c.seg_sums, c.sort_keys, c.sort_keys + c.N, c.big_segs[blockIdx.x]);
+    const int b = blockIdx.x / kBigPieces;
+    if (b >= c.n_big) return;                                    // the host's list of segments beyond kSortCap points
+    bigseg_box_body(c.data, c.seg_points, c.seg_off, c.sort_keys, c.N, c.big_segs[b], blockIdx.x % kBigPieces);
+}
+__global__ __launch_bounds__(kPieceBlock) void k_bigseg_keys_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    const int b = blockIdx.x / kBigPieces;
+    if (b >= c.n_big) return;
+    bigseg_keys_body(c.data, c.seg_points, c.seg_off, c.segbox, c.seg_sums, c.sort_keys, c.N, c.big_segs[b], blockIdx.x % kBigPieces);
+}
+__global__ __launch_bounds__(kPieceBlock) void k_bigseg_scatter_b(const sg::SlotCtx* __restrict__ cx) {
+    const sg::SlotCtx& c = cx[blockIdx.y];
+    const int b = blockIdx.x / kBigPieces;
+    if (b >= c.n_big) return;
+    bigseg_scatter_body(c.seg_off, c.sort_keys, c.sort_keys + c.N, c.N, c.big_segs[b], blockIdx.x % kBigPieces);
 }
 __global__ __launch_bounds__(kBigBlock) void k_bigseg_runs_b(const sg::SlotCtx* __restrict__ cx) {
     const sg::SlotCtx& c = cx[blockIdx.y];
@@ -1258,7 +1335,9 @@ int b_sort_boxes(const SlotCtx* d_ctx, const BatchDims& bd, hipStream_t st, int 
     if (which & 1) k_segment_sort_boxes_b<<<dim3(bd.max_S, bd.nslots), 256, 0, st>>>(d_ctx);
     if ((which & 2) && bd.max_big > 0) {                                       // windows without a big segment exit at once
         const int wins = sg::cdiv(bd.max_N, kWin);
-        k_bigseg_bucket_b<<<dim3(bd.max_big, bd.nslots), kBigBlock, 0, st>>>(d_ctx);
+        k_bigseg_box_b<<<dim3(bd.max_big * kBigPieces, bd.nslots), kPieceBlock, 0, st>>>(d_ctx);
+        k_bigseg_keys_b<<<dim3(bd.max_big * kBigPieces, bd.nslots), kPieceBlock, 0, st>>>(d_ctx);
+        k_bigseg_scatter_b<<<dim3(bd.max_big * kBigPieces, bd.nslots), kPieceBlock, 0, st>>>(d_ctx);
         k_bigseg_runs_b<<<dim3(wins, bd.nslots), kBigBlock, 0, st>>>(d_ctx);
         k_bigseg_boxes_b<<<dim3(wins, bd.nslots), 512, 0, st>>>(d_ctx);
     }
@@ -1329,7 +1408,8 @@ int sg_debug_knn_check(unsigned long long* h_out) {
 }
 #endif
 
-size_t sg_segment_sort_ws_bytes(int N) { return (size_t)std::max(N, 1) * 16; }   // two N-key scratch arrays of k_bigseg_sort_boxes
+// two N-key arrays + one BigScratch record per possible big segment (k_bigseg_box / keys / scatter)
+size_t sg_segment_sort_ws_bytes(int N) { return sg::align_up((size_t)std::max(N, 1) * 16, 64) + bigseg_scratch_slots(std::max(N, 1)) * sizeof(BigScratch) + 64; }
 
 int sg_layer_layout(const float* d_data, int N, const int32_t* d_seg_points, const int32_t* d_seg_off, const int32_t* d_sperm, int S,
                     const int32_t* d_order, const int32_t* d_dst, const int32_t* d_cl, const float* d_cl_mean, int32_t* d_members,
@@ -1356,7 +1436,9 @@ int sg_segment_sort_boxes(const float* d_data, int N, const int32_t* d_seg_point
         if (!d_ws || ws_bytes < sg_segment_sort_ws_bytes(N)) return sg::fail(SG_ENOMEM, "sg_segment_sort_boxes: workspace too small (%zu < %zu)", ws_bytes, sg_segment_sort_ws_bytes(N));
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(d_ws);
         const int wins = sg::cdiv(N, kWin);
-        k_bigseg_bucket<<<S, kBigBlock, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_segbox, d_seg_sums, keys, keys + N);
+        k_bigseg_box<<<dim3(S, kBigPieces), kPieceBlock, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, keys, N);
+        k_bigseg_keys<<<dim3(S, kBigPieces), kPieceBlock, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, d_segbox, d_seg_sums, keys, N);
+        k_bigseg_scatter<<<dim3(S, kBigPieces), kPieceBlock, 0, sg::as_stream(stream)>>>(d_seg_off, keys, keys + N, N);
         k_bigseg_runs<<<wins, kBigBlock, 0, sg::as_stream(stream)>>>(d_seg_off, S, N, keys, keys + N, d_sperm);
         k_bigseg_boxes<<<wins, 512, 0, sg::as_stream(stream)>>>(d_data, d_seg_points, d_seg_off, S, N, d_seg_chunk_off, d_sperm, d_chunk_box);
     }
