@@ -319,3 +319,32 @@ def test_run_infer_log_equals_the_reference_transcript(tmp_path, golden_index, w
     head = text[:at].splitlines()
     assert "Network parameters: %d" % meta[mode]["network_parameters"] in head                 # infer.py:92
     assert any(l.startswith("Load model from ") and l.endswith("checkpoints/exp/models/last.t7") for l in head)      # infer.py:119
+
+
+def test_configs3_full_size_1201_scenes_over_eight_ranks(tmp_path):
+    """BASELINE.json configs[3] AT FULL SIZE on the hardware a test box has: the 1,201-scene set (150k points / 1.5k segments each, seeds 40000 + i) sharded `i mod 8`
+    over EIGHT ranks of `bench.py` as the round-end driver launches it (torch.distributed.run; gloo rendezvous, all ranks on cuda:0, each with its own engine), against the
+    same set on one rank: the all-reduced pseudo-label mIoU over the 1,201 scenes is the same number, every rank's parity check (8 scenes of its last batch against the
+    single pipeline) is green, the communicator saw eight ranks.  The scenes are generated once into a cache both runs read."""
+    import json
+    import subprocess
+    cache = str(tmp_path / "scenes")
+    common = ["--scenes-total", "1201", "--steps", "1", "--warmup", "0", "--repeats", "1", "--no-cpu-baseline", "--no-files", "--no-extras", "--batch", "64",
+              "--parity-scenes", "8", "--no-oos", "--scene-cache", cache]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "gloo", "--gen-workers", "48"] + common, capture_output=True, text=True, timeout=1500,
+                         env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    assert len(os.listdir(cache)) == 1201
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    eight = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                            os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--groups", "4", "--gen-workers", "6"] + common,
+                           capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert eight.returncode == 0, eight.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j8 = json.loads([l for l in eight.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["scaling"] == j8["scaling"] == "strong" and j8["n_gpus"] == 8 and "1201 distinct synthetic scenes" in j8["config"]["workload"]
+    assert j1["parity_check"]["ranks_equal"] and j8["parity_check"]["ranks_equal"]
+    assert j8["comm"]["world_size"] == 8 and j8["comm"]["allreduce_of_ones"] == 8.0
+    assert j1["pseudo_label_mIoU"]["scenes"] == j8["pseudo_label_mIoU"]["scenes"] == 1201
+    assert j1["pseudo_label_mIoU"]["semantic"] == j8["pseudo_label_mIoU"]["semantic"] and j1["pseudo_label_mIoU"]["instance"] == j8["pseudo_label_mIoU"]["instance"]
