@@ -371,6 +371,10 @@ class Engine:
     def set_knn_variant(self, variant: int) -> int:
         return self.lib.sg_engine_set_knn_variant(self.handle, int(variant))
 
+    def set_timing(self, level: int) -> int:
+        """0 = no stage events, 1 = a handful of HIP events per batched launch sequence (mean_stage_ms); returns the previous level."""
+        return self.lib.sg_engine_set_timing(self.handle, int(level))
+
     def mean_stage_ms(self) -> Dict[str, float]:
         """Device time per stage and SCENE: the duration of every batched launch divided by the scenes it covered."""
         buf = (C.c_double * 32)()
