@@ -12,9 +12,13 @@
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
+#include <fcntl.h>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
 
@@ -25,27 +29,59 @@ namespace {
 struct Err { std::string msg; };
 #define PB_FAIL(...) do { char b__[512]; snprintf(b__, sizeof b__, __VA_ARGS__); throw Err{b__}; } while (0)
 
-std::string slurp(const std::string& path) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) PB_FAIL("cannot open %s: %s", path.c_str(), strerror(errno));
-    std::string out;
-    if (fseek(f, 0, SEEK_END) == 0) {
-        const long n = ftell(f);
-        rewind(f);
-        if (n > 0) { out.resize((size_t)n); if (fread(&out[0], 1, (size_t)n, f) != (size_t)n) { fclose(f); PB_FAIL("short read of %s", path.c_str()); } }
+// A source file, memory-mapped read-only (round 6: fread into a zero-filled std::string was a 19 MB fill + a 19 MB copy per scene on top of the one
+// read the conversions and the pack write do anyway; the build is memory-bound once it runs on every core).  The subset of std::string's interface
+// the parsers below use.
+struct Buf {
+    const char* p = nullptr;
+    size_t n = 0;
+    bool mapped = false;
+    std::string own;
+    Buf() = default;
+    Buf(const Buf&) = delete;
+    Buf& operator=(const Buf&) = delete;
+    ~Buf() { if (mapped && p) munmap(const_cast<char*>(p), n); }
+    size_t size() const { return n; }
+    const char* data() const { return p; }
+    char operator[](size_t at) const { return p[at]; }
+    std::string substr(size_t at, size_t len) const { return std::string(p + at, len); }
+    size_t find(char c, size_t from) const {
+        if (from >= n) return std::string::npos;
+        const void* q = memchr(p + from, c, n - from);
+        return q ? (size_t)(static_cast<const char*>(q) - p) : std::string::npos;
     }
-    fclose(f);
-    return out;
+};
+
+std::shared_ptr<Buf> slurp(const std::string& path) {
+    auto b = std::make_shared<Buf>();
+    const int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) PB_FAIL("cannot open %s: %s", path.c_str(), strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 0) { close(fd); PB_FAIL("cannot size %s", path.c_str()); }
+    b->n = (size_t)st.st_size;
+    if (b->n) {
+        void* m = mmap(nullptr, b->n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) { b->p = static_cast<const char*>(m); b->mapped = true; }
+        else {                                               // a file system without mmap: read it
+            b->own.resize(b->n);
+            size_t got = 0;
+            while (got < b->n) { const ssize_t r = read(fd, &b->own[got], b->n - got); if (r <= 0) break; got += (size_t)r; }
+            if (got != b->n) { close(fd); PB_FAIL("short read of %s", path.c_str()); }
+            b->p = b->own.data();
+        }
+    }
+    close(fd);
+    return b;
 }
 
-inline uint16_t rd16(const std::string& b, size_t at) { if (at + 2 > b.size()) PB_FAIL("zip: read past the end"); return (uint16_t)((uint8_t)b[at] | ((uint8_t)b[at + 1] << 8)); }
-inline uint32_t rd32(const std::string& b, size_t at) { if (at + 4 > b.size()) PB_FAIL("zip: read past the end"); uint32_t v; memcpy(&v, b.data() + at, 4); return v; }
-inline uint64_t rd64(const std::string& b, size_t at) { if (at + 8 > b.size()) PB_FAIL("zip: read past the end"); uint64_t v; memcpy(&v, b.data() + at, 8); return v; }
+inline uint16_t rd16(const Buf& b, size_t at) { if (at + 2 > b.size()) PB_FAIL("zip: read past the end"); return (uint16_t)((uint8_t)b[at] | ((uint8_t)b[at + 1] << 8)); }
+inline uint32_t rd32(const Buf& b, size_t at) { if (at + 4 > b.size()) PB_FAIL("zip: read past the end"); uint32_t v; memcpy(&v, b.data() + at, 4); return v; }
+inline uint64_t rd64(const Buf& b, size_t at) { if (at + 8 > b.size()) PB_FAIL("zip: read past the end"); uint64_t v; memcpy(&v, b.data() + at, 8); return v; }
 
 struct Member { size_t data_at = 0, size = 0; };
 
 // name -> (offset of the member's bytes, size) for every STORED member of a zip archive held in `b`
-std::map<std::string, Member> zip_members(const std::string& b, const std::string& path) {
+std::map<std::string, Member> zip_members(const Buf& b, const std::string& path) {
     if (b.size() < 22) PB_FAIL("%s: not a zip archive", path.c_str());
     size_t eocd = std::string::npos;
     for (size_t at = b.size() - 22, stop = b.size() > 65557 ? b.size() - 65557 : 0;; --at) {
@@ -95,7 +131,7 @@ struct Val {
 struct Tensor {
     char type = 0; int item = 0;
     std::vector<long long> shape;
-    std::string file;                    // the archive's bytes (kept alive: a contiguous tensor is a view into them)
+    std::shared_ptr<Buf> file;           // the archive's bytes (kept alive: a contiguous tensor is a view into them)
     std::string own;                     // ... or the gathered copy of a strided view
     const char* data = nullptr;          // contiguous, little endian
     long long numel() const { long long n = 1; for (long long v : shape) n *= v; return n; }
@@ -118,7 +154,7 @@ std::vector<long long> ints_of(const Val& t) {
     return out;
 }
 
-Val unpickle(const std::string& b, size_t at, size_t end) {
+Val unpickle(const Buf& b, size_t at, size_t end) {
     std::vector<Val> st;
     std::map<long long, Val> memo;
     auto need = [&](size_t n) { if (at + n > end) PB_FAIL("pickle: truncated"); };
@@ -178,7 +214,7 @@ Val unpickle(const std::string& b, size_t at, size_t end) {
 Tensor read_pth(const std::string& path) {
     Tensor out;
     out.file = slurp(path);
-    const std::string& b = out.file;
+    const Buf& b = *out.file;
     const auto members = zip_members(b, path);
     std::string prefix;
     int found = 0;
