@@ -279,6 +279,10 @@ __device__ __forceinline__ void bigseg_keys_body(const float* __restrict__ data,
         for (int p = 0; p < kBigPieces; ++p) t += sc.sums[p][tid - 8];
         seg_sums[(size_t)s * 3 + (tid - 8)] = t;
     }
+    // the piece's cell counts in LDS first: a floor's points share a few hundred of the 4,096 cells, and one global atomic per POINT made this launch
+    // (and the scatter) wait on ~150 atomics per address; now one per (piece, occupied cell)
+    __shared__ int lh[kBins];
+    for (int b = tid; b < kBins; b += kPieceBlock) lh[b] = 0;
     __syncthreads();
     int i0, i1;
     piece_range(n, piece, i0, i1);
@@ -287,7 +291,12 @@ __device__ __forceinline__ void bigseg_keys_body(const float* __restrict__ data,
         const float* r = data + (size_t)seg_points[lo + i] * 6;
         const unsigned int m = morton30(r, bx);
         keysA[lo + i] = ((unsigned long long)m << 32) | (unsigned int)i;
-        atomicAdd(&sc.hist[m >> 18], 1);
+        atomicAdd(&lh[m >> 18], 1);
+    }
+    __syncthreads();
+    for (int b = tid; b < kBins; b += kPieceBlock) {
+        const int c = lh[b];
+        if (c) atomicAdd(&sc.hist[b], c);
     }
 }
 
@@ -314,15 +323,26 @@ __device__ __forceinline__ void bigseg_scatter_body(const int32_t* __restrict__ 
     for (int w = 0; w < wave; ++w) off += wsum[w];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) { first[kPer * tid + u] = off; if (piece == 0) sc.first[kPer * tid + u] = off; off += c[u]; }
+    // the piece reserves its keys' places cell by cell (one global atomic per occupied cell: see k_bigseg_keys), then hands them out from LDS
+    __shared__ int lh[kBins];
+    for (int b = tid; b < kBins; b += kPieceBlock) lh[b] = 0;
     __syncthreads();
     int i0, i1;
     piece_range(n, piece, i0, i1);
 #pragma unroll 4
+    for (int i = i0 + tid; i < i1; i += kPieceBlock) atomicAdd(&lh[(unsigned int)(keysA[lo + i] >> 32) >> 18], 1);
+    __syncthreads();
+    for (int b = tid; b < kBins; b += kPieceBlock) {
+        const int c = lh[b];
+        if (c) first[b] += atomicAdd(&sc.cursor[b], c);          // first[b] = where THIS piece's keys of cell b start
+        lh[b] = 0;
+    }
+    __syncthreads();
+#pragma unroll 4
     for (int i = i0 + tid; i < i1; i += kPieceBlock) {
         const unsigned long long k = keysA[lo + i];
         const unsigned int cell = (unsigned int)(k >> 32) >> 18;
-        const int pos = first[cell] + atomicAdd(&sc.cursor[cell], 1);
-        keysB[lo + pos] = k;
+        keysB[lo + first[cell] + atomicAdd(&lh[cell], 1)] = k;
     }
 }
 
