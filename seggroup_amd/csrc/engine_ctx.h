@@ -43,7 +43,7 @@ struct SlotCtx {
     // ---- once per scene: Morton order inside segments, chunk boxes, segment sums ----
     const int32_t* seg_chunk_off;      // [S+1] (params block)
     // the segments of the two larger size classes, listed by the host (params block): a launch over ALL segments dispatched ~12,000 workgroups of
-    // 1,024 threads per batch for the ~60 that had work (k_bigseg_bucket_b 183 us against 88 us for the same segments one scene at a time)
+    // 1,024 threads per batch for the ~60 that had work (round 5's k_bigseg_bucket_b: 183 us against 88 us for the same segments one scene at a time)
     const int32_t* mid_segs;           // segments of 513-2,048 points (FPS on four waves)
     const int32_t* big_segs;           // segments beyond 2,048 points (sixteen-wave FPS, cell-bucketed Morton sort)
     int n_mid, n_big;

@@ -170,9 +170,9 @@ __global__ __launch_bounds__(256) void k_segment_sort_boxes_b(const sg::SlotCtx*
 // Segments of more than kSortCap points (floors, walls: 10k-40k points in ScanNet's over-segmentation) -- same outputs, same order
 // (ascending (morton30, index)), no library sort.  Round 5: three launches instead of one block per segment doing everything
 // (a 29k-point floor kept one workgroup busy for a millisecond: a serial run table by one thread and ~20 LDS sorts one after another):
-//   k_bigseg_bucket (one 1024-thread block per big segment; the others exit at once):  box + coordinate sums; keys into global scratch + LDS
-//       histogram of the TOP 12 Morton bits (16^3 cells); scan; scatter into cell order (keysB); the cells' first positions go to global
-//       memory (into the keysA range of the segment, which the scatter has finished reading: 4,096 ints <= 8 n bytes for n > 2,048);
+//   k_bigseg_box / k_bigseg_keys / k_bigseg_scatter (round 6; round 5: one 1024-thread block per big segment did all three):  box + coordinate sums;
+//       keys into global scratch + histogram of the TOP 12 Morton bits (16^3 cells); scan; scatter into cell order (keysB); the cells' first positions
+//       go to the segment's scratch record (BigScratch below);
 //   k_bigseg_runs (one block per window of kWin = 1,024 positions of the scene's sorted CSR):  the RUN that starts in the window -- from the
 //       first cell that starts in it to the first cell that starts in a later window: whole cells, <= kWin + the last cell's size - 1 keys
 //       -- is sorted in LDS by the full 64-bit key (cells are already in order, so the concatenation of the runs is the total order) and
