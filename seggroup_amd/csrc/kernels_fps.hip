@@ -22,6 +22,10 @@ namespace {
 constexpr int kLdsCap = 8192;        // entries of the LDS carve (16 B each): the chunk-pruned path's per-chunk records, the fallback's points
 constexpr int kSmallMax = sg::kSegSmallMax;       // clusters up to this size run on a single wave (eight points per lane in registers)
 constexpr int kMidMax = sg::kSegMidMax;        // ... up to this size on four waves, beyond on sixteen
+#ifndef SG_FPS_FOUR
+#define SG_FPS_FOUR 256
+#endif
+constexpr int kFourInFlight = SG_FPS_FOUR;
 constexpr int kChunkCap = 2600;      // chunks of a segment whose per-chunk records (52 B) fit the LDS carve of the chunk-pruned path
 
 struct Best {
@@ -348,8 +352,9 @@ __device__ __forceinline__ void fps_sample_body(const float* __restrict__ data, 
                     const int nw = wl_n;
                     // both halves of a wave must run visit() together (its reductions are wave-wide DPP networks): an odd tail
                     // revisits the last listed chunk, which changes nothing
-                    // (long lists -- the first steps touch most of the segment -- four chunks per half wave in flight, short ones two or one)
-                    if (nw > 256) {
+                    // (long lists -- the first steps touch most of the segment -- four chunks per half wave in flight, short ones two or one;
+                    // SG_FPS_FOUR: the list length from which four are in flight: a build-time knob, 256 since round 5)
+                    if (nw > kFourInFlight) {
                         for (int e = 2 * wave; e < nw; e += 128) {
                             const int chs[4] = {wl[min(e + half, nw - 1)], wl[min(e + 32 + half, nw - 1)], wl[min(e + 64 + half, nw - 1)], wl[min(e + 96 + half, nw - 1)]};
                             visit(std::integral_constant<int, 4>{}, chs, qx, qy, qz, false);
