@@ -430,7 +430,11 @@ def main(argv=None):
         mean_ms = runner.mean_stage_ms()
         runner.set_timing(0)
     vec = reduce_accumulators(np.concatenate([acc["iou_sem"], acc["iou_ins"], acc["acc"], [acc["n"]]]), world, args.backend, dev)
-    comm = comm_probe(world, args.backend, dev)
+    # What the collective layer saw.  With ranks (a process group exists since start-up) every rank takes part here.  At N = 1 the probe has to
+    # BUILD a communicator -- and a process that has initialised RCCL runs its later legs a few per cent slower (round 6: the ScanNet-shaped leg
+    # 0.91-0.93 of the headline behind the probe, 0.945-0.95 in runs that timed it in front; single scene 1.61 against 1.50 ms), as a high-priority
+    # stream merely created does -- so there it runs LAST, behind every measured leg.
+    comm = comm_probe(world, args.backend, dev) if world > 1 else None
 
     # ---- parity of the concurrent path: EVERY scene of the LAST timed batch vs a single default-stream pipeline ----
     solo = Pipeline(W, *caps, stream=None, device=dev)
@@ -773,6 +777,8 @@ def main(argv=None):
                              f"cluster trace equals the HIP path: {same}",
                    "anchor_check": anchor}
 
+        if comm is None:
+            comm = comm_probe(world, args.backend, dev)               # N = 1: behind every measured leg (see above)
         I_s, U_s = vec[:40], vec[40:80]
         I_i, U_i = vec[80:120], vec[120:160]
         with np.errstate(divide="ignore", invalid="ignore"):
