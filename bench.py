@@ -431,9 +431,8 @@ def main(argv=None):
         runner.set_timing(0)
     vec = reduce_accumulators(np.concatenate([acc["iou_sem"], acc["iou_ins"], acc["acc"], [acc["n"]]]), world, args.backend, dev)
     # What the collective layer saw.  With ranks (a process group exists since start-up) every rank takes part here.  At N = 1 the probe has to
-    # BUILD a communicator -- and a process that has initialised RCCL runs its later legs a few per cent slower (round 6: the ScanNet-shaped leg
-    # 0.91-0.93 of the headline behind the probe, 0.945-0.95 in runs that timed it in front; single scene 1.61 against 1.50 ms), as a high-priority
-    # stream merely created does -- so there it runs LAST, behind every measured leg.
+    # BUILD (and remove) a communicator; it runs LAST there, behind every measured leg, so that no leg's number can depend on it (a precaution:
+    # an A / B of the timed region with a communicator built up front showed no difference).
     comm = comm_probe(world, args.backend, dev) if world > 1 else None
 
     # ---- parity of the concurrent path: EVERY scene of the LAST timed batch vs a single default-stream pipeline ----
