@@ -303,7 +303,10 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
         # ... and how large an engine this rank's scenes need: it is created below WHILE the loader reads the first batches (it used to be
         # sized by the first batch once that had arrived: ~0.1 s of 124 MB device slots allocated with nothing beside them)
         all_caps = tuple(max(d[k] for d in dims) for k in ('N', 'S', 'E0', 'V')) if dims else None
-        n_load = int(os.environ.get('SG_LOADER_THREADS', '0')) or min(6 if 'txt' not in formats else 8, workers)
+        # Round 6 sweep (tools/sweep_driver.py, 2,048 scenes on tmpfs, two boxes): 4 loader threads 1,895-1,930 scenes/s steady, 6 (the old default)
+        # 1,824-1,852, 8 -- on a slower box -- 1,092 against 1,610-1,694 for 4-6: every further thread is another pack read + bulk upload competing
+        # with the engine's own transfers; with `.txt` output 3-4 threads 1,478-1,488 against 1,445-1,466 for 8
+        n_load = int(os.environ.get('SG_LOADER_THREADS', '0')) or min(4, workers)
         loader = cache.PackLoader(threads=n_load, slots=4 * max(args.batch, 1), slot_bytes=slot_bytes, device=dev,
                                   max_edges=max_edges)
 
