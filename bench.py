@@ -114,6 +114,8 @@ def parse_args(argv=None):
     ap.add_argument("--parity-scenes", type=int, default=64, help="scenes of the last batch re-run on a single pipeline and compared (default: all 64); 0 = no parity legs at all "
                                                                   "(profiled runs: the out-of-step leg launches the batched kernels with ONE scene each, which dilutes per-launch profile averages)")
     ap.add_argument("--no-oos", action="store_true", help="skip the out-of-step parity leg (16 groups x 1 scene) only")
+    ap.add_argument("--label-transfer", default="full", choices=["full", "tables"], help="full = the 14 label vectors of every scene cross PCIe inside the timed region (what SegModel.forward "
+                                                                                         "returns: the metric's definition); tables = only the [14,S] tables do (an EXPERIMENT: what the label copies cost the engine)")
     ap.add_argument("--engine-timing", type=int, default=1, choices=[0, 1], help="1 = the engine records its stage events (~24 per group super-step) INSIDE the timed region too "
                                                                                    "(stage_ms_in_timed_region); 0 = none there, and the stage times under load come from an extra untimed pass")
     ap.add_argument("--profile", action="store_true", help="roctx ranges around the bench's legs and, inside the engine's group threads, around every phase and stage "
@@ -356,7 +358,7 @@ def main(argv=None):
     every = scenes + extra_scenes + strong_scenes
     caps = (max(s.N for s in every), max(s.S for s in every), max(s.E0 for s in every), max(s.V for s in every))
     # stage timing: a handful of HIP events per batched launch sequence (per group of scenes, not per scene)
-    runner = Engine(W, caps, groups=args.groups, per_group=args.per_group, device=dev, timing=args.engine_timing)
+    runner = Engine(W, caps, groups=args.groups, per_group=args.per_group, device=dev, timing=args.engine_timing, label_transfer=args.label_transfer)
     acc = {"iou_sem": np.zeros(80), "iou_ins": np.zeros(80), "acc": np.zeros(4), "n": 0}
     batches = [scenes[k:k + args.batch] for k in range(0, len(scenes), args.batch)]
 

@@ -810,6 +810,11 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
     if (!par.ok || !box.ok) return sg::fail(SG_ENOMEM, "engine: the export phase exceeds the group's parameter / outbox arena");
     for (int i = 0; i < n; ++i) h_ctx[i] = runs_[i].ctx;
     EG_CHECK(arena_copy(par.d, par.h, par.used, true));
+    static const bool want_sdma = !(getenv("SG_ENGINE_LABEL_COPY") && std::string(getenv("SG_ENGINE_LABEL_COPY")) == "hip");
+    const bool label_sdma = want_sdma && sg::sdma_available();
+    std::vector<void*> sd_dst;
+    std::vector<const void*> sd_src;
+    std::vector<size_t> sd_bytes;
     mark(-1);
     rg.next("END.export+evaluate");
     EG_CHECK(sg::b_export_eval(d_ctx, bd, stream));
@@ -819,7 +824,11 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
         const bool compact = eng->label_compact && r.sc->h_seg_of_vertex;
         if (!compact) {
             if (!r.out->h_labels) return sg::fail(SG_EINVAL, "sg_engine: results[].h_labels is null (and the compact label transfer is off, or the scene has no h_seg_of_vertex)");
-            EG_HIP(hipMemcpyAsync(r.out->h_labels, r.pl->labels.p, (size_t)r.n_tables * r.sc->V * 4, hipMemcpyDeviceToHost, stream));
+            // The label vectors (8.4 MB per 150k-vertex scene).  hipMemcpyAsync moves them with a blit KERNEL on this ROCm -- waves on the CUs waiting for
+            // PCIe, 6-7 % of the engine's throughput (sdma.cpp) -- so by default they go over the copy engines instead, behind the stream's sync below
+            // (SG_ENGINE_LABEL_COPY=hip restores the stream copy; it is also the fallback when the HSA path is not there or refuses a pointer)
+            if (label_sdma) { sd_dst.push_back(r.out->h_labels); sd_src.push_back(r.pl->labels.p); sd_bytes.push_back((size_t)r.n_tables * r.sc->V * 4); }
+            else EG_HIP(hipMemcpyAsync(r.out->h_labels, r.pl->labels.p, (size_t)r.n_tables * r.sc->V * 4, hipMemcpyDeviceToHost, stream));
         }
         if (r.out->h_tables) std::memcpy(r.out->h_tables, r.tab.data(), (size_t)r.n_tables * r.sc->S * 4);
     }
@@ -827,6 +836,16 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
     mark(18);
     rg.next("END.sync");
     EG_HIP(timed_sync(stream));
+    if (!sd_dst.empty()) {
+        rg.next("END.labels_sdma");
+        const long long t0 = g_profile ? now_ns() : 0;
+        if (sg::sdma_copy_d2h(sd_dst.data(), sd_src.data(), sd_bytes.data(), (int)sd_dst.size()) != SG_OK) {
+            sg::err_buf()[0] = 0;                                    // not an error of the scene: the stream copy does the same job
+            for (size_t i = 0; i < sd_dst.size(); ++i) EG_HIP(hipMemcpyAsync(sd_dst[i], sd_src[i], sd_bytes[i], hipMemcpyDeviceToHost, stream));
+            EG_HIP(timed_sync(stream));
+        }
+        if (g_profile) tl_ns_sync += now_ns() - t0;
+    }
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
         sg::eval_finish(r.o_cnt, r.max_ins, r.out->iou_sem, r.out->iou_ins, r.out->acc);

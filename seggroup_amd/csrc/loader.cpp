@@ -257,15 +257,25 @@ struct sg_loader {
         // engine's load -- and held inside the gate that wait capped the loader at 2 / 0.8 ms = 2,400 packs/s
         std::unique_ptr<CopyGate> gate(new CopyGate(this));
         lap(3);
+        sg::SdmaTicket sdma;
+        bool by_sdma = false;
         if (dry) {
             unsigned long long acc = 0;
             const unsigned long long* w = reinterpret_cast<const unsigned long long*>(pin);
             for (size_t i = 0; i < size / 8; ++i) acc += w[i];
             dry_sink += acc;
         } else {
+        // Round 6, SG_LOADER_COPY=sdma: the pack goes up through the HSA runtime's copy interface (sdma.cpp) instead of hipMemcpyAsync.  For the engine's
+        // label vectors (device -> host) that path is worth 6 % of the headline; for the uploads it measured +2-3 % (.npy: 1,894-1,928 against 1,840-1,875
+        // scenes/s steady) and nothing with .txt output -- not enough to make it the default (files byte-identical either way: tests/test_gpu_loader.py).
+        static const bool want_sdma = getenv("SG_LOADER_COPY") && std::string(getenv("SG_LOADER_COPY")) == "sdma";
+        if (want_sdma && sg::sdma_available() && sg::sdma_issue(sl.d_blob, pin, size, &sdma) == SG_OK) by_sdma = true;
+        else {
+        sg::err_buf()[0] = 0;
         if (hipMemcpyAsync(sl.d_blob, pin, size, hipMemcpyHostToDevice, st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
         if (hipEventRecord(ev, st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
-        if (adj32) {
+        }
+        if (adj32 && !by_sdma) {
             const size_t n2 = (size_t)E0 * 2;
             k_widen_adj<<<(unsigned)std::min<size_t>((n2 + 255) / 256, 1024), 256, 0, st>>>(reinterpret_cast<const int32_t*>(sl.d_blob + a[1].off),
                                                                                          reinterpret_cast<long long*>(sl.d_blob + wide_off), n2);
@@ -283,6 +293,15 @@ struct sg_loader {
             for (long long v = 0; v < V; ++v) { const int32_t p_ = um[v]; sl.seg_of_vertex[(size_t)v] = (p_ >= 0 && p_ < N) ? sop[p_] : -1; }
         }
         lap(5);
+        if (!dry && by_sdma) {
+            if (sg::sdma_wait(&sdma) != SG_OK) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed (copy engine)", j.path.c_str());
+            if (adj32) {                                             // the widening kernel reads what the copy engine has just written
+                const size_t n2 = (size_t)E0 * 2;
+                k_widen_adj<<<(unsigned)std::min<size_t>((n2 + 255) / 256, 1024), 256, 0, st>>>(reinterpret_cast<const int32_t*>(sl.d_blob + a[1].off),
+                                                                                             reinterpret_cast<long long*>(sl.d_blob + wide_off), n2);
+                if (hipGetLastError() != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: widening the adjacency of %s failed", j.path.c_str());
+            }
+        } else
         if (!dry && hipEventSynchronize(ev) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
         gate.reset();                                                // the pinned buffer has been read: the next worker's copy may start
         lap(7);

@@ -113,6 +113,13 @@ int transpose_square(const float* d_src, float* d_dst, int D, hipStream_t st);  
 // the engine's small per-phase transfers then do not queue behind bulk copies on the copy engines (engine.cpp).  16-byte aligned.
 int copy_by_kernel(void* dst, const void* src, size_t bytes, hipStream_t st);
 
+// device -> pinned-host copies on the copy engines through the HSA runtime (sdma.cpp); the caller falls back to hipMemcpyAsync on any failure
+bool sdma_available();
+int sdma_copy_d2h(void* const* dst, const void* const* src, const size_t* bytes, int n);
+struct SdmaTicket { unsigned long long signal = 0; };
+int sdma_issue(void* dst, const void* src, size_t bytes, SdmaTicket* t);     // one copy, either direction between device and pinned host memory
+int sdma_wait(SdmaTicket* t);
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
