@@ -886,3 +886,50 @@ def test_small_scenes_engine_equals_pipeline_in_every_group_shape(mode_name):
             assert not bad, f"engine {groups} x {per}, run {rep}: scenes whose results differ from the single pipeline's: {bad}"
         eng.close()
     torch.cuda.synchronize()
+
+
+_LABEL_COPY_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import bench
+from seggroup_amd import hip, synthetic, weights
+from seggroup_amd.model import Engine, Pipeline
+from seggroup_amd.scene import DeviceScene
+W = weights.load_npz(os.path.join(sys.argv[1], "tests", "golden", "weights_g2.npz"))
+host = [synthetic.make_scene(20000 + 2500 * i, 200 + 20 * i, 88000 + i, **({"dup_frac": 0.05, "raw_vertices": 26000 + 2500 * i} if i % 3 == 0 else {})) for i in range(12)]
+scenes = [DeviceScene.from_synthetic(h, device="cuda:0") for h in host]
+caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
+eng = Engine(W, caps, groups=3, per_group=4, device="cuda:0", timing=0)
+out = []
+for rep in range(3):
+    out.append([bench.label_digest(r) for r in eng.run(scenes, hip.MODE_INS_INFER)])
+eng.close()
+solo = Pipeline(W, *caps, device="cuda:0")
+want = [bench.label_digest(solo.forward(s, hip.MODE_INS_INFER)) for s in scenes]
+print("RESULT " + json.dumps({"runs": out, "pipeline": want}))
+"""
+
+
+def test_label_vectors_over_the_copy_engines_equal_the_stream_copy():
+    """Round 6: the engine's label vectors leave the device through the HSA runtime's copy interface (csrc/sdma.cpp: the copy engines, issued behind the
+    stream's sync) instead of hipMemcpyAsync, whose blit kernel cost the engine 6 % of its throughput.  Both ways -- the default and
+    SG_ENGINE_LABEL_COPY=hip, which is also the fallback -- must hand the host the same bytes as the single pipeline does: 12 ragged scenes (V != N among
+    them), three runs each (the label buffers are a ring: a copy that had not landed when the host read it would show as a stale digest)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    got = {}
+    for mode in ("sdma", "hip"):
+        env = dict(os.environ)
+        if mode == "hip":
+            env["SG_ENGINE_LABEL_COPY"] = "hip"
+        else:
+            env.pop("SG_ENGINE_LABEL_COPY", None)
+        r = subprocess.run([sys.executable, "-c", _LABEL_COPY_CHILD, ROOT], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for mode in got:
+        for run in got[mode]["runs"]:
+            assert run == got[mode]["pipeline"], mode
+    assert got["sdma"]["pipeline"] == got["hip"]["pipeline"]
