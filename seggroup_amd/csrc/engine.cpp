@@ -40,6 +40,7 @@ using sg::BatchDims;
 using sg::SlotCtx;
 
 constexpr int kMaxGroupEvents = 24;
+#define EG_CHECK_RET(call) do { int rc__ = (call); if (rc__ < 0) return rc__; } while (0)
 
 // SG_ENGINE_PROFILE=1: wall time of the group threads split into host work (grouping, descriptors, launch calls), time
 // blocked in hipStreamSynchronize and time idle waiting for work; printed by sg_engine_destroy -- a development aid
@@ -169,9 +170,37 @@ struct sg_engine {
         // hipMemcpyAsync: on the copy engines they queued behind whatever bulk transfers were in flight -- with the pack loader uploading
         // 13 MB scenes beside the engine, every phase of every group waited for a few of those (tools/exp_h2d_interference.py).
         // SG_ENGINE_COPY=sdma restores the copy-engine path.
+        // SG_ENGINE_COPY=hsa | hsa_par | hsa_box (experiment, round 6): the parameter block and / or the outbox through the HSA runtime's copy interface
+        // (sdma.cpp) -- the parameter block issued and waited for in front of the phase's launches, the outbox fetched BEHIND the phase's stream sync
+        static int hsa_mode() {
+            static const int m = [] { const char* e = getenv("SG_ENGINE_COPY"); const std::string v = e ? e : ""; return v == "hsa" ? 3 : v == "hsa_par" ? 1 : v == "hsa_box" ? 2 : 0; }();
+            return m;
+        }
+        int outbox_and_sync() {                                   // the phase's results on the host, the stream drained
+            if ((hsa_mode() & 2) && sg::sdma_available()) {
+                if (timed_sync(stream) != hipSuccess) return sg::fail(SG_EHIP, "engine: stream sync failed");
+                sg::SdmaTicket t;
+                const long long t0 = g_profile ? now_ns() : 0;
+                if (box.used && (sg::sdma_issue(box.h, box.d, (box.used + 15) / 16 * 16, &t) != SG_OK || sg::sdma_wait(&t) != SG_OK)) {
+                    sg::err_buf()[0] = 0;
+                    EG_CHECK_RET(sg::copy_by_kernel(box.h, box.d, (box.used + 15) / 16 * 16, stream));
+                    if (timed_sync(stream) != hipSuccess) return sg::fail(SG_EHIP, "engine: stream sync failed");
+                }
+                if (g_profile) tl_ns_sync += now_ns() - t0;
+                return SG_OK;
+            }
+            const int rc = arena_copy(box.h, box.d, box.used, false);
+            if (rc < 0) return rc;
+            return timed_sync(stream) == hipSuccess ? SG_OK : sg::fail(SG_EHIP, "engine: stream sync failed");
+        }
         int arena_copy(void* dst, const void* src, size_t bytes, bool to_device) {
             static const bool sdma = getenv("SG_ENGINE_COPY") && std::string(getenv("SG_ENGINE_COPY")) == "sdma";
             if (bytes == 0) return SG_OK;
+            if (to_device && (hsa_mode() & 1) && sg::sdma_available()) {
+                sg::SdmaTicket t;
+                if (sg::sdma_issue(dst, src, (bytes + 15) / 16 * 16, &t) == SG_OK && sg::sdma_wait(&t) == SG_OK) return SG_OK;
+                sg::err_buf()[0] = 0;
+            }
             if (sdma) {
                 if (hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, stream) != hipSuccess) return sg::fail(SG_EHIP, "engine: arena copy failed");
                 return SG_OK;
@@ -379,10 +408,9 @@ int sg_engine::Group::phase_p0(Run* runs_, int n, int mode) {
     mark(2);
     rg.next("P0.edge_distance");
     EG_CHECK(sg::b_edge_distance(d_ctx, bd, stream));
-    EG_CHECK(arena_copy(box.h, box.d, box.used, false));
     mark(3);
     rg.next("P0.sync");
-    EG_HIP(timed_sync(stream));
+    EG_CHECK(outbox_and_sync());
     rg.next("P0.host_grouping");
 
     // ---- host: layer 1 tables, structural grouping, layer 2 tables ----
@@ -662,7 +690,6 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     rg.next(layer == 0 ? "L2.gcn+edge_distance" : "L3.gcn+edge_distance");
     EG_CHECK(sg::b_gcn(d_ctx, bd, 0.125f, stream));
     EG_CHECK(sg::b_edge_distance(d_ctx, bd, stream));
-    EG_CHECK(arena_copy(box.h, box.d, box.used, false));
     for (int i = 0; i < n; ++i) {
         Run& r = runs_[i];
         if (!r.dist_in_outbox) {
@@ -671,7 +698,7 @@ int sg_engine::Group::phase_layer(Run* runs_, int n, int layer) {
     }
     mark(sb + 5);
     rg.next(layer == 0 ? "L2.sync" : "L3.sync");
-    EG_HIP(timed_sync(stream));
+    EG_CHECK(outbox_and_sync());
     rg.next(layer == 0 ? "L2.host_grouping" : "L3.host_grouping");
 
     // ---- host: grouping on the GCN features (model.py:802-815 / 843-856) ----
@@ -832,10 +859,9 @@ int sg_engine::Group::phase_end(Run* runs_, int n, int mode) {
         }
         if (r.out->h_tables) std::memcpy(r.out->h_tables, r.tab.data(), (size_t)r.n_tables * r.sc->S * 4);
     }
-    EG_CHECK(arena_copy(box.h, box.d, box.used, false));
     mark(18);
     rg.next("END.sync");
-    EG_HIP(timed_sync(stream));
+    EG_CHECK(outbox_and_sync());
     if (!sd_dst.empty()) {
         rg.next("END.labels_sdma");
         const long long t0 = g_profile ? now_ns() : 0;
