@@ -95,7 +95,9 @@ def parse_args(argv=None):
     ap.add_argument("--scenes-total", type=int, default=0,
                     help="strong scaling: ONE set of this many scenes sharded i mod W over the ranks (configs[3]: 1201); "
                          "a step = one pass over the rank's shard in batches of --batch")
-    ap.add_argument("--groups", type=int, default=10, help="engine groups per GPU (host thread + HIP stream each); two more than a batch of 64 fills, so that the next batch starts while the last groups of this one finish")
+    ap.add_argument("--groups", type=int, default=14, help="engine groups per GPU (host thread + HIP stream each).  10 through round 5 and most of round 6; with the label vectors off the CUs "
+                                                              "(csrc/sdma.cpp) more groups pay again: 10 / 14 / 16 / 18 / 20 x 8 = 3,420-3,443 / 3,444-3,497 / 3,375-3,504 / 3,295-3,414 / 3,117-3,224 scenes/s "
+                                                              "(beyond 16 the streams share hardware queues: GPU_MAX_HW_QUEUES=16)")
     ap.add_argument("--per-group", type=int, default=8, help="scenes a group advances in lock-step through batched launches")
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--segments", type=int, default=1500)

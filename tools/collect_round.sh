@@ -10,7 +10,7 @@ cd $R
 # scenes of the profiled runs, generated once by an unprofiled process pool: a profiled process must not spawn (the profiler's preload
 # has initialised the GPU before python starts)
 timeout 600 python3 bench.py --generate-only --no-extras --scene-cache $SG_SCENE_CACHE
-timeout 500 bash tools/prof_engine.sh bench 10 8 | head -12
+timeout 500 bash tools/prof_engine.sh bench 14 8 | head -12
 timeout 500 bash tools/prof_engine.sh solo8 1 8 | head -30
 timeout 900 bash tools/pmc_engine.sh $TAG 1 8 > gpurun_out/${TAG}_pmc.log 2>&1
 (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -- python3 $R/tools/time_train.py --steps 6 > $R/gpurun_out/prof_train.log 2>&1)
@@ -21,7 +21,7 @@ cp gpurun_out/solo_scannet_kernel_stats.csv profiles/${TAG}_solo_batched_scannet
 timeout 900 python3 tools/time_driver.py --scenes 2048 --base /dev/shm --skip-nopack --skip-loop --distinct 32 --out-format "npy@6;txt,npy@8" --out profiles/${TAG}_driver_end_to_end.json > gpurun_out/${TAG}_driver.log 2>&1
 timeout 900 python3 tools/host_scale_rehearsal.py --ranks 1,2,4,8 --scenes 768 --rate 3000 --out profiles/${TAG}_host_scale.json > gpurun_out/${TAG}_rehearsal.log 2>&1
 # round 6: the bench under roctx ranges (bench.py --profile: kernel trace + marker trace, no counters) and the overlap experiments' table
-timeout 400 bash tools/prof_ranges.sh $TAG 10 8 > gpurun_out/${TAG}_ranges.log 2>&1
+timeout 400 bash tools/prof_ranges.sh $TAG 14 8 > gpurun_out/${TAG}_ranges.log 2>&1
 for k in marker_api_stats kernel_stats; do cp gpurun_out/${TAG}_ranges_${k}.csv profiles/${TAG}_ranges_${k}.csv 2>/dev/null; done
 [ -f gpurun_out/r06_overlap.txt ] && cp gpurun_out/r06_overlap.txt profiles/${TAG}_overlap_experiments.txt
 [ -f gpurun_out/r06_ec_lever.txt ] && cp gpurun_out/r06_ec_lever.txt profiles/${TAG}_edgeconv_bn2_lever.txt
