@@ -545,6 +545,18 @@ def main(argv=None):
                                     "hbm_bytes_per_scene_launch": {k_: hb.get(k_) for k_ in ("k_cluster_knn_sorted<unseeded>", "k_cluster_knn_sorted<seeded>")},
                                     "algorithmic_bytes_per_scene_launch": 96.0 * args.points,
                                     "source": f"profiles/{PROFILE_TAG}_pmc_kernels.json (SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE of the two kNN launches, separate PMC passes)"}
+        # the WHOLE job against the same issue roof: every batched kernel's SQ_INSTS_VALU per scene (launches per scene from the PMC pass's own launch
+        # counts, `k_mlp1_apply_b` runs once per scene) x the scenes/s of the timed region / the issue rate of 1,024 SIMDs
+        rawk = pmc.get("per_kernel_raw", {}) or {}
+        base_l = (rawk.get("k_mlp1_apply_b", {}) or {}).get("launches", 0)
+        if vmap and base_l:
+            per_scene = sum(v_ * rawk.get(k_, {}).get("launches", base_l) / base_l for k_, v_ in vmap.items())
+            roofline["whole_job_valu"] = {"valu_insts_per_scene": int(per_scene), "scenes_per_s_per_gpu": round(value / world, 1),
+                                          "achieved_ginst_per_s": round(per_scene * value / world / 1e9, 1), "peak_ginst_per_s": VALU_PEAK_GINST,
+                                          "frac": round(per_scene * value / world / 1e9 / VALU_PEAK_GINST, 4),
+                                          "scenes_per_s_at_the_roof": round(VALU_PEAK_GINST * 1e9 / per_scene, 0),
+                                          "what": "all 26 batched kernels of a scene (EdgeConv 38 M, kNN 45.5 M, MLP1 12.8 M, moments, FPS, sort ...) as wave64 VALU instructions, "
+                                                  "against what 1,024 SIMDs issue; MFMA instructions and memory time not counted: a floor on the time, not a model of it"}
         mb = (pmc.get("mfma_busy_share", {}) or {}).get(dom)
         if mb is not None:
             roofline["mfma_busy_share_pmc"] = {"value": mb, "source": f"profiles/{PROFILE_TAG}_pmc_kernels.json (SQ_VALU_MFMA_BUSY_CYCLES, solo batched)"}
