@@ -41,10 +41,9 @@ namespace {
 struct ArrayRef { size_t off = 0, bytes = 0; bool found = false; };
 
 // packs store the [E0,2] adjacency as int32 (half of a pack's bytes were the int64 form: 8.6 of 17 MB at 150k points); the library's
-// kernels take the reference's int64 rows (model.py:724), so the loader widens them on the device, behind the upload on its own stream
-__global__ void k_widen_adj(const int32_t* __restrict__ src, long long* __restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (long long)src[i];
-}
+// kernels take the reference's int64 rows (model.py:724).  The worker widens them IN ITS PINNED BUFFER, behind the file's bytes, and the one
+// upload carries both (through round 6 a kernel on the worker's stream did it on the device: 40k elements that waited 0.5-1.5 ms for a CU
+// among the engine's persistent grids, with the worker waiting for them)
 
 // the header is written by json.dumps: {"name": "...", "N": n, ..., "arrays": {"data": ["<f4", [N, 6], off], ...}}
 bool find_int(const std::string& h, const char* key, long long* out) {
@@ -117,8 +116,9 @@ struct sg_loader {
     };
     struct Job { int ticket = 0; std::string path; int slot = -1; int rc = 0; std::string err; bool done = false; sg_scene sc{}; };
     int device = 0;
-    size_t slot_bytes = 0;              // a pack's bytes (pinned read buffer of every worker)
-    size_t blob_bytes = 0;              // a device slot: the pack + its adjacency widened to int64
+    size_t slot_bytes = 0;              // a pack's bytes
+    size_t pin_bytes = 0;               // pinned read buffer of every worker: the pack + its adjacency widened to int64
+    size_t blob_bytes = 0;              // a device slot: the same
     char* arena = nullptr;              // all slots: one allocation
     std::vector<Slot> slots;
     std::deque<int> free_slots;
@@ -163,7 +163,7 @@ struct sg_loader {
         char* pin = nullptr;
         hipEvent_t ev = nullptr;
         bool ok;
-        if (dry) { pin = static_cast<char*>(aligned_alloc(4096, slot_bytes)); ok = pin != nullptr; if (ok) memset(pin, 0, slot_bytes); }
+        if (dry) { pin = static_cast<char*>(aligned_alloc(4096, pin_bytes)); ok = pin != nullptr; if (ok) memset(pin, 0, pin_bytes); }
         else {
             (void)hipSetDevice(device);
             // a HIGH-priority stream: under the engine's load an upload took 0.85 ms against 0.3 ms on an idle GPU (tools/time_loader.py,
@@ -172,7 +172,7 @@ struct sg_loader {
             (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
             static const bool flat = getenv("SG_LOADER_FLAT_PRIORITY") != nullptr;
             ok = (flat ? hipStreamCreateWithFlags(&st, hipStreamNonBlocking) : hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr_hi)) == hipSuccess &&
-                 hipHostMalloc((void**)&pin, slot_bytes, hipHostMallocDefault) == hipSuccess &&
+                 hipHostMalloc((void**)&pin, pin_bytes, hipHostMallocDefault) == hipSuccess &&
                  hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
         }
         for (;;) {
@@ -239,8 +239,9 @@ struct sg_loader {
         const size_t size = (size_t)stt.st_size - base;
         if (size > slot_bytes) return sg::fail(SG_ENOMEM, "sg_loader: %s holds %zu bytes, a slot %zu", j.path.c_str(), size, slot_bytes);
         const size_t wide_off = (size + 255) / 256 * 256;                                  // the widened adjacency sits behind the file's bytes
-        if (!dry && adj32 && wide_off + (size_t)E0 * 16 > blob_bytes)
-            return sg::fail(SG_ENOMEM, "sg_loader: %s: no room for the widened adjacency (%zu + %zu > %zu)", j.path.c_str(), wide_off, (size_t)E0 * 16, blob_bytes);
+        if (adj32 && wide_off + (size_t)E0 * 16 > pin_bytes)
+            return sg::fail(SG_ENOMEM, "sg_loader: %s: no room for the widened adjacency (%zu + %zu > %zu)", j.path.c_str(), wide_off, (size_t)E0 * 16, pin_bytes);
+        const size_t up_bytes = adj32 ? wide_off + (size_t)E0 * 16 : size;                  // what goes up: the file's bytes (+ the widened rows)
         for (int i = 0; i < 11; ++i)
             if (a[i].off + a[i].bytes > size) return sg::fail(SG_EINVAL, "sg_loader: %s: array %s runs past the end of the file", j.path.c_str(), kNames[i]);
         lap(1);
@@ -251,10 +252,13 @@ struct sg_loader {
             if (r == 0) return sg::fail(SG_EINVAL, "sg_loader: %s is truncated", j.path.c_str());
             got += (size_t)r;
         }
+        if (adj32) {
+            const int32_t* src = reinterpret_cast<const int32_t*>(pin + a[1].off);
+            long long* dst = reinterpret_cast<long long*>(pin + wide_off);
+            for (size_t i = 0, n2 = (size_t)E0 * 2; i < n2; ++i) dst[i] = (long long)src[i];
+        }
         // one upload; the arrays are typed views into the slot's blob (every array starts on a 64-byte boundary of the file)
         lap(2);
-        // the gate covers the COPY only (an event behind it): the widening kernel below waits for its turn on a busy GPU -- ~0.5 ms under the
-        // engine's load -- and held inside the gate that wait capped the loader at 2 / 0.8 ms = 2,400 packs/s
         std::unique_ptr<CopyGate> gate(new CopyGate(this));
         lap(3);
         sg::SdmaTicket sdma;
@@ -269,17 +273,11 @@ struct sg_loader {
         // label vectors (device -> host) that path is worth 6 % of the headline; for the uploads it measured +2-3 % (.npy: 1,894-1,928 against 1,840-1,875
         // scenes/s steady) and nothing with .txt output -- not enough to make it the default (files byte-identical either way: tests/test_gpu_loader.py).
         static const bool want_sdma = getenv("SG_LOADER_COPY") && std::string(getenv("SG_LOADER_COPY")) == "sdma";
-        if (want_sdma && sg::sdma_available() && sg::sdma_issue(sl.d_blob, pin, size, &sdma) == SG_OK) by_sdma = true;
+        if (want_sdma && sg::sdma_available() && sg::sdma_issue(sl.d_blob, pin, up_bytes, &sdma) == SG_OK) by_sdma = true;
         else {
         sg::err_buf()[0] = 0;
-        if (hipMemcpyAsync(sl.d_blob, pin, size, hipMemcpyHostToDevice, st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
+        if (hipMemcpyAsync(sl.d_blob, pin, up_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
         if (hipEventRecord(ev, st) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
-        }
-        if (adj32 && !by_sdma) {
-            const size_t n2 = (size_t)E0 * 2;
-            k_widen_adj<<<(unsigned)std::min<size_t>((n2 + 255) / 256, 1024), 256, 0, st>>>(reinterpret_cast<const int32_t*>(sl.d_blob + a[1].off),
-                                                                                         reinterpret_cast<long long*>(sl.d_blob + wide_off), n2);
-            if (hipGetLastError() != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: widening the adjacency of %s failed", j.path.c_str());
         }
         }
         lap(4);
@@ -295,12 +293,6 @@ struct sg_loader {
         lap(5);
         if (!dry && by_sdma) {
             if (sg::sdma_wait(&sdma) != SG_OK) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed (copy engine)", j.path.c_str());
-            if (adj32) {                                             // the widening kernel reads what the copy engine has just written
-                const size_t n2 = (size_t)E0 * 2;
-                k_widen_adj<<<(unsigned)std::min<size_t>((n2 + 255) / 256, 1024), 256, 0, st>>>(reinterpret_cast<const int32_t*>(sl.d_blob + a[1].off),
-                                                                                             reinterpret_cast<long long*>(sl.d_blob + wide_off), n2);
-                if (hipGetLastError() != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: widening the adjacency of %s failed", j.path.c_str());
-            }
         } else
         if (!dry && hipEventSynchronize(ev) != hipSuccess) return sg::fail(SG_EHIP, "sg_loader: upload of %s failed", j.path.c_str());
         gate.reset();                                                // the pinned buffer has been read: the next worker's copy may start
@@ -340,7 +332,8 @@ sg_loader* sg_loader_create_sized(int threads, int slots, size_t slot_bytes, siz
     // of `slots` of them: start-up and tear-down of the driver)
     // a multiple of 256: every slot starts where the first one does modulo a cache line, so the packs' "every array starts on a 64-byte boundary"
     // holds on the device for slots 1 .. n - 1 too (the sized stride was only a multiple of 16)
-    L->blob_bytes = sg::align_up(max_edges > 0 ? L->slot_bytes + max_edges * 16 + 8192 : 3 * L->slot_bytes + 4096, 256);
+    L->pin_bytes = sg::align_up(max_edges > 0 ? L->slot_bytes + max_edges * 16 + 8192 : 3 * L->slot_bytes + 4096, 4096);
+    L->blob_bytes = L->pin_bytes;
     L->slots.resize((size_t)slots);
     if (L->dry) L->blob_bytes = 0;                               // no device side: the scenes' device pointers are offsets from null
     if (!L->dry && hipMalloc((void**)&L->arena, (size_t)slots * L->blob_bytes) != hipSuccess) {

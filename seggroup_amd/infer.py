@@ -61,7 +61,11 @@ def build_parser() -> argparse.ArgumentParser:
                         "(same files, byte for byte); 'full' = the vectors themselves are copied (8.4 MB per 150k-vertex scene)")
     p.add_argument('--port', type=int, default=2344, help='rendezvous port on 127.0.0.1 (reference: 2344)')
     p.add_argument('--batch', type=int, default=64, help='scenes per batch in the packed fast path (0 = the per-scene SegModel.forward loop)')
-    p.add_argument('--inflight', type=int, default=80, help='scenes in flight per GPU in the packed fast path (engine groups of 8; two groups more than a batch fills)')
+    p.add_argument('--inflight', type=int, default=32,
+                   help='scenes in flight per GPU in the packed fast path (engine groups of 8).  80 -- what the bench, whose inputs are resident, is fastest near -- through most of '
+                        'round 6; with packs to read and files to write beside it the driver is fastest at 32 (2,048 scenes on tmpfs, tools/sweep_driver.py, three boxes: '
+                        '16 / 24 / 32 / 40 / 48 / 56 / 80 in flight = 1,600-1,660 / 1,750-1,850 / 1,860-2,080 / 1,850-1,990 / 1,760-1,950 / 1,610-1,810 / 1,400-1,610 scenes/s): a '
+                        'smaller engine is created sooner (0.07 against 0.18 s) and leaves the loader its share of the GPU')
     p.add_argument('--no-cache', action='store_true', help='do not build / use packed scene files (dataset/scannet/cache/...)')
     p.add_argument('--synthetic', type=int, default=0, metavar='N',
                    help='write N synthetic ScanNet-shaped scenes in the reference\'s on-disk layout under --root (and a random-init '
@@ -306,8 +310,12 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
         # Round 6 sweep (tools/sweep_driver.py, 2,048 scenes on tmpfs, two boxes): 4 loader threads 1,895-1,930 scenes/s steady, 6 (the old default)
         # 1,824-1,852, 8 -- on a slower box -- 1,092 against 1,610-1,694 for 4-6: every further thread is another pack read + bulk upload competing
         # with the engine's own transfers; with `.txt` output 3-4 threads 1,478-1,488 against 1,445-1,466 for 8
+        # ... and with 32 scenes in flight (the default since), 3 against 4 threads, A / B on two boxes: 1,825-1,893 against 1,517-1,831 scenes/s overall on one,
+        # 1,443-1,673 against 1,734-1,861 on the other (whose host reads a pack more slowly): 4 stays.  Reading the next pack WHILE the last one uploads (two staging
+        # buffers per worker) was built and measured too: the loader then idles half of the time and the run is no faster (3 / 4 threads 1,767-1,857 / 1,509-1,820
+        # against 1,825-1,893 / 1,517-1,831 without) -- what the loader takes, the engine loses
         n_load = int(os.environ.get('SG_LOADER_THREADS', '0')) or min(4, workers)
-        loader = cache.PackLoader(threads=n_load, slots=4 * max(args.batch, 1), slot_bytes=slot_bytes, device=dev,
+        loader = cache.PackLoader(threads=n_load, slots=int(os.environ.get('SG_LOADER_SLOT_BATCHES', '4')) * max(args.batch, 1), slot_bytes=slot_bytes, device=dev,
                                   max_edges=max_edges)
 
         class _Loaded:                                      # a future-like handle on a loader ticket
@@ -327,13 +335,16 @@ def _run_packed(rank, world, args, model, scene_list, mine, acc, io, dev):
         return _Loaded(loader.submit(paths[name])) if loader is not None else pool.submit(stage, name)
 
     batches = [names[k:k + args.batch] for k in range(0, len(names), args.batch)]
-    ahead = 2 if loader is not None else 1                 # batches of staging requests outstanding
+    ahead = int(os.environ.get('SG_DRIVER_AHEAD', '2')) if loader is not None else 1                 # batches of staging requests outstanding
     pending_q = [[request(n) for n in batches[k]] for k in range(min(ahead, len(batches)))]
     # Writer threads beyond what the formats need take memory bandwidth from the loader's copies (2,048 scenes on tmpfs, 256-core host,
     # tools/time_driver.py --out-format "npy@6;npy@16;txt,npy@8;txt,npy@16;txt,npy@32"): `.npy` only 1,430-1,500 scenes/s with 6 threads, 1,230
     # with 16; `.txt` + `.npy` (the text of a scene is ~3 ms of one core since the formatter takes small values from a table) 1,290 with 8,
     # 1,205 with 16, 1,150 with 32
-    writer = AsyncLabelWriter(threads=max(2, min(workers, 8 if 'txt' in formats else 6)))
+    # Round 6, with 32 scenes in flight (same sweeps): `.npy` 6 / 8 writer threads 1,860-1,910 / 1,920-1,950 scenes/s; `.txt` + `.npy` 8 / 12 / 16 threads 1,470-1,510 /
+    # 1,650-1,670 / 1,520-1,600.  The count no longer follows -j (the reference's loader processes): it is what the formats need, inside the rank's share of the host
+    cpus = (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)) // max(world, 1)
+    writer = AsyncLabelWriter(threads=int(os.environ.get('SG_WRITER_THREADS', '0')) or max(2, min(12 if 'txt' in formats else 8, max(cpus - 6, 2))))
     runner, done, stalled = None, 0, []
     w = model.export_weights()
     tickets = []

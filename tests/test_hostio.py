@@ -192,3 +192,59 @@ def test_native_pack_builder_refuses_what_it_does_not_know_and_the_python_builde
     monkeypatch.setattr(cache, "_build_native", lambda root_, todo, style, workers: list(todo))       # "refused everything"
     assert cache.build_missing(root, names, workers=2) == len(names) and sorted(calls) == sorted(names)
     assert all(cache.is_current(root, n) for n in names)
+
+
+# ---- pack loader (csrc/loader.cpp), host side: SG_LOADER_DRY=1 makes no HIP call (tools/host_scale_rehearsal.py's mode) --------------
+def test_pack_loader_host_side_without_a_gpu(sg_lib, tmp_path, golden_index, monkeypatch):
+    """The loader's host side without a GPU: every ticket completes -- more packs than slots, a file that is no pack in the middle -- and every
+    scene carries its own header's sizes, its own per-segment arrays and seg_of_vertex table, and an adjacency address behind the file's bytes
+    (the int32 rows are widened to the kernels' int64 in the worker's staging buffer, csrc/loader.cpp)."""
+    import ctypes as C
+    import struct
+    from seggroup_amd import cache, hip
+    from seggroup_amd.scene import seg_of_vertex
+    if not hasattr(sg_lib, "sg_loader_create_sized"):
+        pytest.skip("the sanitizer build holds the host-only sources; the loader is compiled with hipcc")
+    monkeypatch.setenv("SG_LOADER_DRY", "1")
+    root, names = _tree(tmp_path, golden_index)
+    packs = [cache.pack_scene(root, n, force=True) for n in names]
+    bad = str(tmp_path / "not_a_pack.sgpack")
+    open(bad, "wb").write(b"SGPACK00" + b"\0" * 64)
+    order = [packs[i % len(packs)] for i in range(17)]
+    order.insert(7, bad)
+    L = sg_lib.sg_loader_create_sized(3, 4, max(os.path.getsize(p) for p in packs), max(cache.pack_dims(p)["E0"] for p in packs))
+    assert L, sg_lib.sg_last_error()
+    try:
+        tickets = []
+        for p in order[:6]:
+            t = sg_lib.sg_loader_submit(L, p.encode()); assert t > 0; tickets.append((t, p))
+        nxt, seen = 6, 0
+        while tickets:
+            t, p = tickets.pop(0)
+            sc, slot, name = hip.Scene(), C.c_int(-1), C.create_string_buffer(256)
+            rc = sg_lib.sg_loader_wait(L, t, C.byref(sc), C.byref(slot), name, 256)
+            if p == bad:
+                assert rc < 0 and b"not a scene pack" in sg_lib.sg_last_error()
+            else:
+                assert rc == 0, sg_lib.sg_last_error()
+                d = cache.pack_dims(p)
+                assert (sc.N, sc.S, sc.E0, sc.V) == (d["N"], d["S"], d["E0"], d["V"]) and name.value.decode() in p
+                with open(p, "rb") as f:
+                    f.seek(8); (hlen,) = struct.unpack("<I", f.read(4)); hdr = json.loads(f.read(hlen)); body = f.read()
+                def arr(k):
+                    dt, shape, off = hdr["arrays"][k]
+                    return np.frombuffer(body, dtype=np.dtype(dt), count=int(np.prod(shape)), offset=off).reshape(shape)
+                got = np.ctypeslib.as_array(C.cast(sc.h_seg_of_vertex, C.POINTER(C.c_int32)), shape=(sc.V,))
+                assert np.array_equal(got, seg_of_vertex(arr("seg_of_point"), arr("unmap")))
+                for k, ptr in (("seg_first", sc.h_seg_first), ("seg_size", sc.h_seg_size), ("seg_ins", sc.h_seg_ins), ("seg_sem", sc.h_seg_sem)):
+                    assert np.array_equal(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=(sc.S,)), arr(k)), k
+                # dry: device addresses are offsets into a slot that starts at null; the widened adjacency lies behind the file's bytes
+                if arr("adj").dtype == np.int32:
+                    assert (sc.d_adj or 0) >= len(body) and (sc.d_adj or 0) % 256 == 0
+                assert sg_lib.sg_loader_release(L, slot.value) == 0
+                seen += 1
+            if nxt < len(order):
+                t2 = sg_lib.sg_loader_submit(L, order[nxt].encode()); assert t2 > 0; tickets.append((t2, order[nxt])); nxt += 1
+        assert seen == 17
+    finally:
+        sg_lib.sg_loader_destroy(L)

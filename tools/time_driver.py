@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--out-format", default="txt,npy", help="label file formats; several sets separated by ';' share one tree (e.g. 'npy;txt,npy')")
     ap.add_argument("--base", default="/tmp", help="where the input tree and the results live (/dev/shm = tmpfs)")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--inflight", type=int, default=64)
+    ap.add_argument("--inflight", type=int, default=0, help="0 = the driver's own default")
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--out", default=None)
     ap.add_argument("--skip-nopack", action="store_true", help="skip the legs that stage from the reference's files")
@@ -85,7 +85,7 @@ def main():
                 run(["--batch", "0"])                              # warm-up: HIP context, page cache
                 t, r0 = run(["--batch", "0"])
                 o["per_scene_loop"] = {"s": round(t, 3), "scenes_per_s": round(a.scenes / t, 2)}
-            fast = ["--batch", str(a.batch), "--inflight", str(a.inflight)]
+            fast = ["--batch", str(a.batch)] + (["--inflight", str(a.inflight)] if a.inflight else [])
             if not a.skip_nopack:
                 run(fast + ["--no-cache"])                         # warm-up of this leg (engine creation, page cache)
                 t, rn = run(fast + ["--no-cache"])
