@@ -195,12 +195,23 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         scene_list = f.readlines()
 
     dev = None
+    if forward_fn is None:
+        # FIRST: this process onto the CPUs of its GPU's NUMA node -- every thread it has by now (HIP runtime's included) and all later ones, so that
+        # everything it first-touches from here on lies on that node: the engine's pinned buffers, the loader's staging buffers AND the packs a first run
+        # writes (page cache / tmpfs pages stay where their writer ran).  Round 6, 2,048 scenes on tmpfs, packs written from the GPU's node against
+        # the other one: 1,860-1,955 against 1,513-1,668 scenes/s in the runs that read them -- the bind used to come behind the pack build
+        # (tools/sweep_driver.py --pre-bind)
+        torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))
+        dev = torch.device('cuda', torch.cuda.current_device())
+        from .numa import bind_to_gpu_node
+        numa = bind_to_gpu_node(dev.index, getattr(args, 'numa', 'auto'))
+        if numa['bound']:
+            print('[rank %d] GPU %s on NUMA node %d: bound to %d of %d CPUs' % (rank, numa['pci'], numa['numa_node'], numa['cpus_after'], numa['cpus_before']), flush=True)
     if forward_fn is None and args.batch > 0 and not args.no_cache:
-        # packed fast path: build this rank's missing scene packs in worker processes before this process touches the GPU
+        # packed fast path: this rank's missing scene packs are built first (native threads; the Python fallback runs in threads of this process too)
         from . import cache
         mine_names = [scene_list[i][:-1] for i in scene_indices(len(scene_list), rank, world, args.sampler)]
-        # the reference gives every rank workers / ngpus loader processes (infer.py:94); the spawn context (not the order
-        # of calls) is what keeps these children clear of this process's GPU state
+        # the reference gives every rank workers / ngpus loader processes (infer.py:94)
         per_rank = max(1, -(-int(args.workers) // max(world, 1)))
         # ... the ONE-OFF pack build of a tree seen for the first time takes the rank's share of the host instead: a pack is ~20 ms of file
         # reads, a JSON parse and a 13 MB write that release the GIL (round 6: 260 -> see profiles/r06_driver_end_to_end.json `packed_cold`)
@@ -211,12 +222,6 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
     if forward_fn is None:
         from .data import ScanNet
         from .model import SegModel
-        torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))
-        dev = torch.device('cuda', torch.cuda.current_device())
-        from .numa import bind_to_gpu_node
-        numa = bind_to_gpu_node(dev.index, getattr(args, 'numa', 'auto'))      # every thread the process has by now (HIP runtime's included) and all later ones
-        if numa['bound']:
-            print('[rank %d] GPU %s on NUMA node %d: bound to %d of %d CPUs' % (rank, numa['pci'], numa['numa_node'], numa['cpus_after'], numa['cpus_before']), flush=True)
         model = SegModel(exp_name=args.exp_name, cuda=True, visualize=False, sem_infer=args.sem_infer, ins_infer=args.ins_infer,
                          data_root=args.root, out_formats=tuple(args.out_format.split(',')), label_style=args.label_style).to(dev)
         if rank == 0:

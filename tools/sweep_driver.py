@@ -20,8 +20,14 @@ def main():
     ap.add_argument("--scenes", type=int, default=2048)
     ap.add_argument("--format", default="npy")
     ap.add_argument("--workers", type=int, default=6)
+    ap.add_argument("--pre-bind", type=int, default=-1, help="NUMA node whose CPUs this process is confined to BEFORE it writes the tree and the packs "
+                                                              "(tmpfs pages are placed by first touch: are the packs on the GPU's node or on the other one?)")
     ap.add_argument("configs", nargs="+")
     a = ap.parse_args()
+    if a.pre_bind >= 0:
+        from seggroup_amd.numa import parse_cpulist
+        os.sched_setaffinity(0, parse_cpulist(open(f"/sys/devices/system/node/node{a.pre_bind}/cpulist").read()))
+        print(f"pre-bound to node {a.pre_bind}: {len(os.sched_getaffinity(0))} CPUs", flush=True)
     import torch
     from seggroup_amd import infer, synthetic, weights
     root = tempfile.mkdtemp(prefix="sg_sweep_", dir="/dev/shm")
