@@ -19,12 +19,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def spec(full):
-    out = [(150000, 1500, 62000 + i, {}) for i in range(full)]
-    out += [(150000, 1500, 72000 + i, {"seg_profile": "scannet"}) for i in range(max(2, full // 2))]
-    out += [(60000, 600, 72100 + i, {"seg_profile": "scannet"}) for i in range(4)]
-    out += [(3000, 30, 62100 + i, {}) for i in range(8)] + [(3000, 150, 62200 + i, {"min_seg": 1}) for i in range(8)]
-    out += [(20000, 200, 62300 + i, {"dup_frac": 0.1}) for i in range(4)]
+def spec(full, off=0):
+    out = [(150000, 1500, 62000 + off + i, {}) for i in range(full)]
+    out += [(150000, 1500, 72000 + off + i, {"seg_profile": "scannet"}) for i in range(max(2, full // 2))]
+    out += [(60000, 600, 72100 + off + i, {"seg_profile": "scannet"}) for i in range(4)]
+    out += [(3000, 30, 62100 + off + i, {}) for i in range(8)] + [(3000, 150, 62200 + off + i, {"min_seg": 1}) for i in range(8)]
+    out += [(20000, 200, 62300 + off + i, {"dup_frac": 0.1}) for i in range(4)]
     return out
 
 
@@ -39,7 +39,7 @@ def digest(labels, trace, iou_sem, iou_ins):
 
 
 def oracle_job(job):
-    n, s, seed, kw = job
+    n, s, seed, kw, mode = job
     os.environ.setdefault("OMP_NUM_THREADS", "4")
     from threadpoolctl import threadpool_limits
     from oracle import cpu_ref
@@ -48,7 +48,7 @@ def oracle_job(job):
     sc = synthetic.make_scene(n, s, seed, **kw)
     t = time.time()
     with threadpool_limits(limits=4):
-        ref = cpu_ref.forward_scene(sc, W, "ins_infer")
+        ref = cpu_ref.forward_scene(sc, W, mode)
     names = [f"layer_{l}.{k}" for l in (1, 2, 3, 4) for k in ("seg", "ins", "sem")] + ["final.ins", "final.sem"]
     return sc, digest([ref["labels"][nm] for nm in names], ref["trace"], ref["metrics"][0], ref["metrics"][1]), list(ref["trace"]), time.time() - t
 
@@ -58,24 +58,28 @@ def main():
     ap.add_argument("--tag", default="r06")
     ap.add_argument("--full", type=int, default=16)
     ap.add_argument("--workers", type=int, default=24)
+    ap.add_argument("--seed-offset", type=int, default=0, help="added to every seed of the list: a second sweep sees other scenes")
+    ap.add_argument("--groups", type=int, default=14)
+    ap.add_argument("--suffix", default="", help="profiles/<tag>_parity_sweep<suffix>.json")
     a = ap.parse_args()
-    jobs = spec(a.full)
+    jobs = spec(a.full, a.seed_offset)
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
     t0 = time.time()
     with ProcessPoolExecutor(max_workers=min(a.workers, len(jobs)), mp_context=mp.get_context("spawn")) as pool:
-        refs = list(pool.map(oracle_job, jobs))
+        refs = list(pool.map(oracle_job, [j + ("ins_infer",) for j in jobs]))
     t_oracle = time.time() - t0
     from seggroup_amd import hip, weights
     from seggroup_amd.model import Engine
     from seggroup_amd.scene import DeviceScene
     W = weights.load_npz(os.path.join(ROOT, "tests", "golden", "weights_g2.npz"))
+    mode = hip.MODE_INS_INFER
     scenes = [DeviceScene.from_synthetic(r[0], device="cuda:0") for r in refs]
     caps = (max(s.N for s in scenes), max(s.S for s in scenes), max(s.E0 for s in scenes), max(s.V for s in scenes))
-    eng = Engine(W, caps, groups=10, per_group=8, device="cuda:0", timing=0)
+    eng = Engine(W, caps, groups=a.groups, per_group=8, device="cuda:0", timing=0)
     rows, bad = [], 0
     for rep in range(2):
-        res = eng.run(scenes, hip.MODE_INS_INFER)
+        res = eng.run(scenes, mode)
         for (n, s, seed, kw), r, (sc, want, trace, secs) in zip(jobs, res, refs):
             got = digest([r.labels[i] for i in range(r.n_vectors)], r.trace, r.iou_sem, r.iou_ins)
             ok = got == want
@@ -85,10 +89,10 @@ def main():
             elif not ok:
                 rows[len(rows) - len(jobs) + jobs.index((n, s, seed, kw))]["equal"] = False
     eng.close()
-    out = {"what": "fresh seeds through the engine (10 x 8, two runs) against oracle/cpu_ref.py: sha256 over the 14 label vectors + cluster trace + the integer metric tensors",
+    out = {"what": f"fresh seeds through the engine ({a.groups} x 8, two runs, ins_infer, seed offset {a.seed_offset}) against oracle/cpu_ref.py: sha256 over the 14 label vectors + cluster trace + the integer metric tensors",
            "scenes": len(jobs), "unequal": bad, "oracle_pool_s": round(t_oracle, 1), "rows": rows}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"{a.tag}_parity_sweep.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{a.tag}_parity_sweep{a.suffix}.json"), "w"), indent=1)
     print(f"{len(jobs)} fresh scenes x 2 runs: {bad} results differ from the oracle; oracle pool {t_oracle:.0f} s")
     return 1 if bad else 0
 
