@@ -543,7 +543,10 @@ def main(argv=None):
                                     "ms_per_scene_both_launches_solo_batched": round(ms2, 4),
                                     "valu_frac": round(vi / (ms2 * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
                                     "hbm_bytes_per_scene_launch": {k_: hb.get(k_) for k_ in ("k_cluster_knn_sorted<unseeded>", "k_cluster_knn_sorted<seeded>")},
-                                    "algorithmic_bytes_per_scene_launch": 96.0 * args.points,
+                                    # per point: the sorted operand (16 B) + its member position (4) + its point id (4) read, the 20-entry table written (80); the layer-2
+                                    # launch writes the table a second time in point ids for the next layer's seeds (80), the seeded launch reads that row (80) and the
+                                    # seeds' records (16 B per point of the array, gathered out of L2).  (96 B through round 5: the seed tables were not counted.)
+                                    "algorithmic_bytes_per_scene_launch": {"k_cluster_knn_sorted<unseeded>": 184.0 * args.points, "k_cluster_knn_sorted<seeded>": 200.0 * args.points},
                                     "source": f"profiles/{PROFILE_TAG}_pmc_kernels.json (SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE of the two kNN launches, separate PMC passes)"}
         # the WHOLE job against the same issue roof: every batched kernel's SQ_INSTS_VALU per scene (launches per scene from the PMC pass's own launch
         # counts, `k_mlp1_apply_b` runs once per scene) x the scenes/s of the timed region / the issue rate of 1,024 SIMDs
