@@ -216,9 +216,22 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         # ... the ONE-OFF pack build of a tree seen for the first time takes the rank's share of the host instead: a pack is ~20 ms of file
         # reads, a JSON parse and a 13 MB write that release the GIL (round 6: 260 -> see profiles/r06_driver_end_to_end.json `packed_cold`)
         cold = max(per_rank, min(32, (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)) // max(world, 1)))
-        built = cache.build_missing(args.root, sorted(set(mine_names)), args.label_style, workers=cold)
-        if built and rank == 0:
-            io.cprint('Built %d scene packs under dataset/scannet/cache/%s' % (built, args.label_style))
+        # ... in a thread beside the model's construction and the checkpoint's load below (the builder's threads are native, the call releases the GIL): the
+        # ~0.25 s those take are not added to a first run's pack build
+        import threading
+        from . import hip
+        hip.lib()                                       # loaded once, here, not by two threads at the same time
+        build_box = {}
+
+        def _build():
+            try:
+                build_box['built'] = cache.build_missing(args.root, sorted(set(mine_names)), args.label_style, workers=cold)
+            except BaseException as e:                  # re-raised in the caller's thread below
+                build_box['error'] = e
+        build_thread = threading.Thread(target=_build, name='sg-pack-build')
+        build_thread.start()
+    else:
+        build_thread = None
     if forward_fn is None:
         from .data import ScanNet
         from .model import SegModel
@@ -236,6 +249,12 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
             io.cprint('Load model from ' + ckpt_path)
         model.epoch = 'sem_infer' if args.sem_infer else 'ins_infer'
         dataset = ScanNet(label_style=args.label_style, root=args.root)
+        if build_thread is not None:
+            build_thread.join()
+            if 'error' in build_box:
+                raise build_box['error']
+            if build_box.get('built') and rank == 0:
+                io.cprint('Built %d scene packs under dataset/scannet/cache/%s' % (build_box['built'], args.label_style))
 
         def forward_fn(i):   # noqa: F811
             data, weak, info = dataset[i]
