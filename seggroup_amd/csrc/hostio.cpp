@@ -37,7 +37,7 @@ extern "C" {
 // raises KeyError in update_adj then).  Same checks as seggroup_amd.scene.seg_from_lists, ~100x faster than json.load.
 int sg_parse_seg_json(const char* path, int N, int32_t* h_seg_of_point) {
     if (!path || N <= 0 || !h_seg_of_point) return sg::fail(SG_EINVAL, "sg_parse_seg_json: bad arguments");
-    std::string buf;
+    static thread_local std::string buf;                      // the calling thread's own, kept between files (the pack builder parses thousands, csrc/packbuild.cpp)
     const int rc = slurp(path, buf);
     if (rc < 0) return rc;
     const char* p = buf.data();

@@ -29,18 +29,39 @@ namespace {
 struct Err { std::string msg; };
 #define PB_FAIL(...) do { char b__[512]; snprintf(b__, sizeof b__, __VA_ARGS__); throw Err{b__}; } while (0)
 
-// A source file, memory-mapped read-only (round 6: fread into a zero-filled std::string was a 19 MB fill + a 19 MB copy per scene on top of the one
-// read the conversions and the pack write do anyway; the build is memory-bound once it runs on every core).  The subset of std::string's interface
-// the parsers below use.
+// A source file, read into a buffer the calling thread keeps between packs.  (Round 6, first form: fread into a zero-filled std::string -- a 19 MB fill + a
+// 19 MB copy per scene; second form: mmap / munmap per file -- no fill, no copy, but with every large std::vector below also an mmap / munmap of its own
+// (glibc's malloc maps blocks beyond 128 KB) a pack was ~20 map / unmap pairs and a few thousand page faults on ONE address space: 32 builder threads
+// spent their time on the process's mmap lock and on TLB shootdowns, 1,002 packs/s on 8 threads, 1,189-1,438 on 32.  With the allocator told to keep
+// large blocks (MALLOC_MMAP_THRESHOLD_) the same build ran 1,549 on 32.  Now nothing large is mapped or freed per pack: files are pread into pooled
+// buffers, the staging vectors are the thread's own.)  The subset of std::string's interface the parsers below use.
+struct RawPool {
+    std::vector<std::pair<char*, size_t>> idle;
+    ~RawPool() { for (auto& r : idle) free(r.first); }
+    char* get(size_t n, size_t* cap) {
+        size_t best = idle.size();
+        for (size_t k = 0; k < idle.size(); ++k)
+            if (idle[k].second >= n && (best == idle.size() || idle[k].second < idle[best].second)) best = k;
+        if (best < idle.size()) { char* p = idle[best].first; *cap = idle[best].second; idle[best] = idle.back(); idle.pop_back(); return p; }
+        const size_t c = std::max<size_t>(n + n / 4, (size_t)1 << 16);        // room for the next, slightly larger, file of the kind
+        char* p = static_cast<char*>(malloc(c));
+        if (!p) PB_FAIL("out of memory (%zu bytes)", c);
+        *cap = c;
+        return p;
+    }
+    void put(char* p, size_t cap) { if (idle.size() < 16) idle.emplace_back(p, cap); else free(p); }
+};
+thread_local RawPool t_pool;
+
 struct Buf {
     const char* p = nullptr;
     size_t n = 0;
-    bool mapped = false;
-    std::string own;
+    char* raw = nullptr;
+    size_t cap = 0;
     Buf() = default;
     Buf(const Buf&) = delete;
     Buf& operator=(const Buf&) = delete;
-    ~Buf() { if (mapped && p) munmap(const_cast<char*>(p), n); }
+    ~Buf() { if (raw) t_pool.put(raw, cap); }                // (created and destroyed by the thread that builds the pack)
     size_t size() const { return n; }
     const char* data() const { return p; }
     char operator[](size_t at) const { return p[at]; }
@@ -60,15 +81,16 @@ std::shared_ptr<Buf> slurp(const std::string& path) {
     if (fstat(fd, &st) != 0 || st.st_size < 0) { close(fd); PB_FAIL("cannot size %s", path.c_str()); }
     b->n = (size_t)st.st_size;
     if (b->n) {
-        void* m = mmap(nullptr, b->n, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m != MAP_FAILED) { b->p = static_cast<const char*>(m); b->mapped = true; }
-        else {                                               // a file system without mmap: read it
-            b->own.resize(b->n);
-            size_t got = 0;
-            while (got < b->n) { const ssize_t r = read(fd, &b->own[got], b->n - got); if (r <= 0) break; got += (size_t)r; }
-            if (got != b->n) { close(fd); PB_FAIL("short read of %s", path.c_str()); }
-            b->p = b->own.data();
+        try { b->raw = t_pool.get(b->n, &b->cap); } catch (...) { close(fd); throw; }
+        size_t got = 0;
+        while (got < b->n) {
+            const ssize_t r = pread(fd, b->raw + got, b->n - got, (off_t)got);
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) break;
+            got += (size_t)r;
         }
+        if (got != b->n) { close(fd); PB_FAIL("short read of %s", path.c_str()); }
+        b->p = b->raw;
     }
     close(fd);
     return b;
@@ -271,9 +293,9 @@ inline long long int_at(const Tensor& t, size_t e) {
 }
 
 // ndarray.astype(np.int32): wraps like NumPy's cast from int64; *fits = every value in [0, 2^31) (the adjacency's test, same pass)
-std::vector<int32_t> as_i32(const Tensor& t, bool* fits = nullptr) {
+void as_i32(const Tensor& t, std::vector<int32_t>& out, bool* fits = nullptr) {
     const size_t n = (size_t)t.numel();
-    std::vector<int32_t> out(n);
+    out.resize(n);
     long long lo = 0, hi = 0;
     if (t.type == 'i' && t.item == 8) {                      // the usual case (torch.long): a tight loop, unaligned-safe
         const char* p = t.data;
@@ -285,7 +307,6 @@ std::vector<int32_t> as_i32(const Tensor& t, bool* fits = nullptr) {
         for (size_t e = 0; e < n; ++e) { const long long v = int_at(t, e); lo = std::min(lo, v); hi = std::max(hi, v); out[e] = (int32_t)(uint32_t)(unsigned long long)v; }
     }
     if (fits) *fits = lo >= 0 && hi < (1ll << 31);
-    return out;
 }
 
 struct Blob { std::string dtype; std::vector<long long> shape; const void* p; size_t bytes; };
@@ -300,28 +321,37 @@ void build_one(const char* const* src, const char* name, const char* out_path) {
     const long long N = pcl.shape[0];
     if (N <= 0 || N > 0x7fffffffLL) PB_FAIL("%s: bad point count", src[0]);
     if (weak.shape.size() != 2 || weak.shape[0] != N || weak.shape[1] != 2 || weak.type == 'f') PB_FAIL("stage_arrays: inconsistent input shapes");
-    std::vector<float> data_conv;
+    // the staging arrays: the thread's own, resized per pack (see Buf above: nothing large is allocated or freed per pack)
+    struct Scratch { std::vector<float> data_conv; std::vector<int32_t> seg, order, off, first, counts, adj32, unmap, gt, seg_ins, seg_sem; std::vector<int64_t> adj64; };
+    thread_local Scratch t_s;
+    std::vector<float>& data_conv = t_s.data_conv;
     const float* data_p = reinterpret_cast<const float*>(pcl.data);                  // float32: written straight from the archive's bytes
     if (pcl.item != 4) {
         data_conv.resize((size_t)N * 6);
         for (size_t e = 0; e < data_conv.size(); ++e) { double v; memcpy(&v, pcl.data + 8 * e, 8); data_conv[e] = (float)v; }
         data_p = data_conv.data();
     }
-    std::vector<int32_t> seg((size_t)N);
+    std::vector<int32_t>& seg = t_s.seg;
+    seg.resize((size_t)N);
     const int S = sg_parse_seg_json(src[3], (int)N, seg.data());
     if (S <= 0) PB_FAIL("%s", sg_last_error());
-    std::vector<int32_t> order((size_t)N), off((size_t)S + 1), first((size_t)S), counts((size_t)S);
+    std::vector<int32_t>&order = t_s.order, &off = t_s.off, &first = t_s.first, &counts = t_s.counts;
+    order.resize((size_t)N); off.resize((size_t)S + 1); first.resize((size_t)S); counts.resize((size_t)S);
     if (sg_stage_segments(seg.data(), (int)N, S, order.data(), off.data(), first.data(), counts.data()) < 0) PB_FAIL("%s", sg_last_error());
     if (adj_t.type == 'f' || adj_t.numel() % 2 != 0) PB_FAIL("%s: the adjacency is not an integer [E,2] tensor", src[5]);
     const long long E0 = adj_t.numel() / 2;
     bool fits = true;
-    std::vector<int32_t> adj32 = as_i32(adj_t, &fits);       // write_pack: point indices that fit are stored as int32
-    std::vector<int64_t> adj64;
+    std::vector<int32_t>& adj32 = t_s.adj32;
+    as_i32(adj_t, adj32, &fits);                             // write_pack: point indices that fit are stored as int32
+    std::vector<int64_t>& adj64 = t_s.adj64;
+    adj64.clear();
     if (!fits) { adj64.resize((size_t)(2 * E0)); for (size_t e = 0; e < adj64.size(); ++e) adj64[e] = int_at(adj_t, e); }
     if (unmap_t.type == 'f') PB_FAIL("%s: the unmapper is not an integer tensor", src[1]);
-    const std::vector<int32_t> unmap = as_i32(unmap_t), gt = as_i32(gt_t);
+    std::vector<int32_t>&unmap = t_s.unmap, &gt = t_s.gt;
+    as_i32(unmap_t, unmap); as_i32(gt_t, gt);
     const long long V = unmap_t.numel();
-    std::vector<int32_t> seg_ins((size_t)S), seg_sem((size_t)S);
+    std::vector<int32_t>&seg_ins = t_s.seg_ins, &seg_sem = t_s.seg_sem;
+    seg_ins.resize((size_t)S); seg_sem.resize((size_t)S);
     for (int s = 0; s < S; ++s) { seg_ins[s] = (int32_t)int_at(weak, (size_t)first[s] * 2 + 1); seg_sem[s] = (int32_t)int_at(weak, (size_t)first[s] * 2); }
 
     const Blob blobs[11] = {{"<f4", {N, 6}, data_p, (size_t)N * 24},

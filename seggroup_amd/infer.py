@@ -215,7 +215,9 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
         per_rank = max(1, -(-int(args.workers) // max(world, 1)))
         # ... the ONE-OFF pack build of a tree seen for the first time takes the rank's share of the host instead: a pack is ~20 ms of file
         # reads, a JSON parse and a 13 MB write that release the GIL (round 6: 260 -> see profiles/r06_driver_end_to_end.json `packed_cold`)
-        cold = max(per_rank, min(32, (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)) // max(world, 1)))
+        # (threads: the native builder peaks between 16 and 32 -- 1 / 8 / 16 / 32 / 64 threads 182 / 1,123 / 2,054 / 1,791-2,069 / 1,333 packs/s of 150k-point scenes on tmpfs,
+        # tools/time_pack_build.py, since its buffers are the threads' own)
+        cold = max(per_rank, min(24, (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)) // max(world, 1)))
         # ... in a thread beside the model's construction and the checkpoint's load below (the builder's threads are native, the call releases the GIL): the
         # ~0.25 s those take are not added to a first run's pack build
         import threading
@@ -225,7 +227,9 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
 
         def _build():
             try:
+                t_b = time.time()
                 build_box['built'] = cache.build_missing(args.root, sorted(set(mine_names)), args.label_style, workers=cold)
+                build_box['s'] = time.time() - t_b
             except BaseException as e:                  # re-raised in the caller's thread below
                 build_box['error'] = e
         build_thread = threading.Thread(target=_build, name='sg-pack-build')
@@ -253,6 +257,8 @@ def run_worker(rank: int, world: int, args, forward_fn: Optional[Callable] = Non
             build_thread.join()
             if 'error' in build_box:
                 raise build_box['error']
+            if os.environ.get('SG_DRIVER_PROFILE'):
+                print('[driver profile] pack build: %d packs on %d threads in %.3f s' % (build_box.get('built', 0), cold, build_box.get('s', 0.0)), flush=True)
             if build_box.get('built') and rank == 0:
                 io.cprint('Built %d scene packs under dataset/scannet/cache/%s' % (build_box['built'], args.label_style))
 
