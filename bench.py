@@ -560,6 +560,17 @@ def main(argv=None):
                                           "scenes_per_s_at_the_roof": round(VALU_PEAK_GINST * 1e9 / per_scene, 0),
                                           "what": "all 26 batched kernels of a scene (EdgeConv 38 M, kNN 45.5 M, MLP1 12.8 M, moments, FPS, sort ...) as wave64 VALU instructions, "
                                                   "against what 1,024 SIMDs issue; MFMA instructions and memory time not counted: a floor on the time, not a model of it"}
+        # ... and against HBM (the north star asks for the fraction of the HBM roofline): every batched kernel's measured HBM bytes per scene (PMC, corrected as the
+        # guide prescribes and as reported) x the scenes/s of the timed region / 8 TB/s
+        hb_c, hb_u = pmc.get("hbm_bytes_per_scene_launch", {}) or {}, pmc.get("hbm_bytes_uncorrected_per_scene_launch", {}) or {}
+        if hb_c and base_l:
+            tot_c = sum(v_ * rawk.get(k_, {}).get("launches", base_l) / base_l for k_, v_ in hb_c.items())
+            tot_u = sum(v_ * rawk.get(k_, {}).get("launches", base_l) / base_l for k_, v_ in hb_u.items())
+            roofline["whole_job_hbm"] = {"hbm_bytes_per_scene": int(tot_c), "hbm_bytes_per_scene_as_reported": int(tot_u), "peak_tb_per_s": (HBM_PEAK_GBS / 1000.0),
+                                         "achieved_tb_per_s": round(tot_c * value / world / 1e12, 3), "frac": round(tot_c * value / world / 1e12 / (HBM_PEAK_GBS / 1000.0), 4),
+                                         "frac_as_reported": round(tot_u * value / world / 1e12 / (HBM_PEAK_GBS / 1000.0), 4),
+                                         "what": "2 x FETCH_SIZE + WRITE_SIZE of all batched kernels of a scene (solo batched PMC passes) x scenes/s: the job is bound by instruction issue "
+                                                 "(whole_job_valu), not by HBM"}
         mb = (pmc.get("mfma_busy_share", {}) or {}).get(dom)
         if mb is not None:
             roofline["mfma_busy_share_pmc"] = {"value": mb, "source": f"profiles/{PROFILE_TAG}_pmc_kernels.json (SQ_VALU_MFMA_BUSY_CYCLES, solo batched)"}
