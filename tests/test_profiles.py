@@ -55,6 +55,16 @@ def test_the_summaries_bench_py_reads_hold_full_launches_only():
         csv_ms = by["k_edgeconv_hb<2>"]["avg_us"] / pmc["scenes_per_launch"] * 1e-3
         assert abs(line["roofline"]["ms_per_scene_launch"] - csv_ms) <= 0.03 * csv_ms, (line["roofline"]["ms_per_scene_launch"], csv_ms)
         assert line["roofline"]["traffic"] == pmc["hbm_bytes_per_scene_launch"]["k_edgeconv<S2X>"]
+        # ... and its whole-job figures are the PMC file's sums (every batched kernel x its launches per scene) times the line's own rate
+        rl, raw = line["roofline"], pmc["per_kernel_raw"]
+        base = raw["k_mlp1_apply_b"]["launches"]
+        valu = sum(v * raw[k]["launches"] / base for k, v in pmc["valu_insts_per_scene_launch"].items())
+        hbm = sum(v * raw[k]["launches"] / base for k, v in pmc["hbm_bytes_per_scene_launch"].items())
+        assert abs(rl["whole_job_valu"]["valu_insts_per_scene"] - valu) <= 1 and abs(rl["whole_job_hbm"]["hbm_bytes_per_scene"] - hbm) <= 1
+        per_gpu = line["value"] / line["n_gpus"]
+        assert abs(rl["whole_job_valu"]["frac"] - valu * per_gpu / 512e9) < 1e-3 and 0.5 < rl["whole_job_valu"]["frac"] < 1.0
+        assert abs(rl["whole_job_hbm"]["frac"] - hbm * per_gpu / 8e12) < 1e-3 and rl["whole_job_hbm"]["frac"] < 0.5
+        assert rl["frac"] == pytest.approx(rl["achieved"] / rl["peak"], abs=1e-4)
 
 
 def test_a_summary_with_mixed_launch_sizes_fails():
