@@ -671,13 +671,14 @@ def _scan_book():
     return json.load(open(p)) if os.path.exists(p) else {}
 
 
-@pytest.mark.parametrize("workload", ["uniform_150k", "scannet_150k", "scannet_60k", "uniform_500k"])
+@pytest.mark.parametrize("workload", ["uniform_150k", "scannet_150k", "scannet_60k", "uniform_500k", "sem_uniform_150k", "sem_scannet_150k"])
 def test_every_scanned_seed_matches_oracle_and_the_stable_ones_match_the_reference(weight_sets, workload):
     """tests/golden/seed_scan.json (tools/seed_scan.py, build container): for EVERY seed of a workload -- not only the ones a
     fixture screen would keep -- the digests of the oracle's 14 label vectors, of the real reference's (capture B), whether
     the reference agrees with itself (capture A == B) and the decision margins.  The engine must reproduce the oracle's
     digests on every seed, and the reference's wherever the reference is stable (A == B == oracle).  `scannet_*`: surfaces,
-    10k-40k-point floor / wall segments, V != N, every other seed with 15 % exact duplicates (tiled scans)."""
+    10k-40k-point floor / wall segments, V != N, every other seed with 15 % exact duplicates (tiled scans).  `sem_*`: the same in sem_infer mode
+    (weights_g1, th = 3: six label vectors, two layers)."""
     from seggroup_amd import hip, synthetic
     from seggroup_amd.model import BatchRunner
     from seggroup_amd.scene import DeviceScene
@@ -690,13 +691,15 @@ def test_every_scanned_seed_matches_oracle_and_the_stable_ones_match_the_referen
     for sd, h in zip(seeds, host):                                  # the generator still produces the scanned inputs
         assert hashlib.sha256(np.ascontiguousarray(h.data).tobytes()).hexdigest() == e["seeds"][sd]["input_sha"]["data"], sd
     scenes = [DeviceScene.from_synthetic(h, device="cuda:0") for h in host]
-    eng = BatchRunner(weight_sets["ins_infer"], scenes, inflight=8, per_group=4, device="cuda:0")
-    res = eng.run(scenes, hip.MODE_INS_INFER)
+    mode = e.get("mode", "ins_infer")
+    eng = BatchRunner(weight_sets[mode], scenes, inflight=8, per_group=4, device="cuda:0")
+    res = eng.run(scenes, hip.MODE_SEM_INFER if mode == "sem_infer" else hip.MODE_INS_INFER)
     stable = 0
     for sd, r in zip(seeds, res):
         rec = e["seeds"][sd]
-        got = {hip.LABEL_NAMES[i]: hashlib.sha256(np.ascontiguousarray(r.labels[i]).tobytes()).hexdigest() for i in range(14)}
-        assert r.trace == rec["oracle_trace"], (sd, r.trace)
+        assert r.n_vectors == (6 if mode == "sem_infer" else 14)
+        got = {hip.LABEL_NAMES[i]: hashlib.sha256(np.ascontiguousarray(r.labels[i]).tobytes()).hexdigest() for i in range(r.n_vectors)}
+        assert r.trace[:len(rec["oracle_trace"])] == rec["oracle_trace"], (sd, r.trace)
         assert got == rec["oracle_label_sha"], f"seed {sd}: HIP != oracle on {[k for k in got if got[k] != rec['oracle_label_sha'][k]]}"
         if rec.get("labels_A_equal_B") and rec.get("oracle_equals_B"):
             stable += 1

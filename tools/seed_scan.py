@@ -9,7 +9,7 @@ for ALL seeds -- including the ones a fixture screen would reject -- in tests/go
 require HIP == oracle digests on every scanned seed (the rule this build defines) and HIP == reference digests wherever
 the reference is stable (A == B == oracle).  The file also documents how often the reference is unstable at full size.
 
-usage: python tools/seed_scan.py NAME N S PROFILE SEED [SEED ...]
+usage: python tools/seed_scan.py NAME N S PROFILE SEED [SEED ...]          (a NAME that starts with `sem_` is scanned in sem_infer mode: weights_g1, th = 3, six label vectors)
        python tools/seed_scan.py --oracle-only [NAME ...]     (re-run only the oracle for the recorded seeds, e.g. after an oracle fix)
 """
 from __future__ import annotations
@@ -37,15 +37,15 @@ def sha(a):
 def refresh_oracle(names):
     from oracle import cpu_ref
     from seggroup_amd import synthetic, weights as W
-    wts = W.load_npz(os.path.join(REPO, "tests", "golden", "weights_g2.npz"))
     path = os.path.join(REPO, "tests", "golden", "seed_scan.json")
     book = json.load(open(path))
     for name in names or list(book):
         e = book[name]
+        wts = W.load_npz(os.path.join(REPO, "tests", "golden", e.get("weights", "weights_g2.npz")))
         for seed, rec in e["seeds"].items():
             scene = synthetic.make_scene(e["n"], e["s"], int(seed), name=f"scene{int(seed):05d}_00", **e["kw"])
             t0 = time.time()
-            o = cpu_ref.forward_scene(scene, wts, "ins_infer")
+            o = cpu_ref.forward_scene(scene, wts, e.get("mode", "ins_infer"))
             rec["oracle_s"] = round(time.time() - t0, 1)
             rec["oracle_trace"] = o["trace"]
             rec["oracle_stalled"] = bool(o["stalled"])
@@ -72,16 +72,18 @@ def main():
     from oracle import cpu_ref
     from seggroup_amd import synthetic, weights as W
 
-    wts = W.load_npz(os.path.join(REPO, "tests", "golden", "weights_g2.npz"))
+    mode = "sem_infer" if name.startswith("sem_") else "ins_infer"
+    wfile = "weights_g1.npz" if mode == "sem_infer" else "weights_g2.npz"
+    wts = W.load_npz(os.path.join(REPO, "tests", "golden", wfile))
     path = os.path.join(REPO, "tests", "golden", "seed_scan.json")
     book = json.load(open(path)) if os.path.exists(path) else {}
     kw = {} if profile == "voronoi" else {"seg_profile": profile}
-    entry = book.setdefault(name, {"n": n, "s": s, "kw": kw, "mode": "ins_infer", "weights": "weights_g2.npz", "seeds": {}})
+    entry = book.setdefault(name, {"n": n, "s": s, "kw": kw, "mode": mode, "weights": wfile, "seeds": {}})
     for seed in seeds:
         scene = synthetic.make_scene(n, s, seed, name=f"scene{seed:05d}_00", **kw)
         rec = {"input_sha": {k: sha(getattr(scene, k)) for k in ("data", "weak_label", "seg", "adj", "unmap", "gt")}}
         t0 = time.time()
-        o = cpu_ref.forward_scene(scene, wts, "ins_infer")
+        o = cpu_ref.forward_scene(scene, wts, mode)
         rec["oracle_s"] = round(time.time() - t0, 1)
         rec["oracle_trace"] = o["trace"]
         rec["oracle_stalled"] = bool(o["stalled"])
@@ -91,7 +93,7 @@ def main():
         for variant, contig in (("B", True), ("A", False)):
             try:
                 with tempfile.TemporaryDirectory() as wd:
-                    runs[variant] = cap.run_capture(model_mod, scene, wts, "ins_infer", contig, False, wd)
+                    runs[variant] = cap.run_capture(model_mod, scene, wts, mode, contig, False, wd)
             except (MemoryError, RuntimeError) as e:
                 rec["reference_error"] = f"{variant}: {type(e).__name__}: {str(e)[:200]}"
                 break
@@ -101,7 +103,7 @@ def main():
             rec["reference_s"] = round(a["elapsed"], 1)
             rec["reference_threads"] = a["threads"]
             rec["reference_nclusters"] = b["nclusters"]
-            rec["margins"] = cap.margins([d[0], d[2], d[4]], [6.0, 2.0, 2.0])
+            rec["margins"] = cap.margins([d[0]], [3.0]) if mode == "sem_infer" else cap.margins([d[0], d[2], d[4]], [6.0, 2.0, 2.0])
             rec["labels_A_equal_B"] = all(np.array_equal(a["labels"][k], b["labels"][k]) for k in b["labels"])
             rec["reference_label_sha"] = {k: sha(v) for k, v in b["labels"].items()}
             rec["oracle_equals_B"] = rec["reference_label_sha"] == osha
